@@ -1,0 +1,198 @@
+"""TEST INFRASTRUCTURE ONLY -- run in the BUILD CONTAINER (needs /root/reference):
+
+    python -m oracle.make_golden            # rewrites tests/golden/*.npz
+
+Imports the reference's own models/*.py (through oracle/shim.py), drives them with the seeded
+synthetic inputs and recipe parameters of morig_amd/synth.py, and stores *data only* --
+inputs and the reference's outputs -- as small .npz fixtures. Parameters are not stored: they
+are a pure function of (recipe_seed, state_dict key, shape), see synth.recipe_state_dict.
+
+Every fixture is produced by the REFERENCE classes, never by oracle/nets.py; tests then hold
+oracle/nets.py (CPU) and the HIP path (GPU) against these files.
+"""
+from __future__ import annotations
+
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+from morig_amd import synth
+from oracle import shim
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _save(name, meta, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    arrays = {k: (v if isinstance(v, np.ndarray) else _np(v)) for k, v in arrays.items()}
+    arrays["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def _batch_arrays(b, with_skin=False, with_pts=False):
+    d = dict(pos=b.pos, tpl_edge_index=b.tpl_edge_index, geo_edge_index=b.geo_edge_index,
+             batch=b.batch, pred_flow=b.pred_flow)
+    if with_skin:
+        d["skin_input"] = b.skin_input
+    if with_pts:
+        d["pts"], d["pts_batch"] = b.pts, b.pts_batch
+    return d
+
+
+def ragged_batch(seeds_sides, n_pts=0):
+    meshes = [synth.make_mesh(s, n_side=n) for s, n in seeds_sides]
+    clouds = [synth.make_point_cloud(m, int(m.name), n_pts) for m in meshes] if n_pts else None
+    return synth.collate(meshes, clouds)
+
+
+def main():
+    torch.set_grad_enabled(False)
+    torch.manual_seed(0)
+    ref = shim.import_reference_models()
+    bm = sys.modules["models.basic_modules"]
+    rn = sys.modules["models.rignet"]
+
+    small = ragged_batch([(11, 16), (12, 12)])            # 256 + 144 vertices, ragged
+    V = small.pos.shape[0]
+    g = torch.Generator().manual_seed(123)
+
+    # ---- layer fixtures ---------------------------------------------------------------
+    print("layer fixtures")
+    x64 = torch.randn(V, 64, generator=g)
+    m = bm.EdgeConvMotion(nn_x=bm.MLP([128, 128, 128]), nn_pos=bm.MLP([6, 16, 16])).eval()
+    synth.load_recipe(m, 101)
+    _save("edgeconvmotion_c64_h128", dict(recipe_seed=101, cin=64, chalf=128, cpos=3, dpos=16),
+          pos=small.pos, x=x64, edge_index=small.geo_edge_index, out=m(small.pos, x64, small.geo_edge_index))
+
+    x1d = torch.randn(V, generator=g)                      # 1-D feature is unsqueezed (:187)
+    m = bm.EdgeConvMotion(nn_x=bm.MLP([2, 32, 32]), nn_pos=bm.MLP([6, 16, 16])).eval()
+    synth.load_recipe(m, 102)
+    _save("edgeconvmotion_x1d", dict(recipe_seed=102, cin=1, chalf=32, cpos=3, dpos=16),
+          pos=small.pos, x=x1d, edge_index=small.tpl_edge_index, out=m(small.pos, x1d, small.tpl_edge_index))
+
+    x256 = torch.randn(V, 256, generator=g)
+    m = bm.GCUMotion(in_channels=256, out_channels=512).eval()
+    synth.load_recipe(m, 103)
+    _save("gcumotion_256_512", dict(recipe_seed=103, cin=256, cout=512, cpos=3, dpos=16),
+          pos=small.pos, x=x256, tpl_edge_index=small.tpl_edge_index, geo_edge_index=small.geo_edge_index,
+          out=m(small.pos, x256, small.tpl_edge_index, small.geo_edge_index))
+
+    x3 = torch.randn(V, 3, generator=g) * 0.05
+    m = bm.GCU(in_channels=3, out_channels=32).eval()
+    synth.load_recipe(m, 104)
+    _save("gcu_3_32", dict(recipe_seed=104, cin=3, cout=32),
+          x=small.pos, tpl_edge_index=small.tpl_edge_index, geo_edge_index=small.geo_edge_index,
+          out=m(small.pos, small.tpl_edge_index, small.geo_edge_index))
+
+    for F_, out_ in ((3, 32), (64, 3)):
+        feat = x3 if F_ == 3 else x64 / x64.norm(dim=1, keepdim=True)
+        m = rn.GCNRig(chn_feature=F_, chn_output=out_).eval()
+        synth.load_recipe(m, 105 + F_)
+        _save(f"gcnrig_f{F_}_o{out_}", dict(recipe_seed=105 + F_, chn_feature=F_, chn_output=out_),
+              pos=small.pos, feature=feat, tpl_edge_index=small.tpl_edge_index,
+              geo_edge_index=small.geo_edge_index, batch=small.batch,
+              out=m(small.pos, feat, small.tpl_edge_index, small.geo_edge_index, small.batch))
+
+    mo = torch.nn.functional.normalize(torch.randn(V, 5, 32, generator=g), dim=2)
+    m = rn.TemporalAttn(input_size=32, num_heads=2, hidden_size=64, dim_feedforward=512, output_size=64).eval()
+    synth.load_recipe(m, 110)
+    _save("temporalattn_32_64", dict(recipe_seed=110, input_size=32, output_size=64), x=mo, out=m(mo))
+
+    # ---- full networks ----------------------------------------------------------------
+    print("network fixtures")
+    kw = dict(num_keyframes=5, chn_output=3, aggr_method="attn", motion_dim=32)
+    m = ref.__dict__["jointnet_motion"](**kw).eval()
+    synth.load_recipe(m, 201)
+    ma, mg, ps = m(small, small.pred_flow)
+    # post-ops of the caller (training/train_rig.py:224-225)
+    _save("jointnet_ragged", dict(recipe_seed=201, arch="jointnet_motion", kwargs=kw),
+          motion_all=ma, motion_aggr=mg, pred_shift=ps, y_pred=torch.tanh(ps) + small.pos,
+          **_batch_arrays(small))
+    # per-mesh == batched: store single-mesh run of mesh 1 for the collation test
+    one = ragged_batch([(12, 12)])
+    _, _, ps1 = m(one, one.pred_flow)
+    _save("jointnet_single_mesh1", dict(recipe_seed=201, arch="jointnet_motion", kwargs=kw),
+          pred_shift=ps1, **_batch_arrays(one))
+
+    for method in ("mean", "max"):
+        kw2 = dict(num_keyframes=5, chn_output=3, aggr_method=method)
+        m = ref.__dict__["jointnet_motion"](**kw2).eval()
+        synth.load_recipe(m, 202)
+        ma, mg, ps = m(small, small.pred_flow)
+        _save(f"jointnet_{method}", dict(recipe_seed=202, arch="jointnet_motion", kwargs=kw2),
+              motion_aggr=mg, pred_shift=ps, **_batch_arrays(small))
+
+    kw = dict(num_keyframes=5, chn_output=1, aggr_method="attn")
+    m = ref.__dict__["masknet_motion"](**kw).eval()
+    synth.load_recipe(m, 203)
+    ma, mg, pm = m(small, small.pred_flow)
+    _save("masknet_ragged", dict(recipe_seed=203, arch="masknet_motion", kwargs=kw),
+          motion_all=ma, motion_aggr=mg, pred_mask=pm, attn=torch.sigmoid(pm), **_batch_arrays(small))
+
+    kw = dict(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True, motion_dim=32,
+              aggr_method="attn")
+    m = ref.__dict__["skinnet_motion"](**kw).eval()
+    synth.load_recipe(m, 204)
+    ma, mg, sk = m(small, small.pred_flow)
+    _save("skinnet_ragged", dict(recipe_seed=204, arch="skinnet_motion", kwargs=kw),
+          motion_all=ma, motion_aggr=mg, skin_cls_pred=sk, skin_softmax=torch.softmax(sk, dim=1),
+          **_batch_arrays(small, with_skin=True))
+    for dg, lf in ((True, True), (True, False), (False, True)):
+        kw3 = dict(kw, use_Dg=dg, use_Lf=lf)
+        m = ref.__dict__["skinnet_motion"](**kw3).eval()
+        synth.load_recipe(m, 205)
+        _, _, sk = m(small, small.pred_flow)
+        _save(f"skinnet_dg{int(dg)}_lf{int(lf)}", dict(recipe_seed=205, arch="skinnet_motion", kwargs=kw3),
+              skin_cls_pred=sk, **_batch_arrays(small, with_skin=True))
+
+    # ---- CorrNet (GPU-branch semantics, deterministic FPS start) ------------------------
+    print("corrnet fixtures")
+    cb = ragged_batch([(21, 16), (22, 12)], n_pts=768)
+    kw = dict(input_feature=3, output_feature=64, temprature=0.07)
+    m = ref.__dict__["corrnet"](**kw).eval()
+    synth.load_recipe(m, 301)
+    with shim.pretend_cuda_available():
+        ov, op, vis, tau = m(cb, True, False)
+    _save("corrnet_ragged", dict(recipe_seed=301, arch="corrnet", kwargs=kw),
+          out_vtx=ov, out_pts=op, out_vismask=vis, tau=tau, **_batch_arrays(cb, with_pts=True))
+
+    # ---- the headline-size case: one 4096-vertex mesh -----------------------------------
+    print("4k fixture")
+    big = ragged_batch([(31, 64)])
+    kw = dict(num_keyframes=5, chn_output=3, aggr_method="attn", motion_dim=32)
+    m = ref.__dict__["jointnet_motion"](**kw).eval()
+    synth.load_recipe(m, 401, mild=True)
+    ma, mg, ps = m(big, big.pred_flow)
+    # inputs are regenerated from the seed (synth.make_mesh(31, 64)); keep outputs only, fp32
+    _save("jointnet_4k", dict(recipe_seed=401, mild=True, arch="jointnet_motion", kwargs=kw, mesh_seed=31,
+                              n_side=64), motion_aggr=mg, pred_shift=ps,
+          pos_check=big.pos[:8], geo_check=big.geo_edge_index[:, :32])
+
+    # ---- writers (utils/io_utils.py:41-55, training/train_rig.py:253-258) ---------------
+    print("writer fixtures")
+    sys.path.insert(0, shim.REFERENCE_ROOT)
+    pts = np.array([[0.1, 0.25, -0.3], [1.0, 2.0, 3.0], [1e-7, -1e-7, 0.5], [123.456789, 0.0, -0.000001]],
+                   dtype=np.float32)
+    # the reference writer prints its path and writes to disk; run it in a temp dir
+    import tempfile, contextlib
+    if not hasattr(np, "int"):
+        np.int = int            # reference utils/binvox_rw.py:161 predates numpy 1.24
+    iou = __import__("utils.io_utils", fromlist=["output_point_cloud_ply"])
+    with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(io.StringIO()):
+        iou.output_point_cloud_ply(torch.from_numpy(pts), name="kat", output_folder=td)
+        ply = open(os.path.join(td, "kat.ply"), "rb").read()
+    _save("ply_writer_kat", dict(), pts=pts, ply_bytes=np.frombuffer(ply, dtype=np.uint8))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,126 @@
+"""CPU: the oracle (oracle/nets.py) against golden vectors produced by the REFERENCE's own
+models/*.py (oracle/make_golden.py). Oracle and reference share only the third-party-primitive
+restatements, so this pins every line of reference wiring the oracle restates."""
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import data_from, maxdiff
+from morig_amd import synth
+from oracle import nets
+
+TOL = 2e-6   # fp32, same primitive code underneath => only op-ordering noise
+
+
+def _net(meta):
+    m = getattr(nets, meta["arch"])(**meta["kwargs"]).eval()
+    return synth.load_recipe(m, meta["recipe_seed"], mild=meta.get("mild", False))
+
+
+def test_edgeconvmotion_layer():
+    meta, a = load_golden("edgeconvmotion_c64_h128")
+    m = synth.load_recipe(nets.EdgeMaxConvMotion(meta["cin"], meta["chalf"], meta["cpos"], meta["dpos"]).eval(),
+                          meta["recipe_seed"])
+    assert maxdiff(m(a["pos"], a["x"], a["edge_index"]), a["out"]) <= TOL
+
+
+def test_edgeconvmotion_1d_feature():
+    meta, a = load_golden("edgeconvmotion_x1d")
+    m = synth.load_recipe(nets.EdgeMaxConvMotion(1, 32, 3, 16).eval(), meta["recipe_seed"])
+    assert a["x"].dim() == 1
+    assert maxdiff(m(a["pos"], a["x"], a["edge_index"]), a["out"]) <= TOL
+
+
+def test_gcumotion_layer():
+    meta, a = load_golden("gcumotion_256_512")
+    m = synth.load_recipe(nets.GraphConvUnitMotion(256, 512).eval(), meta["recipe_seed"])
+    assert maxdiff(m(a["pos"], a["x"], a["tpl_edge_index"], a["geo_edge_index"]), a["out"]) <= TOL
+
+
+def test_gcu_layer():
+    meta, a = load_golden("gcu_3_32")
+    m = synth.load_recipe(nets.GraphConvUnit(3, 32).eval(), meta["recipe_seed"])
+    assert maxdiff(m(a["x"], a["tpl_edge_index"], a["geo_edge_index"]), a["out"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["gcnrig_f3_o32", "gcnrig_f64_o3"])
+def test_gcnrig(name):
+    meta, a = load_golden(name)
+    m = synth.load_recipe(nets.RigGCN(meta["chn_feature"], meta["chn_output"]).eval(), meta["recipe_seed"])
+    out = m(a["pos"], a["feature"], a["tpl_edge_index"], a["geo_edge_index"], a["batch"])
+    assert maxdiff(out, a["out"]) <= TOL
+
+
+def test_temporal_attention():
+    meta, a = load_golden("temporalattn_32_64")
+    m = synth.load_recipe(nets.ClsTemporalAttention(32, 2, 64, 512, 64).eval(), meta["recipe_seed"])
+    assert maxdiff(m(a["x"]), a["out"]) <= TOL
+
+
+@pytest.mark.parametrize("name,outs", [
+    ("jointnet_ragged", ("motion_all", "motion_aggr", "pred_shift")),
+    ("jointnet_mean", (None, "motion_aggr", "pred_shift")),
+    ("jointnet_max", (None, "motion_aggr", "pred_shift")),
+    ("masknet_ragged", ("motion_all", "motion_aggr", "pred_mask")),
+    ("skinnet_ragged", ("motion_all", "motion_aggr", "skin_cls_pred")),
+    ("skinnet_dg1_lf1", (None, None, "skin_cls_pred")),
+    ("skinnet_dg1_lf0", (None, None, "skin_cls_pred")),
+    ("skinnet_dg0_lf1", (None, None, "skin_cls_pred")),
+])
+def test_full_networks(name, outs):
+    meta, a = load_golden(name)
+    m = _net(meta)
+    d = data_from(a)
+    res = m(d, d.pred_flow)
+    for r, key in zip(res, outs):
+        if key is not None:
+            assert r.shape == a[key].shape
+            assert maxdiff(r, a[key]) <= TOL, key
+
+
+def test_state_dict_contract():
+    """entry counts and sample shapes of SURVEY 8(b)."""
+    j = nets.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn")
+    s = nets.skinnet_motion(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True, motion_dim=32)
+    c = nets.corrnet(input_feature=3, output_feature=64, temprature=0.07)
+    assert len(j.state_dict()) == 443 and len(s.state_dict()) == 450 and len(c.state_dict()) == 336
+    sd = j.state_dict()
+    assert tuple(sd["motionNet.gcu_3.edge_conv_tpl.nn_x.0.0.weight"].shape) == (256, 512)
+    assert tuple(sd["motionNet.mlp_transform.0.0.0.weight"].shape) == (1024, 1862)
+    assert tuple(sd["jointnet.mlp_transform.0.0.0.weight"].shape) == (1024, 1923)
+    assert tuple(s.state_dict()["skinNet.gcu1.edge_conv_tpl.nn_pos.0.0.weight"].shape) == (64, 66)
+    assert sum(p.numel() for p in j.parameters()) == 7881987
+    assert sum(p.numel() for p in c.parameters()) == 4888258
+
+
+def test_collation_single_equals_batched():
+    """a mesh's outputs do not depend on its batch mates (eval mode)."""
+    meta, a = load_golden("jointnet_ragged")
+    _, one = load_golden("jointnet_single_mesh1")
+    sel = a["batch"] == 1
+    # different batch size => different CPU GEMM blocking => last-bit noise on O(3) values
+    assert maxdiff(a["pred_shift"][sel], one["pred_shift"]) <= 2e-5
+    m = _net(meta)
+    d1 = data_from(one)
+    assert maxdiff(m(d1, d1.pred_flow)[2], a["pred_shift"][sel]) <= 2e-5
+
+
+def test_corrnet():
+    meta, a = load_golden("corrnet_ragged")
+    m = _net(meta)
+    d = data_from(a)
+    ov, op, vis, tau = m(d, True, False)
+    assert maxdiff(ov, a["out_vtx"]) <= TOL
+    assert maxdiff(op, a["out_pts"]) <= TOL
+    assert maxdiff(vis, a["out_vismask"]) <= 1e-5
+    assert float(tau) == pytest.approx(0.07)
+    assert m(d, False, False)[2] is None
+
+
+def test_headline_size_fixture_inputs_regenerate():
+    """the 4k fixture stores outputs only; its inputs must regenerate bit-identically from the seed."""
+    meta, a = load_golden("jointnet_4k")
+    mesh = synth.make_mesh(meta["mesh_seed"], n_side=meta["n_side"])
+    assert torch.equal(mesh.pos[:8], a["pos_check"])
+    assert torch.equal(mesh.geo_edge_index[:, :32], a["geo_check"])
+    assert mesh.pos.shape[0] == 4096 and mesh.tpl_edge_index.shape[1] == 24576 + 4096
