@@ -1,0 +1,165 @@
+/*
+ * morig_hip.h -- C ABI of libmorig_hip.so: the MI355X (gfx950) kernels behind MoRig's
+ * geometric-network forward path.
+ *
+ * Boundary contract:
+ *   - plain `extern "C"` functions, plain pointers and sizes, no C++/torch types;
+ *   - every buffer is DEVICE memory owned by the caller (PyTorch-ROCm allocates it); the library
+ *     borrows pointers for the duration of the call and keeps nothing;
+ *   - every call enqueues asynchronously on the given hipStream_t (passed as void*); no hidden
+ *     device synchronisation (the profiling collector is the one documented exception);
+ *   - every call returns 0 or a negative MORIG_E_* code; no exceptions, no abort().
+ *
+ * The reference has no FFI of its own: its native work is delegated to three un-vendored wheels.
+ * Each entry point therefore names the reference CALL SITE (file:line under /root/reference) whose
+ * third-party operator it replaces; INTEGRATION.md shows the Python binding a maintainer would add.
+ *
+ * All matrices are row-major fp32. "ld" = row stride in floats. Unless noted, ld and the column
+ * offset of a matrix handed to a GEMM-type call must be multiples of 4 floats (16-byte rows).
+ */
+#ifndef MORIG_HIP_H
+#define MORIG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MORIG_ABI_VERSION 1
+
+/* status codes */
+#define MORIG_OK              0
+#define MORIG_E_INVALID      -1   /* null pointer, negative size, misaligned ld ...            */
+#define MORIG_E_UNSUPPORTED  -2   /* width / shape the kernels are not instantiated for        */
+#define MORIG_E_HIP          -3   /* a HIP runtime call failed; see morig_last_hip_error()      */
+#define MORIG_E_NODEVICE     -4   /* no gfx950 device visible                                   */
+
+int         morig_abi_version(void);
+const char* morig_strerror(int status);
+int         morig_last_hip_error(void);            /* raw hipError_t of the last MORIG_E_HIP   */
+/* device facts used by the host side for roofline arithmetic; arch must start with "gfx950" */
+int         morig_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_khz, char* arch, int arch_len);
+
+/* --------------------------------------------------------------------------------------------
+ * Graph preparation: COO -> self-loop-normalised CSR by destination.
+ * Replaces, once per forward instead of once per conv:
+ *   remove_self_loops + add_self_loops            models/basic_modules.py:149-150, 188-189
+ *   the implicit sort-free scatter of MessagePassing.propagate(aggr='max')  (:151, :190)
+ *
+ * edge_index : int64 [2, n_edges] contiguous (row 0 = source j, row 1 = target i), as PyG batches it
+ * rowptr     : int32 [n_nodes + 1]   out; rowptr[n_nodes] = E' = #(non-loop edges) + n_nodes
+ * src_sorted : int32 [n_edges + n_nodes] out (capacity; entries beyond E' untouched)
+ * dst_sorted : int32 [n_edges + n_nodes] out (target of every sorted edge, i.e. expanded rowptr)
+ * cursor     : int32 [n_nodes + 1]   scratch
+ * status     : int32 [1] out; set non-zero when an index is outside [0, n_nodes)
+ * Order inside a target's segment is unspecified (max-aggregation is order-free => results are
+ * bit-identical for any order).
+ */
+int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes,
+                    int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
+                    int32_t* cursor, int32_t* status, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Fused dense layer:  Y = scale * act(X * W^T + bias + rowbias[seg[row]]) + shift
+ *                     and/or  P[seg[row]] = max over rows (column-wise)            (pool != NULL)
+ * Replaces nn.Linear -> ReLU -> BatchNorm1d(eval) chains of MLP()   models/basic_modules.py:31-36
+ * and, with `pool`, scatter_max(x, batch) + repeat_interleave       models/rignet.py:62-64, 175-179,
+ *                                                                   models/corrnet.py:43-45
+ * (the broadcast is never materialised: the pooled vector enters the next layer as `rowbias`).
+ */
+typedef struct morig_gemm_args {
+    int32_t M, N, K;          /* logical sizes: Y is M x N, X is M x K                            */
+    const float* X; int32_t ldx;
+    const float* W; int32_t ldw;     /* packed weights [Npad][ldw]: row n = output channel n, ldw >= roundup(K,32),
+                                        zero padded; Npad = N rounded up to the column tile (32/64/128) */
+    const float* bias;        /* [Npad] or NULL                                                   */
+    const float* scale;       /* [Npad] or NULL (=1): BatchNorm eval scale  gamma/sqrt(var+eps)   */
+    const float* shift;       /* [Npad] or NULL (=0): BatchNorm eval shift  beta - mean*scale     */
+    int32_t relu;             /* 1: act = ReLU, 0: identity                                       */
+    const float* rowbias; int32_t ld_rowbias;   /* optional [n_seg][ld_rowbias] added before act  */
+    const int32_t* seg;       /* [M] segment (mesh) id of every row; required with rowbias / pool */
+    float* Y; int32_t ldy;    /* optional output                                                  */
+    float* pool; int32_t ld_pool; int32_t n_seg;  /* optional [n_seg][ld_pool] column max per segment */
+} morig_gemm_args;
+int morig_gemm(const morig_gemm_args* a, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Fused EdgeConv: gather -> 2-layer edge MLP -> segmented max, one pass, no per-edge tensor in HBM.
+ * Replaces EdgeConv / EdgeConvMotion .propagate()           models/basic_modules.py:151-155, 190-195
+ *
+ * For every sorted edge e = (j -> i) and replica r (keyframe), row(i) = r*rep_stride + i
+ * (separate strides for the inputs and the output so a replica-invariant branch, e.g. the position
+ * branch of EdgeConvMotion under the keyframe loop models/rignet.py:85-86, is gathered from ONE copy):
+ *     h1 = s1 * relu(A[row(i)] + B[row(j)]) + t1                  (layer 1 split per vertex:
+ *                                                                  W1 [x_i ; x_j - x_i] = (W1a-W1b) x_i + W1b x_j)
+ *     z  = s2 * relu(W2 h1 + b2) + t2
+ *     out[row(i)] = max over incoming edges of z
+ * H = hidden = output width; supported H: 16, 32, 64, 128, 256.
+ */
+typedef struct morig_edgeconv_args {
+    int32_t H;
+    int32_t n_nodes, replicas;
+    int32_t in_rep_stride;             /* row offset of replica r in A/B: r*in_rep_stride (0 = shared by all replicas) */
+    int32_t out_rep_stride;            /* row offset of replica r in out                                              */
+    const float* A; int32_t lda;       /* per-vertex target term  (incl. layer-1 bias) */
+    const float* B; int32_t ldb;       /* per-vertex source term                         */
+    const int32_t* rowptr; const int32_t* src_sorted; const int32_t* dst_sorted;
+    int32_t edge_capacity;             /* upper bound of E' used to size the launch      */
+    int32_t edge_count;                /* exact E' if the host knows it (0 = unknown); only used for
+                                          the algorithmic-FLOP accounting of morig_prof_collect      */
+    const float* s1; const float* t1;  /* [Hpad] BatchNorm-1 eval affine                  */
+    const float* W2; int32_t ldw;      /* packed [Hpad][ldw], ldw >= roundup(H,32)... see morig_gemm_args.W */
+    const float* b2; const float* s2; const float* t2;   /* [Hpad]                        */
+    float* out; int32_t ldo;           /* out[row][0..H)                                  */
+} morig_edgeconv_args;
+int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Small vertex-parallel operators.
+ */
+/* strided 2-D copy  dst[r*ldd + c] = src[r*lds + c]  (feature slicing input_flow[:, 3t:3t+3],
+ * models/rignet.py:86; torch.cat column placement :65). No alignment requirement. */
+int morig_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream);
+
+/* gather columns: dst[r*ldd + c] = src[r*lds + cols[c]]  (skin_input column selection,
+ * models/rignet.py:158-171). cols: int32 [n_cols] on device. */
+int morig_gather_cols(const float* src, int32_t lds, const int32_t* cols, int32_t n_cols,
+                      float* dst, int32_t ldd, int32_t rows, void* stream);
+
+/* seg_out[r*n_nodes + v] = r*n_graphs + batch[v]  for r < replicas (int64 PyG batch vector in) */
+int morig_make_seg(const int64_t* batch, int32_t n_nodes, int32_t n_graphs, int32_t replicas,
+                   int32_t* seg_out, void* stream);
+
+/* row-wise L2 normalisation  y = x / max(||x||_2, 1e-12)  (F.normalize, models/rignet.py:87,98;
+ * models/corrnet.py:48,60) with a replica-to-token transposition on the way out:
+ * input row m = r*rows_per_rep + v  ->  output address y + v*ld_row + r*ld_rep.               */
+int morig_rownorm(const float* x, int32_t ldx, int32_t rows_per_rep, int32_t replicas, int32_t cols,
+                  float* y, int32_t ld_row, int32_t ld_rep, void* stream);
+
+/* CLS-token temporal attention, exact restructuring of TemporalAttn.forward up to (not incl.) w_o
+ * (models/rignet.py:36-45): only token 0 of the output is consumed, so per vertex and head h
+ *     score_t = <tok_t, g_h>,  g_h = W_k,h^T (W_q,h cls) / sqrt(d)      (tok_0 = cls, tok_1..T = frames)
+ *     y_h     = sum_t softmax(score)_t * tok_t
+ * x: [n][T][C] frames; g: [heads][C]; cls: [C]; y: [n][heads*C] (then one GEMM with W_o,h W_v,h). */
+int morig_cls_attention(const float* x, int32_t n, int32_t T, int32_t C, int32_t heads,
+                        const float* g, const float* cls, float* y, int32_t ldy, void* stream);
+
+/* reductions over keyframes for aggr_method 'mean' / 'max' (models/rignet.py:92-95):
+ * x: [n][T][C] -> y[n][C]; mode 0 = mean, 1 = max */
+int morig_frame_reduce(const float* x, int32_t n, int32_t T, int32_t C, int32_t mode, float* y, int32_t ldy, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline object.
+ */
+#define MORIG_PROF_KINDS 24
+int         morig_prof_enable(int on);                 /* returns previous state */
+int         morig_prof_reset(void);
+const char* morig_prof_name(int kind);                  /* NULL past the last kind */
+/* synchronises the recorded events; per kind: launches, total ms, algorithmic flops, algorithmic bytes */
+int         morig_prof_collect(int kind, int64_t* launches, double* total_ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MORIG_HIP_H */

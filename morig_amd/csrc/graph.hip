@@ -1,0 +1,205 @@
+// Graph preparation and small index-driven copies: HBM-bound integer/byte work.
+//
+// morig_csr_build: COO (int64, PyG layout) -> self-loop-normalised CSR by destination (int32).
+//   pass 1  count   : in-degree of every target over non-loop edges               (atomics, 16 B/edge read)
+//   pass 2  scan    : rowptr = exclusive scan of (in-degree + 1); 3 short launches  (8 B/node)
+//   pass 3  fill    : every edge claims a slot in its target's segment (atomic cursor); one self loop
+//                     per node is appended                                            (16 B/edge read, 8 B/edge write)
+#include "common.h"
+
+namespace morig {
+
+constexpr int SCAN_T = 256;          // threads per scan block
+constexpr int SCAN_I = 8;            // items per thread
+constexpr int SCAN_B = SCAN_T * SCAN_I;
+
+__global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cnt, int* status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
+        const int64_t s = ei[e], d = ei[E + e];
+        if (s < 0 || s >= n || d < 0 || d >= n) { *status = 1; continue; }
+        if (s != d) atomicAdd(&cnt[d], 1);
+    }
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one int per thread (SCAN_T threads); returns exclusive prefix, total in *tot
+__device__ __forceinline__ int block_excl_scan(int v, int* sh /* >= SCAN_T/64 + 1 ints */, int* tot) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int inc = wave_incl_scan(v, lane);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_T / 64; ++i) { const int t = sh[i]; if (i < w) woff += t; total += t; }
+    __syncthreads();
+    *tot = total;
+    return woff + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_T) void scan_reduce_kernel(const int* __restrict__ cnt, int n, int* __restrict__ bsum) {
+    __shared__ int sh[SCAN_T / 64 + 1];
+    const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) if (base + i < n) v += cnt[base + i] + 1;
+    int tot;
+    (void)block_excl_scan(v, sh, &tot);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+
+// single block: in-place exclusive scan of nb block sums; grand total -> *total_out
+__global__ __launch_bounds__(SCAN_T) void scan_blocksums_kernel(int* bsum, int nb, int* total_out) {
+    __shared__ int sh[SCAN_T / 64 + 1];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += SCAN_T) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb ? bsum[i] : 0;
+        int tot;
+        const int ex = block_excl_scan(v, sh, &tot);
+        if (i < nb) bsum[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const int* cnt_in, int n, const int* __restrict__ bsum,
+                                                           int* __restrict__ rowptr, int* cursor) {   // cursor may alias cnt_in
+    __shared__ int sh[SCAN_T / 64 + 1];
+    const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+    int item[SCAN_I];
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) { item[i] = (base + i < n) ? cnt_in[base + i] + 1 : 0; v += item[i]; }
+    int tot;
+    int run = bsum[blockIdx.x] + block_excl_scan(v, sh, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        if (base + i < n) { rowptr[base + i] = run; cursor[base + i] = run; }   // cursor aliases cnt_in: own items only
+        run += item[i];
+    }
+}
+
+__global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cursor,
+                                int* __restrict__ srcS, int* __restrict__ dstS) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t total = E + n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        int s, d;
+        if (e < E) {
+            const int64_t s64 = ei[e], d64 = ei[E + e];
+            if (s64 < 0 || s64 >= n || d64 < 0 || d64 >= n || s64 == d64) continue;
+            s = (int)s64; d = (int)d64;
+        } else {
+            s = d = (int)(e - E);
+        }
+        const int pos = atomicAdd(&cursor[d], 1);
+        srcS[pos] = s;
+        dstS[pos] = d;
+    }
+}
+
+__global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int rows, int cols) {
+    const int64_t n = (int64_t)rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / cols; const int c = (int)(i - r * cols);
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+__global__ void gather_cols_kernel(const float* __restrict__ src, int lds, const int* __restrict__ cols, int ncols,
+                                   float* __restrict__ dst, int ldd, int rows) {
+    const int64_t n = (int64_t)rows * ncols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / ncols; const int c = (int)(i - r * ncols);
+        dst[r * ldd + c] = src[r * lds + cols[c]];
+    }
+}
+
+__global__ void make_seg_kernel(const int64_t* __restrict__ batch, int n, int ng, int reps, int* __restrict__ seg) {
+    const int64_t total = (int64_t)n * reps;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int r = (int)(i / n); const int v = (int)(i - (int64_t)r * n);
+        seg[i] = r * ng + (int)batch[v];
+    }
+}
+
+static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
+    int64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace morig
+
+using namespace morig;
+
+extern "C" int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes,
+                               int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
+                               int32_t* cursor, int32_t* status, void* stream) {
+    if (!edge_index || !rowptr || !src_sorted || !dst_sorted || !cursor || !status) return MORIG_E_INVALID;
+    if (n_edges < 0 || n_nodes <= 0) return MORIG_E_INVALID;
+    if (n_edges + (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;   // int32 edge ids
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nb = cdiv(n_nodes, SCAN_B);
+    int* bsum = dst_sorted;                       // scratch until the fill pass (capacity >= n_nodes >= nb)
+    ProfScope ps(K_CSR, s, 0.0, 16.0 * n_edges * 2 + 8.0 * n_edges + 12.0 * n_nodes);
+    MORIG_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)(n_nodes + 1) * sizeof(int), s));
+    MORIG_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), s));
+    if (n_edges > 0) {
+        hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, edge_index, n_edges, n_nodes, cursor, status);
+        MORIG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, bsum);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nb, rowptr + n_nodes);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, bsum, rowptr, cursor);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(grid_for(n_edges + n_nodes)), dim3(256), 0, s, edge_index, n_edges, n_nodes,
+                       cursor, src_sorted, dst_sorted);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream) {
+    if (!src || !dst || rows < 0 || cols < 0 || lds < cols || ldd < cols) return MORIG_E_INVALID;
+    if (rows == 0 || cols == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_COPY, s, 0.0, 8.0 * rows * cols);
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_gather_cols(const float* src, int32_t lds, const int32_t* cols, int32_t n_cols,
+                                 float* dst, int32_t ldd, int32_t rows, void* stream) {
+    if (!src || !dst || !cols || rows < 0 || n_cols <= 0 || ldd < n_cols) return MORIG_E_INVALID;
+    if (rows == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_COPY, s, 0.0, 8.0 * rows * n_cols);
+    hipLaunchKernelGGL(gather_cols_kernel, dim3(grid_for((int64_t)rows * n_cols)), dim3(256), 0, s, src, lds, cols, n_cols, dst, ldd, rows);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_make_seg(const int64_t* batch, int32_t n_nodes, int32_t n_graphs, int32_t replicas,
+                              int32_t* seg_out, void* stream) {
+    if (!batch || !seg_out || n_nodes <= 0 || n_graphs <= 0 || replicas <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_MISC, s, 0.0, 12.0 * n_nodes * replicas);
+    hipLaunchKernelGGL(make_seg_kernel, dim3(grid_for((int64_t)n_nodes * replicas)), dim3(256), 0, s, batch, n_nodes, n_graphs, replicas, seg_out);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}

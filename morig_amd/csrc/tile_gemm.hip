@@ -1,0 +1,395 @@
+// The one MFMA tile engine behind both hot operators of the MoRig forward path:
+//
+//   morig_gemm      dense vertex layer   Y = s*act(X W^T + b + rowbias[seg]) + t   [+ per-mesh column max]
+//   morig_edgeconv  fused EdgeConv       out[i] = max_{j->i} s2*relu(W2 (s1*relu(A_i + B_j) + t1) + b2) + t2
+//
+// Both are a [rows x K] x [K x N] contraction on v_mfma_f32_32x32x2_f32 (exact fp32, k-ordered fma
+// chain) with a 128-row workgroup tile; they differ only in how the A operand tile is PRODUCED
+// (dense rows vs gather-add-ReLU-affine of two per-vertex rows named by the CSR) and how the
+// accumulator tile is CONSUMED (store vs segmented max over rows).
+//
+// Layout facts used below (cdna_hip_programming.md section 3, MI355X_MICROARCH.md LDS table):
+//   * 32x32x2 f32 MFMA: A operand lane l -> A[i = l&31][k = l>>5]; B operand lane l -> B[k = l>>5][j = l&31];
+//     D register r of lane l -> D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+//   * K order inside a group of 8 is permuted so that ONE ds_read_b128 feeds 4 consecutive MFMAs:
+//     MFMA m of group q multiplies k = 8q+m (lanes 0-31) and k = 8q+4+m (lanes 32-63). Both operands
+//     use the same permutation, so the sum is the same set of products.
+//   * LDS rows are padded to KC+4 floats: for ds_read_b128 the 16-lane service groups then touch
+//     16 distinct 16-byte slots (36*r mod 64 and 20*r mod 64 are 4*(odd*r mod 16)) -> conflict-free.
+#include "common.h"
+
+namespace morig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { LOAD_DENSE = 0, LOAD_EDGE = 1 };
+enum { MODE_STORE = 0, MODE_POOL = 1, MODE_EDGEMAX = 2 };
+
+struct TileParams {
+    int M, N, K;                 // rows (edge: capacity), logical out width, contraction length
+    const float* W; int ldw;
+    const float* bias; const float* scale; const float* shift; int relu;
+    // dense loader
+    const float* X; int ldx;
+    // edge loader
+    const float* A; int lda; const float* B; int ldb;
+    const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
+    const float* s1; const float* t1;
+    // epilogue
+    const float* rowbias; int ld_rowbias; const int* seg;
+    float* Y; int ldy;           // store target / edge-max target / pool target
+    int tiles_n;
+};
+
+template <int BN, int KC, int LOAD, int MODE>
+__global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const TileParams p) {
+    constexpr int BM = 128;
+    constexpr int WN = (BN >= 128) ? 2 : 1;
+    constexpr int WM = 4 / WN;
+    constexpr int MT = BM / WM / 32;
+    constexpr int NT = BN / WN / 32;
+    constexpr int LDK = KC + 4;
+    constexpr int TPR = KC / 4;                 // loader threads per tile row
+    constexpr int RPP = 256 / TPR;              // tile rows per loader pass
+    constexpr int PA = BM / RPP;
+    constexpr int PB = (BN + RPP - 1) / RPP;
+    constexpr int ZC = BN < 64 ? BN : 64;       // epilogue column block
+    constexpr int ZLD = ZC + 1;
+    constexpr int NCB = BN / ZC;
+    constexpr int SM_MAIN = (BM + BN) * LDK;
+    constexpr int SM_Z = (MODE == MODE_STORE) ? 0 : BM * ZLD;
+    constexpr int SM = SM_MAIN > SM_Z ? SM_MAIN : SM_Z;
+    static_assert(BN % 32 == 0 && KC % 8 == 0, "tile shape");
+
+    __shared__ __attribute__((aligned(16))) float smem[SM + BM];
+    float* sA = smem;
+    float* sB = smem + BM * LDK;
+    int* sseg = reinterpret_cast<int*>(smem + SM);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn, rep;
+    if (LOAD == LOAD_DENSE) { tn = lin % p.tiles_n; tm = lin / p.tiles_n; rep = 0; }
+    else { rep = lin / p.tiles_per_rep; tm = lin - rep * p.tiles_per_rep; tn = 0; }
+    const int row0 = tm * BM;
+
+    int Etot = 0;
+    if (LOAD == LOAD_EDGE) {
+        Etot = p.rowptr[p.n_nodes];
+        if (row0 >= Etot) return;               // block-uniform
+    }
+
+    // ---- loader set-up -------------------------------------------------------------------
+    const int lrow = tid / TPR, lkq = tid % TPR;
+    const float* pa[PA];
+    const float* pb[PA];                        // edge only
+    bool va[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int r = lrow + i * RPP;
+        const int row = row0 + r;
+        if (LOAD == LOAD_DENSE) {
+            va[i] = row < p.M;
+            pa[i] = p.X + (size_t)(va[i] ? row : 0) * p.ldx + 4 * lkq;
+            pb[i] = nullptr;
+            if (MODE != MODE_STORE || p.seg != nullptr) {
+                if (lkq == 0) sseg[r] = (va[i] && p.seg) ? p.seg[row] : -1;
+            }
+        } else {
+            va[i] = row < Etot;
+            const int d = va[i] ? p.dstS[row] : -1;
+            const int s = va[i] ? p.srcS[row] : 0;
+            const size_t base = (size_t)rep * p.rep_in;
+            pa[i] = p.A + (base + (va[i] ? d : 0)) * p.lda + 4 * lkq;
+            pb[i] = p.B + (base + s) * p.ldb + 4 * lkq;
+            if (lkq == 0) sseg[r] = d;
+        }
+    }
+    const float* pw = p.W + (size_t)(tn * BN + lrow) * p.ldw + 4 * lkq;
+
+    f32x4 ra[PA], rb[PA], rw[PB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[i] = z; rb[i] = z;
+            const int k = k0 + 4 * lkq;
+            if (va[i] && k < p.K) {
+                ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
+                if (LOAD == LOAD_EDGE) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + k0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            if (BN % RPP == 0 || lrow + i * RPP < BN)
+                rw[i] = *reinterpret_cast<const f32x4*>(pw + (size_t)i * RPP * p.ldw + k0);
+        }
+    };
+    auto stage = [&](int k0) {
+        const int k = k0 + 4 * lkq;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            f32x4 v = ra[i];
+            if (LOAD == LOAD_EDGE) {
+                f32x4 s1 = {1.f, 1.f, 1.f, 1.f}, t1 = {0.f, 0.f, 0.f, 0.f};
+                if (k < p.K) {
+                    s1 = *reinterpret_cast<const f32x4*>(p.s1 + k);
+                    t1 = *reinterpret_cast<const f32x4*>(p.t1 + k);
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float h = v[c] + rb[i][c];
+                    h = h > 0.f ? h : 0.f;
+                    v[c] = va[i] ? (h * s1[c] + t1[c]) : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[c] = (k + c < p.K) ? v[c] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(&sA[(lrow + i * RPP) * LDK + 4 * lkq]) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            if (BN % RPP == 0 || lrow + i * RPP < BN)
+                *reinterpret_cast<f32x4*>(&sB[(lrow + i * RPP) * LDK + 4 * lkq]) = rw[i];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // ---- main loop: register prefetch of chunk c+1 under the MFMAs of chunk c ---------------
+    const int nchunk = (p.K + KC - 1) / KC;
+    fetch(0);
+    for (int c = 0; c < nchunk; ++c) {
+        __syncthreads();                        // previous chunk's fragment reads are done
+        stage(c * KC);
+        __syncthreads();
+        if (c + 1 < nchunk) fetch((c + 1) * KC);
+        const float* a0 = sA + (wm * MT * 32 + l31) * LDK + 4 * hi;
+        const float* b0 = sB + (wn * NT * 32 + l31) * LDK + 4 * hi;
+#pragma unroll
+        for (int kk = 0; kk < KC / 8; ++kk) {
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const f32x4*>(a0 + mt * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bf[nt] = *reinterpret_cast<const f32x4*>(b0 + nt * 32 * LDK + kk * 8);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][j], bf[nt][j], acc[mt][nt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------
+    const int colw0 = tn * BN + wn * NT * 32;   // first global column of this wave
+    if (MODE == MODE_STORE) {
+        __syncthreads();                        // sseg visible (written before the loop; harmless otherwise)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = colw0 + nt * 32 + l31;
+            if (col >= p.N) continue;
+            const float b = p.bias ? p.bias[col] : 0.f;
+            const float sc = p.scale ? p.scale[col] : 1.f;
+            const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int row = row0 + rl;
+                    if (row < p.M) {
+                        float v = acc[mt][nt][r] + b;
+                        if (p.rowbias) v += p.rowbias[(size_t)sseg[rl] * p.ld_rowbias + col];
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                        p.Y[(size_t)row * p.ldy + col] = v * sc + sh;
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // segmented max over tile rows, one column block of ZC columns at a time, staged through LDS
+    float* Z = smem;
+    bool first_cont = false, last_cont = false;
+    if (MODE == MODE_EDGEMAX) {
+        // sseg was written before the main loop; every thread passed >= 1 barrier since
+        const int d0 = sseg[0];
+        first_cont = p.rowptr[d0] < row0;
+        if (row0 + BM < Etot) last_cont = p.rowptr[sseg[BM - 1] + 1] > row0 + BM;
+    }
+    constexpr int G = 256 / ZC;                 // row groups in the reduce phase
+    constexpr int RG = BM / G;
+    const int zc = tid % ZC, zg = tid / ZC;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        __syncthreads();                        // main-loop reads / previous block's reduce done
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int colw = wn * NT * 32 + nt * 32;            // tile-local first column of this fragment
+            if (colw >= cb * ZC && colw < (cb + 1) * ZC) {
+                const int col = tn * BN + colw + l31;
+                const float b = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+                const float sc = (p.scale && col < p.N) ? p.scale[col] : 1.f;
+                const float sh = (p.shift && col < p.N) ? p.shift[col] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int rl = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        float v = acc[mt][nt][r] + b;
+                        if (p.relu) v = v > 0.f ? v : 0.f;
+                        Z[rl * ZLD + (colw - cb * ZC) + l31] = v * sc + sh;
+                    }
+            }
+        }
+        __syncthreads();
+        const int col = tn * BN + cb * ZC + zc;
+        if (col < p.N) {
+            const int r0 = zg * RG;
+            if (MODE == MODE_POOL) {
+                // every output is shared with other tiles -> all atomic; groups reduce their own rows
+                int r = r0;
+                while (r < r0 + RG) {
+                    const int s = sseg[r];
+                    if (s < 0) break;
+                    float m = Z[r * ZLD + zc];
+                    ++r;
+                    while (r < r0 + RG && sseg[r] == s) { m = fmaxf(m, Z[r * ZLD + zc]); ++r; }
+                    atomic_max_f32(p.Y + (size_t)s * p.ldy + col, m);
+                }
+            } else {
+                // a thread owns the segments that START in its row group and follows them to their end
+                int r = r0;
+                if (zg > 0) { const int sp = sseg[r0 - 1]; while (r < r0 + RG && sseg[r] == sp) ++r; }
+                while (r < r0 + RG) {
+                    const int s = sseg[r];
+                    if (s < 0) break;
+                    const int rs = r;
+                    float m = Z[r * ZLD + zc];
+                    ++r;
+                    while (r < BM && sseg[r] == s) { m = fmaxf(m, Z[r * ZLD + zc]); ++r; }
+                    float* o = p.Y + ((size_t)rep * p.rep_out + s) * p.ldy + col;
+                    const bool partial = (rs == 0 && first_cont) || (r == BM && last_cont);
+                    if (partial) atomic_max_f32(o, m); else *o = m;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BN, int KC, int LOAD, int MODE>
+static int launch_tile(const TileParams& p, int nblocks, hipStream_t s) {
+    hipLaunchKernelGGL((tile_kernel<BN, KC, LOAD, MODE>), dim3(nblocks), dim3(256), 0, s, p);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace morig
+
+using namespace morig;
+
+extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
+    if (!a || !a->X || !a->W) return MORIG_E_INVALID;
+    if (a->M < 0 || a->N <= 0 || a->K <= 0) return MORIG_E_INVALID;
+    if (a->M == 0) return MORIG_OK;
+    if ((a->ldx & 3) || (a->ldw & 3) || !aligned16(a->X) || !aligned16(a->W)) return MORIG_E_INVALID;
+    if (a->ldx < ((a->K + 3) & ~3) || a->ldw < ((a->K + 31) & ~31)) return MORIG_E_INVALID;
+    const bool pool = a->pool != nullptr;
+    if (!pool && !a->Y) return MORIG_E_INVALID;
+    if (pool && a->Y) return MORIG_E_UNSUPPORTED;           // one consumer per launch
+    if ((pool || a->rowbias) && !a->seg) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+    TileParams p = {};
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.W = a->W; p.ldw = a->ldw;
+    p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.relu = a->relu;
+    p.X = a->X; p.ldx = a->ldx;
+    p.rowbias = a->rowbias; p.ld_rowbias = a->ld_rowbias; p.seg = a->seg;
+    const int tiles_m = cdiv(a->M, 128);
+    const double flops = 2.0 * a->M * (double)a->N * a->K;
+    const double bytes = 4.0 * ((double)a->M * a->K + (double)a->N * a->K + (pool ? 0.0 : (double)a->M * a->N));
+
+    if (pool) {
+        if (a->n_seg <= 0 || a->ld_pool < a->N) return MORIG_E_INVALID;
+        // identity of the integer-atomic float max
+        MORIG_HIP_TRY(hipMemsetAsync(a->pool, 0xFF, (size_t)a->n_seg * a->ld_pool * sizeof(float), s));
+        p.Y = a->pool; p.ldy = a->ld_pool;
+        p.tiles_n = cdiv(a->N, 128);
+        ProfScope ps(K_GEMM_POOL, s, flops, bytes);
+        return launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
+    }
+    p.Y = a->Y; p.ldy = a->ldy;
+    if (a->N > 64) {
+        p.tiles_n = cdiv(a->N, 128);
+        ProfScope ps(K_GEMM_BN128, s, flops, bytes);
+        return launch_tile<128, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m * p.tiles_n, s);
+    } else if (a->N > 32) {
+        p.tiles_n = 1;
+        ProfScope ps(K_GEMM_BN64, s, flops, bytes);
+        return launch_tile<64, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m, s);
+    } else {
+        p.tiles_n = 1;
+        ProfScope ps(K_GEMM_BN32, s, flops, bytes);
+        return launch_tile<32, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m, s);
+    }
+}
+
+extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
+    if (!a->s1 || !a->t1 || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
+    if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
+    if (a->in_rep_stride < 0 || (a->replicas > 1 && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
+    if ((a->lda & 3) || (a->ldb & 3) || (a->ldw & 3) || !aligned16(a->A) || !aligned16(a->B) || !aligned16(a->W2) ||
+        !aligned16(a->s1) || !aligned16(a->t1)) return MORIG_E_INVALID;
+    if (a->ldo < a->H || a->lda < a->H || a->ldb < a->H || a->ldw < a->H) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+
+    TileParams p = {};
+    p.M = a->edge_capacity; p.N = a->H; p.K = a->H;
+    p.W = a->W2; p.ldw = a->ldw;
+    p.bias = a->b2; p.scale = a->s2; p.shift = a->t2; p.relu = 1;
+    p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb;
+    p.rowptr = a->rowptr; p.srcS = a->src_sorted; p.dstS = a->dst_sorted;
+    p.n_nodes = a->n_nodes; p.rep_in = a->in_rep_stride; p.rep_out = a->out_rep_stride;
+    p.s1 = a->s1; p.t1 = a->t1;
+    p.Y = a->out; p.ldy = a->ldo;
+    p.tiles_per_rep = cdiv(a->edge_capacity, 128);
+    p.tiles_n = 1;
+    const int nblocks = p.tiles_per_rep * a->replicas;
+
+    // tile-straddling target segments combine through integer-atomic float max: pre-fill identity
+    const size_t rows = (size_t)(a->replicas - 1) * a->out_rep_stride + a->n_nodes;
+    MORIG_HIP_TRY(hipMemset2DAsync(a->out, (size_t)a->ldo * sizeof(float), 0xFF, (size_t)a->H * sizeof(float), rows, s));
+
+    const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
+    const double flops = 2.0 * E * a->H * (double)a->H;
+    const double bytes = 4.0 * (2.0 * E * a->H) ;    // gathered operand rows (mostly L2 hits)
+    switch (a->H) {
+        case 16:  { ProfScope ps(K_EDGE_H16, s, flops, bytes);  return launch_tile<32, 16, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }
+        case 32:  { ProfScope ps(K_EDGE_H32, s, flops, bytes);  return launch_tile<32, 32, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }
+        case 64:  { ProfScope ps(K_EDGE_H64, s, flops, bytes);  return launch_tile<64, 32, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }
+        case 128: { ProfScope ps(K_EDGE_H128, s, flops, bytes); return launch_tile<128, 32, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }
+        case 256: { ProfScope ps(K_EDGE_H256, s, flops, bytes); return launch_tile<256, 16, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }
+        default: return MORIG_E_UNSUPPORTED;
+    }
+}

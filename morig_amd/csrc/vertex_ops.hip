@@ -1,0 +1,122 @@
+// Small vertex-parallel operators of the forward path: HBM-bound, one pass each.
+#include "common.h"
+
+namespace morig {
+
+// one wave per row; y = x / max(||x||, 1e-12)  (torch.nn.functional.normalize, p=2, eps=1e-12)
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, int ldx, int rows_per_rep, int reps, int cols,
+                                                      float* __restrict__ y, int ld_row, int ld_rep) {
+    const int lane = threadIdx.x & 63;
+    const int64_t total = (int64_t)rows_per_rep * reps;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); m < total; m += wstride) {
+        const float* xr = x + m * ldx;
+        float ss = 0.f;
+        for (int c = lane; c < cols; c += 64) { const float v = xr[c]; ss += v * v; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+        const int r = (int)(m / rows_per_rep);
+        const int64_t v = m - (int64_t)r * rows_per_rep;
+        float* yr = y + v * ld_row + (int64_t)r * ld_rep;
+        for (int c = lane; c < cols; c += 64) yr[c] = xr[c] * inv;
+    }
+}
+
+// CLS-only temporal attention (see include/morig_hip.h). One thread per vertex; g and cls in LDS.
+constexpr int ATT_TMAX = 8;
+__global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restrict__ x, int n, int T, int C, int heads,
+                                                            const float* __restrict__ g, const float* __restrict__ cls,
+                                                            float* __restrict__ y, int ldy) {
+    extern __shared__ float sh[];               // g [heads*C] then cls [C]
+    float* sg = sh;
+    float* sc = sh + heads * C;
+    for (int i = threadIdx.x; i < heads * C; i += blockDim.x) sg[i] = g[i];
+    for (int i = threadIdx.x; i < C; i += blockDim.x) sc[i] = cls[i];
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const float* xv = x + (size_t)v * T * C;
+    for (int h = 0; h < heads; ++h) {
+        const float* gh = sg + h * C;
+        float s[ATT_TMAX + 1];
+        float s0 = 0.f;
+        for (int c = 0; c < C; ++c) s0 += sc[c] * gh[c];
+        s[0] = s0;
+        float mx = s0;
+#pragma unroll
+        for (int t = 0; t < ATT_TMAX; ++t) {
+            float d = -INFINITY;
+            if (t < T) {
+                d = 0.f;
+                const float* xt = xv + t * C;
+                for (int c = 0; c < C; ++c) d += xt[c] * gh[c];
+            }
+            s[t + 1] = d;
+            mx = fmaxf(mx, d);
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int t = 0; t <= ATT_TMAX; ++t) { s[t] = (t <= T) ? __expf(s[t] - mx) : 0.f; den += s[t]; }
+        const float inv = 1.0f / den;
+        float* yo = y + (size_t)v * ldy + h * C;
+        for (int c = 0; c < C; ++c) {
+            float a = s[0] * sc[c];
+#pragma unroll
+            for (int t = 0; t < ATT_TMAX; ++t) if (t < T) a += s[t + 1] * xv[t * C + c];
+            yo[c] = a * inv;
+        }
+    }
+}
+
+__global__ void frame_reduce_kernel(const float* __restrict__ x, int n, int T, int C, int mode, float* __restrict__ y, int ldy) {
+    const int64_t total = (int64_t)n * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t v = i / C; const int c = (int)(i - v * C);
+        const float* xv = x + v * T * C + c;
+        float a = xv[0];
+        for (int t = 1; t < T; ++t) { const float b = xv[t * C]; a = mode ? fmaxf(a, b) : a + b; }
+        y[v * ldy + c] = mode ? a : a / (float)T;
+    }
+}
+
+}  // namespace morig
+
+using namespace morig;
+
+extern "C" int morig_rownorm(const float* x, int32_t ldx, int32_t rows_per_rep, int32_t replicas, int32_t cols,
+                             float* y, int32_t ld_row, int32_t ld_rep, void* stream) {
+    if (!x || !y || rows_per_rep <= 0 || replicas <= 0 || cols <= 0 || ldx < cols) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t rows = (int64_t)rows_per_rep * replicas;
+    int64_t blocks = (rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    ProfScope ps(K_ROWNORM, s, 3.0 * rows * cols, 8.0 * rows * cols);
+    hipLaunchKernelGGL(rownorm_kernel, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows_per_rep, replicas, cols, y, ld_row, ld_rep);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_cls_attention(const float* x, int32_t n, int32_t T, int32_t C, int32_t heads,
+                                   const float* g, const float* cls, float* y, int32_t ldy, void* stream) {
+    if (!x || !g || !cls || !y || n <= 0 || C <= 0 || heads <= 0 || ldy < heads * C) return MORIG_E_INVALID;
+    if (T < 1 || T > ATT_TMAX) return MORIG_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_ATTN, s, 4.0 * n * heads * (T + 1) * C, 4.0 * n * (T * C + heads * C));
+    hipLaunchKernelGGL(cls_attention_kernel, dim3(cdiv(n, 256)), dim3(256), (size_t)(heads + 1) * C * sizeof(float), s,
+                       x, n, T, C, heads, g, cls, y, ldy);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_frame_reduce(const float* x, int32_t n, int32_t T, int32_t C, int32_t mode, float* y, int32_t ldy, void* stream) {
+    if (!x || !y || n <= 0 || T <= 0 || C <= 0 || ldy < C || (mode != 0 && mode != 1)) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int64_t blocks = ((int64_t)n * C + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ProfScope ps(K_MISC, s, (double)n * T * C, 4.0 * n * C * (T + 1));
+    hipLaunchKernelGGL(frame_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, x, n, T, C, mode, y, ldy);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}

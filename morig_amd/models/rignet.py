@@ -1,0 +1,356 @@
+"""Drop-in mirror of the reference's ``models/rignet.py`` (same names, signatures, state_dict keys;
+/root/reference/models/rignet.py:10-220) running eval-mode forwards on the MI355X-native op layer.
+
+Data-flow restructurings (all exact up to fp32 rounding):
+  * the ``num_keyframes`` loop over ``motionNet`` (:85-88) is ONE pass over R = num_keyframes
+    replicas of the vertex set (rows r*V + v); the position branch of every EdgeConvMotion is
+    computed once and shared by the replicas;
+  * ``torch.cat([...])`` inputs (:62, :65) are column windows of one wide activation buffer
+    ``[x_1 | x_2 | x_3 | pos,0 | feature]``; the consuming Linear's weight columns are permuted once;
+  * ``scatter_max`` + ``repeat_interleave`` (:63-64) = pooled epilogue of the mlp_glb GEMM + a
+    per-mesh row bias (x_global @ W_g^T) in the first mlp_transform layer;
+  * TemporalAttn (:36-46) keeps only token 0, so only the CLS query is evaluated.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+from torch.nn import Linear, Sequential
+
+from .. import packing
+from ..native import Mat
+from ..runtime import get_ops
+from .basic_modules import MLP, GCUMotion, NativeModule, _padded_copy
+
+__all__ = ["jointnet_motion", "masknet_motion", "skinnet_motion"]
+
+
+def _num_graphs(data, batch: torch.Tensor) -> int:
+    ng = getattr(data, "num_graphs", None)
+    if ng is None:
+        ng = int(batch.max().item()) + 1          # one host sync, as torch_scatter's dim_size inference does
+    return int(ng)
+
+
+class TemporalAttn(NativeModule):
+    """models/rignet.py:10-46."""
+
+    def __init__(self, input_size, num_heads, hidden_size, dim_feedforward, output_size):
+        super().__init__()
+        self.num_heads = num_heads
+        self.w_qs = Linear(input_size, hidden_size * num_heads, bias=False)
+        self.w_ks = Linear(input_size, hidden_size * num_heads, bias=False)
+        self.w_vs = Linear(input_size, hidden_size * num_heads, bias=False)
+        self.w_o = Linear(hidden_size * num_heads, hidden_size, bias=False)
+        self.feedforward = MLP([hidden_size, dim_feedforward, output_size])
+        self.cls_token = torch.nn.Parameter(torch.randn(1, 1, input_size))
+
+    def _pack(self):
+        nh = self.num_heads
+        Wq, Wk, Wv, Wo = (w.weight.detach().double() for w in (self.w_qs, self.w_ks, self.w_vs, self.w_o))
+        d = Wq.shape[0] // nh
+        cls = self.cls_token.detach().double().reshape(-1)
+        q = Wq @ cls                                          # CLS query, all heads
+        g, mix = [], []
+        for h in range(nh):
+            sl = slice(h * d, (h + 1) * d)
+            g.append(Wk[sl].t() @ q[sl] / math.sqrt(d))       # score_t = <tok_t, g_h>
+            mix.append(Wo[:, sl] @ Wv[sl])                    # w_o(head h of values) = (Wo_h Wv_h) y_h
+        return dict(g=torch.stack(g).float().contiguous(), cls=cls.float().contiguous(),
+                    mix=packing.pack_linear(torch.cat(mix, dim=1).float()),
+                    ff1=packing.pack_mlp_layer(self.feedforward[0]),
+                    ff2=packing.pack_mlp_layer(self.feedforward[1]))
+
+    def run(self, ops, x: torch.Tensor, out: Mat):
+        """x: [n, T, C] contiguous -> out [n, output_size] window."""
+        dev = x.device
+        pk = self.packed(dev)
+        n = x.shape[0]
+        y = ops.empty(n, pk["g"].shape[0] * x.shape[2], dev)
+        ops.cls_attention(x, pk["g"], pk["cls"], Mat.of(y))
+        res = ops.empty(n, pk["mix"].N, dev)
+        ops.gemm(Mat.of(y), pk["mix"], relu=False, Y=Mat.of(res))
+        h = ops.empty(n, pk["ff1"].N, dev)
+        ops.gemm(Mat.of(res), pk["ff1"], relu=True, Y=Mat.of(h))
+        ops.gemm(Mat.of(h), pk["ff2"], relu=True, Y=out)
+
+    def forward(self, x):
+        self._require_eval()
+        ops = get_ops()
+        x = x.float().contiguous()
+        out = ops.empty(x.shape[0], self.feedforward[1][0].out_features, x.device)
+        self.run(ops, x, Mat.of(out))
+        return out
+
+
+class GCNRig(NativeModule):
+    """models/rignet.py:49-67."""
+
+    X1, X2, X3, POS = 0, 64, 320, 832          # column offsets in the wide activation buffer
+    FEAT = 836                                  # pos occupies 832..834, 835 is a zero pad
+
+    def __init__(self, chn_feature, chn_output, aggr="max"):
+        super().__init__()
+        self.chn_feature, self.chn_output = chn_feature, chn_output
+        self.gcu_1 = GCUMotion(in_channels=chn_feature, out_channels=64, dim_pos_feat=16, aggr=aggr)
+        self.gcu_2 = GCUMotion(in_channels=64, out_channels=256, dim_pos_feat=16, aggr=aggr)
+        self.gcu_3 = GCUMotion(in_channels=256, out_channels=512, dim_pos_feat=16, aggr=aggr)
+        self.mlp_glb = MLP([(64 + 256 + 512), 1024])
+        self.mlp_transform = Sequential(MLP([1024 + 3 + chn_feature + 64 + 256 + 512, 1024, 256]), Linear(256, chn_output))
+
+    @property
+    def wide_ld(self):
+        return (self.FEAT + self.chn_feature + 3) // 4 * 4
+
+    def _pack(self):
+        F = self.chn_feature
+        l1 = self.mlp_transform[0][0]
+        W = l1[0].weight.detach()
+        # reference column order of mlp_transform's input (:65): [x_global(1024) | pos(3) | feature(F) | x_1 x_2 x_3(832)]
+        Wg, Wrest = W[:, :1024], W[:, 1024:]
+        in_cols = ([self.POS + i for i in range(3)] + [self.FEAT + i for i in range(F)] + list(range(832)))
+        return dict(
+            glb=packing.pack_mlp_layer(self.mlp_glb[0]),
+            g=packing.pack_linear(Wg),                                   # x_global @ Wg^T  -> per-mesh row bias
+            t1=packing.pack_linear(Wrest, l1[0].bias, l1[2], in_cols=in_cols, k_total=self.FEAT + F),
+            t2=packing.pack_mlp_layer(self.mlp_transform[0][1]),
+            t3=packing.pack_linear(self.mlp_transform[1].weight, self.mlp_transform[1].bias),
+        )
+
+    def run(self, ops, pos4: torch.Tensor, write_feature, csr_tpl, csr_geo, seg: torch.Tensor, n_graphs: int,
+            replicas: int, out: Mat):
+        """pos4: [n, 4] (pos, 0); write_feature(Mat window [R*n, F]) fills the feature columns;
+        seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window."""
+        dev = pos4.device
+        pk = self.packed(dev)
+        n, R, F = pos4.shape[0], replicas, self.chn_feature
+        M = n * R
+        wide = ops.empty(M, self.wide_ld, dev)
+        for r in range(R):
+            ops.copy2d(Mat.of(pos4), Mat.of(wide, self.POS, 4, r * n, n))
+        write_feature(Mat.of(wide, self.FEAT, F))
+        posm = Mat.of(pos4, 0, 3)
+        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, 64), R)
+        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, 64), csr_tpl, csr_geo, Mat.of(wide, self.X2, 256), R)
+        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, 256), csr_tpl, csr_geo, Mat.of(wide, self.X3, 512), R)
+        pooled = ops.empty(R * n_graphs, 1024, dev)
+        ops.gemm(Mat.of(wide, 0, 832), pk["glb"], relu=True, seg=seg, pool=pooled)
+        gb = ops.empty(R * n_graphs, 1024, dev)
+        ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
+        h1 = ops.empty(M, 1024, dev)
+        ops.gemm(Mat.of(wide, 0, self.FEAT + F), pk["t1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg)
+        h2 = ops.empty(M, 256, dev)
+        ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2))
+        ops.gemm(Mat.of(h2), pk["t3"], relu=False, Y=out)
+
+    def forward(self, pos, feature, tpl_edge_index, geo_edge_index, batch):
+        self._require_eval()
+        ops = get_ops()
+        dev = pos.device
+        n = pos.shape[0]
+        ng = int(batch.max().item()) + 1
+        pos4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        ops.copy2d(Mat.of(pos.float().contiguous()), Mat.of(pos4, 0, 3))
+        feature = feature.unsqueeze(-1) if feature.dim() == 1 else feature
+        feat = feature.float().contiguous()
+        out = ops.empty(n, self.chn_output, dev)
+        self.run(ops, pos4, lambda w: ops.copy2d(Mat.of(feat), w), ops.csr_build(tpl_edge_index, n),
+                 ops.csr_build(geo_edge_index, n), ops.make_seg(batch, ng, 1), ng, 1, Mat.of(out))
+        return out
+
+
+class _MotionBackbone(NativeModule):
+    """Shared front half of JointNetMotion / MaskNetMotion / SkinMotion: motionNet over the keyframes,
+    row normalisation, aggregation (models/rignet.py:82-98, 115-131, 194-203)."""
+
+    def _motion(self, ops, data, input_flow, aggr_method, aggr_out_dim):
+        dev = data.pos.device
+        n = data.pos.shape[0]
+        T = self.num_keyframes
+        ng = _num_graphs(data, data.batch)
+        flow = input_flow.float().contiguous()
+        assert flow.shape[1] >= 3 * T
+        pos4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        ops.copy2d(Mat.of(data.pos.float().contiguous()), Mat.of(pos4, 0, 3))
+        csr_tpl = ops.csr_build(data.tpl_edge_index, n)
+        csr_geo = ops.csr_build(data.geo_edge_index, n)
+        seg_T = ops.make_seg(data.batch, ng, T)
+
+        def write_flow(w: Mat):                       # feature of replica t = input_flow[:, 3t:3t+3]  (:86)
+            for t in range(T):
+                ops.copy2d(Mat.of(flow, 3 * t, 3), Mat.of(w.base, w.col0, 3, t * n, n))
+
+        C = self.motionNet.chn_output
+        raw = ops.empty(T * n, C, dev)
+        self.motionNet.run(ops, pos4, write_flow, csr_tpl, csr_geo, seg_T, ng, T, Mat.of(raw))
+        motion_all = torch.empty((n, T, C), dtype=torch.float32, device=dev)
+        ops.rownorm(Mat.of(raw), n, T, motion_all, T * C, C)          # F.normalize + torch.stack(dim=1)
+
+        pre = ops.empty(n, aggr_out_dim, dev)
+        if aggr_method == "attn":
+            self.aggragator.run(ops, motion_all, Mat.of(pre))
+        elif aggr_method in ("mean", "max"):
+            ops.frame_reduce(motion_all, aggr_method, Mat.of(pre))
+        else:
+            raise NotImplementedError
+        motion_aggr = torch.empty((n, aggr_out_dim), dtype=torch.float32, device=dev)
+        ops.rownorm(Mat.of(pre), n, 1, motion_aggr, aggr_out_dim, 0)
+        seg_1 = seg_T[:n]
+        return dict(pos4=pos4, csr_tpl=csr_tpl, csr_geo=csr_geo, seg=seg_1, ng=ng, motion_all=motion_all,
+                    motion_aggr=motion_aggr)
+
+
+class _MotionHead(_MotionBackbone):
+    _head = None
+
+    def __init__(self, num_keyframes, chn_output, aggr_method, aggr="max"):
+        super().__init__()
+        self.num_keyframes = num_keyframes
+        self.aggr_method = aggr_method
+        self.motionNet = GCNRig(chn_feature=3, chn_output=32, aggr=aggr)
+        if self.aggr_method == "attn":
+            self.aggragator = TemporalAttn(input_size=32, num_heads=2, hidden_size=64, dim_feedforward=512, output_size=64)
+            setattr(self, self._head, GCNRig(chn_feature=64, chn_output=chn_output, aggr=aggr))
+        else:
+            setattr(self, self._head, GCNRig(chn_feature=32, chn_output=chn_output, aggr=aggr))
+
+    def forward(self, data, input_flow):
+        self._require_eval()
+        ops = get_ops()
+        head = getattr(self, self._head)
+        st = self._motion(ops, data, input_flow, self.aggr_method, head.chn_feature)
+        n = data.pos.shape[0]
+        aggr = st["motion_aggr"]
+        out = torch.empty((n, head.chn_output), dtype=torch.float32, device=aggr.device)
+        head.run(ops, st["pos4"], lambda w: ops.copy2d(Mat.of(aggr), w), st["csr_tpl"], st["csr_geo"], st["seg"],
+                 st["ng"], 1, Mat.of(out))
+        return st["motion_all"], aggr, out
+
+
+class JointNetMotion(_MotionHead):
+    """models/rignet.py:70-100 -> (motion_all, motion_aggr, pred_shift)."""
+    _head = "jointnet"
+
+
+class MaskNetMotion(_MotionHead):
+    """models/rignet.py:103-133 -> (motion_all, motion_aggr, pred_mask logits)."""
+    _head = "masknet"
+
+
+class SkinNet_inner(NativeModule):
+    """models/rignet.py:136-182."""
+
+    def __init__(self, nearest_bone, use_Dg, use_Lf, motion_dim, use_motion, aggr="max"):
+        super().__init__()
+        self.use_Dg = use_Dg
+        self.use_Lf = use_Lf
+        self.num_nearest_bone = nearest_bone
+        self.input_dim = 3 + nearest_bone * (6 + int(bool(use_Dg)) + int(bool(use_Lf)))
+        d = self.input_dim
+        self.gcu1 = GCUMotion(in_channels=motion_dim, out_channels=256, in_channel_pos=d, dim_pos_feat=64, aggr=aggr)
+        self.gcu2 = GCUMotion(in_channels=256, out_channels=256, in_channel_pos=d, dim_pos_feat=64, aggr=aggr)
+        self.gcu3 = GCUMotion(in_channels=256, out_channels=256, in_channel_pos=d, dim_pos_feat=64, aggr=aggr)
+        self.multi_layer_tranform2 = MLP([256, 512, 1024])
+        self.cls_branch = Sequential(MLP([1024 + 256, 1024, 512]), Linear(512, self.num_nearest_bone))
+
+    def sample_columns(self, total: int):
+        """index form of the boolean column selections of :158-171 (8 values per bone:
+        6 coords, 1/Dg, leaf flag; drop the switched-off ones, keep the first ``nearest_bone`` bones)."""
+        keep = [c for c in range(total) if not ((c % 8 == 6 and not self.use_Dg) or (c % 8 == 7 and not self.use_Lf))]
+        return keep[: self.input_dim - 3]
+
+    def _pack(self):
+        l1 = self.cls_branch[0][0]
+        W = l1[0].weight.detach()                     # input order (:180): [x_3(256) | x_global(1024)]
+        return dict(
+            m1=packing.pack_mlp_layer(self.multi_layer_tranform2[0]),
+            m2=packing.pack_mlp_layer(self.multi_layer_tranform2[1]),
+            g=packing.pack_linear(W[:, 256:]),
+            c1=packing.pack_linear(W[:, :256], l1[0].bias, l1[2]),
+            c2=packing.pack_mlp_layer(self.cls_branch[0][1]),
+            c3=packing.pack_linear(self.cls_branch[1].weight, self.cls_branch[1].bias),
+        )
+
+    def run(self, ops, data, motion: torch.Tensor, csr_tpl, csr_geo, seg, n_graphs: int, out: Mat):
+        dev = motion.device
+        pk = self.packed(dev)
+        n = motion.shape[0]
+        mdim = motion.shape[1]
+        motion = _padded_copy(ops, motion.float())
+        P = self.input_dim
+        ldp = (P + 3) // 4 * 4
+        raw = torch.zeros((n, ldp), dtype=torch.float32, device=dev)          # [pos | selected samples]  (:173)
+        ops.copy2d(Mat.of(data.pos.float().contiguous()), Mat.of(raw, 0, 3))
+        skin = data.skin_input.float().contiguous()
+        cols = torch.tensor(self.sample_columns(skin.shape[1]), dtype=torch.int32, device=dev)
+        ops.gather_cols(Mat.of(skin), cols, Mat.of(raw, 3, P - 3))
+        posm = Mat.of(raw, 0, P)
+        x1 = ops.empty(n, 256, dev)
+        self.gcu1.run(ops, posm, Mat.of(motion, 0, mdim), csr_tpl, csr_geo, Mat.of(x1))
+        g1 = ops.empty(n, 512, dev)
+        ops.gemm(Mat.of(x1), pk["m1"], relu=True, Y=Mat.of(g1))
+        pooled = ops.empty(n_graphs, 1024, dev)
+        ops.gemm(Mat.of(g1), pk["m2"], relu=True, seg=seg, pool=pooled)
+        x2 = ops.empty(n, 256, dev)
+        self.gcu2.run(ops, posm, Mat.of(x1), csr_tpl, csr_geo, Mat.of(x2))
+        x3 = ops.empty(n, 256, dev)
+        self.gcu3.run(ops, posm, Mat.of(x2), csr_tpl, csr_geo, Mat.of(x3))
+        gb = ops.empty(n_graphs, 1024, dev)
+        ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
+        h1 = ops.empty(n, 1024, dev)
+        ops.gemm(Mat.of(x3), pk["c1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg)
+        h2 = ops.empty(n, 512, dev)
+        ops.gemm(Mat.of(h1), pk["c2"], relu=True, Y=Mat.of(h2))
+        ops.gemm(Mat.of(h2), pk["c3"], relu=False, Y=out)
+
+    def forward(self, data, motion):
+        self._require_eval()
+        ops = get_ops()
+        n = motion.shape[0]
+        ng = _num_graphs(data, data.batch)
+        motion = motion.float().contiguous()
+        out = torch.empty((n, self.num_nearest_bone), dtype=torch.float32, device=motion.device)
+        self.run(ops, data, motion, ops.csr_build(data.tpl_edge_index, n), ops.csr_build(data.geo_edge_index, n),
+                 ops.make_seg(data.batch, ng, 1), ng, Mat.of(out))
+        return out
+
+
+class SkinMotion(_MotionBackbone):
+    """models/rignet.py:185-205 -> (motion_all, motion_aggr, skin_cls_pred)."""
+
+    def __init__(self, nearest_bone, use_Dg, use_Lf, num_keyframes, use_motion, motion_dim, aggr="max"):
+        super().__init__()
+        self.num_keyframes = num_keyframes
+        self.motion_dim = motion_dim
+        self.motionNet = GCNRig(chn_feature=3, chn_output=motion_dim, aggr=aggr)
+        self.aggragator = TemporalAttn(input_size=motion_dim, num_heads=2, hidden_size=64, dim_feedforward=512,
+                                       output_size=motion_dim)
+        self.skinNet = SkinNet_inner(nearest_bone, use_Dg, use_Lf, motion_dim, use_motion, aggr)
+
+    def forward(self, data, input_flow):
+        self._require_eval()
+        ops = get_ops()
+        st = self._motion(ops, data, input_flow, "attn", self.motion_dim)
+        n = data.pos.shape[0]
+        aggr = st["motion_aggr"]
+        out = torch.empty((n, self.skinNet.num_nearest_bone), dtype=torch.float32, device=aggr.device)
+        self.skinNet.run(ops, data, aggr, st["csr_tpl"], st["csr_geo"], st["seg"], st["ng"], Mat.of(out))
+        return st["motion_all"], aggr, out
+
+
+def jointnet_motion(**kwargs):
+    return JointNetMotion(num_keyframes=kwargs["num_keyframes"], chn_output=kwargs["chn_output"],
+                          aggr_method=kwargs["aggr_method"])
+
+
+def masknet_motion(**kwargs):
+    return MaskNetMotion(num_keyframes=kwargs["num_keyframes"], chn_output=kwargs["chn_output"],
+                         aggr_method=kwargs["aggr_method"])
+
+
+def skinnet_motion(**kwargs):
+    return SkinMotion(nearest_bone=kwargs["nearest_bone"], use_Dg=kwargs["use_Dg"], use_Lf=kwargs["use_Lf"],
+                      num_keyframes=kwargs["num_keyframes"], use_motion=kwargs["use_motion"],
+                      motion_dim=kwargs["motion_dim"])

@@ -1,0 +1,327 @@
+"""ctypes binding of libmorig_hip.so (the C ABI in include/morig_hip.h) + the op layer the
+network plans are written against.
+
+There is NO fallback: if the shared library is missing, or a tensor is not on a ROCm device, the
+product path raises. (tests/ inject a torch emulation of the *same op interface* to check the host
+logic on CPU; that emulation lives under tests/ and is never importable from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmorig_hip.so")
+
+c_f32p = C.c_void_p
+c_i32p = C.c_void_p
+c_i64p = C.c_void_p
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("X", c_f32p), ("ldx", C.c_int32),
+        ("W", c_f32p), ("ldw", C.c_int32),
+        ("bias", c_f32p), ("scale", c_f32p), ("shift", c_f32p),
+        ("relu", C.c_int32),
+        ("rowbias", c_f32p), ("ld_rowbias", C.c_int32),
+        ("seg", c_i32p),
+        ("Y", c_f32p), ("ldy", C.c_int32),
+        ("pool", c_f32p), ("ld_pool", C.c_int32), ("n_seg", C.c_int32),
+    ]
+
+
+class EdgeConvArgs(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32),
+        ("n_nodes", C.c_int32), ("replicas", C.c_int32),
+        ("in_rep_stride", C.c_int32), ("out_rep_stride", C.c_int32),
+        ("A", c_f32p), ("lda", C.c_int32),
+        ("B", c_f32p), ("ldb", C.c_int32),
+        ("rowptr", c_i32p), ("src_sorted", c_i32p), ("dst_sorted", c_i32p),
+        ("edge_capacity", C.c_int32), ("edge_count", C.c_int32),
+        ("s1", c_f32p), ("t1", c_f32p),
+        ("W2", c_f32p), ("ldw", C.c_int32),
+        ("b2", c_f32p), ("s2", c_f32p), ("t2", c_f32p),
+        ("out", c_f32p), ("ldo", C.c_int32),
+    ]
+
+
+_SIGNATURES = {
+    "morig_abi_version": (C.c_int, []),
+    "morig_strerror": (C.c_char_p, [C.c_int]),
+    "morig_last_hip_error": (C.c_int, []),
+    "morig_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
+    "morig_csr_build": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
+    "morig_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
+    "morig_copy2d": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "morig_gather_cols": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
+    "morig_make_seg": (C.c_int, [c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
+    "morig_rownorm": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
+    "morig_cls_attention": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_frame_reduce": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_prof_enable": (C.c_int, [C.c_int]),
+    "morig_prof_reset": (C.c_int, []),
+    "morig_prof_name": (C.c_char_p, [C.c_int]),
+    "morig_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+class MorigNativeError(RuntimeError):
+    pass
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libmorig_hip.so and type every export. Raises if the library was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise MorigNativeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C morig_amd/csrc`). There is no CPU fallback for the MoRig forward path.")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the header and the build disagree
+        fn.restype, fn.argtypes = res, args
+    if lib.morig_abi_version() != 1:
+        raise MorigNativeError("libmorig_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        lib = load_library()
+        msg = lib.morig_strerror(status).decode()
+        if status == -3:
+            msg += f" [hipError_t={lib.morig_last_hip_error()}]"
+        raise MorigNativeError(f"{what}: {msg}")
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------------
+# the op interface the plans use
+# ---------------------------------------------------------------------------------------------
+@dataclass
+class Mat:
+    """A column window of a row-major fp32 2-D tensor: rows [row0, row0+rows), cols [col0, col0+cols)."""
+    base: torch.Tensor
+    row0: int
+    col0: int
+    rows: int
+    cols: int
+
+    @staticmethod
+    def of(t: torch.Tensor, col0: int = 0, cols: Optional[int] = None, row0: int = 0, rows: Optional[int] = None) -> "Mat":
+        assert t.dim() == 2 and t.dtype == torch.float32 and t.stride(1) == 1, "need a row-major fp32 matrix"
+        cols = t.shape[1] - col0 if cols is None else cols
+        rows = t.shape[0] - row0 if rows is None else rows
+        assert 0 <= col0 and col0 + cols <= t.shape[1] and 0 <= row0 and row0 + rows <= t.shape[0]
+        return Mat(t, row0, col0, rows, cols)
+
+    @property
+    def ld(self) -> int:
+        return self.base.stride(0)
+
+    @property
+    def ptr(self) -> int:
+        return self.base.data_ptr() + 4 * (self.row0 * self.ld + self.col0)
+
+    def view(self) -> torch.Tensor:
+        return self.base[self.row0:self.row0 + self.rows, self.col0:self.col0 + self.cols]
+
+
+@dataclass
+class CSR:
+    rowptr: torch.Tensor      # int32 [n+1]
+    src: torch.Tensor         # int32 [cap]
+    dst: torch.Tensor         # int32 [cap]
+    n_nodes: int
+    capacity: int
+    status: torch.Tensor      # int32 [1], non-zero = index out of range (checked lazily)
+    edge_count: int = 0       # exact E' when known (accounting only)
+
+
+def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise MorigNativeError("the MoRig native forward path needs ROCm device tensors (no CPU fallback); "
+                                   "move the model and data to 'cuda'")
+
+
+class NativeOps:
+    """Thin, validating wrappers: tensors in, C ABI calls out, everything on the current stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise MorigNativeError("no ROCm device visible: the MoRig forward path has no CPU fallback")
+
+    # -- allocation (PyTorch owns all device memory) -------------------------------------------
+    def empty(self, rows, cols, device, dtype=torch.float32):
+        return torch.empty((rows, cols), device=device, dtype=dtype)
+
+    # -- graph --------------------------------------------------------------------------------
+    def csr_build(self, edge_index: torch.Tensor, n_nodes: int) -> CSR:
+        _need_gpu(edge_index)
+        ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
+        E = ei.shape[1]
+        dev = ei.device
+        cap = E + n_nodes
+        rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        src = torch.empty(cap, dtype=torch.int32, device=dev)
+        dst = torch.empty(cap, dtype=torch.int32, device=dev)
+        cursor = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        check(self.lib.morig_csr_build(_p(ei), E, n_nodes, _p(rowptr), _p(src), _p(dst), _p(cursor), _p(status), _stream()),
+              "morig_csr_build")
+        return CSR(rowptr, src, dst, n_nodes, cap, status)
+
+    # -- dense ----------------------------------------------------------------------------------
+    def gemm(self, X: Mat, lin, relu: bool, Y: Optional[Mat] = None, rowbias: Optional[Mat] = None,
+             seg: Optional[torch.Tensor] = None, pool: Optional[torch.Tensor] = None, affine: bool = True):
+        _need_gpu(X.base, lin.W)
+        a = GemmArgs()
+        a.M, a.N, a.K = X.rows, lin.N, lin.K
+        assert X.cols == lin.K, (X.cols, lin.K)
+        a.X, a.ldx = X.ptr, X.ld
+        a.W, a.ldw = lin.W.data_ptr(), lin.W.stride(0)
+        a.bias = lin.bias.data_ptr() if lin.bias is not None else 0
+        a.scale = lin.scale.data_ptr() if (affine and lin.scale is not None) else 0
+        a.shift = lin.shift.data_ptr() if (affine and lin.shift is not None) else 0
+        a.relu = 1 if relu else 0
+        if rowbias is not None:
+            a.rowbias, a.ld_rowbias = rowbias.ptr, rowbias.ld
+        a.seg = seg.data_ptr() if seg is not None else 0
+        if Y is not None:
+            assert Y.rows == X.rows and Y.cols == lin.N
+            a.Y, a.ldy = Y.ptr, Y.ld
+        if pool is not None:
+            assert pool.shape[1] >= lin.N and pool.is_contiguous()
+            a.pool, a.ld_pool, a.n_seg = pool.data_ptr(), pool.stride(0), pool.shape[0]
+        check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")
+
+    # -- fused edge conv ----------------------------------------------------------------------------
+    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
+                 in_rep_stride: int = 0, out_rep_stride: int = 0):
+        _need_gpu(A.base, B.base, out.base)
+        a = EdgeConvArgs()
+        a.H = ec.H
+        a.n_nodes, a.replicas = csr.n_nodes, replicas
+        a.in_rep_stride, a.out_rep_stride = in_rep_stride, out_rep_stride
+        a.A, a.lda = A.ptr, A.ld
+        a.B, a.ldb = B.ptr, B.ld
+        a.rowptr, a.src_sorted, a.dst_sorted = csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr()
+        a.edge_capacity, a.edge_count = csr.capacity, csr.edge_count
+        a.s1, a.t1 = ec.s1.data_ptr(), ec.t1.data_ptr()
+        a.W2, a.ldw = ec.W2.data_ptr(), ec.W2.stride(0)
+        a.b2, a.s2, a.t2 = ec.b2.data_ptr(), ec.s2.data_ptr(), ec.t2.data_ptr()
+        a.out, a.ldo = out.ptr, out.ld
+        check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
+
+    # -- small ops ------------------------------------------------------------------------------------
+    def copy2d(self, src: Mat, dst: Mat):
+        _need_gpu(src.base, dst.base)
+        assert src.rows == dst.rows and src.cols == dst.cols
+        check(self.lib.morig_copy2d(src.ptr, src.ld, dst.ptr, dst.ld, src.rows, src.cols, _stream()), "morig_copy2d")
+
+    def gather_cols(self, src: Mat, cols: torch.Tensor, dst: Mat):
+        _need_gpu(src.base, cols, dst.base)
+        assert cols.dtype == torch.int32 and dst.cols == cols.numel() and src.rows == dst.rows
+        check(self.lib.morig_gather_cols(src.ptr, src.ld, _p(cols), cols.numel(), dst.ptr, dst.ld, src.rows, _stream()),
+              "morig_gather_cols")
+
+    def make_seg(self, batch: torch.Tensor, n_graphs: int, replicas: int) -> torch.Tensor:
+        _need_gpu(batch)
+        b = batch if (batch.dtype == torch.int64 and batch.is_contiguous()) else batch.long().contiguous()
+        n = b.numel()
+        seg = torch.empty(n * replicas, dtype=torch.int32, device=b.device)
+        check(self.lib.morig_make_seg(_p(b), n, n_graphs, replicas, _p(seg), _stream()), "morig_make_seg")
+        return seg
+
+    def rownorm(self, x: Mat, rows_per_rep: int, replicas: int, y: torch.Tensor, ld_row: int, ld_rep: int):
+        _need_gpu(x.base, y)
+        assert x.rows == rows_per_rep * replicas
+        check(self.lib.morig_rownorm(x.ptr, x.ld, rows_per_rep, replicas, x.cols, _p(y), ld_row, ld_rep, _stream()),
+              "morig_rownorm")
+
+    def cls_attention(self, x: torch.Tensor, g: torch.Tensor, cls: torch.Tensor, y: Mat):
+        _need_gpu(x, g, cls, y.base)
+        n, T, Cc = x.shape
+        assert x.is_contiguous() and g.is_contiguous() and cls.is_contiguous()
+        heads = g.shape[0]
+        check(self.lib.morig_cls_attention(_p(x), n, T, Cc, heads, _p(g), _p(cls), y.ptr, y.ld, _stream()),
+              "morig_cls_attention")
+
+    def frame_reduce(self, x: torch.Tensor, mode: str, y: Mat):
+        _need_gpu(x, y.base)
+        n, T, Cc = x.shape
+        assert x.is_contiguous()
+        check(self.lib.morig_frame_reduce(_p(x), n, T, Cc, 0 if mode == "mean" else 1, y.ptr, y.ld, _stream()),
+              "morig_frame_reduce")
+
+
+_ops: Optional[NativeOps] = None
+
+
+def get_ops() -> NativeOps:
+    """The process-wide op layer. Raises (loudly) when the HIP library or a GPU is missing."""
+    global _ops
+    if _ops is None:
+        _ops = NativeOps()
+    return _ops
+
+
+# ---------------------------------------------------------------------------------------------
+# profiling helpers for bench.py
+# ---------------------------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    load_library().morig_prof_enable(1 if on else 0)
+
+
+def prof_reset() -> None:
+    load_library().morig_prof_reset()
+
+
+def prof_collect():
+    """-> {kernel name: dict(launches, ms, flops, bytes)} for kinds that ran."""
+    lib = load_library()
+    out = {}
+    k = 0
+    while True:
+        nm = lib.morig_prof_name(k)
+        if nm is None:
+            break
+        n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
+        check(lib.morig_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "morig_prof_collect")
+        if n.value:
+            out[nm.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        k += 1
+    return out
+
+
+def device_info():
+    lib = load_library()
+    cu, lds, clk = C.c_int(), C.c_int(), C.c_int()
+    arch = C.create_string_buffer(64)
+    st = lib.morig_device_info(C.byref(cu), C.byref(lds), C.byref(clk), arch, 64)
+    return dict(status=st, cu_count=cu.value, lds_bytes_per_cu=lds.value, clock_khz=clk.value, arch=arch.value.decode())

@@ -1,0 +1,128 @@
+"""Host-side parameter packing for the HIP kernels (pure tensor algebra, device-agnostic).
+
+What is restructured, exactly:
+  * eval-mode BatchNorm -> per-channel affine  y = s*x + t,  s = gamma/sqrt(var+eps), t = beta - mean*s.
+    MLP() is Linear -> ReLU -> BN (models/basic_modules.py:33), so the affine is applied AFTER the
+    ReLU by the producing kernel's epilogue (and, inside the fused edge kernel, to the hidden layer
+    while it is gathered). Nothing is folded across a ReLU.
+  * first edge Linear per vertex:  W1 [x_i ; x_j - x_i] = (W1a - W1b) x_i + W1b x_j
+    (message of EdgeConv / EdgeConvMotion, models/basic_modules.py:153-155, 192-195).
+  * concatenations become column placement: weights are column-permuted once so activations can
+    stay where their producer wrote them.
+Weights are zero padded to the kernels' tile grid: rows to 32/64/128, K to a multiple of 32.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+
+def _roundup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def col_tile(n: int) -> int:
+    """column tile the GEMM launcher picks for a logical width n (morig_gemm in tile_gemm.hip)."""
+    return 128 if n > 64 else (64 if n > 32 else 32)
+
+
+def bn_affine(bn: nn.BatchNorm1d):
+    s = bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)
+    t = bn.bias.detach().float() - bn.running_mean.detach().float() * s
+    return s, t
+
+
+@dataclass
+class PackedLinear:
+    W: torch.Tensor                     # [Npad, Kpad]
+    bias: Optional[torch.Tensor]        # [Npad]
+    scale: Optional[torch.Tensor]       # [Npad]   (BN eval affine; None = identity)
+    shift: Optional[torch.Tensor]
+    N: int
+    K: int
+
+
+@dataclass
+class PackedEdge:
+    """second half of an edge MLP: hidden affine (BN1), Linear2, BN2; H = width."""
+    H: int
+    s1: torch.Tensor
+    t1: torch.Tensor
+    W2: torch.Tensor                    # [max(H,32), roundup(H,32)]
+    b2: torch.Tensor
+    s2: torch.Tensor
+    t2: torch.Tensor
+
+
+def _pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
+    if v is None:
+        return None
+    out = torch.full((n,), fill, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v.float()
+    return out.contiguous()
+
+
+def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[nn.BatchNorm1d] = None,
+                in_cols: Optional[Sequence[int]] = None, k_total: Optional[int] = None,
+                row_tile: Optional[int] = None) -> PackedLinear:
+    """weight [N, K_src]. ``in_cols[j]`` = position of source column j in the kernel's input row
+    (default identity); ``k_total`` = logical K of the kernel input (>= max(in_cols)+1)."""
+    W = weight.detach().float()
+    N, Ksrc = W.shape
+    if in_cols is None:
+        in_cols = list(range(Ksrc))
+    K = max(in_cols) + 1 if k_total is None else k_total
+    Npad = _roundup(N, row_tile or col_tile(N))
+    Kpad = _roundup(K, 32)
+    Wp = torch.zeros((Npad, Kpad), dtype=torch.float32, device=W.device)
+    Wp[:N, torch.as_tensor(list(in_cols), device=W.device)] = W
+    s = t = None
+    if bn is not None:
+        s, t = bn_affine(bn)
+    return PackedLinear(Wp.contiguous(), _pad_vec(bias.detach() if bias is not None else torch.zeros(N, device=W.device), Npad),
+                        _pad_vec(s, Npad, 1.0), _pad_vec(t, Npad), N, K)
+
+
+def pack_mlp_layer(layer: nn.Sequential, **kw) -> PackedLinear:
+    """one ``Seq(Linear, ReLU, BN)`` of MLP()."""
+    return pack_linear(layer[0].weight, layer[0].bias, layer[2], **kw)
+
+
+def pack_edge_pair(mlps: Sequence[nn.Sequential]):
+    """Edge MLPs ``MLP([2C, H, H])`` of several graphs sharing the same vertex input.
+    Returns (vertex PackedLinear producing [A_0 | B_0 | A_1 | B_1 ...] of width 2*H*len, [PackedEdge])."""
+    rows, biases, edges = [], [], []
+    H = mlps[0][0][0].weight.shape[0]
+    for m in mlps:
+        lin1, bn1 = m[0][0], m[0][2]
+        lin2, bn2 = m[1][0], m[1][2]
+        W1 = lin1.weight.detach().float()
+        C = W1.shape[1] // 2
+        Wa, Wb = W1[:, :C], W1[:, C:]
+        rows += [Wa - Wb, Wb]
+        biases += [lin1.bias.detach().float(), torch.zeros_like(lin1.bias, dtype=torch.float32)]
+        s1, t1 = bn_affine(bn1)
+        s2, t2 = bn_affine(bn2)
+        Hp, Kp = max(H, 32), _roundup(H, 32)
+        W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=W1.device)
+        W2[:H, :H] = lin2.weight.detach().float()
+        edges.append(PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2.contiguous(),
+                                _pad_vec(lin2.bias.detach(), Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp)))
+    vertex = pack_linear(torch.cat(rows, 0), torch.cat(biases, 0))
+    return vertex, edges
+
+
+def to_device(obj, device):
+    """move a (nested) packed structure to ``device``."""
+    if isinstance(obj, torch.Tensor):
+        return obj.to(device)
+    if isinstance(obj, (PackedLinear, PackedEdge)):
+        return type(obj)(**{k: to_device(v, device) for k, v in obj.__dict__.items()})
+    if isinstance(obj, dict):
+        return {k: to_device(v, device) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to_device(v, device) for v in obj)
+    return obj

@@ -1,0 +1,122 @@
+"""TEST DOUBLE (tests/ only): a torch-CPU emulation of the op interface in morig_amd/native.py.
+
+It exists so the HOST logic of the product -- parameter packing, column placement in the wide
+activation buffers, replica handling, plan wiring -- can be checked against the oracle on a machine
+without a GPU. It mimics what each HIP kernel computes from the *packed* structures (including the
+zero-padding conventions), not what the reference computes. The product never imports this file;
+without the HIP library the product raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from morig_amd.native import CSR, Mat
+
+
+class EmuOps:
+    name = "emulated"
+
+    def empty(self, rows, cols, device, dtype=torch.float32):
+        # poison, so a plan that reads something it never wrote fails loudly
+        return torch.full((rows, cols), float("nan"), dtype=dtype, device=device)
+
+    # -- graph ----------------------------------------------------------------------------------
+    def csr_build(self, edge_index, n_nodes, n_src=None, skip_negative=False):
+        src, dst = edge_index[0].long(), edge_index[1].long()
+        if skip_negative:
+            keep = (src >= 0) & (dst >= 0)
+            src, dst = src[keep], dst[keep]
+        n_src = n_nodes if n_src is None else n_src
+        assert int(src.min()) >= 0 and int(src.max()) < n_src and int(dst.min()) >= 0 and int(dst.max()) < n_nodes
+        keep = src != dst
+        loop = torch.arange(n_nodes)
+        src = torch.cat([src[keep], loop])
+        dst = torch.cat([dst[keep], loop])
+        order = torch.sort(dst, stable=True)[1]
+        src, dst = src[order], dst[order]
+        rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64)
+        rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
+        cap = edge_index.shape[1] + n_nodes
+        pad = cap - src.numel()
+        junk = torch.full((pad,), -12345, dtype=torch.int32)
+        return CSR(rowptr.int(), torch.cat([src.int(), junk]), torch.cat([dst.int(), junk]), n_nodes, cap,
+                   torch.zeros(1, dtype=torch.int32), edge_count=int(src.numel()))
+
+    # -- dense -------------------------------------------------------------------------------------
+    @staticmethod
+    def _x(X: Mat, K: int):
+        assert X.ld % 4 == 0 and X.col0 % 4 == 0, "GEMM operand rows must be 16-byte aligned"
+        assert X.cols == K
+        v = X.view()
+        assert not torch.isnan(v).any(), "GEMM reads uninitialised memory"
+        return v
+
+    def gemm(self, X: Mat, lin, relu, Y=None, rowbias=None, seg=None, pool=None, affine=True):
+        x = self._x(X, lin.K)
+        acc = x @ lin.W[: lin.N, : lin.K].t()
+        assert float(lin.W[lin.N:].abs().sum()) == 0 and float(lin.W[:, lin.K:].abs().sum()) == 0, "padding must be zero"
+        acc = acc + lin.bias[: lin.N]
+        if rowbias is not None:
+            acc = acc + rowbias.view()[seg.long()][:, : lin.N]
+        if relu:
+            acc = torch.relu(acc)
+        if affine and lin.scale is not None:
+            acc = acc * lin.scale[: lin.N] + lin.shift[: lin.N]
+        if pool is not None:
+            assert Y is None
+            out = torch.full_like(pool, float("nan"))
+            idx = seg.long()
+            for s in torch.unique(idx):
+                out[s, : lin.N] = acc[idx == s].max(dim=0)[0]
+            pool.copy_(out)
+        else:
+            Y.view().copy_(acc)
+
+    # -- fused edge conv ---------------------------------------------------------------------------
+    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0):
+        assert A.ld % 4 == 0 and A.col0 % 4 == 0 and B.ld % 4 == 0 and B.col0 % 4 == 0
+        H = ec.H
+        E = int(csr.rowptr[-1])
+        src, dst = csr.src[:E].long(), csr.dst[:E].long()
+        n = csr.n_nodes
+        for r in range(replicas):
+            a = A.base[A.row0 + r * in_rep_stride + dst, A.col0:A.col0 + H]
+            b = B.base[B.row0 + r * in_rep_stride + src, B.col0:B.col0 + H]
+            assert not torch.isnan(a).any() and not torch.isnan(b).any()
+            h1 = torch.relu(a + b) * ec.s1[:H] + ec.t1[:H]
+            z = torch.relu(h1 @ ec.W2[:H, :H].t() + ec.b2[:H]) * ec.s2[:H] + ec.t2[:H]
+            res = torch.full((n, H), float("-inf"))
+            res = res.scatter_reduce(0, dst[:, None].expand(-1, H), z, reduce="amax", include_self=True)
+            out.base[out.row0 + r * out_rep_stride: out.row0 + r * out_rep_stride + n, out.col0:out.col0 + H] = res
+
+    # -- small ops -----------------------------------------------------------------------------------
+    def copy2d(self, src: Mat, dst: Mat):
+        dst.view().copy_(src.view())
+
+    def gather_cols(self, src: Mat, cols, dst: Mat):
+        dst.view().copy_(src.view()[:, cols.long()])
+
+    def make_seg(self, batch, n_graphs, replicas):
+        return torch.cat([batch.int() + r * n_graphs for r in range(replicas)])
+
+    def rownorm(self, x: Mat, rows_per_rep, replicas, y, ld_row, ld_rep):
+        v = x.view()
+        nrm = v / torch.clamp(v.norm(dim=1, keepdim=True), min=1e-12)
+        flat = y.view(-1)
+        C = x.cols
+        for r in range(replicas):
+            blk = nrm[r * rows_per_rep:(r + 1) * rows_per_rep]
+            idx = (torch.arange(rows_per_rep)[:, None] * ld_row + r * ld_rep + torch.arange(C)[None, :]).reshape(-1)
+            flat[idx] = blk.reshape(-1)
+
+    def cls_attention(self, x, g, cls, y: Mat):
+        n, T, C = x.shape
+        tok = torch.cat([cls.view(1, 1, C).expand(n, 1, C), x], dim=1)          # n x (T+1) x C
+        outs = []
+        for h in range(g.shape[0]):
+            a = torch.softmax(tok @ g[h], dim=1)                                # n x (T+1)
+            outs.append((a[:, :, None] * tok).sum(1))
+        y.view().copy_(torch.cat(outs, dim=1))
+
+    def frame_reduce(self, x, mode, y: Mat):
+        y.view().copy_(x.mean(1) if mode == "mean" else x.max(1)[0])

@@ -23,3 +23,18 @@ def data_from(arrs, device="cpu"):
 
 def maxdiff(a, b):
     return (a.detach().cpu().double() - b.detach().cpu().double()).abs().max().item()
+
+
+def excess(a, b, atol, rtol):
+    """max over elements of |a-b| - (atol + rtol*|b|); <= 0 means within tolerance."""
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return ((a - b).abs() - (atol + rtol * b.abs())).max().item()
+
+
+def rel_excess(a, b, tol):
+    """|a-b|_inf relative to max(1, |b|_inf), minus tol: the parity criterion used for network outputs
+    ("within 1e-4 fp32" of BASELINE.json, normalised by the output scale when that exceeds 1)."""
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    return (a - b).abs().max().item() / max(1.0, b.abs().max().item()) - tol

@@ -1,0 +1,223 @@
+"""GPU: every C-ABI entry point of libmorig_hip.so against a torch restatement of what the kernel is
+specified to compute (tests/emulate.py, run on CPU on the same seeded inputs). Integer/index results
+must be bit-exact; fp32 contractions within 2e-5 * scale (different summation order only)."""
+import pytest
+import torch
+
+from emulate import EmuOps
+from helpers import maxdiff
+from morig_amd import packing
+from morig_amd.native import Mat
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from morig_amd import native
+    return native.get_ops()
+
+
+def _rand_graph(n, e, seed, hub=None):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n, (e,), generator=g)
+    dst = torch.randint(0, n, (e,), generator=g)
+    if hub is not None:                       # one target with a huge in-degree (segment spans several tiles)
+        k = e // 3
+        dst[:k] = hub
+    src[::7] = dst[::7]                       # self loops to strip
+    return torch.stack([src, dst])
+
+
+def _segments(csr, E):
+    rp = csr.rowptr.cpu().long()
+    src = csr.src.cpu()[:E].long()
+    return [sorted(src[rp[i]:rp[i + 1]].tolist()) for i in range(csr.n_nodes)]
+
+
+@pytest.mark.parametrize("n,e,hub", [(50, 400, None), (3000, 40000, 17), (5000, 0, None), (1, 5, None)])
+def test_csr_build(ops, n, e, hub):
+    ei = _rand_graph(n, e, 3, hub) if e else torch.zeros((2, 0), dtype=torch.long)
+    ref = EmuOps().csr_build(ei, n) if e else None
+    got = ops.csr_build(ei.to(DEV), n)
+    torch.cuda.synchronize()
+    assert int(got.status.item()) == 0
+    if e == 0:
+        assert got.rowptr.cpu().tolist() == list(range(n + 1))
+        assert got.src.cpu()[:n].tolist() == list(range(n))
+        return
+    assert torch.equal(got.rowptr.cpu(), ref.rowptr)
+    E = int(ref.rowptr[-1])
+    assert torch.equal(got.dst.cpu()[:E], ref.dst[:E])
+    assert _segments(got, E) == _segments(ref, E)
+
+
+def test_csr_build_flags_bad_index(ops):
+    ei = torch.tensor([[0, 1, 9], [1, 2, 0]])
+    got = ops.csr_build(ei.to(DEV), 3)
+    torch.cuda.synchronize()
+    assert int(got.status.item()) != 0
+
+
+def _lin(N, K, seed, bn=True):
+    g = torch.Generator().manual_seed(seed)
+    W = torch.randn(N, K, generator=g) / (K ** 0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    p = packing.pack_linear(W, b)
+    if bn:
+        Np = p.W.shape[0]
+        p.scale = torch.randn(Np, generator=g)
+        p.shift = torch.randn(Np, generator=g) * 0.2
+    return p
+
+
+GEMM_CASES = [
+    # M, N, K, relu, bn
+    (1, 3, 3, False, False), (130, 32, 64, True, True), (257, 64, 33, True, True), (1000, 100, 835, True, True),
+    (513, 128, 832, False, False), (300, 1024, 1859, True, True), (128, 256, 1024, True, True), (77, 5, 512, False, False),
+    (4096, 512, 544, True, True),
+]
+
+
+@pytest.mark.parametrize("M,N,K,relu,bn", GEMM_CASES)
+def test_gemm_store(ops, M, N, K, relu, bn):
+    g = torch.Generator().manual_seed(M + N + K)
+    ld = (K + 3) // 4 * 4 + 8
+    xb = torch.randn(M, ld, generator=g)
+    xb[:, 4 + K:] = float("nan")                          # anything beyond K must never be read into the sum
+    lin = _lin(N, K, 11, bn)
+    yb_ref = torch.zeros(M, N + 5)
+    EmuOps().gemm(Mat.of(xb, 4, K), lin, relu, Y=Mat.of(yb_ref, 2, N))
+    xg, ling = xb.to(DEV), packing.to_device(lin, DEV)
+    yb = torch.zeros(M, N + 5, device=DEV)
+    ops.gemm(Mat.of(xg, 4, K), ling, relu, Y=Mat.of(yb, 2, N))
+    torch.cuda.synchronize()
+    scale = max(1.0, yb_ref.abs().max().item())
+    assert maxdiff(yb, yb_ref) <= 2e-5 * scale
+    assert float(yb[:, :2].abs().sum()) == 0 and float(yb[:, 2 + N:].abs().sum()) == 0     # window respected
+
+
+@pytest.mark.parametrize("M,N,K,nseg", [(1000, 1024, 832, 7), (130, 512, 256, 130), (4096, 1024, 64, 1), (300, 200, 100, 3)])
+def test_gemm_pool_and_rowbias(ops, M, N, K, nseg):
+    g = torch.Generator().manual_seed(M + nseg)
+    x = torch.randn(M, (K + 3) // 4 * 4, generator=g)
+    seg = torch.sort(torch.randint(0, nseg, (M,), generator=g))[0].int()
+    seg[0], seg[-1] = 0, nseg - 1
+    if nseg == 130:
+        seg = torch.arange(M).int()
+    present = torch.unique(seg.long())
+    lin = _lin(N, K, 5)
+    pool_ref = torch.zeros(nseg, N)
+    EmuOps().gemm(Mat.of(x, 0, K), lin, True, seg=seg, pool=pool_ref)
+    pool = torch.zeros(nseg, N, device=DEV)
+    ops.gemm(Mat.of(x.to(DEV), 0, K), packing.to_device(lin, DEV), True, seg=seg.to(DEV), pool=pool)
+    torch.cuda.synchronize()
+    assert maxdiff(pool[present.to(DEV)], pool_ref[present]) <= 2e-5 * max(1.0, pool_ref[present].abs().max().item())
+    # row bias indexed by segment
+    rb = torch.randn(nseg, N, generator=g)
+    y_ref = torch.zeros(M, N)
+    EmuOps().gemm(Mat.of(x, 0, K), lin, True, Y=Mat.of(y_ref), rowbias=Mat.of(rb), seg=seg)
+    y = torch.zeros(M, N, device=DEV)
+    ops.gemm(Mat.of(x.to(DEV), 0, K), packing.to_device(lin, DEV), True, Y=Mat.of(y), rowbias=Mat.of(rb.to(DEV)), seg=seg.to(DEV))
+    torch.cuda.synchronize()
+    assert maxdiff(y, y_ref) <= 2e-5 * max(1.0, y_ref.abs().max().item())
+
+
+def _edge_pack(H, seed):
+    g = torch.Generator().manual_seed(seed)
+    Hp, Kp = max(H, 32), (H + 31) // 32 * 32
+    W2 = torch.zeros(Hp, Kp)
+    W2[:H, :H] = torch.randn(H, H, generator=g) / (H ** 0.5)
+
+    def vec(n, fill, f):
+        v = torch.full((n,), fill)
+        v[:H] = f(H)
+        return v
+    rn = lambda k: torch.randn(k, generator=g)
+    return packing.PackedEdge(H, vec(Kp, 1.0, rn), vec(Kp, 0.0, lambda k: rn(k) * 0.2), W2, vec(Hp, 0.0, lambda k: rn(k) * 0.1),
+                              vec(Hp, 1.0, rn), vec(Hp, 0.0, lambda k: rn(k) * 0.2))
+
+
+@pytest.mark.parametrize("H", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("n,e,hub,reps,shared", [(300, 2500, 5, 1, False), (1500, 9000, None, 3, False), (700, 5000, 3, 2, True)])
+def test_edgeconv(ops, H, n, e, hub, reps, shared):
+    g = torch.Generator().manual_seed(H + n)
+    ei = _rand_graph(n, e, 9, hub)
+    rows_in = n if shared else n * reps
+    ab = torch.randn(rows_in, 2 * H + 4, generator=g)
+    ec = _edge_pack(H, 21)
+    emu = EmuOps()
+    csr_ref = emu.csr_build(ei, n)
+    out_ref = torch.zeros(n * reps, H + 3)
+    emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_ref, ec, Mat.of(out_ref, 0, H), replicas=reps,
+                 in_rep_stride=0 if shared else n, out_rep_stride=n)
+    csr = ops.csr_build(ei.to(DEV), n)
+    abg = ab.to(DEV)
+    out = torch.zeros(n * reps, H + 3, device=DEV)
+    ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), csr, packing.to_device(ec, DEV), Mat.of(out, 0, H), replicas=reps,
+                 in_rep_stride=0 if shared else n, out_rep_stride=n)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    assert maxdiff(out, out_ref) <= 2e-5 * max(1.0, out_ref.abs().max().item())
+    assert float(out[:, H:].abs().sum()) == 0
+
+
+def test_edgeconv_sign_cases(ops):
+    """negative BN scales (max of a decreasing function) and all-negative outputs (the integer-atomic
+    max identity must not leak)."""
+    H, n = 32, 400
+    ei = _rand_graph(n, 6000, 4, hub=11)
+    ec = _edge_pack(H, 2)
+    ec.s2 = -ec.s2.abs()
+    ec.t2 = ec.t2 - 5.0
+    ab = torch.randn(n, 2 * H)
+    emu = EmuOps()
+    out_ref = torch.zeros(n, H)
+    emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), emu.csr_build(ei, n), ec, Mat.of(out_ref))
+    out = torch.zeros(n, H, device=DEV)
+    abg = ab.to(DEV)
+    ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), ops.csr_build(ei.to(DEV), n), packing.to_device(ec, DEV), Mat.of(out))
+    torch.cuda.synchronize()
+    assert out_ref.max().item() < 0
+    assert maxdiff(out, out_ref) <= 2e-5 * out_ref.abs().max().item()
+
+
+def test_small_ops(ops):
+    g = torch.Generator().manual_seed(1)
+    emu = EmuOps()
+    src = torch.randn(33, 15, generator=g)
+    dst_ref, dst = torch.zeros(40, 9), torch.zeros(40, 9, device=DEV)
+    emu.copy2d(Mat.of(src, 3, 3), Mat.of(dst_ref, 5, 3, 7, 33))
+    ops.copy2d(Mat.of(src.to(DEV), 3, 3), Mat.of(dst, 5, 3, 7, 33))
+    assert torch.equal(dst.cpu(), dst_ref)
+    cols = torch.tensor([0, 2, 5, 14], dtype=torch.int32)
+    o_ref, o = torch.zeros(33, 6), torch.zeros(33, 6, device=DEV)
+    emu.gather_cols(Mat.of(src), cols, Mat.of(o_ref, 1, 4))
+    ops.gather_cols(Mat.of(src.to(DEV)), cols.to(DEV), Mat.of(o, 1, 4))
+    assert torch.equal(o.cpu(), o_ref)
+    batch = torch.tensor([0, 0, 1, 1, 1, 2])
+    assert torch.equal(ops.make_seg(batch.to(DEV), 3, 2).cpu(), emu.make_seg(batch, 3, 2))
+    x = torch.randn(5 * 37, 32, generator=g)
+    x[3] = 0.0                                                      # zero row: eps clamp, no NaN
+    y_ref, y = torch.zeros(37, 5, 32), torch.zeros(37, 5, 32, device=DEV)
+    emu.rownorm(Mat.of(x), 37, 5, y_ref, 160, 32)
+    ops.rownorm(Mat.of(x.to(DEV)), 37, 5, y, 160, 32)
+    assert maxdiff(y, y_ref) <= 1e-6 and not torch.isnan(y).any()
+    xa = torch.nn.functional.normalize(torch.randn(70, 5, 32, generator=g), dim=2)
+    gq, cls = torch.randn(2, 32, generator=g), torch.randn(32, generator=g)
+    a_ref, a = torch.zeros(70, 64), torch.zeros(70, 64, device=DEV)
+    emu.cls_attention(xa, gq, cls, Mat.of(a_ref))
+    ops.cls_attention(xa.to(DEV), gq.to(DEV), cls.to(DEV), Mat.of(a))
+    assert maxdiff(a, a_ref) <= 2e-6
+    for mode in ("mean", "max"):
+        r_ref, r = torch.zeros(70, 32), torch.zeros(70, 32, device=DEV)
+        emu.frame_reduce(xa, mode, Mat.of(r_ref))
+        ops.frame_reduce(xa.to(DEV), mode, Mat.of(r))
+        assert maxdiff(r, r_ref) <= 1e-6
+
+
+def test_cpu_tensors_are_refused(ops):
+    from morig_amd.native import MorigNativeError
+    with pytest.raises(MorigNativeError):
+        ops.copy2d(Mat.of(torch.zeros(2, 2)), Mat.of(torch.zeros(2, 2)))

@@ -1,0 +1,131 @@
+"""GPU: the drop-in modules (morig_amd.models) on the HIP path, through the C ABI, against
+ (1) golden vectors produced by the reference's own models/*.py (tests/golden), and
+ (2) the CPU oracle on fresh seeded inputs.
+Criterion (BASELINE.json: "within 1e-4 fp32"): max |diff| <= 1e-4 * max(1, max |reference|)."""
+import pytest
+import torch
+
+from conftest import load_golden
+from helpers import data_from, rel_excess
+from morig_amd import models, synth
+from morig_amd.models import basic_modules as bm, rignet as rn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 1e-4
+
+
+def test_native_library_is_loaded_and_gfx950():
+    from morig_amd import native
+    info = native.device_info()
+    assert info["status"] == 0 and info["arch"].startswith("gfx950"), info
+    assert native.get_ops().name == "hip"
+
+
+def test_edgeconvmotion_layer():
+    meta, a = load_golden("edgeconvmotion_c64_h128")
+    m = bm.EdgeConvMotion(nn_x=bm.MLP([128, 128, 128]), nn_pos=bm.MLP([6, 16, 16])).eval()
+    synth.load_recipe(m, meta["recipe_seed"]).to(DEV)
+    out = m(a["pos"].to(DEV), a["x"].to(DEV), a["edge_index"].to(DEV))
+    assert rel_excess(out, a["out"], TOL) <= 0
+
+
+def test_edgeconvmotion_1d_feature():
+    meta, a = load_golden("edgeconvmotion_x1d")
+    m = bm.EdgeConvMotion(nn_x=bm.MLP([2, 32, 32]), nn_pos=bm.MLP([6, 16, 16])).eval()
+    synth.load_recipe(m, meta["recipe_seed"]).to(DEV)
+    assert rel_excess(m(a["pos"].to(DEV), a["x"].to(DEV), a["edge_index"].to(DEV)), a["out"], TOL) <= 0
+
+
+def test_gcumotion_layer():
+    meta, a = load_golden("gcumotion_256_512")
+    m = synth.load_recipe(bm.GCUMotion(256, 512).eval(), meta["recipe_seed"]).to(DEV)
+    out = m(a["pos"].to(DEV), a["x"].to(DEV), a["tpl_edge_index"].to(DEV), a["geo_edge_index"].to(DEV))
+    assert rel_excess(out, a["out"], TOL) <= 0
+
+
+def test_gcu_layer():
+    meta, a = load_golden("gcu_3_32")
+    m = synth.load_recipe(bm.GCU(3, 32).eval(), meta["recipe_seed"]).to(DEV)
+    assert rel_excess(m(a["x"].to(DEV), a["tpl_edge_index"].to(DEV), a["geo_edge_index"].to(DEV)), a["out"], TOL) <= 0
+
+
+@pytest.mark.parametrize("name", ["gcnrig_f3_o32", "gcnrig_f64_o3"])
+def test_gcnrig(name):
+    meta, a = load_golden(name)
+    m = synth.load_recipe(rn.GCNRig(meta["chn_feature"], meta["chn_output"]).eval(), meta["recipe_seed"]).to(DEV)
+    out = m(a["pos"].to(DEV), a["feature"].to(DEV), a["tpl_edge_index"].to(DEV), a["geo_edge_index"].to(DEV), a["batch"].to(DEV))
+    assert rel_excess(out, a["out"], TOL) <= 0
+
+
+def test_temporal_attention():
+    meta, a = load_golden("temporalattn_32_64")
+    m = synth.load_recipe(rn.TemporalAttn(32, 2, 64, 512, 64).eval(), meta["recipe_seed"]).to(DEV)
+    assert rel_excess(m(a["x"].to(DEV)), a["out"], TOL) <= 0
+
+
+@pytest.mark.parametrize("name,outs", [
+    ("jointnet_ragged", ("motion_all", "motion_aggr", "pred_shift")),
+    ("jointnet_mean", (None, "motion_aggr", "pred_shift")),
+    ("jointnet_max", (None, "motion_aggr", "pred_shift")),
+    ("masknet_ragged", ("motion_all", "motion_aggr", "pred_mask")),
+    ("skinnet_ragged", ("motion_all", "motion_aggr", "skin_cls_pred")),
+    ("skinnet_dg1_lf1", (None, None, "skin_cls_pred")),
+    ("skinnet_dg1_lf0", (None, None, "skin_cls_pred")),
+    ("skinnet_dg0_lf1", (None, None, "skin_cls_pred")),
+])
+def test_networks_against_reference_goldens(name, outs):
+    meta, a = load_golden(name)
+    m = models.__dict__[meta["arch"]](**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"]).to(DEV)
+    d = data_from(a, DEV)
+    res = m(d, d.pred_flow)
+    torch.cuda.synchronize()
+    for r, key in zip(res, outs):
+        if key is not None:
+            assert r.is_cuda and r.shape == a[key].shape
+            assert rel_excess(r, a[key], TOL) <= 0, key
+
+
+def test_jointnet_headline_size_mesh_against_reference_golden():
+    """one 4096-vertex mesh, the size BASELINE.json's metric is quoted on."""
+    meta, a = load_golden("jointnet_4k")
+    mesh = synth.collate([synth.make_mesh(meta["mesh_seed"], n_side=meta["n_side"])])
+    m = models.jointnet_motion(**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
+    d = mesh.to(DEV)
+    _, aggr, shift = m(d, d.pred_flow)
+    assert rel_excess(aggr, a["motion_aggr"], TOL) <= 0
+    assert rel_excess(shift, a["pred_shift"], TOL) <= 0
+
+
+def test_batched_equals_per_mesh_and_is_deterministic():
+    """size-independent properties at a larger batch: a mesh's outputs do not depend on its batch
+    mates and two runs are bit-identical (integer-atomic max is order-free)."""
+    meshes = [synth.make_mesh(50 + i, n_side=s) for i, s in enumerate((32, 24, 32, 16))]
+    m = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
+    synth.load_recipe(m, 77, mild=True).to(DEV)
+    full = synth.collate(meshes).to(DEV)
+    ma, mg, ps = m(full, full.pred_flow)
+    ma2, mg2, ps2 = m(full, full.pred_flow)
+    assert torch.equal(ps, ps2) and torch.equal(ma, ma2) and torch.equal(mg, mg2)
+    off = 0
+    for mesh in meshes:
+        one = synth.collate([mesh]).to(DEV)
+        _, _, p1 = m(one, one.pred_flow)
+        n = mesh.pos.shape[0]
+        assert rel_excess(ps[off:off + n], p1, 2e-5) <= 0
+        off += n
+
+
+def test_against_oracle_on_fresh_inputs():
+    from oracle import nets
+    kw = dict(num_keyframes=5, chn_output=1, aggr_method="attn")
+    ours = synth.load_recipe(models.masknet_motion(**kw).eval(), 909)
+    ref = synth.load_recipe(nets.masknet_motion(**kw).eval(), 909)
+    batch = synth.make_batch([71, 72, 73], n_side=20)
+    want = ref(batch, batch.pred_flow)
+    d = batch.to(DEV)
+    got = ours.to(DEV)(d, d.pred_flow)
+    for g, w in zip(got, want):
+        assert rel_excess(g, w, TOL) <= 0

@@ -1,0 +1,121 @@
+"""CPU: the product's HOST logic (packing, column placement, replica handling, plan wiring) run on a
+torch emulation of the op layer (tests/emulate.py) and held against golden vectors from the
+reference. This does NOT exercise the HIP kernels (tests/test_gpu_*.py do, on an MI355X)."""
+import pytest
+import torch
+
+import morig_amd.runtime as runtime
+from conftest import load_golden
+from emulate import EmuOps
+from helpers import data_from, maxdiff, rel_excess
+from morig_amd import models, synth
+from morig_amd.models import basic_modules as bm, rignet as rn
+
+TOL = 2e-5
+
+
+@pytest.fixture(autouse=True)
+def emulated_ops():
+    runtime._test_ops = EmuOps()
+    yield
+    runtime._test_ops = None
+
+
+def test_state_dict_keys_match_reference_layout():
+    from oracle import nets
+    for arch, kw in [("jointnet_motion", dict(num_keyframes=5, chn_output=3, aggr_method="attn")),
+                     ("masknet_motion", dict(num_keyframes=5, chn_output=1, aggr_method="attn")),
+                     ("skinnet_motion", dict(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5,
+                                             use_motion=True, motion_dim=32))]:
+        ours = models.__dict__[arch](**kw, extra_ignored=1) if False else models.__dict__[arch](**kw)
+        ref = getattr(nets, arch)(**kw)
+        a, b = ours.state_dict(), ref.state_dict()
+        assert list(a.keys()) == list(b.keys())
+        assert all(a[k].shape == b[k].shape for k in a)
+
+
+def test_factories_ignore_extra_kwargs():
+    # training/train_rig.py:83 passes motion_dim to jointnet_motion; train_skin.py:88 passes aggr_method
+    models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn", motion_dim=32)
+    models.skinnet_motion(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True,
+                          motion_dim=32, aggr_method="attn")
+
+
+def test_train_mode_is_refused():
+    m = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn")
+    _, a = load_golden("jointnet_ragged")
+    d = data_from(a)
+    with pytest.raises(NotImplementedError):
+        m.train()(d, d.pred_flow)
+
+
+def test_edgeconvmotion_layer():
+    meta, a = load_golden("edgeconvmotion_c64_h128")
+    m = bm.EdgeConvMotion(nn_x=bm.MLP([128, 128, 128]), nn_pos=bm.MLP([6, 16, 16])).eval()
+    synth.load_recipe(m, meta["recipe_seed"])
+    assert maxdiff(m(a["pos"], a["x"], a["edge_index"]), a["out"]) <= TOL
+
+
+def test_edgeconvmotion_1d_feature():
+    meta, a = load_golden("edgeconvmotion_x1d")
+    m = bm.EdgeConvMotion(nn_x=bm.MLP([2, 32, 32]), nn_pos=bm.MLP([6, 16, 16])).eval()
+    synth.load_recipe(m, meta["recipe_seed"])
+    assert maxdiff(m(a["pos"], a["x"], a["edge_index"]), a["out"]) <= TOL
+
+
+def test_gcumotion_layer():
+    meta, a = load_golden("gcumotion_256_512")
+    m = synth.load_recipe(bm.GCUMotion(256, 512).eval(), meta["recipe_seed"])
+    assert maxdiff(m(a["pos"], a["x"], a["tpl_edge_index"], a["geo_edge_index"]), a["out"]) <= TOL
+
+
+def test_gcu_layer():
+    meta, a = load_golden("gcu_3_32")
+    m = synth.load_recipe(bm.GCU(3, 32).eval(), meta["recipe_seed"])
+    assert maxdiff(m(a["x"], a["tpl_edge_index"], a["geo_edge_index"]), a["out"]) <= TOL
+
+
+@pytest.mark.parametrize("name", ["gcnrig_f3_o32", "gcnrig_f64_o3"])
+def test_gcnrig(name):
+    meta, a = load_golden(name)
+    m = synth.load_recipe(rn.GCNRig(meta["chn_feature"], meta["chn_output"]).eval(), meta["recipe_seed"])
+    out = m(a["pos"], a["feature"], a["tpl_edge_index"], a["geo_edge_index"], a["batch"])
+    assert maxdiff(out, a["out"]) <= TOL
+
+
+def test_temporal_attention_cls_only():
+    meta, a = load_golden("temporalattn_32_64")
+    m = synth.load_recipe(rn.TemporalAttn(32, 2, 64, 512, 64).eval(), meta["recipe_seed"])
+    assert maxdiff(m(a["x"]), a["out"]) <= TOL
+
+
+@pytest.mark.parametrize("name,outs", [
+    ("jointnet_ragged", ("motion_all", "motion_aggr", "pred_shift")),
+    ("jointnet_mean", (None, "motion_aggr", "pred_shift")),
+    ("jointnet_max", (None, "motion_aggr", "pred_shift")),
+    ("masknet_ragged", ("motion_all", "motion_aggr", "pred_mask")),
+    ("skinnet_ragged", ("motion_all", "motion_aggr", "skin_cls_pred")),
+    ("skinnet_dg1_lf1", (None, None, "skin_cls_pred")),
+    ("skinnet_dg1_lf0", (None, None, "skin_cls_pred")),
+    ("skinnet_dg0_lf1", (None, None, "skin_cls_pred")),
+])
+def test_full_networks(name, outs):
+    meta, a = load_golden(name)
+    m = models.__dict__[meta["arch"]](**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"])
+    d = data_from(a)
+    res = m(d, d.pred_flow)
+    for r, key in zip(res, outs):
+        if key is not None:
+            assert r.shape == a[key].shape and r.is_contiguous()
+            assert rel_excess(r, a[key], TOL) <= 0, key     # skin logits reach |30|: normalise by output scale
+
+
+def test_packed_cache_invalidation():
+    meta, a = load_golden("gcu_3_32")
+    m = bm.GCU(3, 32).eval()
+    synth.load_recipe(m, 1)
+    o1 = m(a["x"], a["tpl_edge_index"], a["geo_edge_index"])
+    synth.load_recipe(m, meta["recipe_seed"])           # load_state_dict must drop the packed cache
+    o2 = m(a["x"], a["tpl_edge_index"], a["geo_edge_index"])
+    assert maxdiff(o2, a["out"]) <= TOL and maxdiff(o1, o2) > 1e-3
