@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- meshes/sec of the jointnet_motion eval-mode forward on synthetic 4 k-vertex meshes.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one forward of `jointnet_motion(num_keyframes=5, chn_output=3, aggr_method='attn')` over
+a device-resident batch of 64 synthetic 4096-vertex meshes PER GPU (BASELINE.json configs[1]; weak
+scaling), including the COO->CSR graph preparation and, for N > 1, the RCCL all-gather of
+pred_shift. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def _mesh(args):
+    from morig_amd import synth
+    return synth.make_mesh(args[0], n_side=args[1], with_skin=False)
+
+
+def build_batch(seeds, n_side):
+    from morig_amd import synth
+    import multiprocessing as mp
+    nproc = max(1, min(len(seeds), (os.cpu_count() or 8) // 4, 32))
+    if nproc > 1:
+        torch.set_num_threads(1)
+        with mp.get_context("fork").Pool(nproc) as pool:
+            meshes = pool.map(_mesh, [(s, n_side) for s in seeds])
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // 2))
+    else:
+        meshes = [_mesh((s, n_side)) for s in seeds]
+    b = synth.collate(meshes)
+    b.num_graphs = len(seeds)
+    return b
+
+
+def cpu_baseline(seconds, n_side, rank0_batch_seed):
+    """the CPU oracle (oracle/nets.py, 'port') timed on this host's cores on a bounded sample."""
+    from morig_amd import synth
+    from oracle import nets
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    kw = dict(num_keyframes=5, chn_output=3, aggr_method="attn")
+    m = synth.load_recipe(nets.jointnet_motion(**kw).eval(), 0, mild=True)
+    n_mesh = 2
+    batch = synth.collate([synth.make_mesh(rank0_batch_seed + i, n_side=n_side, with_skin=False) for i in range(n_mesh)])
+    with torch.no_grad():
+        m(batch, batch.pred_flow)                                   # warm-up (thread pools, allocator)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            m(batch, batch.pred_flow)
+            reps += 1
+            if time.perf_counter() - t0 >= seconds or reps >= 50:
+                break
+        dt = time.perf_counter() - t0
+    return dict(value=round(n_mesh * reps / dt, 4), unit="meshes/s", cores=cores, kind="port",
+                sample=f"{reps} forwards of a {n_mesh}-mesh batch ({n_side * n_side} vertices each), torch {torch.__version__} CPU, "
+                       f"{cores} threads, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="meshes per GPU")
+    ap.add_argument("--n-side", type=int, default=64, help="mesh grid side (64 -> 4096 vertices)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from morig_amd import dist as mdist, models, native, synth
+
+    B = args.batch
+    data = build_batch([1000 + rank * B + i for i in range(B)], args.n_side).to(dev)
+    model = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
+    synth.load_recipe(model, 0, mild=True).to(dev)
+    n_vert = data.pos.shape[0]
+
+    def step():
+        motion_all, motion_aggr, pred_shift = model(data, data.pred_flow)
+        gathered = mdist.all_gather_rows(pred_shift, equal_rows=True) if world > 1 else pred_shift
+        return gathered
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        fence()
+        native.prof_reset()
+        native.prof_enable(True)                      # HIP events around every launch, on the launch stream
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t0
+        native.prof_enable(False)
+    prof = native.prof_collect()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    assert out.shape[0] == n_vert * world and bool(torch.isfinite(out).all())
+
+    if rank == 0:
+        total_ms = sum(v["ms"] for v in prof.values())
+        dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        roof = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                    frac=round(achieved / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                    launches_per_step=dom["launches"] / args.steps,
+                    avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+                    share_of_gpu_time=round(dom["ms"] / total_ms, 4))
+        breakdown = {k: dict(ms_per_step=round(v["ms"] / args.steps, 3),
+                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+                             launches_per_step=v["launches"] / args.steps)
+                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        all_flops = sum(v["flops"] for v in prof.values())
+        res = {
+            "metric": "meshes/sec jointnet_motion forward, 4 k-vert synthetic",
+            "value": round(world * B * args.steps / dt, 2), "unit": "meshes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"jointnet_motion(num_keyframes=5, attn) eval forward, batch={B} synthetic "
+                                   f"{args.n_side * args.n_side}-vertex meshes per GPU (BASELINE.json configs[1]), "
+                                   "COO->CSR prep + forward" + (" + RCCL all-gather of pred_shift" if world > 1 else ""),
+                       "meshes_per_gpu": B, "vertices_per_mesh": args.n_side * args.n_side,
+                       "parallelism": f"mesh-sharded dp{world}"},
+            "roofline": roof,
+            "whole_forward_tflops": round(all_flops / args.steps / (dt / args.steps) / 1e12, 2),
+            "kernels": breakdown,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,8 +148,8 @@ using namespace morig;
 extern "C" int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes,
                                int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
                                int32_t* cursor, int32_t* status, void* stream) {
-    if (!edge_index || !rowptr || !src_sorted || !dst_sorted || !cursor || !status) return MORIG_E_INVALID;
-    if (n_edges < 0 || n_nodes <= 0) return MORIG_E_INVALID;
+    if (!rowptr || !src_sorted || !dst_sorted || !cursor || !status) return MORIG_E_INVALID;
+    if (n_edges < 0 || n_nodes <= 0 || (n_edges > 0 && !edge_index)) return MORIG_E_INVALID;
     if (n_edges + (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;   // int32 edge ids
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nb = cdiv(n_nodes, SCAN_B);

@@ -76,16 +76,18 @@ def make_mesh(seed: int, n_side: int = 64, geo_radius: Optional[float] = None,
     # geodesic-ball edges, Euclidean distance standing in for geodesic distance
     if geo_radius is None:
         geo_radius = 0.06 * 64.0 / n_side
-    d2 = ((pos[:, None, :] - pos[None, :, :]) ** 2).sum(-1)
-    np.fill_diagonal(d2, 1e9)
-    src, dst = [], []
-    for i in range(V):
-        ball = np.nonzero(d2[i] <= geo_radius * geo_radius)[0]
-        if len(ball) > geo_max_nn:
-            ball = rng.choice(ball, geo_max_nn, replace=False)
-        src.append(np.full(len(ball), i, dtype=np.int64))
-        dst.append(ball.astype(np.int64))
-    geo = np.stack([np.concatenate(src), np.concatenate(dst)], axis=0)
+    pt = torch.from_numpy(pos)
+    d2 = torch.cdist(pt, pt, compute_mode="donot_use_mm_for_euclid_dist") ** 2
+    d2.fill_diagonal_(1e9)
+    # random subset of <= geo_max_nn ball members per row (np.random.choice in the reference):
+    # the members with the smallest random keys
+    keys = torch.from_numpy(rng.random((V, V), dtype=np.float32))
+    keys[d2 > geo_radius * geo_radius] = 2.0
+    k = min(geo_max_nn, V - 1)
+    val, pick = torch.topk(keys, k, dim=1, largest=False, sorted=True)
+    valid = val < 2.0
+    rows = torch.arange(V)[:, None].expand(-1, k)
+    geo = torch.stack([rows[valid], pick[valid]], dim=0).numpy().astype(np.int64)
 
     loops = np.stack([np.arange(V), np.arange(V)], axis=0)
     tpl = np.concatenate([tpl, loops], axis=1)     # datasets/dataset_rig.py:121

@@ -10,6 +10,6 @@ from morig_amd import native
 print("device_info:", native.device_info())
 PY
 } > gpurun_out/env.txt 2>&1
-python -m pytest tests/test_gpu_kernels.py -q -m gpu -x --timeout=600 2>&1 | tail -60 > gpurun_out/pytest_kernels.txt
+python -m pytest tests/test_gpu_kernels.py -q -m gpu --timeout=600 2>&1 | tail -60 > gpurun_out/pytest_kernels.txt
 python -m pytest tests/test_gpu_networks.py -q -m gpu --timeout=900 2>&1 | tail -80 > gpurun_out/pytest_networks.txt
 tail -5 gpurun_out/pytest_kernels.txt; tail -5 gpurun_out/pytest_networks.txt
