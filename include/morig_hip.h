@@ -59,6 +59,13 @@ int         morig_device_info(int* cu_count, int* lds_bytes_per_cu, int* clock_k
 int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes,
                     int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
                     int32_t* cursor, int32_t* status, void* stream);
+/* bipartite form used by PointConv (PyG applies remove_self_loops/add_self_loops(num_nodes =
+ * min(N_src, N_dst)) to the raw (source, target) index pairs even though they index different sets):
+ * sources in [0, n_src_nodes), targets in [0, n_nodes), n_src_nodes >= n_nodes; pairs with a negative
+ * index (unused ball-query slots) are skipped when skip_negative != 0. */
+int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_t n_src_nodes, int32_t n_nodes,
+                              int32_t skip_negative, int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
+                              int32_t* cursor, int32_t* status, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Fused dense layer:  Y = scale * act(X * W^T + bias + rowbias[seg[row]]) + shift
@@ -115,6 +122,24 @@ typedef struct morig_edgeconv_args {
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 
+/* PointConv (3-layer local_nn, models/basic_modules.py:72,82-84; PyG PointConv.message) in two passes:
+ *   morig_edge_hidden : Z[e] = s2*relu(W2 (s1*relu(A_i + B_j) + t1) + b2) + t2 for every sorted edge e (< E');
+ *                       same arguments as morig_edgeconv, `out` = Z [edge_capacity][ldo], replicas = 1
+ *   morig_segmax_gemm : out[i] = max_{e -> i} scale*act(W X[e] + bias) + shift   (layer 3 + aggr='max')
+ * With x = None the message is the offset alone; with features it is [x_j ‖ pos_j - pos_i], whose first
+ * Linear splits per vertex exactly like EdgeConv's: B_j = W1 [x_j ‖ pos_j] + b1, A_i = -W1p pos_i.        */
+int morig_edge_hidden(const morig_edgeconv_args* a, void* stream);
+typedef struct morig_segmax_args {
+    int32_t N, K;
+    const float* X; int32_t ldx;         /* per-edge rows [edge_capacity][ldx]                       */
+    const float* W; int32_t ldw;         /* packed like morig_gemm_args.W (rows padded to 32/64/128/256) */
+    const float* bias; const float* scale; const float* shift; int32_t relu;
+    const int32_t* rowptr; const int32_t* dst_sorted; int32_t n_nodes;
+    int32_t edge_capacity; int32_t edge_count;
+    float* out; int32_t ldo;             /* [n_nodes][ldo]                                          */
+} morig_segmax_args;
+int morig_segmax_gemm(const morig_segmax_args* a, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Small vertex-parallel operators.
  */
@@ -148,6 +173,36 @@ int morig_cls_attention(const float* x, int32_t n, int32_t T, int32_t C, int32_t
 /* reductions over keyframes for aggr_method 'mean' / 'max' (models/rignet.py:92-95):
  * x: [n][T][C] -> y[n][C]; mode 0 = mean, 1 = max */
 int morig_frame_reduce(const float* x, int32_t n, int32_t T, int32_t C, int32_t mode, float* y, int32_t ldy, void* stream);
+
+/* --------------------------------------------------------------------------------------------
+ * CorrNet point branch (models/corrnet.py:50-73, models/basic_modules.py:66-138). Clouds are contiguous
+ * row ranges given by int32 offset arrays ptr[n_clouds + 1] (PyG's sorted `batch` vector).
+ */
+/* torch_cluster.fps (basic_modules.py:75): per cloud out_ptr[b+1]-out_ptr[b] samples, first = ptr[b] +
+ * start[b] (start == NULL: first point), then repeatedly the point farthest from the chosen set
+ * (lowest index on ties). idx_out: GLOBAL row indices, clouds concatenated. */
+int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, const int32_t* out_ptr, const int32_t* start,
+              int32_t n_clouds, int32_t max_cloud_points, int32_t* idx_out, void* stream);
+/* torch_cluster.radius, CUDA-kernel semantics (basic_modules.py:77): for every centre y the first max_nbrs
+ * points x of its cloud, in index order, with |x-y|^2 < r^2. coo: int64 [2][n_centres*max_nbrs]
+ * (row 0 = x index, row 1 = centre index; unused slots -1), the layout morig_csr_build_bipartite reads. */
+int morig_ball_query(const float* x, int32_t ldx, const int32_t* ptr_x, const float* y, int32_t ldy,
+                     const int32_t* ptr_y, int32_t n_clouds, int32_t n_centres, float radius,
+                     int32_t max_nbrs, int64_t* coo, void* stream);
+/* torch_geometric.nn.knn_interpolate (basic_modules.py:134), k <= 3: weights 1/clamp(d^2, 1e-16).
+ * idx_ws/wgt_ws: scratch [n_targets][3]. */
+int morig_knn_interpolate(const float* feat, int32_t ldf, int32_t C, const float* pos_x, int32_t ldx,
+                          const int32_t* ptr_x, const float* pos_y, int32_t ldy, const int32_t* ptr_y,
+                          int32_t n_clouds, int32_t n_targets, int32_t max_targets_per_cloud, int32_t k,
+                          int32_t* idx_ws, float* wgt_ws, float* out, int32_t ldo, void* stream);
+/* knn(out_pts, out_vtx, 1, cosine=True) on L2-normalised rows (corrnet.py:64): arg-max dot product
+ * within the cloud; C must be 64. */
+int morig_cosine_nn(const float* v, int32_t ldv, const int32_t* ptr_v, const float* p, int32_t ldp,
+                    const int32_t* ptr_p, int32_t n_clouds, int32_t max_rows_per_cloud, int32_t C,
+                    int32_t* nn, float* sim, void* stream);
+/* dst[r] = src[idx[r]] (pos[idx], out_pts[nn]); idx < 0 -> zeros */
+int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t rows, int32_t cols,
+                      float* dst, int32_t ldd, void* stream);
 
 /* --------------------------------------------------------------------------------------------
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline object.

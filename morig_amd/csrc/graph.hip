@@ -13,11 +13,13 @@ constexpr int SCAN_T = 256;          // threads per scan block
 constexpr int SCAN_I = 8;            // items per thread
 constexpr int SCAN_B = SCAN_T * SCAN_I;
 
-__global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cnt, int* status) {
+__global__ void csr_count_kernel(const int64_t* __restrict__ ei, int64_t E, int nsrc, int n, int skipneg,
+                                 int* __restrict__ cnt, int* status) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += stride) {
         const int64_t s = ei[e], d = ei[E + e];
-        if (s < 0 || s >= n || d < 0 || d >= n) { *status = 1; continue; }
+        if (skipneg && (s < 0 || d < 0)) continue;
+        if (s < 0 || s >= nsrc || d < 0 || d >= n) { *status = 1; continue; }
         if (s != d) atomicAdd(&cnt[d], 1);
     }
 }
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const int* cnt_in, i
     }
 }
 
-__global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E, int n, int* __restrict__ cursor,
+__global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E, int nsrc, int n, int* __restrict__ cursor,
                                 int* __restrict__ srcS, int* __restrict__ dstS) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t total = E + n;
@@ -96,7 +98,7 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E, int n
         int s, d;
         if (e < E) {
             const int64_t s64 = ei[e], d64 = ei[E + e];
-            if (s64 < 0 || s64 >= n || d64 < 0 || d64 >= n || s64 == d64) continue;
+            if (s64 < 0 || s64 >= nsrc || d64 < 0 || d64 >= n || s64 == d64) continue;
             s = (int)s64; d = (int)d64;
         } else {
             s = d = (int)(e - E);
@@ -148,6 +150,13 @@ using namespace morig;
 extern "C" int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes,
                                int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
                                int32_t* cursor, int32_t* status, void* stream) {
+    return morig_csr_build_bipartite(edge_index, n_edges, n_nodes, n_nodes, 0, rowptr, src_sorted, dst_sorted, cursor, status, stream);
+}
+
+extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_t n_src_nodes, int32_t n_nodes,
+                                         int32_t skip_negative, int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
+                                         int32_t* cursor, int32_t* status, void* stream) {
+    if (n_src_nodes < n_nodes) return MORIG_E_INVALID;
     if (!rowptr || !src_sorted || !dst_sorted || !cursor || !status) return MORIG_E_INVALID;
     if (n_edges < 0 || n_nodes <= 0 || (n_edges > 0 && !edge_index)) return MORIG_E_INVALID;
     if (n_edges + (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;   // int32 edge ids
@@ -158,7 +167,7 @@ extern "C" int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32
     MORIG_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)(n_nodes + 1) * sizeof(int), s));
     MORIG_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), s));
     if (n_edges > 0) {
-        hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, edge_index, n_edges, n_nodes, cursor, status);
+        hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, edge_index, n_edges, n_src_nodes, n_nodes, skip_negative, cursor, status);
         MORIG_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, bsum);
@@ -167,7 +176,7 @@ extern "C" int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, bsum, rowptr, cursor);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(csr_fill_kernel, dim3(grid_for(n_edges + n_nodes)), dim3(256), 0, s, edge_index, n_edges, n_nodes,
+    hipLaunchKernelGGL(csr_fill_kernel, dim3(grid_for(n_edges + n_nodes)), dim3(256), 0, s, edge_index, n_edges, n_src_nodes, n_nodes,
                        cursor, src_sorted, dst_sorted);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;

@@ -1,1 +1,337 @@
+// CorrNet point-branch operators (models/corrnet.py:50-73, models/basic_modules.py:66-138): farthest point
+// sampling, ball query, k-NN (k<=3) inverse-distance interpolation, cosine 1-NN, row gather.
+// All are distance scans over one cloud at a time: HBM/LDS-bound integer+fp32 work, no GEMM shape.
+//
+// Squared distances are evaluated as ((dx*dx + dy*dy) + dz*dz) with every product and sum rounded to
+// fp32 separately (__fmul_rn/__fadd_rn, no FMA contraction), so arg-max / arg-min / "< r^2" decisions
+// are bit-identical to the fp32 restatement they are tested against (ties -> lowest index).
 #include "common.h"
+
+namespace morig {
+
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Farthest point sampling: one 1024-thread workgroup per cloud; every thread keeps PPT points and their
+// running min-distance in registers; per sample one block-wide arg-max (value desc, index asc).
+// ---------------------------------------------------------------------------------------------------
+constexpr int FPS_T = 1024;
+
+template <int PPT>
+__global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
+                                                    const int* __restrict__ out_ptr, const int* __restrict__ start,
+                                                    int* __restrict__ idx_out) {
+    __shared__ float s_val[FPS_T / 64];
+    __shared__ int s_idx[FPS_T / 64];
+    __shared__ float s_cur[3];
+    __shared__ int s_sel;
+    const int b = blockIdx.x;
+    const int p0 = ptr[b], n = ptr[b + 1] - p0;
+    const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
+    if (n <= 0 || m <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = tid + i * FPS_T;
+        if (j < n) {
+            const float* q = pos + (size_t)(p0 + j) * ldp;
+            px[i] = q[0]; py[i] = q[1]; pz[i] = q[2];
+            dist[i] = INFINITY;
+        } else { px[i] = py[i] = pz[i] = 0.f; dist[i] = -1.f; }        // never selected
+    }
+    int cur = start ? start[b] : 0;
+    if (cur < 0 || cur >= n) cur = 0;
+    for (int s = 0; s < m; ++s) {
+        if (tid == 0) {
+            idx_out[o0 + s] = p0 + cur;
+            const float* q = pos + (size_t)(p0 + cur) * ldp;
+            s_cur[0] = q[0]; s_cur[1] = q[1]; s_cur[2] = q[2];
+        }
+        __syncthreads();
+        if (s + 1 == m) break;
+        const float cx = s_cur[0], cy = s_cur[1], cz = s_cur[2];
+        float bv = -1.f; int bi = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int j = tid + i * FPS_T;
+            if (j < n) {
+                const float d = sqdist3(px[i], py[i], pz[i], cx, cy, cz);
+                dist[i] = fminf(dist[i], d);
+                if (dist[i] > bv) { bv = dist[i]; bi = j; }        // j ascending within a thread: first max kept
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { s_val[w] = bv; s_idx[w] = bi; }
+        __syncthreads();
+        if (w == 0) {
+            float v = lane < FPS_T / 64 ? s_val[lane] : -2.f;
+            int ix = lane < FPS_T / 64 ? s_idx[lane] : 0x7fffffff;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                const float ov = __shfl_xor(v, o, 64);
+                const int oi = __shfl_xor(ix, o, 64);
+                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+            }
+            if (lane == 0) s_sel = ix;
+        }
+        __syncthreads();
+        cur = s_sel;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Ball query (torch_cluster.radius CUDA semantics): one wave per centre scans its cloud in index order,
+// 64 points per step; ballot + popcount keeps the first `max_nbrs` hits with d^2 < r^2 in order.
+// Writes an int64 COO (row 0 = source point, row 1 = centre), unused slots = -1, ready for morig_csr_build.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ x, int ldx, const int* __restrict__ ptr_x,
+                                                         const float* __restrict__ y, int ldy, const int* __restrict__ ptr_y,
+                                                         int n_clouds, int n_centres, float r2, int max_nbrs,
+                                                         int64_t* __restrict__ coo) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= n_centres) return;
+    // cloud of this centre: binary search in ptr_y
+    int lo = 0, hi = n_clouds;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ptr_y[mid] <= k) lo = mid; else hi = mid; }
+    const int xs = ptr_x[lo], xe = ptr_x[lo + 1];
+    const float cx = y[(size_t)k * ldy], cy = y[(size_t)k * ldy + 1], cz = y[(size_t)k * ldy + 2];
+    const int64_t E = (int64_t)n_centres * max_nbrs;
+    int64_t* src = coo + (int64_t)k * max_nbrs;
+    int64_t* dst = coo + E + (int64_t)k * max_nbrs;
+    int count = 0;
+    for (int base = xs; base < xe && count < max_nbrs; base += 64) {
+        const int j = base + lane;
+        bool hit = false;
+        if (j < xe) {
+            const float* q = x + (size_t)j * ldx;
+            hit = sqdist3(cx, cy, cz, q[0], q[1], q[2]) < r2;      // (y - x)^2: same value as (x - y)^2
+        }
+        const unsigned long long mask = __ballot(hit);
+        const int rank = count + __popcll(mask & ((1ull << lane) - 1ull));
+        if (hit && rank < max_nbrs) { src[rank] = j; dst[rank] = k; }
+        count += __popcll(mask);
+    }
+    if (count > max_nbrs) count = max_nbrs;
+    for (int s = count + lane; s < max_nbrs; s += 64) { src[s] = -1; dst[s] = -1; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// k-NN (k <= 3) of every target among the sources of its cloud + inverse-squared-distance weights.
+// One thread per target; sources staged through LDS in tiles of 1024 points. Order: (d^2, index) ascending.
+// ---------------------------------------------------------------------------------------------------
+constexpr int KNN_TILE = 1024;
+__global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xs, int ldx, const int* __restrict__ ptr_x,
+                                                   const float* __restrict__ yt, int ldy, const int* __restrict__ ptr_y,
+                                                   int n_clouds, int k, int* __restrict__ idx, float* __restrict__ wgt) {
+    __shared__ float sx[KNN_TILE * 3];
+    // blocks are assigned per (cloud, chunk of 256 targets): blockIdx.y = cloud
+    const int c = blockIdx.y;
+    const int ys = ptr_y[c], ye = ptr_y[c + 1];
+    const int x0 = ptr_x[c], x1 = ptr_x[c + 1];
+    const int t = ys + blockIdx.x * blockDim.x + threadIdx.x;
+    if (ys + (int)(blockIdx.x * blockDim.x) >= ye) return;          // block-uniform
+    const bool live = t < ye;
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (live) { const float* q = yt + (size_t)t * ldy; tx = q[0]; ty = q[1]; tz = q[2]; }
+    float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
+    int i0 = -1, i1 = -1, i2 = -1;
+    for (int base = x0; base < x1; base += KNN_TILE) {
+        const int cnt = min(KNN_TILE, x1 - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            const float* q = xs + (size_t)(base + i) * ldx;
+            sx[3 * i] = q[0]; sx[3 * i + 1] = q[1]; sx[3 * i + 2] = q[2];
+        }
+        __syncthreads();
+        if (live) {
+            for (int i = 0; i < cnt; ++i) {
+                const float d = sqdist3(sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], tx, ty, tz);   // (x - y)^2
+                const int j = base + i;
+                if (d < d2) {                        // strict: on ties the earlier (lower) index stays ahead
+                    if (d < d1) {
+                        d2 = d1; i2 = i1;
+                        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; } else { d1 = d; i1 = j; }
+                    } else { d2 = d; i2 = j; }
+                }
+            }
+        }
+    }
+    if (!live) return;
+    const float dd[3] = {d0, d1, d2};
+    const int ii[3] = {i0, i1, i2};
+    for (int s = 0; s < 3; ++s) {
+        const bool ok = s < k && ii[s] >= 0;
+        idx[(size_t)t * 3 + s] = ok ? ii[s] : -1;
+        wgt[(size_t)t * 3 + s] = ok ? 1.0f / fmaxf(dd[s], 1e-16f) : 0.f;
+    }
+}
+
+// out[t][c] = sum_s w_s * x[idx_s][c] / sum_s w_s   (scatter_add order s = 0,1,2; division last)
+__global__ __launch_bounds__(256) void knn_interp_kernel(const float* __restrict__ x, int ldx, int C, const int* __restrict__ idx,
+                                                         const float* __restrict__ wgt, int n_targets, float* __restrict__ out, int ldo) {
+    const int64_t total = (int64_t)n_targets * C;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t t = i / C; const int c = (int)(i - t * C);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int j = idx[t * 3 + s];
+            if (j >= 0) {
+                const float w = wgt[t * 3 + s];
+                num = __fadd_rn(num, __fmul_rn(x[(size_t)j * ldx + c], w));
+                den = __fadd_rn(den, w);
+            }
+        }
+        out[t * ldo + c] = num / den;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// cosine 1-NN (models/corrnet.py:64 / :68-73): for every vertex the point of the same cloud with the
+// largest dot product (rows are already L2-normalised). One thread per vertex (its C-vector in
+// registers), points streamed through LDS. Ties -> lowest index.
+// ---------------------------------------------------------------------------------------------------
+constexpr int COS_C = 64;
+constexpr int COS_TILE = 128;
+__global__ __launch_bounds__(256) void cosine_nn_kernel(const float* __restrict__ v, int ldv, const int* __restrict__ ptr_v,
+                                                        const float* __restrict__ p, int ldp, const int* __restrict__ ptr_p,
+                                                        int* __restrict__ nn, float* __restrict__ sim) {
+    __shared__ float sp[COS_TILE * COS_C];
+    const int c = blockIdx.y;
+    const int vs = ptr_v[c], ve = ptr_v[c + 1];
+    const int ps = ptr_p[c], pe = ptr_p[c + 1];
+    if (vs + (int)(blockIdx.x * blockDim.x) >= ve) return;
+    const int t = vs + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = t < ve;
+    float q[COS_C];
+#pragma unroll
+    for (int i = 0; i < COS_C; ++i) q[i] = live ? v[(size_t)t * ldv + i] : 0.f;
+    float best = -INFINITY; int bi = -1;
+    for (int base = ps; base < pe; base += COS_TILE) {
+        const int cnt = min(COS_TILE, pe - base);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt * COS_C; i += blockDim.x) {
+            const int r = i / COS_C, cc = i - r * COS_C;
+            sp[i] = p[(size_t)(base + r) * ldp + cc];
+        }
+        __syncthreads();
+        for (int r = 0; r < cnt; ++r) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int i = 0; i < COS_C; i += 4) {
+                a0 += q[i] * sp[r * COS_C + i];
+                a1 += q[i + 1] * sp[r * COS_C + i + 1];
+                a2 += q[i + 2] * sp[r * COS_C + i + 2];
+                a3 += q[i + 3] * sp[r * COS_C + i + 3];
+            }
+            const float s = (a0 + a1) + (a2 + a3);
+            if (s > best) { best = s; bi = base + r; }
+        }
+    }
+    if (live) { nn[t] = bi; sim[t] = best; }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, int lds, const int* __restrict__ idx, int rows, int cols,
+                                   float* __restrict__ dst, int ldd) {
+    const int64_t total = (int64_t)rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / cols; const int c = (int)(i - r * cols);
+        const int j = idx[r];
+        dst[r * ldd + c] = j >= 0 ? src[(size_t)j * lds + c] : 0.f;
+    }
+}
+
+}  // namespace morig
+
+using namespace morig;
+
+extern "C" int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, const int32_t* out_ptr, const int32_t* start,
+                         int32_t n_clouds, int32_t max_cloud_points, int32_t* idx_out, void* stream) {
+    if (!pos || !ptr || !out_ptr || !idx_out || n_clouds <= 0 || ldp < 3 || max_cloud_points <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int ppt = cdiv(max_cloud_points, FPS_T);
+    ProfScope ps(K_FPS, s, 0.0, 0.0);
+#define MORIG_FPS_CASE(P) hipLaunchKernelGGL((fps_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
+    if (ppt <= 1) MORIG_FPS_CASE(1);
+    else if (ppt <= 2) MORIG_FPS_CASE(2);
+    else if (ppt <= 4) MORIG_FPS_CASE(4);
+    else if (ppt <= 8) MORIG_FPS_CASE(8);
+    else if (ppt <= 16) MORIG_FPS_CASE(16);
+    else if (ppt <= 32) MORIG_FPS_CASE(32);
+    else return MORIG_E_UNSUPPORTED;               // > 32768 points per cloud
+#undef MORIG_FPS_CASE
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_ball_query(const float* x, int32_t ldx, const int32_t* ptr_x, const float* y, int32_t ldy,
+                                const int32_t* ptr_y, int32_t n_clouds, int32_t n_centres, float radius,
+                                int32_t max_nbrs, int64_t* coo, void* stream) {
+    if (!x || !y || !ptr_x || !ptr_y || !coo || n_clouds <= 0 || n_centres < 0 || max_nbrs <= 0 || ldx < 3 || ldy < 3) return MORIG_E_INVALID;
+    if (n_centres == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const float r2 = (float)((double)radius * (double)radius);
+    ProfScope ps(K_BALL, s, 0.0, 16.0 * n_centres * max_nbrs);
+    hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(n_centres, 4)), dim3(256), 0, s, x, ldx, ptr_x, y, ldy, ptr_y, n_clouds,
+                       n_centres, r2, max_nbrs, coo);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_knn_interpolate(const float* feat, int32_t ldf, int32_t C, const float* pos_x, int32_t ldx,
+                                     const int32_t* ptr_x, const float* pos_y, int32_t ldy, const int32_t* ptr_y,
+                                     int32_t n_clouds, int32_t n_targets, int32_t max_targets_per_cloud, int32_t k,
+                                     int32_t* idx_ws, float* wgt_ws, float* out, int32_t ldo, void* stream) {
+    if (!feat || !pos_x || !pos_y || !ptr_x || !ptr_y || !idx_ws || !wgt_ws || !out) return MORIG_E_INVALID;
+    if (k < 1 || k > 3) return MORIG_E_UNSUPPORTED;
+    if (n_clouds <= 0 || n_targets < 0 || C <= 0 || ldo < C || ldf < C || ldx < 3 || ldy < 3) return MORIG_E_INVALID;
+    if (n_targets == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_KNN_INTERP, s, 0.0, 4.0 * n_targets * (double)C * (k + 1));
+    hipLaunchKernelGGL(knn3_kernel, dim3(cdiv(max_targets_per_cloud, 256), n_clouds), dim3(256), 0, s, pos_x, ldx, ptr_x, pos_y, ldy,
+                       ptr_y, n_clouds, k, idx_ws, wgt_ws);
+    MORIG_LAUNCH_CHECK();
+    int64_t blocks = ((int64_t)n_targets * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(knn_interp_kernel, dim3((int)blocks), dim3(256), 0, s, feat, ldf, C, idx_ws, wgt_ws, n_targets, out, ldo);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_cosine_nn(const float* v, int32_t ldv, const int32_t* ptr_v, const float* p, int32_t ldp,
+                               const int32_t* ptr_p, int32_t n_clouds, int32_t max_rows_per_cloud, int32_t C,
+                               int32_t* nn, float* sim, void* stream) {
+    if (!v || !p || !ptr_v || !ptr_p || !nn || !sim || n_clouds <= 0 || max_rows_per_cloud <= 0) return MORIG_E_INVALID;
+    if (C != COS_C) return MORIG_E_UNSUPPORTED;
+    if (ldv < C || ldp < C) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_COSINE_NN, s, 0.0, 0.0);
+    hipLaunchKernelGGL(cosine_nn_kernel, dim3(cdiv(max_rows_per_cloud, 256), n_clouds), dim3(256), 0, s, v, ldv, ptr_v, p, ldp, ptr_p, nn, sim);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t rows, int32_t cols,
+                                 float* dst, int32_t ldd, void* stream) {
+    if (!src || !idx || !dst || rows < 0 || cols <= 0 || ldd < cols) return MORIG_E_INVALID;
+    if (rows == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int64_t blocks = ((int64_t)rows * cols + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    ProfScope ps(K_COPY, s, 0.0, 8.0 * rows * cols);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((int)blocks), dim3(256), 0, s, src, lds, idx, rows, cols, dst, ldd);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}

@@ -78,11 +78,13 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const Ti
     else { rep = lin / p.tiles_per_rep; tm = lin - rep * p.tiles_per_rep; tn = 0; }
     const int row0 = tm * BM;
 
+    constexpr bool EDGE_ROWS = (LOAD == LOAD_EDGE) || (MODE == MODE_EDGEMAX);   // tile rows = sorted edges
     int Etot = 0;
-    if (LOAD == LOAD_EDGE) {
+    if (EDGE_ROWS) {
         Etot = p.rowptr[p.n_nodes];
         if (row0 >= Etot) return;               // block-uniform
     }
+    const int Mlim = EDGE_ROWS ? Etot : p.M;
 
     // ---- loader set-up -------------------------------------------------------------------
     const int lrow = tid / TPR, lkq = tid % TPR;
@@ -94,10 +96,12 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const Ti
         const int r = lrow + i * RPP;
         const int row = row0 + r;
         if (LOAD == LOAD_DENSE) {
-            va[i] = row < p.M;
+            va[i] = row < Mlim;
             pa[i] = p.X + (size_t)(va[i] ? row : 0) * p.ldx + 4 * lkq;
             pb[i] = nullptr;
-            if (MODE != MODE_STORE || p.seg != nullptr) {
+            if (MODE == MODE_EDGEMAX) {
+                if (lkq == 0) sseg[r] = va[i] ? p.dstS[row] : -1;
+            } else if (MODE != MODE_STORE || p.seg != nullptr) {
                 if (lkq == 0) sseg[r] = (va[i] && p.seg) ? p.seg[row] : -1;
             }
         } else {
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const Ti
                 for (int r = 0; r < 16; ++r) {
                     const int rl = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const int row = row0 + rl;
-                    if (row < p.M) {
+                    if (row < Mlim) {
                         float v = acc[mt][nt][r] + b;
                         if (p.rowbias) v += p.rowbias[(size_t)sseg[rl] * p.ld_rowbias + col];
                         if (p.relu) v = v > 0.f ? v : 0.f;
@@ -352,6 +356,69 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         ProfScope ps(K_GEMM_BN32, s, flops, bytes);
         return launch_tile<32, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m, s);
     }
+}
+
+static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
+    if (!a || !a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
+    if (!a->s1 || !a->t1 || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
+    if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
+    if ((a->lda & 3) || (a->ldb & 3) || (a->ldw & 3) || !aligned16(a->A) || !aligned16(a->B) || !aligned16(a->W2) ||
+        !aligned16(a->s1) || !aligned16(a->t1)) return MORIG_E_INVALID;
+    if (a->ldo < a->H || a->lda < a->H || a->ldb < a->H || a->ldw < a->H) return MORIG_E_INVALID;
+    p.M = a->edge_capacity; p.N = a->H; p.K = a->H;
+    p.W = a->W2; p.ldw = a->ldw;
+    p.bias = a->b2; p.scale = a->s2; p.shift = a->t2; p.relu = 1;
+    p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb;
+    p.rowptr = a->rowptr; p.srcS = a->src_sorted; p.dstS = a->dst_sorted;
+    p.n_nodes = a->n_nodes; p.rep_in = a->in_rep_stride; p.rep_out = a->out_rep_stride;
+    p.s1 = a->s1; p.t1 = a->t1;
+    p.Y = a->out; p.ldy = a->ldo;
+    p.tiles_per_rep = cdiv(a->edge_capacity, 128);
+    p.tiles_n = 1;
+    return MORIG_OK;
+}
+
+extern "C" int morig_edge_hidden(const morig_edgeconv_args* a, void* stream) {
+    TileParams p = {};
+    const int st = edge_common(a, p);
+    if (st != MORIG_OK) return st;
+    if (a->replicas != 1) return MORIG_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity);
+    const double flops = 2.0 * E * a->H * (double)a->H;
+    ProfScope ps(K_POINTCONV, s, flops, 4.0 * 3.0 * E * a->H);
+    switch (a->H) {
+        case 32:  return launch_tile<32, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        case 64:  return launch_tile<64, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        case 128: return launch_tile<128, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        case 256: return launch_tile<256, 16, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        default: return MORIG_E_UNSUPPORTED;
+    }
+}
+
+extern "C" int morig_segmax_gemm(const morig_segmax_args* a, void* stream) {
+    if (!a || !a->X || !a->W || !a->rowptr || !a->dst_sorted || !a->out) return MORIG_E_INVALID;
+    if (a->N <= 0 || a->K <= 0 || a->n_nodes <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
+    if ((a->ldx & 3) || (a->ldw & 3) || !aligned16(a->X) || !aligned16(a->W)) return MORIG_E_INVALID;
+    if (a->ldx < ((a->K + 3) & ~3) || a->ldw < ((a->K + 31) & ~31) || a->ldo < a->N) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    TileParams p = {};
+    p.M = a->edge_capacity; p.N = a->N; p.K = a->K;
+    p.W = a->W; p.ldw = a->ldw;
+    p.bias = a->bias; p.scale = a->scale; p.shift = a->shift; p.relu = a->relu;
+    p.X = a->X; p.ldx = a->ldx;
+    p.rowptr = a->rowptr; p.dstS = a->dst_sorted; p.n_nodes = a->n_nodes;
+    p.Y = a->out; p.ldy = a->ldo;
+    p.tiles_per_rep = cdiv(a->edge_capacity, 128);
+    p.tiles_n = 1;
+    MORIG_HIP_TRY(hipMemset2DAsync(a->out, (size_t)a->ldo * sizeof(float), 0xFF, (size_t)a->N * sizeof(float), (size_t)a->n_nodes, s));
+    const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity);
+    ProfScope ps(K_POINTCONV, s, 2.0 * E * a->N * (double)a->K, 4.0 * E * a->K);
+    if (a->N <= 32)       return launch_tile<32, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    else if (a->N <= 64)  return launch_tile<64, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    else if (a->N <= 128) return launch_tile<128, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    else if (a->N <= 256) return launch_tile<256, 16, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    return MORIG_E_UNSUPPORTED;
 }
 
 extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {

@@ -233,3 +233,58 @@ class GCUMotion(NativeModule):
         self.run(ops, Mat.of(pos, 0, pk["vp"].K), Mat.of(x, 0, pk["vx"].K),
                  ops.csr_build(tpl_edge_index, n), ops.csr_build(geo_edge_index, n), Mat.of(out))
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# PointNet++ blocks of the CorrNet point branch (models/basic_modules.py:66-138). These classes hold
+# the parameters under the reference's state_dict keys; the arithmetic is driven by CorrNet.forward
+# (morig_amd/models/corrnet.py) through the op layer.
+# ------------------------------------------------------------------------------------------------
+class PointConv(torch.nn.Module):
+    """parameter holder with PyG PointConv's attribute names (``local_nn``; ``global_nn`` unused)."""
+
+    def __init__(self, local_nn=None, global_nn=None):
+        super().__init__()
+        self.local_nn = local_nn
+        self.global_nn = global_nn
+
+
+class SAModule(NativeModule):
+    """models/basic_modules.py:66-86: fps -> radius ball (<= max_num_neighbors) -> PointConv(max)."""
+
+    def __init__(self, ratio, r, nn, max_num_neighbors):
+        super().__init__()
+        self.ratio = ratio
+        self.r = r
+        self.max_num_neighbors = max_num_neighbors
+        self.conv = PointConv(nn)
+
+    def _pack(self):
+        cx = self.conv.local_nn[0][0].weight.shape[1] - 3
+        return packing.pack_pointconv(self.conv.local_nn, cx)
+
+
+class GlobalSAModule(NativeModule):
+    """models/basic_modules.py:115-125: nn([x ‖ pos]) -> global_max_pool."""
+
+    def __init__(self, nn):
+        super().__init__()
+        self.nn = nn
+
+    def _pack(self):
+        return [packing.pack_mlp_layer(l) for l in self.nn]
+
+
+class FPModule(NativeModule):
+    """models/basic_modules.py:127-138: knn_interpolate(k) -> cat skip -> nn."""
+
+    def __init__(self, k, nn):
+        super().__init__()
+        self.k = k
+        self.nn = nn
+
+    def _pack(self):
+        return [packing.pack_mlp_layer(l) for l in self.nn]
+
+
+__all__ += ["PointConv", "SAModule", "GlobalSAModule", "FPModule"]

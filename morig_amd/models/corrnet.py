@@ -1,5 +1,21 @@
-"""Drop-in mirror of the reference's ``models/corrnet.py`` (/root/reference/models/corrnet.py:10-82)."""
+"""Drop-in mirror of the reference's ``models/corrnet.py`` (/root/reference/models/corrnet.py:10-82):
+same class / factory names, ``forward(data, train_vismask, random_start=True)`` signature, returned
+tuple and state_dict keys; eval-mode arithmetic on the MI355X-native op layer.
+
+Semantics follow the branch the reference takes on a GPU (``torch.cuda.is_available()``):
+deterministic ``radius`` (first 64 hits in index order, strict <; models/basic_modules.py:76-78) and
+cosine 1-NN matching (models/corrnet.py:63-65). Restructurings (exact up to fp32 rounding):
+  * vertex branch: as GCNRig -- wide buffer [x_1|x_2|x_3|x_4|vtx,0], pooled GEMM epilogue, x_global as a
+    per-mesh row bias (:43-47);
+  * PointConv's first Linear on [x_j ‖ pos_j - pos_i] splits per point: B_j = W1 [x_j ‖ pos_j] + b1,
+    A_i = -W1p pos_i; PyG's bipartite self-loop quirk (drop src==dst index pairs, append (k,k)) is what
+    morig_csr_build_bipartite implements;
+  * FP4 interpolates from ONE global point per cloud with k=1, i.e. broadcasts the pooled vector: it
+    enters FP4's first Linear as a per-cloud row bias (the (x*w)/w round trip is dropped: <= 1 ulp).
+"""
 from __future__ import annotations
+
+import math
 
 import torch
 from torch.nn import Linear as Lin, Parameter, Sequential as Seq
@@ -7,17 +23,28 @@ from torch.nn import Linear as Lin, Parameter, Sequential as Seq
 from .. import packing
 from ..native import Mat
 from ..runtime import get_ops
-from .basic_modules import GCU, MLP, NativeModule
+from .basic_modules import GCU, MLP, FPModule, GlobalSAModule, NativeModule, SAModule
 
 __all__ = ["corrnet"]
 
 
+def _ptr(counts, device):
+    p = [0]
+    for c in counts:
+        p.append(p[-1] + int(c))
+    return torch.tensor(p, dtype=torch.int32, device=device)
+
+
 class CorrNet(NativeModule):
+    X = (0, 32, 96, 352)            # column offsets of x_1..x_4 in the wide vertex buffer
+    VTX = 864                       # vtx occupies 864..866, 867 is a zero pad
+
     def __init__(self, input_feature, output_feature, temprature, aggr="max"):
         super().__init__()
         self.input_feature = input_feature
         self.output_feature = output_feature
         self.temprature = Parameter(torch.Tensor([temprature]))
+
         self.vtx_gcu_1 = GCU(in_channels=3, out_channels=32, aggr=aggr)
         self.vtx_gcu_2 = GCU(in_channels=32, out_channels=64, aggr=aggr)
         self.vtx_gcu_3 = GCU(in_channels=64, out_channels=256, aggr=aggr)
@@ -25,8 +52,203 @@ class CorrNet(NativeModule):
         self.vtx_mlp_glb = MLP([(32 + 64 + 256 + 512), 1024])
         self.vtx_mlp = Seq(MLP([1024 + 3 + 32 + 64 + 256 + 512, 1024, 256]), Lin(256, output_feature))
 
+        self.pts_sa1_module = SAModule(0.5, 0.12, MLP([input_feature, 32, 32, 64]), max_num_neighbors=64)
+        self.pts_sa2_module = SAModule(0.25, 0.25, MLP([64 + 3, 64, 64, 128]), max_num_neighbors=64)
+        self.pts_sa3_module = SAModule(0.25, 0.5, MLP([128 + 3, 256, 256, 256]), max_num_neighbors=64)
+        self.pts_sa4_module = GlobalSAModule(MLP([256 + 3, 256, 256, 512]))
+
+        self.pts_fp4_module = FPModule(1, MLP([512 + 256, 256, 256]))
+        self.pts_fp3_module = FPModule(3, MLP([256 + 128, 256, 128]))
+        self.pts_fp2_module = FPModule(3, MLP([128 + 64, 128, 64]))
+        self.pts_fp1_module = FPModule(3, MLP([64, 64, 64]))
+        self.pts_mlp = Seq(MLP([64, 64]), Lin(64, output_feature))
+
+        self.lin_vismask = Seq(MLP([2 * output_feature + 1, 256, 128, 64]), Lin(64, 1))
+
+    # ------------------------------------------------------------------------------------------
+    def _pack(self):
+        l1 = self.vtx_mlp[0][0]
+        W = l1[0].weight.detach()        # input order (:46): [x_global(1024) | vtx(3) | x_1..x_4(864)]
+        in_cols = [self.VTX + i for i in range(3)] + list(range(864))
+        fp4 = self.pts_fp4_module.nn     # input order (FPModule): [interpolated global(512) | x_skip(256)]
+        W4 = fp4[0][0].weight.detach()
+        return dict(
+            glb=packing.pack_mlp_layer(self.vtx_mlp_glb[0]),
+            g=packing.pack_linear(W[:, :1024]),
+            t1=packing.pack_linear(W[:, 1024:], l1[0].bias, l1[2], in_cols=in_cols, k_total=self.VTX + 3),
+            t2=packing.pack_mlp_layer(self.vtx_mlp[0][1]),
+            t3=packing.pack_linear(self.vtx_mlp[1].weight, self.vtx_mlp[1].bias),
+            fp4_g=packing.pack_linear(W4[:, :512]),
+            fp4_1=packing.pack_linear(W4[:, 512:], fp4[0][0].bias, fp4[0][2]),
+            fp4_2=packing.pack_mlp_layer(fp4[1]),
+            pm1=packing.pack_mlp_layer(self.pts_mlp[0][0]),
+            pm2=packing.pack_linear(self.pts_mlp[1].weight, self.pts_mlp[1].bias),
+            vis=[packing.pack_mlp_layer(l) for l in self.lin_vismask[0]],
+            vis_out=packing.pack_linear(self.lin_vismask[1].weight, self.lin_vismask[1].bias),
+        )
+
+    # ------------------------------------------------------------------------------------------
+    def _vertex_branch(self, ops, data, seg, n_graphs):
+        dev = data.vtx.device
+        pk = self.packed(dev)
+        n = data.vtx.shape[0]
+        ld = self.VTX + 4
+        wide = ops.empty(n, ld, dev)
+        v4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        ops.copy2d(Mat.of(data.vtx.float().contiguous()), Mat.of(v4, 0, 3))
+        ops.copy2d(Mat.of(v4), Mat.of(wide, self.VTX, 4))
+        csr_tpl = ops.csr_build(data.tpl_edge_index, n)
+        csr_geo = ops.csr_build(data.geo_edge_index, n)
+        gcus = (self.vtx_gcu_1, self.vtx_gcu_2, self.vtx_gcu_3, self.vtx_gcu_4)
+        widths = (32, 64, 256, 512)
+        x_in = Mat.of(wide, self.VTX, 3)
+        for g, off, w in zip(gcus, self.X, widths):
+            out = Mat.of(wide, off, w)
+            g.run(ops, x_in, csr_tpl, csr_geo, out)
+            x_in = out
+        pooled = ops.empty(n_graphs, 1024, dev)
+        ops.gemm(Mat.of(wide, 0, 864), pk["glb"], relu=True, seg=seg, pool=pooled)
+        gb = ops.empty(n_graphs, 1024, dev)
+        ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
+        h1 = ops.empty(n, 1024, dev)
+        ops.gemm(Mat.of(wide, 0, self.VTX + 3), pk["t1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg)
+        h2 = ops.empty(n, 256, dev)
+        ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2))
+        raw = ops.empty(n, self.output_feature, dev)
+        ops.gemm(Mat.of(h2), pk["t3"], relu=False, Y=Mat.of(raw))
+        out_vtx = torch.empty((n, self.output_feature), dtype=torch.float32, device=dev)
+        ops.rownorm(Mat.of(raw), n, 1, out_vtx, self.output_feature, 0)
+        return out_vtx
+
+    def _set_abstraction(self, ops, sa: SAModule, xp: torch.Tensor, cx: int, counts, ptr, random_start, n_clouds):
+        """xp: [N, ld] = [x(cx) | pos(3) | pad]; returns (x_new [M, H3], pos_new4 [M,4], counts_new, ptr_new)."""
+        dev = xp.device
+        pk = sa.packed(dev)
+        N = xp.shape[0]
+        new_counts = [int(math.ceil(sa.ratio * c)) for c in counts]
+        out_ptr = _ptr(new_counts, dev)
+        M = sum(new_counts)
+        start = None
+        if random_start:
+            start = torch.tensor([int(torch.randint(c, (1,))) for c in counts], dtype=torch.int32, device=dev)
+        posm = Mat.of(xp, cx, 3)
+        idx = ops.fps(posm, ptr, out_ptr, start, n_clouds, max(counts), M)
+        pos_new = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+        ops.gather_rows(posm, idx, Mat.of(pos_new, 0, 3))
+        coo = ops.ball_query(posm, ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, sa.r, sa.max_num_neighbors)
+        csr = ops.csr_build(coo, M, n_src=N, skip_negative=True)
+        H = pk["edge"].H
+        bsrc = ops.empty(N, H, dev)
+        ops.gemm(Mat.of(xp, 0, cx + 3), pk["src"], relu=False, Y=Mat.of(bsrc))
+        atgt = ops.empty(M, H, dev)
+        ops.gemm(Mat.of(pos_new, 0, 3), pk["tgt"], relu=False, Y=Mat.of(atgt))
+        z = ops.empty(csr.capacity, H, dev)
+        ops.edge_hidden(Mat.of(atgt), Mat.of(bsrc), csr, pk["edge"], Mat.of(z))
+        x_new = ops.empty(M, pk["last"].N, dev)
+        ops.segmax_gemm(Mat.of(z), pk["last"], True, csr, Mat.of(x_new))
+        return x_new, pos_new, new_counts, out_ptr
+
+    @staticmethod
+    def _with_pos(ops, x: torch.Tensor, pos4: torch.Tensor):
+        """[x | pos | 0] with a 16-byte aligned row stride."""
+        n, c = x.shape
+        ld = (c + 3 + 3) // 4 * 4
+        buf = torch.zeros((n, ld), dtype=torch.float32, device=x.device)
+        ops.copy2d(Mat.of(x), Mat.of(buf, 0, c))
+        ops.copy2d(Mat.of(pos4, 0, 3), Mat.of(buf, c, 3))
+        return buf
+
+    def _point_branch(self, ops, data, counts0, random_start):
+        dev = data.pts.device
+        pk = self.packed(dev)
+        B = len(counts0)
+        N0 = data.pts.shape[0]
+        pos0 = torch.zeros((N0, 4), dtype=torch.float32, device=dev)
+        ops.copy2d(Mat.of(data.pts.float().contiguous()), Mat.of(pos0, 0, 3))
+        ptr0 = _ptr(counts0, dev)
+        x1, pos1, c1, ptr1 = self._set_abstraction(ops, self.pts_sa1_module, pos0, 0, counts0, ptr0, random_start, B)
+        xp1 = self._with_pos(ops, x1, pos1)
+        x2, pos2, c2, ptr2 = self._set_abstraction(ops, self.pts_sa2_module, xp1, 64, c1, ptr1, random_start, B)
+        xp2 = self._with_pos(ops, x2, pos2)
+        x3, pos3, c3, ptr3 = self._set_abstraction(ops, self.pts_sa3_module, xp2, 128, c2, ptr2, random_start, B)
+        xp3 = self._with_pos(ops, x3, pos3)
+        M3 = x3.shape[0]
+        seg3 = torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev),
+                                       torch.tensor(c3, device=dev))
+        # SA4: global set abstraction
+        g4 = self.pts_sa4_module.packed(dev)
+        a = ops.empty(M3, 256, dev)
+        ops.gemm(Mat.of(xp3, 0, 259), g4[0], relu=True, Y=Mat.of(a))
+        b = ops.empty(M3, 256, dev)
+        ops.gemm(Mat.of(a), g4[1], relu=True, Y=Mat.of(b))
+        pooled = ops.empty(B, 512, dev)
+        ops.gemm(Mat.of(b), g4[2], relu=True, seg=seg3, pool=pooled)
+        # FP4: broadcast of the pooled vector (k=1 from one global point) -> row bias
+        gb = ops.empty(B, 256, dev)
+        ops.gemm(Mat.of(pooled), pk["fp4_g"], relu=False, Y=Mat.of(gb))
+        f4a = ops.empty(M3, 256, dev)
+        ops.gemm(Mat.of(x3), pk["fp4_1"], relu=True, Y=Mat.of(f4a), rowbias=Mat.of(gb), seg=seg3)
+        f4 = ops.empty(M3, 256, dev)
+        ops.gemm(Mat.of(f4a), pk["fp4_2"], relu=True, Y=Mat.of(f4))
+
+        def propagate(fp: FPModule, feat, pos_x, ptr_x, skip, pos_y, ptr_y, counts_y):
+            layers = fp.packed(dev)
+            ny, cf = pos_y.shape[0], feat.shape[1]
+            cs = 0 if skip is None else skip.shape[1]
+            cat = ops.empty(ny, cf + cs, dev)
+            ops.knn_interpolate(Mat.of(feat), Mat.of(pos_x, 0, 3), ptr_x, Mat.of(pos_y, 0, 3), ptr_y, B, max(counts_y),
+                                fp.k, Mat.of(cat, 0, cf))
+            if skip is not None:
+                ops.copy2d(Mat.of(skip), Mat.of(cat, cf, cs))
+            h = cat
+            for lay in layers:
+                o = ops.empty(ny, lay.N, dev)
+                ops.gemm(Mat.of(h), lay, relu=True, Y=Mat.of(o))
+                h = o
+            return h
+
+        f3 = propagate(self.pts_fp3_module, f4, pos3, ptr3, x2, pos2, ptr2, c2)
+        f2 = propagate(self.pts_fp2_module, f3, pos2, ptr2, x1, pos1, ptr1, c1)
+        f1 = propagate(self.pts_fp1_module, f2, pos1, ptr1, None, pos0, ptr0, counts0)
+        p1 = ops.empty(N0, 64, dev)
+        ops.gemm(Mat.of(f1), pk["pm1"], relu=True, Y=Mat.of(p1))
+        raw = ops.empty(N0, self.output_feature, dev)
+        ops.gemm(Mat.of(p1), pk["pm2"], relu=False, Y=Mat.of(raw))
+        out_pts = torch.empty((N0, self.output_feature), dtype=torch.float32, device=dev)
+        ops.rownorm(Mat.of(raw), N0, 1, out_pts, self.output_feature, 0)
+        return out_pts, ptr0
+
     def forward(self, data, train_vismask, random_start=True):
-        raise NotImplementedError("CorrNet native path: under construction")
+        self._require_eval()
+        ops = get_ops()
+        dev = data.vtx.device
+        pk = self.packed(dev)
+        B = getattr(data, "num_graphs", None)
+        vb, pb = data.vtx_batch, data.pts_batch
+        if B is None:
+            B = int(max(int(vb.max().item()), int(pb.max().item()))) + 1
+        counts = torch.stack([torch.bincount(vb, minlength=B), torch.bincount(pb, minlength=B)]).tolist()   # one sync
+        vcounts, pcounts = counts
+        seg = ops.make_seg(vb, B, 1)
+        out_vtx = self._vertex_branch(ops, data, seg, B)
+        out_pts, ptr_p = self._point_branch(ops, data, pcounts, random_start)
+        out_vismask = None
+        if train_vismask:
+            n, C = out_vtx.shape
+            nn, sim = ops.cosine_nn(Mat.of(out_vtx), _ptr(vcounts, dev), Mat.of(out_pts), ptr_p, B, max(vcounts))
+            ld = (2 * C + 1 + 3) // 4 * 4
+            comb = torch.zeros((n, ld), dtype=torch.float32, device=dev)      # [out_vtx | out_pts[nn] | <.,.>]  (:65)
+            ops.copy2d(Mat.of(out_vtx), Mat.of(comb, 0, C))
+            ops.gather_rows(Mat.of(out_pts), nn, Mat.of(comb, C, C))
+            ops.copy2d(Mat.of(sim.view(-1, 1)), Mat.of(comb, 2 * C, 1))
+            h = Mat.of(comb, 0, 2 * C + 1)
+            for lay in pk["vis"]:
+                o = ops.empty(n, lay.N, dev)
+                ops.gemm(h, lay, relu=True, Y=Mat.of(o))
+                h = Mat.of(o)
+            out_vismask = torch.empty((n, 1), dtype=torch.float32, device=dev)
+            ops.gemm(h, pk["vis_out"], relu=False, Y=Mat.of(out_vismask))
+        return out_vtx, out_pts, out_vismask, self.temprature
 
 
 def corrnet(**kwargs):

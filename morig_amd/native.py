@@ -52,13 +52,34 @@ class EdgeConvArgs(C.Structure):
     ]
 
 
+class SegmaxArgs(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("K", C.c_int32),
+        ("X", c_f32p), ("ldx", C.c_int32),
+        ("W", c_f32p), ("ldw", C.c_int32),
+        ("bias", c_f32p), ("scale", c_f32p), ("shift", c_f32p), ("relu", C.c_int32),
+        ("rowptr", c_i32p), ("dst_sorted", c_i32p), ("n_nodes", C.c_int32),
+        ("edge_capacity", C.c_int32), ("edge_count", C.c_int32),
+        ("out", c_f32p), ("ldo", C.c_int32),
+    ]
+
+
 _SIGNATURES = {
     "morig_abi_version": (C.c_int, []),
     "morig_strerror": (C.c_char_p, [C.c_int]),
     "morig_last_hip_error": (C.c_int, []),
     "morig_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "morig_csr_build": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
+    "morig_csr_build_bipartite": (C.c_int, [c_i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "morig_edge_hidden": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
+    "morig_segmax_gemm": (C.c_int, [C.POINTER(SegmaxArgs), C.c_void_p]),
+    "morig_fps": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
+    "morig_ball_query": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, c_i64p, C.c_void_p]),
+    "morig_knn_interpolate": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_cosine_nn": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
+    "morig_gather_rows": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_copy2d": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "morig_gather_cols": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -181,7 +202,8 @@ class NativeOps:
         return torch.empty((rows, cols), device=device, dtype=dtype)
 
     # -- graph --------------------------------------------------------------------------------
-    def csr_build(self, edge_index: torch.Tensor, n_nodes: int) -> CSR:
+    def csr_build(self, edge_index: torch.Tensor, n_nodes: int, n_src: Optional[int] = None,
+                  skip_negative: bool = False) -> CSR:
         _need_gpu(edge_index)
         ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
         E = ei.shape[1]
@@ -192,8 +214,13 @@ class NativeOps:
         dst = torch.empty(cap, dtype=torch.int32, device=dev)
         cursor = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
         status = torch.empty(1, dtype=torch.int32, device=dev)
-        check(self.lib.morig_csr_build(_p(ei), E, n_nodes, _p(rowptr), _p(src), _p(dst), _p(cursor), _p(status), _stream()),
-              "morig_csr_build")
+        if n_src is None and not skip_negative:
+            check(self.lib.morig_csr_build(_p(ei), E, n_nodes, _p(rowptr), _p(src), _p(dst), _p(cursor), _p(status), _stream()),
+                  "morig_csr_build")
+        else:
+            check(self.lib.morig_csr_build_bipartite(_p(ei), E, n_nodes if n_src is None else n_src, n_nodes,
+                                                     1 if skip_negative else 0, _p(rowptr), _p(src), _p(dst), _p(cursor),
+                                                     _p(status), _stream()), "morig_csr_build_bipartite")
         return CSR(rowptr, src, dst, n_nodes, cap, status)
 
     # -- dense ----------------------------------------------------------------------------------
@@ -224,6 +251,10 @@ class NativeOps:
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
                  in_rep_stride: int = 0, out_rep_stride: int = 0):
         _need_gpu(A.base, B.base, out.base)
+        a = self._edge_args(A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride)
+        check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
+
+    def _edge_args(self, A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride):
         a = EdgeConvArgs()
         a.H = ec.H
         a.n_nodes, a.replicas = csr.n_nodes, replicas
@@ -236,7 +267,74 @@ class NativeOps:
         a.W2, a.ldw = ec.W2.data_ptr(), ec.W2.stride(0)
         a.b2, a.s2, a.t2 = ec.b2.data_ptr(), ec.s2.data_ptr(), ec.t2.data_ptr()
         a.out, a.ldo = out.ptr, out.ld
-        check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
+        return a
+
+    def edge_hidden(self, A: Mat, B: Mat, csr: CSR, ec, Z: Mat):
+        """per-edge hidden activations Z [capacity, H] (rows >= E' untouched)."""
+        _need_gpu(A.base, B.base, Z.base)
+        assert Z.rows == csr.capacity and Z.cols == ec.H
+        a = self._edge_args(A, B, csr, ec, Z, 1, 0, 0)
+        check(self.lib.morig_edge_hidden(C.byref(a), _stream()), "morig_edge_hidden")
+
+    def segmax_gemm(self, X: Mat, lin, relu: bool, csr: CSR, out: Mat):
+        _need_gpu(X.base, out.base)
+        assert X.rows == csr.capacity and X.cols == lin.K and out.rows == csr.n_nodes and out.cols == lin.N
+        a = SegmaxArgs()
+        a.N, a.K = lin.N, lin.K
+        a.X, a.ldx = X.ptr, X.ld
+        a.W, a.ldw = lin.W.data_ptr(), lin.W.stride(0)
+        a.bias = lin.bias.data_ptr() if lin.bias is not None else 0
+        a.scale = lin.scale.data_ptr() if lin.scale is not None else 0
+        a.shift = lin.shift.data_ptr() if lin.shift is not None else 0
+        a.relu = 1 if relu else 0
+        a.rowptr, a.dst_sorted, a.n_nodes = csr.rowptr.data_ptr(), csr.dst.data_ptr(), csr.n_nodes
+        a.edge_capacity, a.edge_count = csr.capacity, csr.edge_count
+        a.out, a.ldo = out.ptr, out.ld
+        check(self.lib.morig_segmax_gemm(C.byref(a), _stream()), "morig_segmax_gemm")
+
+    # -- point clouds ---------------------------------------------------------------------------------
+    def fps(self, pos: Mat, ptr: torch.Tensor, out_ptr: torch.Tensor, start: Optional[torch.Tensor], n_clouds: int,
+            max_cloud_points: int, n_samples: int) -> torch.Tensor:
+        _need_gpu(pos.base, ptr, out_ptr)
+        idx = torch.empty(n_samples, dtype=torch.int32, device=pos.base.device)
+        check(self.lib.morig_fps(pos.ptr, pos.ld, _p(ptr), _p(out_ptr), _p(start), n_clouds, max_cloud_points, _p(idx), _stream()),
+              "morig_fps")
+        return idx
+
+    def ball_query(self, x: Mat, ptr_x: torch.Tensor, y: Mat, ptr_y: torch.Tensor, n_clouds: int, radius: float,
+                   max_nbrs: int) -> torch.Tensor:
+        _need_gpu(x.base, y.base, ptr_x, ptr_y)
+        coo = torch.empty((2, y.rows * max_nbrs), dtype=torch.int64, device=x.base.device)
+        check(self.lib.morig_ball_query(x.ptr, x.ld, _p(ptr_x), y.ptr, y.ld, _p(ptr_y), n_clouds, y.rows, float(radius),
+                                        max_nbrs, _p(coo), _stream()), "morig_ball_query")
+        return coo
+
+    def knn_interpolate(self, feat: Mat, pos_x: Mat, ptr_x: torch.Tensor, pos_y: Mat, ptr_y: torch.Tensor, n_clouds: int,
+                        max_targets_per_cloud: int, k: int, out: Mat):
+        _need_gpu(feat.base, pos_x.base, pos_y.base, out.base)
+        nt = pos_y.rows
+        dev = feat.base.device
+        idx = torch.empty((nt, 3), dtype=torch.int32, device=dev)
+        wgt = torch.empty((nt, 3), dtype=torch.float32, device=dev)
+        assert out.rows == nt and out.cols == feat.cols
+        check(self.lib.morig_knn_interpolate(feat.ptr, feat.ld, feat.cols, pos_x.ptr, pos_x.ld, _p(ptr_x), pos_y.ptr, pos_y.ld,
+                                             _p(ptr_y), n_clouds, nt, max_targets_per_cloud, k, _p(idx), _p(wgt), out.ptr, out.ld,
+                                             _stream()), "morig_knn_interpolate")
+
+    def cosine_nn(self, v: Mat, ptr_v: torch.Tensor, p: Mat, ptr_p: torch.Tensor, n_clouds: int, max_rows_per_cloud: int):
+        _need_gpu(v.base, p.base)
+        dev = v.base.device
+        nn = torch.empty(v.rows, dtype=torch.int32, device=dev)
+        sim = torch.empty(v.rows, dtype=torch.float32, device=dev)
+        check(self.lib.morig_cosine_nn(v.ptr, v.ld, _p(ptr_v), p.ptr, p.ld, _p(ptr_p), n_clouds, max_rows_per_cloud, v.cols,
+                                       _p(nn), _p(sim), _stream()), "morig_cosine_nn")
+        return nn, sim
+
+    def gather_rows(self, src: Mat, idx: torch.Tensor, dst: Mat):
+        _need_gpu(src.base, idx, dst.base)
+        assert idx.dtype == torch.int32 and dst.rows == idx.numel() and dst.cols == src.cols
+        check(self.lib.morig_gather_rows(src.ptr, src.ld, _p(idx), idx.numel(), src.cols, dst.ptr, dst.ld, _stream()),
+              "morig_gather_rows")
 
     # -- small ops ------------------------------------------------------------------------------------
     def copy2d(self, src: Mat, dst: Mat):

@@ -115,6 +115,26 @@ def pack_edge_pair(mlps: Sequence[nn.Sequential]):
     return vertex, edges
 
 
+def pack_pointconv(local_nn: nn.Sequential, cx: int):
+    """PointConv local_nn = MLP([cx+3, H, H, H3]) on [x_j ‖ pos_j - pos_i] (PyG PointConv.message):
+    -> source linear over [x | pos] (K = cx+3, with bias), target linear -W1p over the centre position,
+       PackedEdge for BN1/Linear2/BN2, PackedLinear for Linear3/BN3."""
+    l1, l2, l3 = local_nn[0], local_nn[1], local_nn[2]
+    W1 = l1[0].weight.detach().float()
+    H = W1.shape[0]
+    assert W1.shape[1] == cx + 3 and l2[0].weight.shape == (H, H), "PointConv hidden layers must be square"
+    src = pack_linear(W1, l1[0].bias)
+    tgt = pack_linear(-W1[:, cx:], None)
+    s1, t1 = bn_affine(l1[2])
+    s2, t2 = bn_affine(l2[2])
+    Hp, Kp = max(H, 32), _roundup(H, 32)
+    W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=W1.device)
+    W2[:H, :H] = l2[0].weight.detach().float()
+    edge = PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2.contiguous(), _pad_vec(l2[0].bias.detach(), Hp),
+                      _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp))
+    return dict(src=src, tgt=tgt, edge=edge, last=pack_mlp_layer(l3))
+
+
 def to_device(obj, device):
     """move a (nested) packed structure to ``device``."""
     if isinstance(obj, torch.Tensor):

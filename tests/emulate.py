@@ -120,3 +120,101 @@ class EmuOps:
 
     def frame_reduce(self, x, mode, y: Mat):
         y.view().copy_(x.mean(1) if mode == "mean" else x.max(1)[0])
+
+
+# ------------------------------------------------------------------------------------------------
+# CorrNet point-branch ops (emulated with the oracle's primitive restatements)
+# ------------------------------------------------------------------------------------------------
+from oracle import pyg_primitives as _P      # noqa: E402  (tests may import the oracle)
+
+
+def _batch_from_ptr(ptr):
+    p = ptr.long().tolist()
+    return torch.cat([torch.full((p[i + 1] - p[i],), i, dtype=torch.long) for i in range(len(p) - 1)])
+
+
+def _emu_edge_hidden(self, A: Mat, B: Mat, csr: CSR, ec, Z: Mat):
+    H = ec.H
+    E = int(csr.rowptr[-1])
+    src, dst = csr.src[:E].long(), csr.dst[:E].long()
+    a = A.base[A.row0 + dst, A.col0:A.col0 + H]
+    b = B.base[B.row0 + src, B.col0:B.col0 + H]
+    assert not torch.isnan(a).any() and not torch.isnan(b).any()
+    h1 = torch.relu(a + b) * ec.s1[:H] + ec.t1[:H]
+    Z.view()[:E] = torch.relu(h1 @ ec.W2[:H, :H].t() + ec.b2[:H]) * ec.s2[:H] + ec.t2[:H]
+
+
+def _emu_segmax_gemm(self, X: Mat, lin, relu, csr: CSR, out: Mat):
+    E = int(csr.rowptr[-1])
+    x = X.view()[:E]
+    assert not torch.isnan(x).any()
+    z = x @ lin.W[: lin.N, : lin.K].t() + lin.bias[: lin.N]
+    if relu:
+        z = torch.relu(z)
+    if lin.scale is not None:
+        z = z * lin.scale[: lin.N] + lin.shift[: lin.N]
+    res = torch.full((csr.n_nodes, lin.N), float("-inf"))
+    res = res.scatter_reduce(0, csr.dst[:E].long()[:, None].expand(-1, lin.N), z, reduce="amax", include_self=True)
+    out.view().copy_(res)
+
+
+def _emu_fps(self, pos: Mat, ptr, out_ptr, start, n_clouds, max_cloud_points, n_samples):
+    p = pos.view()[:, :3]
+    pp, oo = ptr.long().tolist(), out_ptr.long().tolist()
+    out = []
+    for b in range(n_clouds):
+        n, m = pp[b + 1] - pp[b], oo[b + 1] - oo[b]
+        pts = p[pp[b]:pp[b + 1]]
+        cur = int(start[b]) if start is not None else 0
+        dist = torch.full((n,), float("inf"))
+        for _ in range(m):
+            out.append(cur + pp[b])
+            dist = torch.minimum(dist, ((pts - pts[cur]) ** 2).sum(-1))
+            cur = int(torch.argmax(dist))
+    assert len(out) == n_samples
+    return torch.tensor(out, dtype=torch.int32)
+
+
+def _emu_ball_query(self, x: Mat, ptr_x, y: Mat, ptr_y, n_clouds, radius, max_nbrs):
+    row, col = _P.radius(x.view()[:, :3], y.view()[:, :3], radius, _batch_from_ptr(ptr_x), _batch_from_ptr(ptr_y),
+                         max_num_neighbors=max_nbrs)
+    M = y.rows
+    coo = torch.full((2, M * max_nbrs), -1, dtype=torch.int64)
+    slot = torch.zeros(M, dtype=torch.long)
+    for r, c in zip(row.tolist(), col.tolist()):
+        coo[0, r * max_nbrs + slot[r]] = c
+        coo[1, r * max_nbrs + slot[r]] = r
+        slot[r] += 1
+    return coo
+
+
+def _emu_knn_interpolate(self, feat: Mat, pos_x: Mat, ptr_x, pos_y: Mat, ptr_y, n_clouds, max_targets_per_cloud, k, out: Mat):
+    res = _P.knn_interpolate(feat.view(), pos_x.view()[:, :3], pos_y.view()[:, :3], _batch_from_ptr(ptr_x),
+                             _batch_from_ptr(ptr_y), k=k)
+    out.view().copy_(res)
+
+
+def _emu_cosine_nn(self, v: Mat, ptr_v, p: Mat, ptr_p, n_clouds, max_rows_per_cloud):
+    vv, pp = v.view(), p.view()
+    pv, pq = ptr_v.long().tolist(), ptr_p.long().tolist()
+    nn = torch.empty(v.rows, dtype=torch.int32)
+    sim = torch.empty(v.rows)
+    for c in range(n_clouds):
+        s = vv[pv[c]:pv[c + 1]] @ pp[pq[c]:pq[c + 1]].t()
+        m, i = s.max(dim=1)
+        nn[pv[c]:pv[c + 1]] = (i + pq[c]).int()
+        sim[pv[c]:pv[c + 1]] = m
+    return nn, sim
+
+
+def _emu_gather_rows(self, src: Mat, idx, dst: Mat):
+    dst.view().copy_(src.view()[idx.long()])
+
+
+EmuOps.edge_hidden = _emu_edge_hidden
+EmuOps.segmax_gemm = _emu_segmax_gemm
+EmuOps.fps = _emu_fps
+EmuOps.ball_query = _emu_ball_query
+EmuOps.knn_interpolate = _emu_knn_interpolate
+EmuOps.cosine_nn = _emu_cosine_nn
+EmuOps.gather_rows = _emu_gather_rows

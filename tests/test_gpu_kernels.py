@@ -221,3 +221,104 @@ def test_cpu_tensors_are_refused(ops):
     from morig_amd.native import MorigNativeError
     with pytest.raises(MorigNativeError):
         ops.copy2d(Mat.of(torch.zeros(2, 2)), Mat.of(torch.zeros(2, 2)))
+
+
+# ---------------------------------------------------------------------------------------------------
+# CorrNet point-branch kernels
+# ---------------------------------------------------------------------------------------------------
+def _clouds(counts, seed):
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.rand(sum(counts), 3, generator=g)
+    pos4 = torch.zeros(sum(counts), 4)
+    pos4[:, :3] = pos
+    ptr = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int32)
+    return pos4, ptr
+
+
+@pytest.mark.parametrize("counts,ratio,rand", [([700, 33, 1500], 0.5, False), ([8192, 4096], 0.25, True), ([5], 0.5, False)])
+def test_fps_bit_exact(ops, counts, ratio, rand):
+    import math
+    pos4, ptr = _clouds(counts, 7)
+    newc = [math.ceil(ratio * c) for c in counts]
+    optr = torch.tensor([0] + list(torch.tensor(newc).cumsum(0)), dtype=torch.int32)
+    start = torch.tensor([c // 3 for c in counts], dtype=torch.int32) if rand else None
+    want = EmuOps().fps(Mat.of(pos4, 0, 3), ptr, optr, start, len(counts), max(counts), sum(newc))
+    got = ops.fps(Mat.of(pos4.to(DEV), 0, 3), ptr.to(DEV), optr.to(DEV), None if start is None else start.to(DEV),
+                  len(counts), max(counts), sum(newc))
+    assert torch.equal(got.cpu(), want)
+
+
+def test_ball_query_and_bipartite_csr_bit_exact(ops):
+    counts = [900, 300]
+    pos4, ptr = _clouds(counts, 3)
+    cidx = torch.cat([torch.arange(0, 900, 3), 900 + torch.arange(0, 300, 2)])
+    cen = pos4[cidx].contiguous()
+    cptr = torch.tensor([0, 300, 450], dtype=torch.int32)
+    emu = EmuOps()
+    for r, mx in ((0.12, 64), (0.3, 16)):
+        want = emu.ball_query(Mat.of(pos4, 0, 3), ptr, Mat.of(cen, 0, 3), cptr, 2, r, mx)
+        got = ops.ball_query(Mat.of(pos4.to(DEV), 0, 3), ptr.to(DEV), Mat.of(cen.to(DEV), 0, 3), cptr.to(DEV), 2, r, mx)
+        assert torch.equal(got.cpu(), want)
+        cw = emu.csr_build(want, cen.shape[0], n_src=pos4.shape[0], skip_negative=True)
+        cg = ops.csr_build(got, cen.shape[0], n_src=pos4.shape[0], skip_negative=True)
+        torch.cuda.synchronize()
+        assert int(cg.status.item()) == 0 and torch.equal(cg.rowptr.cpu(), cw.rowptr)
+        E = int(cw.rowptr[-1])
+        assert _segments(cg, E) == _segments(cw, E)
+
+
+@pytest.mark.parametrize("H,N3", [(32, 64), (64, 128), (256, 256)])
+def test_pointconv_two_pass(ops, H, N3):
+    g = torch.Generator().manual_seed(H)
+    n_src, n_dst = 1200, 500
+    src = torch.randint(0, n_src, (9000,), generator=g)
+    dst = torch.randint(0, n_dst, (9000,), generator=g)
+    src[::5] = -1
+    ei = torch.stack([src, torch.where(src < 0, torch.full_like(dst, -1), dst)])
+    emu = EmuOps()
+    ec = _edge_pack(H, 4)
+    lin = _lin(N3, H, 6)
+    A, Bm = torch.randn(n_dst, H, generator=g), torch.randn(n_src, H, generator=g)
+    cw = emu.csr_build(ei, n_dst, n_src=n_src, skip_negative=True)
+    zw = torch.full((cw.capacity, H), float("nan"))
+    emu.edge_hidden(Mat.of(A), Mat.of(Bm), cw, ec, Mat.of(zw))
+    ow = torch.zeros(n_dst, N3)
+    emu.segmax_gemm(Mat.of(zw), lin, True, cw, Mat.of(ow))
+    cg = ops.csr_build(ei.to(DEV), n_dst, n_src=n_src, skip_negative=True)
+    zg = torch.zeros(cg.capacity, H, device=DEV)
+    ops.edge_hidden(Mat.of(A.to(DEV)), Mat.of(Bm.to(DEV)), cg, packing.to_device(ec, DEV), Mat.of(zg))
+    og = torch.zeros(n_dst, N3, device=DEV)
+    ops.segmax_gemm(Mat.of(zg), packing.to_device(lin, DEV), True, cg, Mat.of(og))
+    torch.cuda.synchronize()
+    assert maxdiff(og, ow) <= 2e-5 * max(1.0, ow.abs().max().item())
+
+
+@pytest.mark.parametrize("k", [1, 3])
+def test_knn_interpolate(ops, k):
+    xs, px = _clouds([300, 1, 2500], 5)
+    ys, py = _clouds([700, 40, 5000], 6)
+    ys[3, :3] = xs[10, :3]                       # coincident point: 1e-16 clamp
+    g = torch.Generator().manual_seed(2)
+    feat = torch.randn(xs.shape[0], 20, generator=g)
+    want = torch.zeros(ys.shape[0], 24)
+    EmuOps().knn_interpolate(Mat.of(feat), Mat.of(xs, 0, 3), px, Mat.of(ys, 0, 3), py, 3, 5000, k, Mat.of(want, 0, 20))
+    got = torch.zeros(ys.shape[0], 24, device=DEV)
+    ops.knn_interpolate(Mat.of(feat.to(DEV)), Mat.of(xs.to(DEV), 0, 3), px.to(DEV), Mat.of(ys.to(DEV), 0, 3), py.to(DEV),
+                        3, 5000, k, Mat.of(got, 0, 20))
+    assert maxdiff(got, want) <= 1e-5 * max(1.0, want.abs().max().item())
+
+
+def test_cosine_nn_and_gather_rows(ops):
+    g = torch.Generator().manual_seed(8)
+    v = torch.nn.functional.normalize(torch.randn(700, 64, generator=g), dim=1)
+    p = torch.nn.functional.normalize(torch.randn(1900, 64, generator=g), dim=1)
+    pv = torch.tensor([0, 300, 700], dtype=torch.int32)
+    pp = torch.tensor([0, 900, 1900], dtype=torch.int32)
+    nw, sw = EmuOps().cosine_nn(Mat.of(v), pv, Mat.of(p), pp, 2, 400)
+    ng, sg = ops.cosine_nn(Mat.of(v.to(DEV)), pv.to(DEV), Mat.of(p.to(DEV)), pp.to(DEV), 2, 400)
+    assert maxdiff(sg, sw) <= 2e-6
+    assert (ng.cpu() != nw).float().mean().item() <= 0.005       # only fp-order near-ties may differ
+    idx = torch.tensor([5, 0, -1, 1899], dtype=torch.int32)
+    out = torch.zeros(4, 70, device=DEV)
+    ops.gather_rows(Mat.of(p.to(DEV)), idx.to(DEV), Mat.of(out, 3, 64))
+    assert torch.equal(out.cpu()[0, 3:67], p[5]) and float(out[2].abs().sum()) == 0 and torch.equal(out.cpu()[3, 3:67], p[1899])

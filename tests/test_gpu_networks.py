@@ -129,3 +129,30 @@ def test_against_oracle_on_fresh_inputs():
     got = ours.to(DEV)(d, d.pred_flow)
     for g, w in zip(got, want):
         assert rel_excess(g, w, TOL) <= 0
+
+
+def test_corrnet_against_reference_golden():
+    """vertex branch + PointNet++ point branch + cosine matching + vis-mask, deterministic FPS start."""
+    meta, a = load_golden("corrnet_ragged")
+    m = models.corrnet(**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"]).to(DEV)
+    d = data_from(a, DEV)
+    ov, op, vis, tau = m(d, True, False)
+    torch.cuda.synchronize()
+    assert rel_excess(ov, a["out_vtx"], TOL) <= 0
+    assert rel_excess(op, a["out_pts"], TOL) <= 0
+    assert rel_excess(vis, a["out_vismask"], TOL) <= 0
+    assert float(tau) == pytest.approx(0.07)
+    assert m(d, False, True)[2] is None
+
+
+def test_corrnet_larger_clouds_against_oracle():
+    from oracle import nets
+    kw = dict(input_feature=3, output_feature=64, temprature=0.07)
+    ours = synth.load_recipe(models.corrnet(**kw).eval(), 31, mild=True)
+    ref = synth.load_recipe(nets.corrnet(**kw).eval(), 31, mild=True)
+    batch = synth.make_batch([81, 82], n_side=24, n_pts=2048)
+    want = ref(batch, True, False)
+    got = ours.to(DEV)(batch.to(DEV), True, False)
+    for g, w in zip(got[:3], want[:3]):
+        assert rel_excess(g, w, TOL) <= 0

@@ -119,3 +119,20 @@ def test_packed_cache_invalidation():
     synth.load_recipe(m, meta["recipe_seed"])           # load_state_dict must drop the packed cache
     o2 = m(a["x"], a["tpl_edge_index"], a["geo_edge_index"])
     assert maxdiff(o2, a["out"]) <= TOL and maxdiff(o1, o2) > 1e-3
+
+
+def test_corrnet_state_dict_and_forward():
+    from oracle import nets
+    meta, a = load_golden("corrnet_ragged")
+    m = models.corrnet(**meta["kwargs"]).eval()
+    ref = nets.corrnet(**meta["kwargs"])
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    synth.load_recipe(m, meta["recipe_seed"])
+    d = data_from(a)
+    ov, op, vis, tau = m(d, True, False)
+    assert rel_excess(ov, a["out_vtx"], TOL) <= 0
+    assert rel_excess(op, a["out_pts"], TOL) <= 0
+    assert rel_excess(vis, a["out_vismask"], 1e-4) <= 0
+    assert tau is m.temprature
+    assert m(d, False, False)[2] is None
+    m(d, False, True)       # random FPS start runs
