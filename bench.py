@@ -27,21 +27,22 @@ PEAK_HBM_GBS = 8000.0
 
 def _mesh(args):
     from morig_amd import synth
-    return synth.make_mesh(args[0], n_side=args[1], with_skin=False)
+    return synth.make_mesh(args[0], n_side=args[1], with_skin=args[2])
 
 
-def build_batch(seeds, n_side):
+def build_batch(seeds, n_side, with_skin=False, n_pts=0):
     from morig_amd import synth
     import multiprocessing as mp
     nproc = max(1, min(len(seeds), (os.cpu_count() or 8) // 4, 32))
     if nproc > 1:
         torch.set_num_threads(1)
         with mp.get_context("fork").Pool(nproc) as pool:
-            meshes = pool.map(_mesh, [(s, n_side) for s in seeds])
+            meshes = pool.map(_mesh, [(s, n_side, with_skin) for s in seeds])
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // 2))
     else:
-        meshes = [_mesh((s, n_side)) for s in seeds]
-    b = synth.collate(meshes)
+        meshes = [_mesh((s, n_side, with_skin)) for s in seeds]
+    clouds = [synth.make_point_cloud(m, int(m.name), n_pts) for m in meshes] if n_pts else None
+    b = synth.collate(meshes, clouds)
     b.num_graphs = len(seeds)
     return b
 
@@ -97,6 +98,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="meshes per GPU")
     ap.add_argument("--n-side", type=int, default=64, help="mesh grid side (64 -> 4096 vertices)")
+    ap.add_argument("--workload", default="jointnet", choices=["jointnet", "mask_skin", "corrnet"],
+                    help="jointnet = BASELINE.json configs[1] (the headline metric); mask_skin = configs[2]; "
+                         "corrnet = configs[3] (8192-point clouds, 32 pairs per GPU)")
+    ap.add_argument("--n-pts", type=int, default=8192)
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
 
@@ -115,15 +120,41 @@ def main():
     from morig_amd import dist as mdist, models, native, synth
 
     B = args.batch
-    data = build_batch([1000 + rank * B + i for i in range(B)], args.n_side).to(dev)
-    model = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
-    synth.load_recipe(model, 0, mild=True).to(dev)
+    if args.workload == "corrnet" and args.batch == 64:
+        B = 32                                         # configs[3]: 256 pairs over 8 GPUs
+    with_skin = args.workload == "mask_skin"
+    data = build_batch([1000 + rank * B + i for i in range(B)], args.n_side, with_skin=with_skin,
+                       n_pts=args.n_pts if args.workload == "corrnet" else 0).to(dev)
     n_vert = data.pos.shape[0]
+    gather = (lambda t: mdist.all_gather_rows(t, equal_rows=True)) if world > 1 else (lambda t: t)
+    if args.workload == "jointnet":
+        model = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
+        synth.load_recipe(model, 0, mild=True).to(dev)
 
-    def step():
-        motion_all, motion_aggr, pred_shift = model(data, data.pred_flow)
-        gathered = mdist.all_gather_rows(pred_shift, equal_rows=True) if world > 1 else pred_shift
-        return gathered
+        def step():
+            motion_all, motion_aggr, pred_shift = model(data, data.pred_flow)
+            return gather(pred_shift)
+    elif args.workload == "mask_skin":
+        model = models.masknet_motion(num_keyframes=5, chn_output=1, aggr_method="attn").eval()
+        skin = models.skinnet_motion(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True,
+                                     motion_dim=32).eval()
+        synth.load_recipe(model, 0, mild=True).to(dev)
+        synth.load_recipe(skin, 1, mild=True).to(dev)
+
+        def step():
+            mask = model(data, data.pred_flow)[2]
+            sk = skin(data, data.pred_flow)[2]
+            gather(mask)
+            return gather(sk)
+    else:
+        model = models.corrnet(input_feature=3, output_feature=64, temprature=0.07).eval()
+        synth.load_recipe(model, 0, mild=True).to(dev)
+
+        def step():
+            out_vtx, out_pts, vis, _ = model(data, True, False)
+            gather(out_pts)
+            gather(vis)
+            return gather(out_vtx)
 
     def fence():
         torch.cuda.synchronize()
@@ -150,6 +181,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     assert out.shape[0] == n_vert * world and bool(torch.isfinite(out).all())
+    if args.workload != "jointnet" and rank == 0:
+        pass
 
     if rank == 0:
         total_ms = sum(v["ms"] for v in prof.values())
@@ -165,23 +198,30 @@ def main():
                              launches_per_step=v["launches"] / args.steps)
                      for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         all_flops = sum(v["flops"] for v in prof.values())
+        names = {"jointnet": ("meshes/sec jointnet_motion forward, 4 k-vert synthetic",
+                              "jointnet_motion(num_keyframes=5, attn) eval forward", "BASELINE.json configs[1]"),
+                 "mask_skin": ("meshes/sec masknet_motion + skinnet_motion forward, 4 k-vert synthetic",
+                               "masknet_motion + skinnet_motion(nearest_bone=5) eval forwards", "BASELINE.json configs[2]"),
+                 "corrnet": ("pairs/sec corrnet forward, 4 k-vert mesh + 8 k-point cloud",
+                             f"corrnet(train_vismask=True, random_start=False) eval forward, {args.n_pts}-point clouds",
+                             "BASELINE.json configs[3]")}[args.workload]
         res = {
-            "metric": "meshes/sec jointnet_motion forward, 4 k-vert synthetic",
-            "value": round(world * B * args.steps / dt, 2), "unit": "meshes/s",
+            "metric": names[0],
+            "value": round(world * B * args.steps / dt, 2), "unit": "pairs/s" if args.workload == "corrnet" else "meshes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"jointnet_motion(num_keyframes=5, attn) eval forward, batch={B} synthetic "
-                                   f"{args.n_side * args.n_side}-vertex meshes per GPU (BASELINE.json configs[1]), "
-                                   "COO->CSR prep + forward" + (" + RCCL all-gather of pred_shift" if world > 1 else ""),
+            "config": {"workload": f"{names[1]}, batch={B} synthetic "
+                                   f"{args.n_side * args.n_side}-vertex meshes per GPU ({names[2]}), "
+                                   "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if world > 1 else ""),
                        "meshes_per_gpu": B, "vertices_per_mesh": args.n_side * args.n_side,
                        "parallelism": f"mesh-sharded dp{world}"},
             "roofline": roof,
             "whole_forward_tflops": round(all_flops / args.steps / (dt / args.steps) / 1e12, 2),
             "kernels": breakdown,
         }
-        if world == 1 and args.cpu_seconds > 0:
+        if world == 1 and args.cpu_seconds > 0 and args.workload == "jointnet":
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)
         else:
             res["cpu_baseline"] = None
