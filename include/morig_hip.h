@@ -68,6 +68,16 @@ int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_
                               int32_t* cursor, int32_t* status, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Arithmetic. Default: fp32 operands on v_mfma_f32_32x32x2_f32 (exact fp32 products, k-ordered fma).
+ * Split-fp16 fast path (selected per call by passing W_split): each fp32 operand x is split on the fly
+ * into hi = fp16(x), lo = fp16(x - hi) and the product evaluated as hi*hi + hi*lo + lo*hi on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation -- fp16 products are exact in fp32 and the omitted
+ * lo*lo term is 2^-22 relative, so the result is fp32-class (measured ~1e-6 of scale) at 5.3x the
+ * fp32-MFMA rate. Weights are pre-split by the host: every 32-float chunk of a packed weight row is
+ * replaced by [32 halves hi | 32 halves lo] (same bytes, same strides). Operands must stay inside the
+ * fp16 range (|x| < 65000); otherwise the kernel raises *overflow and the caller must redo the layer
+ * on the fp32 path (morig_amd.models does this for the whole forward).
+ *
  * Fused dense layer:  Y = scale * act(X * W^T + bias + rowbias[seg[row]]) + shift
  *                     and/or  P[seg[row]] = max over rows (column-wise)            (pool != NULL)
  * Replaces nn.Linear -> ReLU -> BatchNorm1d(eval) chains of MLP()   models/basic_modules.py:31-36
@@ -88,6 +98,9 @@ typedef struct morig_gemm_args {
     const int32_t* seg;       /* [M] segment (mesh) id of every row; required with rowbias / pool */
     float* Y; int32_t ldy;    /* optional output                                                  */
     float* pool; int32_t ld_pool; int32_t n_seg;  /* optional [n_seg][ld_pool] column max per segment */
+    /* optional fast path (see "split-fp16" below): W_split has the shape/stride of W; overflow is an int32
+     * on the device that the kernel sets to 1 if an operand left the fp16 range (result then invalid). */
+    const void* W_split; int32_t* overflow;
 } morig_gemm_args;
 int morig_gemm(const morig_gemm_args* a, void* stream);
 
@@ -119,6 +132,7 @@ typedef struct morig_edgeconv_args {
     const float* W2; int32_t ldw;      /* packed [Hpad][ldw], ldw >= roundup(H,32)... see morig_gemm_args.W */
     const float* b2; const float* s2; const float* t2;   /* [Hpad]                        */
     float* out; int32_t ldo;           /* out[row][0..H)                                  */
+    const void* W2_split; int32_t* overflow;   /* optional split-fp16 fast path (H >= 32), as in morig_gemm_args */
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 
@@ -137,6 +151,7 @@ typedef struct morig_segmax_args {
     const int32_t* rowptr; const int32_t* dst_sorted; int32_t n_nodes;
     int32_t edge_capacity; int32_t edge_count;
     float* out; int32_t ldo;             /* [n_nodes][ldo]                                          */
+    const void* W_split; int32_t* overflow;
 } morig_segmax_args;
 int morig_segmax_gemm(const morig_segmax_args* a, void* stream);
 
@@ -207,7 +222,7 @@ int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t
 /* --------------------------------------------------------------------------------------------
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline object.
  */
-#define MORIG_PROF_KINDS 24
+#define MORIG_PROF_KINDS 40
 int         morig_prof_enable(int on);                 /* returns previous state */
 int         morig_prof_reset(void);
 const char* morig_prof_name(int kind);                  /* NULL past the last kind */

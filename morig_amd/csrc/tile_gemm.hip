@@ -22,6 +22,17 @@ namespace morig {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// Arithmetic modes of the contraction:
+//   PREC_F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak).
+//   PREC_F16X3 : every fp32 operand is split x = hi + lo with hi = fp16(x), lo = fp16(x - hi); the product
+//                is  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_f16 with fp32 accumulation (3 MFMAs per
+//                16 k = 5.3x the fp32-MFMA rate). fp16 products are exact in fp32, the dropped lo*lo term
+//                and the rounding of lo are both ~2^-22 relative: fp32-class accuracy. |x| must stay below
+//                the fp16 range; the loader raises `ovf` otherwise and the host re-runs in PREC_F32.
+enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 
 enum { LOAD_DENSE = 0, LOAD_EDGE = 1 };
 enum { MODE_STORE = 0, MODE_POOL = 1, MODE_EDGEMAX = 2 };
@@ -40,10 +51,11 @@ struct TileParams {
     const float* rowbias; int ld_rowbias; const int* seg;
     float* Y; int ldy;           // store target / edge-max target / pool target
     int tiles_n;
+    int* ovf;                    // PREC_F16X3: set to 1 when an operand leaves the fp16 range
 };
 
-template <int BN, int KC, int LOAD, int MODE>
-__global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const TileParams p) {
+template <int BN, int KC, int LOAD, int MODE, int PREC>
+__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) void tile_kernel(const TileParams p) {
     constexpr int BM = 128;
     constexpr int WN = (BN >= 128) ? 2 : 1;
     constexpr int WM = 4 / WN;
@@ -61,6 +73,7 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const Ti
     constexpr int SM_Z = (MODE == MODE_STORE) ? 0 : BM * ZLD;
     constexpr int SM = SM_MAIN > SM_Z ? SM_MAIN : SM_Z;
     static_assert(BN % 32 == 0 && KC % 8 == 0, "tile shape");
+    static_assert(PREC == PREC_F32 || KC == 32, "the split-fp16 LDS image is [hi 32 halves | lo 32 halves] per row chunk");
 
     __shared__ __attribute__((aligned(16))) float smem[SM + BM];
     float* sA = smem;
@@ -155,7 +168,22 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const Ti
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = (k + c < p.K) ? v[c] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(&sA[(lrow + i * RPP) * LDK + 4 * lkq]) = v;
+            if (PREC == PREC_F32) {
+                *reinterpret_cast<f32x4*>(&sA[(lrow + i * RPP) * LDK + 4 * lkq]) = v;
+            } else {
+                f16x4 h, l;
+                bool bad = false;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    h[c] = (_Float16)v[c];
+                    l[c] = (_Float16)(v[c] - (float)h[c]);
+                    bad |= !(fabsf(v[c]) < 65000.f);
+                }
+                if (bad) *p.ovf = 1;
+                char* rowp = reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4);
+                *reinterpret_cast<f16x4*>(rowp + 8 * lkq) = h;
+                *reinterpret_cast<f16x4*>(rowp + 64 + 8 * lkq) = l;
+            }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -180,6 +208,33 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const Ti
         stage(c * KC);
         __syncthreads();
         if (c + 1 < nchunk) fetch((c + 1) * KC);
+        if (PREC == PREC_F16X3) {
+            const char* a0 = reinterpret_cast<const char*>(sA) + (wm * MT * 32 + l31) * (LDK * 4) + 16 * hi;
+            const char* b0 = reinterpret_cast<const char*>(sB) + (wn * NT * 32 + l31) * (LDK * 4) + 16 * hi;
+#pragma unroll
+            for (int st = 0; st < KC / 16; ++st) {
+                f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    ah[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDK * 4 + 32 * st);
+                    al[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDK * 4 + 32 * st + 64);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    bh[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDK * 4 + 32 * st);
+                    bl[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDK * 4 + 32 * st + 64);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+            continue;
+        }
         const float* a0 = sA + (wm * MT * 32 + l31) * LDK + 4 * hi;
         const float* b0 = sB + (wn * NT * 32 + l31) * LDK + 4 * hi;
 #pragma unroll
@@ -298,9 +353,9 @@ __global__ __launch_bounds__(256, (BN == 256 ? 2 : 1)) void tile_kernel(const Ti
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BN, int KC, int LOAD, int MODE>
+template <int BN, int KC, int LOAD, int MODE, int PREC = PREC_F32>
 static int launch_tile(const TileParams& p, int nblocks, hipStream_t s) {
-    hipLaunchKernelGGL((tile_kernel<BN, KC, LOAD, MODE>), dim3(nblocks), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((tile_kernel<BN, KC, LOAD, MODE, PREC>), dim3(nblocks), dim3(256), 0, s, p);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -333,28 +388,37 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
     const double flops = 2.0 * a->M * (double)a->N * a->K;
     const double bytes = 4.0 * ((double)a->M * a->K + (double)a->N * a->K + (pool ? 0.0 : (double)a->M * a->N));
 
+    const bool f16 = a->W_split != nullptr;
+    if (f16) {
+        if (!a->overflow || !aligned16(a->W_split)) return MORIG_E_INVALID;
+        p.W = static_cast<const float*>(a->W_split); p.ovf = a->overflow;
+    }
     if (pool) {
         if (a->n_seg <= 0 || a->ld_pool < a->N) return MORIG_E_INVALID;
         // identity of the integer-atomic float max
         MORIG_HIP_TRY(hipMemsetAsync(a->pool, 0xFF, (size_t)a->n_seg * a->ld_pool * sizeof(float), s));
         p.Y = a->pool; p.ldy = a->ld_pool;
         p.tiles_n = cdiv(a->N, 128);
-        ProfScope ps(K_GEMM_POOL, s, flops, bytes);
-        return launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
+        ProfScope ps(f16 ? K_GEMM16_POOL : K_GEMM_POOL, s, flops, bytes);
+        return f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
+                   : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
     }
     p.Y = a->Y; p.ldy = a->ldy;
     if (a->N > 64) {
         p.tiles_n = cdiv(a->N, 128);
-        ProfScope ps(K_GEMM_BN128, s, flops, bytes);
-        return launch_tile<128, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m * p.tiles_n, s);
+        ProfScope ps(f16 ? K_GEMM16_BN128 : K_GEMM_BN128, s, flops, bytes);
+        return f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_STORE, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
+                   : launch_tile<128, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m * p.tiles_n, s);
     } else if (a->N > 32) {
         p.tiles_n = 1;
-        ProfScope ps(K_GEMM_BN64, s, flops, bytes);
-        return launch_tile<64, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m, s);
+        ProfScope ps(f16 ? K_GEMM16_BN64 : K_GEMM_BN64, s, flops, bytes);
+        return f16 ? launch_tile<64, 32, LOAD_DENSE, MODE_STORE, PREC_F16X3>(p, tiles_m, s)
+                   : launch_tile<64, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m, s);
     } else {
         p.tiles_n = 1;
-        ProfScope ps(K_GEMM_BN32, s, flops, bytes);
-        return launch_tile<32, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m, s);
+        ProfScope ps(f16 ? K_GEMM16_BN32 : K_GEMM_BN32, s, flops, bytes);
+        return f16 ? launch_tile<32, 32, LOAD_DENSE, MODE_STORE, PREC_F16X3>(p, tiles_m, s)
+                   : launch_tile<32, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m, s);
     }
 }
 
@@ -375,6 +439,10 @@ static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
     p.Y = a->out; p.ldy = a->ldo;
     p.tiles_per_rep = cdiv(a->edge_capacity, 128);
     p.tiles_n = 1;
+    if (a->W2_split) {
+        if (!a->overflow || !aligned16(a->W2_split) || a->H < 32) return MORIG_E_INVALID;
+        p.W = static_cast<const float*>(a->W2_split); p.ovf = a->overflow;
+    }
     return MORIG_OK;
 }
 
@@ -386,12 +454,17 @@ extern "C" int morig_edge_hidden(const morig_edgeconv_args* a, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity);
     const double flops = 2.0 * E * a->H * (double)a->H;
-    ProfScope ps(K_POINTCONV, s, flops, 4.0 * 3.0 * E * a->H);
+    const bool f16 = a->W2_split != nullptr;
+    ProfScope ps(f16 ? K_POINTCONV16 : K_POINTCONV, s, flops, 4.0 * 3.0 * E * a->H);
     switch (a->H) {
-        case 32:  return launch_tile<32, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
-        case 64:  return launch_tile<64, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
-        case 128: return launch_tile<128, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
-        case 256: return launch_tile<256, 16, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        case 32:  return f16 ? launch_tile<32, 32, LOAD_EDGE, MODE_STORE, PREC_F16X3>(p, p.tiles_per_rep, s)
+                             : launch_tile<32, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        case 64:  return f16 ? launch_tile<64, 32, LOAD_EDGE, MODE_STORE, PREC_F16X3>(p, p.tiles_per_rep, s)
+                             : launch_tile<64, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        case 128: return f16 ? launch_tile<128, 32, LOAD_EDGE, MODE_STORE, PREC_F16X3>(p, p.tiles_per_rep, s)
+                             : launch_tile<128, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
+        case 256: return f16 ? launch_tile<256, 32, LOAD_EDGE, MODE_STORE, PREC_F16X3>(p, p.tiles_per_rep, s)
+                             : launch_tile<256, 16, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
         default: return MORIG_E_UNSUPPORTED;
     }
 }
@@ -413,36 +486,31 @@ extern "C" int morig_segmax_gemm(const morig_segmax_args* a, void* stream) {
     p.tiles_n = 1;
     MORIG_HIP_TRY(hipMemset2DAsync(a->out, (size_t)a->ldo * sizeof(float), 0xFF, (size_t)a->N * sizeof(float), (size_t)a->n_nodes, s));
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity);
-    ProfScope ps(K_POINTCONV, s, 2.0 * E * a->N * (double)a->K, 4.0 * E * a->K);
-    if (a->N <= 32)       return launch_tile<32, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
-    else if (a->N <= 64)  return launch_tile<64, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
-    else if (a->N <= 128) return launch_tile<128, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
-    else if (a->N <= 256) return launch_tile<256, 16, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    const bool f16 = a->W_split != nullptr;
+    if (f16) {
+        if (!a->overflow || !aligned16(a->W_split)) return MORIG_E_INVALID;
+        p.W = static_cast<const float*>(a->W_split); p.ovf = a->overflow;
+    }
+    ProfScope ps(f16 ? K_POINTCONV16 : K_POINTCONV, s, 2.0 * E * a->N * (double)a->K, 4.0 * E * a->K);
+    if (a->N <= 32)       return f16 ? launch_tile<32, 32, LOAD_DENSE, MODE_EDGEMAX, PREC_F16X3>(p, p.tiles_per_rep, s)
+                                     : launch_tile<32, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    else if (a->N <= 64)  return f16 ? launch_tile<64, 32, LOAD_DENSE, MODE_EDGEMAX, PREC_F16X3>(p, p.tiles_per_rep, s)
+                                     : launch_tile<64, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    else if (a->N <= 128) return f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_EDGEMAX, PREC_F16X3>(p, p.tiles_per_rep, s)
+                                     : launch_tile<128, 32, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
+    else if (a->N <= 256) return f16 ? launch_tile<256, 32, LOAD_DENSE, MODE_EDGEMAX, PREC_F16X3>(p, p.tiles_per_rep, s)
+                                     : launch_tile<256, 16, LOAD_DENSE, MODE_EDGEMAX>(p, p.tiles_per_rep, s);
     return MORIG_E_UNSUPPORTED;
 }
 
 extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
-    if (!a || !a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
-    if (!a->s1 || !a->t1 || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
-    if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
-    if (a->in_rep_stride < 0 || (a->replicas > 1 && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
-    if ((a->lda & 3) || (a->ldb & 3) || (a->ldw & 3) || !aligned16(a->A) || !aligned16(a->B) || !aligned16(a->W2) ||
-        !aligned16(a->s1) || !aligned16(a->t1)) return MORIG_E_INVALID;
-    if (a->ldo < a->H || a->lda < a->H || a->ldb < a->H || a->ldw < a->H) return MORIG_E_INVALID;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-
     TileParams p = {};
-    p.M = a->edge_capacity; p.N = a->H; p.K = a->H;
-    p.W = a->W2; p.ldw = a->ldw;
-    p.bias = a->b2; p.scale = a->s2; p.shift = a->t2; p.relu = 1;
-    p.A = a->A; p.lda = a->lda; p.B = a->B; p.ldb = a->ldb;
-    p.rowptr = a->rowptr; p.srcS = a->src_sorted; p.dstS = a->dst_sorted;
-    p.n_nodes = a->n_nodes; p.rep_in = a->in_rep_stride; p.rep_out = a->out_rep_stride;
-    p.s1 = a->s1; p.t1 = a->t1;
-    p.Y = a->out; p.ldy = a->ldo;
-    p.tiles_per_rep = cdiv(a->edge_capacity, 128);
-    p.tiles_n = 1;
+    const int st = edge_common(a, p);
+    if (st != MORIG_OK) return st;
+    if (a->in_rep_stride < 0 || (a->replicas > 1 && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblocks = p.tiles_per_rep * a->replicas;
+    const bool f16 = a->W2_split != nullptr;
 
     // tile-straddling target segments combine through integer-atomic float max: pre-fill identity
     const size_t rows = (size_t)(a->replicas - 1) * a->out_rep_stride + a->n_nodes;
@@ -451,6 +519,15 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
     const double flops = 2.0 * E * a->H * (double)a->H;
     const double bytes = 4.0 * (2.0 * E * a->H) ;    // gathered operand rows (mostly L2 hits)
+    if (f16) {
+        switch (a->H) {
+            case 32:  { ProfScope ps(K_EDGE16_H32, s, flops, bytes);  return launch_tile<32, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
+            case 64:  { ProfScope ps(K_EDGE16_H64, s, flops, bytes);  return launch_tile<64, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
+            case 128: { ProfScope ps(K_EDGE16_H128, s, flops, bytes); return launch_tile<128, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
+            case 256: { ProfScope ps(K_EDGE16_H256, s, flops, bytes); return launch_tile<256, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
+            default: return MORIG_E_UNSUPPORTED;
+        }
+    }
     switch (a->H) {
         case 16:  { ProfScope ps(K_EDGE_H16, s, flops, bytes);  return launch_tile<32, 16, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }
         case 32:  { ProfScope ps(K_EDGE_H32, s, flops, bytes);  return launch_tile<32, 32, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }

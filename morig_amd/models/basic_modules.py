@@ -64,6 +64,18 @@ class NativeModule(torch.nn.Module):
     def _pack(self):
         raise NotImplementedError
 
+    def forward(self, *args, **kwargs):
+        """eval-mode forward on the HIP path. The whole forward runs inside the op layer's precision
+        guard: split-fp16 MFMA first; if a kernel saw an operand outside the fp16 range the forward is
+        repeated with fp32 MFMA (morig_amd.native.NativeOps.guarded)."""
+        self._require_eval()
+        ops = get_ops()
+        dev = next(self.parameters()).device
+        return ops.guarded(dev, lambda: self._forward(*args, **kwargs))
+
+    def _forward(self, *args, **kwargs):
+        raise NotImplementedError
+
     def _require_eval(self):
         if self.training:
             raise NotImplementedError(
@@ -100,8 +112,7 @@ class EdgeConv(NativeModule):
         vertex, (edge,) = packing.pack_edge_pair([self.nn_pos])
         return dict(vertex=vertex, edge=edge)
 
-    def forward(self, x, edge_index):
-        self._require_eval()
+    def _forward(self, x, edge_index):
         ops = get_ops()
         x = _padded_copy(ops, _as_matrix(x))
         pk = self.packed(x.device)
@@ -128,8 +139,7 @@ class EdgeConvMotion(NativeModule):
         vp, (ep,) = packing.pack_edge_pair([self.nn_pos])
         return dict(vx=vx, ex=ex, vp=vp, ep=ep)
 
-    def forward(self, pos, x, edge_index):
-        self._require_eval()
+    def _forward(self, pos, x, edge_index):
         ops = get_ops()
         x = _padded_copy(ops, _as_matrix(x))
         pos = _padded_copy(ops, _as_matrix(pos))
@@ -171,8 +181,7 @@ class GCU(NativeModule):
         ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["eg"], Mat.of(ec, H, H))
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out)
 
-    def forward(self, pos, tpl_edge_index, geo_edge_index):
-        self._require_eval()
+    def _forward(self, pos, tpl_edge_index, geo_edge_index):
         ops = get_ops()
         x = _padded_copy(ops, _as_matrix(pos))
         n = x.shape[0]
@@ -222,8 +231,7 @@ class GCUMotion(NativeModule):
                      replicas=replicas, in_rep_stride=0, out_rep_stride=n)
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out)
 
-    def forward(self, pos, x, tpl_edge_index, geo_edge_index):
-        self._require_eval()
+    def _forward(self, pos, x, tpl_edge_index, geo_edge_index):
         ops = get_ops()
         x = _padded_copy(ops, _as_matrix(x))
         pos = _padded_copy(ops, _as_matrix(pos))

@@ -218,8 +218,7 @@ class CorrNet(NativeModule):
         ops.rownorm(Mat.of(raw), N0, 1, out_pts, self.output_feature, 0)
         return out_pts, ptr0
 
-    def forward(self, data, train_vismask, random_start=True):
-        self._require_eval()
+    def _forward(self, data, train_vismask, random_start=True):
         ops = get_ops()
         dev = data.vtx.device
         pk = self.packed(dev)

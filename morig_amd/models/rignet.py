@@ -76,8 +76,7 @@ class TemporalAttn(NativeModule):
         ops.gemm(Mat.of(res), pk["ff1"], relu=True, Y=Mat.of(h))
         ops.gemm(Mat.of(h), pk["ff2"], relu=True, Y=out)
 
-    def forward(self, x):
-        self._require_eval()
+    def _forward(self, x):
         ops = get_ops()
         x = x.float().contiguous()
         out = ops.empty(x.shape[0], self.feedforward[1][0].out_features, x.device)
@@ -145,8 +144,7 @@ class GCNRig(NativeModule):
         ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2))
         ops.gemm(Mat.of(h2), pk["t3"], relu=False, Y=out)
 
-    def forward(self, pos, feature, tpl_edge_index, geo_edge_index, batch):
-        self._require_eval()
+    def _forward(self, pos, feature, tpl_edge_index, geo_edge_index, batch):
         ops = get_ops()
         dev = pos.device
         n = pos.shape[0]
@@ -216,8 +214,7 @@ class _MotionHead(_MotionBackbone):
         else:
             setattr(self, self._head, GCNRig(chn_feature=32, chn_output=chn_output, aggr=aggr))
 
-    def forward(self, data, input_flow):
-        self._require_eval()
+    def _forward(self, data, input_flow):
         ops = get_ops()
         head = getattr(self, self._head)
         st = self._motion(ops, data, input_flow, self.aggr_method, head.chn_feature)
@@ -305,8 +302,7 @@ class SkinNet_inner(NativeModule):
         ops.gemm(Mat.of(h1), pk["c2"], relu=True, Y=Mat.of(h2))
         ops.gemm(Mat.of(h2), pk["c3"], relu=False, Y=out)
 
-    def forward(self, data, motion):
-        self._require_eval()
+    def _forward(self, data, motion):
         ops = get_ops()
         n = motion.shape[0]
         ng = _num_graphs(data, data.batch)
@@ -329,8 +325,7 @@ class SkinMotion(_MotionBackbone):
                                        output_size=motion_dim)
         self.skinNet = SkinNet_inner(nearest_bone, use_Dg, use_Lf, motion_dim, use_motion, aggr)
 
-    def forward(self, data, input_flow):
-        self._require_eval()
+    def _forward(self, data, input_flow):
         ops = get_ops()
         st = self._motion(ops, data, input_flow, "attn", self.motion_dim)
         n = data.pos.shape[0]

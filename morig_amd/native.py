@@ -33,6 +33,7 @@ class GemmArgs(C.Structure):
         ("seg", c_i32p),
         ("Y", c_f32p), ("ldy", C.c_int32),
         ("pool", c_f32p), ("ld_pool", C.c_int32), ("n_seg", C.c_int32),
+        ("W_split", C.c_void_p), ("overflow", c_i32p),
     ]
 
 
@@ -49,6 +50,7 @@ class EdgeConvArgs(C.Structure):
         ("W2", c_f32p), ("ldw", C.c_int32),
         ("b2", c_f32p), ("s2", c_f32p), ("t2", c_f32p),
         ("out", c_f32p), ("ldo", C.c_int32),
+        ("W2_split", C.c_void_p), ("overflow", c_i32p),
     ]
 
 
@@ -61,6 +63,7 @@ class SegmaxArgs(C.Structure):
         ("rowptr", c_i32p), ("dst_sorted", c_i32p), ("n_nodes", C.c_int32),
         ("edge_capacity", C.c_int32), ("edge_count", C.c_int32),
         ("out", c_f32p), ("ldo", C.c_int32),
+        ("W_split", C.c_void_p), ("overflow", c_i32p),
     ]
 
 
@@ -196,6 +199,44 @@ class NativeOps:
         self.lib = load_library()
         if not torch.cuda.is_available():
             raise MorigNativeError("no ROCm device visible: the MoRig forward path has no CPU fallback")
+        # arithmetic of the MFMA contractions: "f16x3" = split-fp16 fast path with overflow guard
+        # (default), "f32" = fp32 MFMA everywhere. MORIG_PRECISION overrides.
+        self.precision = os.environ.get("MORIG_PRECISION", "f16x3")
+        assert self.precision in ("f16x3", "f32")
+        self._ovf = {}
+        self._depth = 0
+        self._force_f32 = False
+
+    # -- split-fp16 guard -------------------------------------------------------------------------
+    @property
+    def fast(self) -> bool:
+        return self.precision == "f16x3" and not self._force_f32
+
+    def _flag(self, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        if key not in self._ovf:
+            self._ovf[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return self._ovf[key]
+
+    def guarded(self, device, fn):
+        """Run ``fn()`` (a whole forward) on the fast path; if any kernel reported an operand outside the
+        fp16 range, run it again on the fp32 path. Nested calls run inside the outer guard."""
+        if self._depth > 0 or not self.fast:
+            return fn()
+        flag = self._flag(device)
+        flag.zero_()
+        self._depth += 1
+        try:
+            out = fn()
+        finally:
+            self._depth -= 1
+        if int(flag.item()) != 0:                     # one 4-byte D2H read per forward
+            self._force_f32 = True
+            try:
+                out = fn()
+            finally:
+                self._force_f32 = False
+        return out
 
     # -- allocation (PyTorch owns all device memory) -------------------------------------------
     def empty(self, rows, cols, device, dtype=torch.float32):
@@ -245,6 +286,8 @@ class NativeOps:
         if pool is not None:
             assert pool.shape[1] >= lin.N and pool.is_contiguous()
             a.pool, a.ld_pool, a.n_seg = pool.data_ptr(), pool.stride(0), pool.shape[0]
+        if self.fast and lin.Wsplit is not None:
+            a.W_split, a.overflow = lin.Wsplit.data_ptr(), self._flag(X.base.device).data_ptr()
         check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")
 
     # -- fused edge conv ----------------------------------------------------------------------------
@@ -267,6 +310,8 @@ class NativeOps:
         a.W2, a.ldw = ec.W2.data_ptr(), ec.W2.stride(0)
         a.b2, a.s2, a.t2 = ec.b2.data_ptr(), ec.s2.data_ptr(), ec.t2.data_ptr()
         a.out, a.ldo = out.ptr, out.ld
+        if self.fast and ec.W2split is not None:
+            a.W2_split, a.overflow = ec.W2split.data_ptr(), self._flag(A.base.device).data_ptr()
         return a
 
     def edge_hidden(self, A: Mat, B: Mat, csr: CSR, ec, Z: Mat):
@@ -290,6 +335,8 @@ class NativeOps:
         a.rowptr, a.dst_sorted, a.n_nodes = csr.rowptr.data_ptr(), csr.dst.data_ptr(), csr.n_nodes
         a.edge_capacity, a.edge_count = csr.capacity, csr.edge_count
         a.out, a.ldo = out.ptr, out.ld
+        if self.fast and lin.Wsplit is not None:
+            a.W_split, a.overflow = lin.Wsplit.data_ptr(), self._flag(X.base.device).data_ptr()
         check(self.lib.morig_segmax_gemm(C.byref(a), _stream()), "morig_segmax_gemm")
 
     # -- point clouds ---------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ class PackedLinear:
     shift: Optional[torch.Tensor]
     N: int
     K: int
+    Wsplit: Optional[torch.Tensor] = None   # split-fp16 image of W (same shape/stride), None = fp32 only
 
 
 @dataclass
@@ -55,6 +56,25 @@ class PackedEdge:
     b2: torch.Tensor
     s2: torch.Tensor
     t2: torch.Tensor
+    W2split: Optional[torch.Tensor] = None
+
+
+F16_SAFE_MAX = 6.0e4
+
+
+def split_f16(Wp: torch.Tensor) -> Optional[torch.Tensor]:
+    """Split-fp16 image of a packed weight matrix [Npad, Kpad] (Kpad % 32 == 0): every 32-float chunk of
+    a row becomes [32 halves hi | 32 halves lo] with hi = fp16(w), lo = fp16(w - hi); same bytes, so the
+    kernels' weight loader is unchanged (include/morig_hip.h, "split-fp16"). None if a weight does not
+    fit the fp16 range."""
+    N, Kp = Wp.shape
+    assert Kp % 32 == 0
+    if not bool(torch.isfinite(Wp).all()) or float(Wp.abs().max()) >= F16_SAFE_MAX:
+        return None
+    hi = Wp.half()
+    lo = (Wp - hi.float()).half()
+    img = torch.stack([hi.view(N, Kp // 32, 32), lo.view(N, Kp // 32, 32)], dim=2)     # [N, Kc, 2, 32] halves
+    return img.reshape(N, Kp * 2).contiguous().view(torch.float32)
 
 
 def _pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[torch.Tensor]:
@@ -82,8 +102,9 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: O
     s = t = None
     if bn is not None:
         s, t = bn_affine(bn)
-    return PackedLinear(Wp.contiguous(), _pad_vec(bias.detach() if bias is not None else torch.zeros(N, device=W.device), Npad),
-                        _pad_vec(s, Npad, 1.0), _pad_vec(t, Npad), N, K)
+    Wp = Wp.contiguous()
+    return PackedLinear(Wp, _pad_vec(bias.detach() if bias is not None else torch.zeros(N, device=W.device), Npad),
+                        _pad_vec(s, Npad, 1.0), _pad_vec(t, Npad), N, K, split_f16(Wp))
 
 
 def pack_mlp_layer(layer: nn.Sequential, **kw) -> PackedLinear:
@@ -109,8 +130,10 @@ def pack_edge_pair(mlps: Sequence[nn.Sequential]):
         Hp, Kp = max(H, 32), _roundup(H, 32)
         W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=W1.device)
         W2[:H, :H] = lin2.weight.detach().float()
-        edges.append(PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2.contiguous(),
-                                _pad_vec(lin2.bias.detach(), Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp)))
+        W2 = W2.contiguous()
+        edges.append(PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2,
+                                _pad_vec(lin2.bias.detach(), Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp),
+                                split_f16(W2) if H >= 32 else None))
     vertex = pack_linear(torch.cat(rows, 0), torch.cat(biases, 0))
     return vertex, edges
 
@@ -130,8 +153,9 @@ def pack_pointconv(local_nn: nn.Sequential, cx: int):
     Hp, Kp = max(H, 32), _roundup(H, 32)
     W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=W1.device)
     W2[:H, :H] = l2[0].weight.detach().float()
-    edge = PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2.contiguous(), _pad_vec(l2[0].bias.detach(), Hp),
-                      _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp))
+    W2 = W2.contiguous()
+    edge = PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2, _pad_vec(l2[0].bias.detach(), Hp),
+                      _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp), split_f16(W2) if H >= 32 else None)
     return dict(src=src, tgt=tgt, edge=edge, last=pack_mlp_layer(l3))
 
 

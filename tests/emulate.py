@@ -15,6 +15,10 @@ from morig_amd.native import CSR, Mat
 
 class EmuOps:
     name = "emulated"
+    precision = "f32"
+
+    def guarded(self, device, fn):
+        return fn()
 
     def empty(self, rows, cols, device, dtype=torch.float32):
         # poison, so a plan that reads something it never wrote fails loudly

@@ -13,10 +13,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def ops(request):
+    """every kernel test runs on both arithmetic paths: split-fp16 MFMA (default) and fp32 MFMA."""
     from morig_amd import native
-    return native.get_ops()
+    o = native.get_ops()
+    prev = o.precision
+    o.precision = request.param
+    yield o
+    o.precision = prev
 
 
 def _rand_graph(n, e, seed, hub=None):
@@ -322,3 +327,29 @@ def test_cosine_nn_and_gather_rows(ops):
     out = torch.zeros(4, 70, device=DEV)
     ops.gather_rows(Mat.of(p.to(DEV)), idx.to(DEV), Mat.of(out, 3, 64))
     assert torch.equal(out.cpu()[0, 3:67], p[5]) and float(out[2].abs().sum()) == 0 and torch.equal(out.cpu()[3, 3:67], p[1899])
+
+
+def test_split_fp16_overflow_is_flagged_and_forward_falls_back():
+    """operands beyond the fp16 range: the fast kernels raise the flag, NativeOps.guarded re-runs in fp32."""
+    from morig_amd import native, synth
+    from morig_amd.models import basic_modules as bm
+    from oracle import nets
+    o = native.get_ops()
+    assert o.precision == "f16x3"
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(300, 8, generator=g) * 3.0e5                  # way outside fp16
+    lin = _lin(64, 8, 3, bn=False)
+    flag = o._flag(torch.device("cuda", torch.cuda.current_device()))
+    flag.zero_()
+    y = torch.zeros(300, 64, device=DEV)
+    o.gemm(Mat.of(x.to(DEV)), packing.to_device(lin, DEV), False, Y=Mat.of(y))
+    assert int(flag.item()) == 1
+    # module level: huge features through a GCU still match the oracle (fp32 redo)
+    batch = synth.make_batch([5], n_side=10)
+    feat = batch.pos * 1.0e6
+    ours = synth.load_recipe(bm.GCU(3, 32).eval(), 9).to(DEV)
+    ref = synth.load_recipe(nets.GraphConvUnit(3, 32).eval(), 9)
+    want = ref(feat, batch.tpl_edge_index, batch.geo_edge_index)
+    got = ours(feat.to(DEV), batch.tpl_edge_index.to(DEV), batch.geo_edge_index.to(DEV))
+    assert torch.isfinite(got).all()
+    assert maxdiff(got, want) <= 1e-4 * max(1.0, want.abs().max().item())
