@@ -17,6 +17,7 @@
 //   * LDS rows are padded to KC+4 floats: for ds_read_b128 the 16-lane service groups then touch
 //     16 distinct 16-byte slots (36*r mod 64 and 20*r mod 64 are 4*(odd*r mod 16)) -> conflict-free.
 #include "common.h"
+#include <stdlib.h>
 
 namespace morig {
 
@@ -52,7 +53,16 @@ struct TileParams {
     float* Y; int ldy;           // store target / edge-max target / pool target
     int tiles_n;
     int* ovf;                    // PREC_F16X3: set to 1 when an operand leaves the fp16 range
+    int out_copies;              // EDGEMAX: write every result to this many replica slots (>= 1)
+    int dbg;                     // ablation switches for tools/microbench.py (MORIG_DEBUG_FLAGS; 0 in production)
 };
+enum { DBG_NO_EPILOGUE = 1, DBG_NO_MFMA = 2, DBG_NO_GATHER = 4, DBG_NO_WLOAD = 8, DBG_NO_STAGE = 16 };
+
+static int debug_flags() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("MORIG_DEBUG_FLAGS"); v = e ? atoi(e) : 0; }
+    return v;
+}
 
 template <int BN, int KC, int LOAD, int MODE, int PREC>
 __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) void tile_kernel(const TileParams p) {
@@ -68,7 +78,6 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     constexpr int PB = (BN + RPP - 1) / RPP;
     constexpr int ZC = BN < 64 ? BN : 64;       // epilogue column block
     constexpr int ZLD = ZC + 1;
-    constexpr int NCB = BN / ZC;
     constexpr int SM_MAIN = (BM + BN) * LDK;
     constexpr int SM_Z = (MODE == MODE_STORE) ? 0 : BM * ZLD;
     constexpr int SM = SM_MAIN > SM_Z ? SM_MAIN : SM_Z;
@@ -130,20 +139,25 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     const float* pw = p.W + (size_t)(tn * BN + lrow) * p.ldw + 4 * lkq;
 
     f32x4 ra[PA], rb[PA], rw[PB];
+    f32x4 rs1 = {1.f, 1.f, 1.f, 1.f}, rt1 = {0.f, 0.f, 0.f, 0.f};      // hidden-layer affine of this thread's 4 k's
     auto fetch = [&](int k0) {
+        if (LOAD == LOAD_EDGE && k0 + 4 * lkq < p.K) {
+            rs1 = *reinterpret_cast<const f32x4*>(p.s1 + k0 + 4 * lkq);
+            rt1 = *reinterpret_cast<const f32x4*>(p.t1 + k0 + 4 * lkq);
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             ra[i] = z; rb[i] = z;
             const int k = k0 + 4 * lkq;
-            if (va[i] && k < p.K) {
+            if (va[i] && k < p.K && !(p.dbg & DBG_NO_GATHER)) {
                 ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
                 if (LOAD == LOAD_EDGE) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + k0);
             }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            if (BN % RPP == 0 || lrow + i * RPP < BN)
+            if ((BN % RPP == 0 || lrow + i * RPP < BN) && !(p.dbg & DBG_NO_WLOAD))
                 rw[i] = *reinterpret_cast<const f32x4*>(pw + (size_t)i * RPP * p.ldw + k0);
         }
     };
@@ -153,16 +167,11 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         for (int i = 0; i < PA; ++i) {
             f32x4 v = ra[i];
             if (LOAD == LOAD_EDGE) {
-                f32x4 s1 = {1.f, 1.f, 1.f, 1.f}, t1 = {0.f, 0.f, 0.f, 0.f};
-                if (k < p.K) {
-                    s1 = *reinterpret_cast<const f32x4*>(p.s1 + k);
-                    t1 = *reinterpret_cast<const f32x4*>(p.t1 + k);
-                }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float h = v[c] + rb[i][c];
                     h = h > 0.f ? h : 0.f;
-                    v[c] = va[i] ? (h * s1[c] + t1[c]) : 0.f;
+                    v[c] = va[i] ? (h * rs1[c] + rt1[c]) : 0.f;
                 }
             } else {
 #pragma unroll
@@ -205,9 +214,10 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     fetch(0);
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();                        // previous chunk's fragment reads are done
-        stage(c * KC);
+        if (!(p.dbg & DBG_NO_STAGE) || c == 0) stage(c * KC);
         __syncthreads();
         if (c + 1 < nchunk) fetch((c + 1) * KC);
+        if (p.dbg & DBG_NO_MFMA) continue;
         if (PREC == PREC_F16X3) {
             const char* a0 = reinterpret_cast<const char*>(sA) + (wm * MT * 32 + l31) * (LDK * 4) + 16 * hi;
             const char* b0 = reinterpret_cast<const char*>(sB) + (wn * NT * 32 + l31) * (LDK * 4) + 16 * hi;
@@ -255,6 +265,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
+    if (p.dbg & DBG_NO_EPILOGUE) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
     const int colw0 = tn * BN + wn * NT * 32;   // first global column of this wave
     if (MODE == MODE_STORE) {
         __syncthreads();                        // sseg visible (written before the loop; harmless otherwise)
@@ -283,7 +294,9 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         return;
     }
 
-    // segmented max over tile rows, one column block of ZC columns at a time, staged through LDS
+    // Segmented max over tile rows. The accumulator tile goes through LDS in column blocks of ZC (all four
+    // waves write one or two fragments per pass); thread (column, row group) then preloads 16 rows at a time
+    // (independent LDS reads, no dependent chain) and runs the segmented scan in registers.
     float* Z = smem;
     bool first_cont = false, last_cont = false;
     if (MODE == MODE_EDGEMAX) {
@@ -292,69 +305,124 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         first_cont = p.rowptr[d0] < row0;
         if (row0 + BM < Etot) last_cont = p.rowptr[sseg[BM - 1] + 1] > row0 + BM;
     }
+    constexpr int NTP = ((ZC / 32) / WN) >= 1 ? ((ZC / 32) / WN) : 1;    // fragments per wave per pass
+    constexpr int NPASS = NT / NTP;
+    static_assert(NTP * WN * 32 == ZC && NPASS * NTP == NT, "epilogue column blocking");
     constexpr int G = 256 / ZC;                 // row groups in the reduce phase
-    constexpr int RG = BM / G;
+    constexpr int RG = BM / G;                  // 32 (ZC = 64) or 16 (ZC = 32)
+    constexpr int EXT = 32;                     // look-ahead rows for a segment running past its group
     const int zc = tid % ZC, zg = tid / ZC;
+    const int r0 = zg * RG;
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-        __syncthreads();                        // main-loop reads / previous block's reduce done
+    for (int cb = 0; cb < NPASS; ++cb) {
+        __syncthreads();                        // main-loop reads / previous pass's scan done
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int colw = wn * NT * 32 + nt * 32;            // tile-local first column of this fragment
-            if (colw >= cb * ZC && colw < (cb + 1) * ZC) {
-                const int col = tn * BN + colw + l31;
-                const float b = (p.bias && col < p.N) ? p.bias[col] : 0.f;
-                const float sc = (p.scale && col < p.N) ? p.scale[col] : 1.f;
-                const float sh = (p.shift && col < p.N) ? p.shift[col] : 0.f;
+        for (int j = 0; j < NTP; ++j) {
+            const int nt = cb * NTP + j;
+            const int col = tn * BN + wn * NT * 32 + nt * 32 + l31;
+            const float b = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+            const float sc = (p.scale && col < p.N) ? p.scale[col] : 1.f;
+            const float sh = (p.shift && col < p.N) ? p.shift[col] : 0.f;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int rl = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        float v = acc[mt][nt][r] + b;
-                        if (p.relu) v = v > 0.f ? v : 0.f;
-                        Z[rl * ZLD + (colw - cb * ZC) + l31] = v * sc + sh;
-                    }
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int rl = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = acc[mt][nt][r] + b;
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    Z[rl * ZLD + (wn * NTP + j) * 32 + l31] = v * sc + sh;
+                }
         }
         __syncthreads();
-        const int col = tn * BN + cb * ZC + zc;
-        if (col < p.N) {
-            const int r0 = zg * RG;
-            if (MODE == MODE_POOL) {
-                // every output is shared with other tiles -> all atomic; groups reduce their own rows
-                int r = r0;
-                while (r < r0 + RG) {
-                    const int s = sseg[r];
-                    if (s < 0) break;
-                    float m = Z[r * ZLD + zc];
-                    ++r;
-                    while (r < r0 + RG && sseg[r] == s) { m = fmaxf(m, Z[r * ZLD + zc]); ++r; }
-                    atomic_max_f32(p.Y + (size_t)s * p.ldy + col, m);
+        const int wz = zc / (NTP * 32), jz = (zc >> 5) % NTP;
+        const int col = tn * BN + wz * NT * 32 + (cb * NTP + jz) * 32 + (zc & 31);
+        if (col >= p.N) continue;
+        const float* zcolp = Z + zc;
+        if (MODE == MODE_POOL) {
+            // every output is shared with other tiles -> all atomic; each group reduces its own rows
+            int cur = -2; bool open = false; float m = 0.f;
+#pragma unroll
+            for (int bt = 0; bt < RG / 16; ++bt) {
+                const int rb0 = r0 + bt * 16;
+                float zv[16]; int sv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sv[i] = sseg[rb0 + i]; zv[i] = zcolp[(rb0 + i) * ZLD]; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (sv[i] != cur) {
+                        if (open) atomic_max_f32(p.Y + (size_t)cur * p.ldy + col, m);
+                        cur = sv[i]; open = cur >= 0; m = zv[i];
+                    } else if (open) m = fmaxf(m, zv[i]);
                 }
-            } else {
-                // a thread owns the segments that START in its row group and follows them to their end
-                int r = r0;
-                if (zg > 0) { const int sp = sseg[r0 - 1]; while (r < r0 + RG && sseg[r] == sp) ++r; }
-                while (r < r0 + RG) {
-                    const int s = sseg[r];
-                    if (s < 0) break;
-                    const int rs = r;
-                    float m = Z[r * ZLD + zc];
-                    ++r;
-                    while (r < BM && sseg[r] == s) { m = fmaxf(m, Z[r * ZLD + zc]); ++r; }
-                    float* o = p.Y + ((size_t)rep * p.rep_out + s) * p.ldy + col;
-                    const bool partial = (rs == 0 && first_cont) || (r == BM && last_cont);
+            }
+            if (open) atomic_max_f32(p.Y + (size_t)cur * p.ldy + col, m);
+        } else {
+            // a thread owns the segments that START in its row group and follows them to their end
+            float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
+            auto flush = [&](int sg, float m, int rs, int rend) {
+                const bool partial = (rs == 0 && first_cont) || (rend == BM && last_cont);
+                for (int q = 0; q < p.out_copies; ++q) {              // replica-invariant branches are broadcast
+                    float* o = obase + ((size_t)q * p.rep_out + sg) * p.ldy;
                     if (partial) atomic_max_f32(o, m); else *o = m;
                 }
+            };
+            int cur = (zg > 0) ? sseg[r0 - 1] : -2;
+            bool open = false, done = false;
+            float m = 0.f; int rs = 0, rnext = r0;
+#pragma unroll
+            for (int bt = 0; bt < (RG + EXT) / 16; ++bt) {
+                const int rb0 = r0 + bt * 16;
+                if (done || rb0 >= BM) break;
+                float zv[16]; int sv[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sv[i] = sseg[rb0 + i]; zv[i] = zcolp[(rb0 + i) * ZLD]; }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (!done) {
+                        if (sv[i] != cur) {
+                            if (open) flush(cur, m, rs, rb0 + i);
+                            if (bt * 16 + i >= RG) { open = false; done = true; }      // next segment is not mine
+                            else { cur = sv[i]; open = cur >= 0; m = zv[i]; rs = rb0 + i; }
+                        } else if (open) m = fmaxf(m, zv[i]);
+                    }
+                }
+                rnext = rb0 + 16;
+            }
+            if (open && !done) {                // longer than the look-ahead window, or runs to the tile end
+                int r = rnext;
+                while (r < BM && sseg[r] == cur) { m = fmaxf(m, zcolp[r * ZLD]); ++r; }
+                flush(cur, m, rs, r);
             }
         }
     }
 }
 
+// Rows of `out` whose segment straddles a 128-edge tile boundary are combined with integer-atomic float max
+// by the two (or more) tiles involved: only THOSE rows need the identity pattern 0xFFFFFFFF beforehand.
+__global__ __launch_bounds__(64) void init_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
+                                                                int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out) {
+    const int e = (blockIdx.x + 1) * 128;
+    if (e >= rowptr[n_nodes]) return;
+    const int d = dstS[e];
+    if (rowptr[d] >= e) return;                       // a segment starts exactly on the boundary: no sharing
+    unsigned* o = reinterpret_cast<unsigned*>(out + ((size_t)blockIdx.y * rep_out + d) * ldo);
+    for (int c = threadIdx.x; c < H; c += 64) o[c] = 0xFFFFFFFFu;
+}
+
+static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
+                              int rep_out, int slots, hipStream_t s) {
+    const int nb = cdiv(edge_capacity, 128) - 1;
+    if (nb <= 0) return MORIG_OK;
+    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(nb, slots), dim3(64), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int BN, int KC, int LOAD, int MODE, int PREC = PREC_F32>
-static int launch_tile(const TileParams& p, int nblocks, hipStream_t s) {
+static int launch_tile(const TileParams& p0, int nblocks, hipStream_t s) {
+    TileParams p = p0;
+    p.dbg = debug_flags();
     hipLaunchKernelGGL((tile_kernel<BN, KC, LOAD, MODE, PREC>), dim3(nblocks), dim3(256), 0, s, p);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
@@ -439,6 +507,7 @@ static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
     p.Y = a->out; p.ldy = a->ldo;
     p.tiles_per_rep = cdiv(a->edge_capacity, 128);
     p.tiles_n = 1;
+    p.out_copies = a->out_copies > 0 ? a->out_copies : 1;
     if (a->W2_split) {
         if (!a->overflow || !aligned16(a->W2_split) || a->H < 32) return MORIG_E_INVALID;
         p.W = static_cast<const float*>(a->W2_split); p.ovf = a->overflow;
@@ -484,7 +553,9 @@ extern "C" int morig_segmax_gemm(const morig_segmax_args* a, void* stream) {
     p.Y = a->out; p.ldy = a->ldo;
     p.tiles_per_rep = cdiv(a->edge_capacity, 128);
     p.tiles_n = 1;
-    MORIG_HIP_TRY(hipMemset2DAsync(a->out, (size_t)a->ldo * sizeof(float), 0xFF, (size_t)a->N * sizeof(float), (size_t)a->n_nodes, s));
+    p.out_copies = 1;
+    { const int st = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->N, a->out, a->ldo, 0, 1, s);
+      if (st != MORIG_OK) return st; }
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity);
     const bool f16 = a->W_split != nullptr;
     if (f16) {
@@ -507,14 +578,19 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     TileParams p = {};
     const int st = edge_common(a, p);
     if (st != MORIG_OK) return st;
-    if (a->in_rep_stride < 0 || (a->replicas > 1 && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
+    if (a->in_rep_stride < 0 || ((a->replicas > 1 || a->out_copies > 1) && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblocks = p.tiles_per_rep * a->replicas;
     const bool f16 = a->W2_split != nullptr;
 
-    // tile-straddling target segments combine through integer-atomic float max: pre-fill identity
-    const size_t rows = (size_t)(a->replicas - 1) * a->out_rep_stride + a->n_nodes;
-    MORIG_HIP_TRY(hipMemset2DAsync(a->out, (size_t)a->ldo * sizeof(float), 0xFF, (size_t)a->H * sizeof(float), rows, s));
+    // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
+    if (a->out_copies > 1 && a->replicas != 1) return MORIG_E_INVALID;
+    {
+        const int slots = a->out_copies > 1 ? a->out_copies : a->replicas;
+        const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
+                                           a->out_rep_stride, slots, s);
+        if (st2 != MORIG_OK) return st2;
+    }
 
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
     const double flops = 2.0 * E * a->H * (double)a->H;

@@ -1,0 +1,7 @@
+#!/bin/bash
+mkdir -p gpurun_out
+OUT=gpurun_out/microbench_${1:-x}.txt
+FLAGS=${2:-"0 1"}
+: > $OUT
+for f in $FLAGS ; do MORIG_DEBUG_FLAGS=$f python tools/microbench.py f16x3 16 >> $OUT 2>&1; done
+grep -v amdgpu.ids $OUT
