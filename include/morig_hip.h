@@ -133,8 +133,6 @@ typedef struct morig_edgeconv_args {
     const float* b2; const float* s2; const float* t2;   /* [Hpad]                        */
     float* out; int32_t ldo;           /* out[row][0..H)                                  */
     const void* W2_split; int32_t* overflow;   /* optional split-fp16 fast path (H >= 32), as in morig_gemm_args */
-    int32_t out_copies;                /* > 1 (with replicas == 1): write the result to out_copies replica slots,
-                                          row offset q*out_rep_stride -- a replica-invariant branch computed once */
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 

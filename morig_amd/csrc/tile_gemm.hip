@@ -18,6 +18,7 @@
 //     16 distinct 16-byte slots (36*r mod 64 and 20*r mod 64 are 4*(odd*r mod 16)) -> conflict-free.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace morig {
 
@@ -53,7 +54,6 @@ struct TileParams {
     float* Y; int ldy;           // store target / edge-max target / pool target
     int tiles_n;
     int* ovf;                    // PREC_F16X3: set to 1 when an operand leaves the fp16 range
-    int out_copies;              // EDGEMAX: write every result to this many replica slots (>= 1)
     int dbg;                     // ablation switches for tools/microbench.py (MORIG_DEBUG_FLAGS; 0 in production)
 };
 enum { DBG_NO_EPILOGUE = 1, DBG_NO_MFMA = 2, DBG_NO_GATHER = 4, DBG_NO_WLOAD = 8, DBG_NO_STAGE = 16 };
@@ -313,11 +313,14 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     constexpr int EXT = 32;                     // look-ahead rows for a segment running past its group
     const int zc = tid % ZC, zg = tid / ZC;
     const int r0 = zg * RG;
-#pragma unroll
-    for (int cb = 0; cb < NPASS; ++cb) {
+    // one instantiation per column pass: `cb` must be a compile-time constant so that acc[][] keeps
+    // static register indices (a runtime-indexed accumulator array would live in scratch memory)
+    auto run_pass = [&](auto cb_const) {
+        constexpr int cb = decltype(cb_const)::value;
         __syncthreads();                        // main-loop reads / previous pass's scan done
 #pragma unroll
         for (int j = 0; j < NTP; ++j) {
+            constexpr int dummy = 0; (void)dummy;
             const int nt = cb * NTP + j;
             const int col = tn * BN + wn * NT * 32 + nt * 32 + l31;
             const float b = (p.bias && col < p.N) ? p.bias[col] : 0.f;
@@ -336,7 +339,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         __syncthreads();
         const int wz = zc / (NTP * 32), jz = (zc >> 5) % NTP;
         const int col = tn * BN + wz * NT * 32 + (cb * NTP + jz) * 32 + (zc & 31);
-        if (col >= p.N) continue;
+        if (col >= p.N) return;
         const float* zcolp = Z + zc;
         if (MODE == MODE_POOL) {
             // every output is shared with other tiles -> all atomic; each group reduces its own rows
@@ -360,11 +363,9 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
             // a thread owns the segments that START in its row group and follows them to their end
             float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
             auto flush = [&](int sg, float m, int rs, int rend) {
+                float* o = obase + (size_t)sg * p.ldy;
                 const bool partial = (rs == 0 && first_cont) || (rend == BM && last_cont);
-                for (int q = 0; q < p.out_copies; ++q) {              // replica-invariant branches are broadcast
-                    float* o = obase + ((size_t)q * p.rep_out + sg) * p.ldy;
-                    if (partial) atomic_max_f32(o, m); else *o = m;
-                }
+                if (partial) atomic_max_f32(o, m); else *o = m;
             };
             int cur = (zg > 0) ? sseg[r0 - 1] : -2;
             bool open = false, done = false;
@@ -394,7 +395,12 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
                 flush(cur, m, rs, r);
             }
         }
-    }
+    };
+    run_pass(std::integral_constant<int, 0>{});
+    if constexpr (NPASS > 1) run_pass(std::integral_constant<int, 1>{});
+    if constexpr (NPASS > 2) run_pass(std::integral_constant<int, 2>{});
+    if constexpr (NPASS > 3) run_pass(std::integral_constant<int, 3>{});
+    static_assert(NPASS <= 4, "column passes");
 }
 
 // Rows of `out` whose segment straddles a 128-edge tile boundary are combined with integer-atomic float max
@@ -507,7 +513,6 @@ static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
     p.Y = a->out; p.ldy = a->ldo;
     p.tiles_per_rep = cdiv(a->edge_capacity, 128);
     p.tiles_n = 1;
-    p.out_copies = a->out_copies > 0 ? a->out_copies : 1;
     if (a->W2_split) {
         if (!a->overflow || !aligned16(a->W2_split) || a->H < 32) return MORIG_E_INVALID;
         p.W = static_cast<const float*>(a->W2_split); p.ovf = a->overflow;
@@ -553,7 +558,6 @@ extern "C" int morig_segmax_gemm(const morig_segmax_args* a, void* stream) {
     p.Y = a->out; p.ldy = a->ldo;
     p.tiles_per_rep = cdiv(a->edge_capacity, 128);
     p.tiles_n = 1;
-    p.out_copies = 1;
     { const int st = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->N, a->out, a->ldo, 0, 1, s);
       if (st != MORIG_OK) return st; }
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity);
@@ -578,15 +582,14 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     TileParams p = {};
     const int st = edge_common(a, p);
     if (st != MORIG_OK) return st;
-    if (a->in_rep_stride < 0 || ((a->replicas > 1 || a->out_copies > 1) && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
+    if (a->in_rep_stride < 0 || (a->replicas > 1 && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblocks = p.tiles_per_rep * a->replicas;
     const bool f16 = a->W2_split != nullptr;
 
     // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
-    if (a->out_copies > 1 && a->replicas != 1) return MORIG_E_INVALID;
     {
-        const int slots = a->out_copies > 1 ? a->out_copies : a->replicas;
+        const int slots = a->replicas;
         const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
                                            a->out_rep_stride, slots, s);
         if (st2 != MORIG_OK) return st2;

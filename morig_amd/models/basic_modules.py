@@ -225,11 +225,12 @@ class GCUMotion(NativeModule):
                      replicas=replicas, in_rep_stride=n, out_rep_stride=n)
         ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H + D, H),
                      replicas=replicas, in_rep_stride=n, out_rep_stride=n)
-        # position branch: independent of the keyframe -> computed once, written to every replica slot
-        ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(ec, H, D),
-                     replicas=1, out_rep_stride=n, out_copies=replicas)
-        ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(ec, 2 * H + D, D),
-                     replicas=1, out_rep_stride=n, out_copies=replicas)
+        # position branch: independent of the keyframe -> computed once into replica 0, copied to the others
+        ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(ec, H, D, 0, n))
+        ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(ec, 2 * H + D, D, 0, n))
+        for r in range(1, replicas):
+            ops.copy2d(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, r * n, n))
+            ops.copy2d(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, r * n, n))
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out)
 
     def _forward(self, pos, x, tpl_edge_index, geo_edge_index):

@@ -51,7 +51,6 @@ class EdgeConvArgs(C.Structure):
         ("b2", c_f32p), ("s2", c_f32p), ("t2", c_f32p),
         ("out", c_f32p), ("ldo", C.c_int32),
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
-        ("out_copies", C.c_int32),
     ]
 
 
@@ -293,15 +292,13 @@ class NativeOps:
 
     # -- fused edge conv ----------------------------------------------------------------------------
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
-                 in_rep_stride: int = 0, out_rep_stride: int = 0, out_copies: int = 1):
-        """out_copies > 1 (replicas == 1): one computation written to out_copies replica slots."""
+                 in_rep_stride: int = 0, out_rep_stride: int = 0):
         _need_gpu(A.base, B.base, out.base)
-        a = self._edge_args(A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride, out_copies)
+        a = self._edge_args(A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride)
         check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
 
-    def _edge_args(self, A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride, out_copies=1):
+    def _edge_args(self, A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride):
         a = EdgeConvArgs()
-        a.out_copies = out_copies
         a.H = ec.H
         a.n_nodes, a.replicas = csr.n_nodes, replicas
         a.in_rep_stride, a.out_rep_stride = in_rep_stride, out_rep_stride

@@ -77,15 +77,7 @@ class EmuOps:
             Y.view().copy_(acc)
 
     # -- fused edge conv ---------------------------------------------------------------------------
-    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0, out_copies=1):
-        if out_copies > 1:
-            assert replicas == 1
-            n = csr.n_nodes
-            self.edgeconv(A, B, csr, ec, out, 1, 0, 0, 1)
-            first = out.base[out.row0: out.row0 + n, out.col0:out.col0 + ec.H].clone()
-            for q in range(1, out_copies):
-                out.base[out.row0 + q * out_rep_stride: out.row0 + q * out_rep_stride + n, out.col0:out.col0 + ec.H] = first
-            return
+    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0):
         assert A.ld % 4 == 0 and A.col0 % 4 == 0 and B.ld % 4 == 0 and B.col0 % 4 == 0
         H = ec.H
         E = int(csr.rowptr[-1])

@@ -353,21 +353,3 @@ def test_split_fp16_overflow_is_flagged_and_forward_falls_back():
     got = ours(feat.to(DEV), batch.tpl_edge_index.to(DEV), batch.geo_edge_index.to(DEV))
     assert torch.isfinite(got).all()
     assert maxdiff(got, want) <= 1e-4 * max(1.0, want.abs().max().item())
-
-
-def test_edgeconv_broadcast_to_replica_slots(ops):
-    H, n, copies = 16, 500, 4
-    ei = _rand_graph(n, 4000, 12, hub=3)
-    ec = _edge_pack(H, 5)
-    ab = torch.randn(n, 2 * H)
-    emu = EmuOps()
-    want = torch.zeros(n * copies, H + 2)
-    emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), emu.csr_build(ei, n), ec, Mat.of(want, 0, H), replicas=1,
-                 out_rep_stride=n, out_copies=copies)
-    got = torch.zeros(n * copies, H + 2, device=DEV)
-    abg = ab.to(DEV)
-    ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), ops.csr_build(ei.to(DEV), n), packing.to_device(ec, DEV), Mat.of(got, 0, H),
-                 replicas=1, out_rep_stride=n, out_copies=copies)
-    torch.cuda.synchronize()
-    assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
-    assert torch.equal(got[:n], got[n:2 * n]) and torch.equal(got[:n], got[3 * n:])
