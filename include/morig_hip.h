@@ -222,7 +222,7 @@ int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t
 /* --------------------------------------------------------------------------------------------
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline object.
  */
-#define MORIG_PROF_KINDS 40
+#define MORIG_PROF_KINDS 48
 int         morig_prof_enable(int on);                 /* returns previous state */
 int         morig_prof_reset(void);
 const char* morig_prof_name(int kind);                  /* NULL past the last kind */

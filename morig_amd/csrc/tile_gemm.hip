@@ -26,6 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));        // what __builtin_amdgcn_cvt_pkrtz returns
 
 // Arithmetic modes of the contraction:
 //   PREC_F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak).
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     f32x4 ra[PA], rb[PA], rw[PB];
     f32x4 rs1 = {1.f, 1.f, 1.f, 1.f}, rt1 = {0.f, 0.f, 0.f, 0.f};      // hidden-layer affine of this thread's 4 k's
     auto fetch = [&](int k0) {
-        if (LOAD == LOAD_EDGE && k0 + 4 * lkq < p.K) {
+        if (LOAD == LOAD_EDGE && p.s1 != nullptr && k0 + 4 * lkq < p.K) {   // NULL: affine already folded into W2/b2
             rs1 = *reinterpret_cast<const f32x4*>(p.s1 + k0 + 4 * lkq);
             rt1 = *reinterpret_cast<const f32x4*>(p.t1 + k0 + 4 * lkq);
         }
@@ -167,28 +168,34 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         for (int i = 0; i < PA; ++i) {
             f32x4 v = ra[i];
             if (LOAD == LOAD_EDGE) {
+                if (p.s1 != nullptr) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float h = v[c] + rb[i][c];
-                    h = h > 0.f ? h : 0.f;
-                    v[c] = va[i] ? (h * rs1[c] + rt1[c]) : 0.f;
+                    for (int c = 0; c < 4; ++c) {
+                        float h = v[c] + rb[i][c];
+                        h = h > 0.f ? h : 0.f;
+                        v[c] = va[i] ? (h * rs1[c] + rt1[c]) : 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + rb[i][c], 0.f);      // invalid rows were fetched as 0
                 }
-            } else {
+            } else if (k0 + KC > p.K) {                 // only the last chunk can cross K
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = (k + c < p.K) ? v[c] : 0.f;
             }
             if (PREC == PREC_F32) {
                 *reinterpret_cast<f32x4*>(&sA[(lrow + i * RPP) * LDK + 4 * lkq]) = v;
             } else {
+                // hi = fp16(x) (round-toward-zero, 2 per instruction), lo = fp16(x - hi): x - hi is exact in fp32
+                const f16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+                const f16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                const f16x2 l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
+                const f16x2 l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+                const float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                if (!(amax < 65000.f)) *p.ovf = 1;                     // also catches NaN
                 f16x4 h, l;
-                bool bad = false;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    h[c] = (_Float16)v[c];
-                    l[c] = (_Float16)(v[c] - (float)h[c]);
-                    bad |= !(fabsf(v[c]) < 65000.f);
-                }
-                if (bad) *p.ovf = 1;
+                h[0] = (_Float16)h01[0]; h[1] = (_Float16)h01[1]; h[2] = (_Float16)h23[0]; h[3] = (_Float16)h23[1];
+                l[0] = (_Float16)l01[0]; l[1] = (_Float16)l01[1]; l[2] = (_Float16)l23[0]; l[3] = (_Float16)l23[1];
                 char* rowp = reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4);
                 *reinterpret_cast<f16x4*>(rowp + 8 * lkq) = h;
                 *reinterpret_cast<f16x4*>(rowp + 64 + 8 * lkq) = l;
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     constexpr int RG = BM / G;                  // 32 (ZC = 64) or 16 (ZC = 32)
     constexpr int EXT = 32;                     // look-ahead rows for a segment running past its group
     const int zc = tid % ZC, zg = tid / ZC;
-    const int r0 = zg * RG;
+    const int r0 = (ZC == 64) ? __builtin_amdgcn_readfirstlane(zg * RG) : zg * RG;
     // one instantiation per column pass: `cb` must be a compile-time constant so that acc[][] keeps
     // static register indices (a runtime-indexed accumulator array would live in scratch memory)
     auto run_pass = [&](auto cb_const) {
@@ -349,7 +356,10 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
                 const int rb0 = r0 + bt * 16;
                 float zv[16]; int sv[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { sv[i] = sseg[rb0 + i]; zv[i] = zcolp[(rb0 + i) * ZLD]; }
+                for (int i = 0; i < 16; ++i) {
+                    sv[i] = (ZC == 64) ? __builtin_amdgcn_readfirstlane(sseg[rb0 + i]) : sseg[rb0 + i];
+                    zv[i] = zcolp[(rb0 + i) * ZLD];
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     if (sv[i] != cur) {
@@ -367,7 +377,10 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
                 const bool partial = (rs == 0 && first_cont) || (rend == BM && last_cont);
                 if (partial) atomic_max_f32(o, m); else *o = m;
             };
-            int cur = (zg > 0) ? sseg[r0 - 1] : -2;
+            // segment ids are identical for all lanes of a wave when ZC == 64 (zg = wave id): pull them into
+            // SGPRs so the boundary tests are scalar compares + scalar branches instead of exec-mask code
+            auto uni = [&](int v) -> int { return (ZC == 64) ? __builtin_amdgcn_readfirstlane(v) : v; };
+            int cur = uni((zg > 0) ? sseg[r0 - 1] : -2);
             bool open = false, done = false;
             float m = 0.f; int rs = 0, rnext = r0;
 #pragma unroll
@@ -376,7 +389,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
                 if (done || rb0 >= BM) break;
                 float zv[16]; int sv[16];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) { sv[i] = sseg[rb0 + i]; zv[i] = zcolp[(rb0 + i) * ZLD]; }
+                for (int i = 0; i < 16; ++i) { sv[i] = uni(sseg[rb0 + i]); zv[i] = zcolp[(rb0 + i) * ZLD]; }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
                     if (!done) {
@@ -478,6 +491,12 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
                    : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
     }
     p.Y = a->Y; p.ldy = a->ldy;
+    if (f16 && a->N >= 256 && a->N % 256 == 0 && !getenv("MORIG_NO_BN256")) {
+        // wide layers: 128 x 256 tile -- the on-the-fly operand split is amortised over twice the columns
+        p.tiles_n = a->N / 256;
+        ProfScope ps(K_GEMM16_BN256, s, flops, bytes);
+        return launch_tile<256, 32, LOAD_DENSE, MODE_STORE, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
+    }
     if (a->N > 64) {
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_BN128 : K_GEMM_BN128, s, flops, bytes);
@@ -498,7 +517,7 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
 
 static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
     if (!a || !a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
-    if (!a->s1 || !a->t1 || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
+    if ((a->s1 == nullptr) != (a->t1 == nullptr) || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
     if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
     if ((a->lda & 3) || (a->ldb & 3) || (a->ldw & 3) || !aligned16(a->A) || !aligned16(a->B) || !aligned16(a->W2) ||
         !aligned16(a->s1) || !aligned16(a->t1)) return MORIG_E_INVALID;

@@ -23,22 +23,31 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     }
 }
 
-// CLS-only temporal attention (see include/morig_hip.h). One thread per vertex; g and cls in LDS.
+// CLS-only temporal attention (see include/morig_hip.h). A 256-thread block owns 64 vertices: their frames are
+// loaded coalesced into LDS (row stride T*C+1 -> conflict-free per-vertex reads), thread (vertex, head) does the
+// (T+1)-way softmax and the weighted token sum, results leave through LDS so the stores are coalesced too.
 constexpr int ATT_TMAX = 8;
+constexpr int ATT_VB = 64;
 __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restrict__ x, int n, int T, int C, int heads,
                                                             const float* __restrict__ g, const float* __restrict__ cls,
                                                             float* __restrict__ y, int ldy) {
-    extern __shared__ float sh[];               // g [heads*C] then cls [C]
+    extern __shared__ float sh[];               // g [heads*C] | cls [C] | frames [VB][T*C+1] | out [VB][heads*C+1]
+    const int TC = T * C, HC = heads * C;
     float* sg = sh;
-    float* sc = sh + heads * C;
-    for (int i = threadIdx.x; i < heads * C; i += blockDim.x) sg[i] = g[i];
+    float* sc = sg + HC;
+    float* sx = sc + C;
+    float* so = sx + ATT_VB * (TC + 1);
+    const int v0 = blockIdx.x * ATT_VB;
+    const int nv = min(ATT_VB, n - v0);
+    for (int i = threadIdx.x; i < HC; i += blockDim.x) sg[i] = g[i];
     for (int i = threadIdx.x; i < C; i += blockDim.x) sc[i] = cls[i];
+    const float* xb = x + (size_t)v0 * TC;
+    for (int i = threadIdx.x; i < nv * TC; i += blockDim.x) { const int v = i / TC, c = i - v * TC; sx[v * (TC + 1) + c] = xb[i]; }
     __syncthreads();
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    const float* xv = x + (size_t)v * T * C;
-    for (int h = 0; h < heads; ++h) {
+    for (int w = threadIdx.x; w < nv * heads; w += blockDim.x) {
+        const int v = w % nv, h = w / nv;       // consecutive lanes -> consecutive vertices
         const float* gh = sg + h * C;
+        const float* xv = sx + v * (TC + 1);
         float s[ATT_TMAX + 1];
         float s0 = 0.f;
         for (int c = 0; c < C; ++c) s0 += sc[c] * gh[c];
@@ -49,8 +58,7 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
             float d = -INFINITY;
             if (t < T) {
                 d = 0.f;
-                const float* xt = xv + t * C;
-                for (int c = 0; c < C; ++c) d += xt[c] * gh[c];
+                for (int c = 0; c < C; ++c) d += xv[t * C + c] * gh[c];
             }
             s[t + 1] = d;
             mx = fmaxf(mx, d);
@@ -59,7 +67,7 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
 #pragma unroll
         for (int t = 0; t <= ATT_TMAX; ++t) { s[t] = (t <= T) ? __expf(s[t] - mx) : 0.f; den += s[t]; }
         const float inv = 1.0f / den;
-        float* yo = y + (size_t)v * ldy + h * C;
+        float* yo = so + v * (HC + 1) + h * C;
         for (int c = 0; c < C; ++c) {
             float a = s[0] * sc[c];
 #pragma unroll
@@ -67,6 +75,8 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
             yo[c] = a * inv;
         }
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nv * HC; i += blockDim.x) { const int v = i / HC, c = i - v * HC; y[(size_t)(v0 + v) * ldy + c] = so[v * (HC + 1) + c]; }
 }
 
 __global__ void frame_reduce_kernel(const float* __restrict__ x, int n, int T, int C, int mode, float* __restrict__ y, int ldy) {
@@ -104,8 +114,9 @@ extern "C" int morig_cls_attention(const float* x, int32_t n, int32_t T, int32_t
     if (T < 1 || T > ATT_TMAX) return MORIG_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_ATTN, s, 4.0 * n * heads * (T + 1) * C, 4.0 * n * (T * C + heads * C));
-    hipLaunchKernelGGL(cls_attention_kernel, dim3(cdiv(n, 256)), dim3(256), (size_t)(heads + 1) * C * sizeof(float), s,
-                       x, n, T, C, heads, g, cls, y, ldy);
+    const size_t lds = ((size_t)(heads + 1) * C + (size_t)ATT_VB * (T * C + 1) + (size_t)ATT_VB * (heads * C + 1)) * sizeof(float);
+    if (lds > 64 * 1024) return MORIG_E_UNSUPPORTED;
+    hipLaunchKernelGGL(cls_attention_kernel, dim3(cdiv(n, ATT_VB)), dim3(256), lds, s, x, n, T, C, heads, g, cls, y, ldy);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -306,7 +306,8 @@ class NativeOps:
         a.B, a.ldb = B.ptr, B.ld
         a.rowptr, a.src_sorted, a.dst_sorted = csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr()
         a.edge_capacity, a.edge_count = csr.capacity, csr.edge_count
-        a.s1, a.t1 = ec.s1.data_ptr(), ec.t1.data_ptr()
+        if ec.s1 is not None:
+            a.s1, a.t1 = ec.s1.data_ptr(), ec.t1.data_ptr()
         a.W2, a.ldw = ec.W2.data_ptr(), ec.W2.stride(0)
         a.b2, a.s2, a.t2 = ec.b2.data_ptr(), ec.s2.data_ptr(), ec.t2.data_ptr()
         a.out, a.ldo = out.ptr, out.ld

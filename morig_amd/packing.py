@@ -50,8 +50,8 @@ class PackedLinear:
 class PackedEdge:
     """second half of an edge MLP: hidden affine (BN1), Linear2, BN2; H = width."""
     H: int
-    s1: torch.Tensor
-    t1: torch.Tensor
+    s1: Optional[torch.Tensor]          # None: the hidden affine is folded into W2 / b2
+    t1: Optional[torch.Tensor]
     W2: torch.Tensor                    # [max(H,32), roundup(H,32)]
     b2: torch.Tensor
     s2: torch.Tensor
@@ -83,6 +83,13 @@ def _pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[t
     out = torch.full((n,), fill, dtype=torch.float32, device=v.device)
     out[: v.numel()] = v.float()
     return out.contiguous()
+
+
+def fold_hidden_affine(W2: torch.Tensor, b2: torch.Tensor, s1: torch.Tensor, t1: torch.Tensor):
+    """W2 (s1*h + t1) + b2 = (W2 diag(s1)) h + (b2 + W2 t1): the BatchNorm that follows the FIRST edge ReLU is a
+    linear map in front of Linear2, so it folds into Linear2 exactly (evaluated in fp64, rounded once)."""
+    W = W2.double()
+    return (W * s1.double()[None, :]).float(), (b2.double() + W @ t1.double()).float()
 
 
 def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[nn.BatchNorm1d] = None,
@@ -128,11 +135,11 @@ def pack_edge_pair(mlps: Sequence[nn.Sequential]):
         s1, t1 = bn_affine(bn1)
         s2, t2 = bn_affine(bn2)
         Hp, Kp = max(H, 32), _roundup(H, 32)
+        Wf, bf = fold_hidden_affine(lin2.weight.detach().float(), lin2.bias.detach().float(), s1, t1)
         W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=W1.device)
-        W2[:H, :H] = lin2.weight.detach().float()
+        W2[:H, :H] = Wf
         W2 = W2.contiguous()
-        edges.append(PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2,
-                                _pad_vec(lin2.bias.detach(), Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp),
+        edges.append(PackedEdge(H, None, None, W2, _pad_vec(bf, Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp),
                                 split_f16(W2) if H >= 32 else None))
     vertex = pack_linear(torch.cat(rows, 0), torch.cat(biases, 0))
     return vertex, edges
@@ -151,11 +158,12 @@ def pack_pointconv(local_nn: nn.Sequential, cx: int):
     s1, t1 = bn_affine(l1[2])
     s2, t2 = bn_affine(l2[2])
     Hp, Kp = max(H, 32), _roundup(H, 32)
+    Wf, bf = fold_hidden_affine(l2[0].weight.detach().float(), l2[0].bias.detach().float(), s1, t1)
     W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=W1.device)
-    W2[:H, :H] = l2[0].weight.detach().float()
+    W2[:H, :H] = Wf
     W2 = W2.contiguous()
-    edge = PackedEdge(H, _pad_vec(s1, Kp, 1.0), _pad_vec(t1, Kp), W2, _pad_vec(l2[0].bias.detach(), Hp),
-                      _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp), split_f16(W2) if H >= 32 else None)
+    edge = PackedEdge(H, None, None, W2, _pad_vec(bf, Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp),
+                      split_f16(W2) if H >= 32 else None)
     return dict(src=src, tgt=tgt, edge=edge, last=pack_mlp_layer(l3))
 
 

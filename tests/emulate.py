@@ -87,7 +87,9 @@ class EmuOps:
             a = A.base[A.row0 + r * in_rep_stride + dst, A.col0:A.col0 + H]
             b = B.base[B.row0 + r * in_rep_stride + src, B.col0:B.col0 + H]
             assert not torch.isnan(a).any() and not torch.isnan(b).any()
-            h1 = torch.relu(a + b) * ec.s1[:H] + ec.t1[:H]
+            h1 = torch.relu(a + b)
+            if ec.s1 is not None:
+                h1 = h1 * ec.s1[:H] + ec.t1[:H]
             z = torch.relu(h1 @ ec.W2[:H, :H].t() + ec.b2[:H]) * ec.s2[:H] + ec.t2[:H]
             res = torch.full((n, H), float("-inf"))
             res = res.scatter_reduce(0, dst[:, None].expand(-1, H), z, reduce="amax", include_self=True)
@@ -144,7 +146,9 @@ def _emu_edge_hidden(self, A: Mat, B: Mat, csr: CSR, ec, Z: Mat):
     a = A.base[A.row0 + dst, A.col0:A.col0 + H]
     b = B.base[B.row0 + src, B.col0:B.col0 + H]
     assert not torch.isnan(a).any() and not torch.isnan(b).any()
-    h1 = torch.relu(a + b) * ec.s1[:H] + ec.t1[:H]
+    h1 = torch.relu(a + b)
+    if ec.s1 is not None:
+        h1 = h1 * ec.s1[:H] + ec.t1[:H]
     Z.view()[:E] = torch.relu(h1 @ ec.W2[:H, :H].t() + ec.b2[:H]) * ec.s2[:H] + ec.t2[:H]
 
 
