@@ -101,6 +101,11 @@ typedef struct morig_gemm_args {
     /* optional fast path (see "split-fp16" below): W_split has the shape/stride of W; overflow is an int32
      * on the device that the kernel sets to 1 if an operand left the fp16 range (result then invalid). */
     const void* W_split; int32_t* overflow;
+    /* split-fp16 ACTIVATIONS (only with W_split): a matrix window whose first column and row stride are
+     * multiples of 32 floats and whose every aligned 32-column chunk holds [32 halves hi | 32 halves lo].
+     * x_split: X is in that layout (loader becomes a plain copy: the hi/lo split was done once by the
+     * producer instead of once per column tile); y_split: write Y in that layout. */
+    int32_t x_split, y_split;
 } morig_gemm_args;
 int morig_gemm(const morig_gemm_args* a, void* stream);
 
@@ -161,6 +166,10 @@ int morig_segmax_gemm(const morig_segmax_args* a, void* stream);
 /* strided 2-D copy  dst[r*ldd + c] = src[r*lds + c]  (feature slicing input_flow[:, 3t:3t+3],
  * models/rignet.py:86; torch.cat column placement :65). No alignment requirement. */
 int morig_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream);
+/* copy into a zero-padded slot: dst[r][c] = c < cols ? src[r][c] : 0 for c < slot_cols; with split != 0 the slot
+ * (slot_cols % 32 == 0, 128-byte aligned) is written in the split-fp16 activation layout; *overflow as in morig_gemm. */
+int morig_copy2d_pad(const float* src, int32_t lds, int32_t rows, int32_t cols, float* dst, int32_t ldd,
+                     int32_t slot_cols, int32_t split, int32_t* overflow, void* stream);
 
 /* gather columns: dst[r*ldd + c] = src[r*lds + cols[c]]  (skin_input column selection,
  * models/rignet.py:158-171). cols: int32 [n_cols] on device. */

@@ -118,6 +118,24 @@ __global__ void copy2d_kernel(const float* __restrict__ src, int lds, float* __r
     }
 }
 
+typedef __fp16 f16x2_t __attribute__((ext_vector_type(2)));
+__global__ void copy2d_pad_kernel(const float* __restrict__ src, int lds, int rows, int cols, float* __restrict__ dst, int ldd,
+                                  int slot, int split, int* ovf) {
+    const int64_t n = (int64_t)rows * slot;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / slot; const int c = (int)(i - r * slot);
+        const float v = c < cols ? src[r * lds + c] : 0.f;
+        if (!split) { dst[r * ldd + c] = v; continue; }
+        const f16x2_t h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+        const f16x2_t l = __builtin_amdgcn_cvt_pkrtz(v - (float)h[0], 0.f);
+        if (!(fabsf(v) < 65000.f)) *ovf = 1;
+        __fp16* yh = reinterpret_cast<__fp16*>(dst + r * ldd) + (c >> 5) * 64 + (c & 31);
+        yh[0] = h[0];
+        yh[32] = l[0];
+    }
+}
+
 __global__ void gather_cols_kernel(const float* __restrict__ src, int lds, const int* __restrict__ cols, int ncols,
                                    float* __restrict__ dst, int ldd, int rows) {
     const int64_t n = (int64_t)rows * ncols;
@@ -188,6 +206,19 @@ extern "C" int morig_copy2d(const float* src, int32_t lds, float* dst, int32_t l
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_COPY, s, 0.0, 8.0 * rows * cols);
     hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((int64_t)rows * cols)), dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_copy2d_pad(const float* src, int32_t lds, int32_t rows, int32_t cols, float* dst, int32_t ldd,
+                                int32_t slot_cols, int32_t split, int32_t* overflow, void* stream) {
+    if (!src || !dst || rows < 0 || cols < 0 || slot_cols < cols || lds < cols || ldd < slot_cols) return MORIG_E_INVALID;
+    if (split && (!overflow || (slot_cols & 31) || (ldd & 31) || (reinterpret_cast<uintptr_t>(dst) & 127))) return MORIG_E_INVALID;
+    if (rows == 0 || slot_cols == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_COPY, s, 0.0, 4.0 * rows * (cols + slot_cols));
+    hipLaunchKernelGGL(copy2d_pad_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, dst, ldd,
+                       slot_cols, split, overflow);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -55,6 +55,7 @@ struct TileParams {
     float* Y; int ldy;           // store target / edge-max target / pool target
     int tiles_n;
     int* ovf;                    // PREC_F16X3: set to 1 when an operand leaves the fp16 range
+    int x16, y16;                // PREC_F16X3 dense: X already in split-fp16 layout / store Y in split-fp16 layout
     int dbg;                     // ablation switches for tools/microbench.py (MORIG_DEBUG_FLAGS; 0 in production)
 };
 enum { DBG_NO_EPILOGUE = 1, DBG_NO_MFMA = 2, DBG_NO_GATHER = 4, DBG_NO_WLOAD = 8, DBG_NO_STAGE = 16 };
@@ -179,12 +180,15 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + rb[i][c], 0.f);      // invalid rows were fetched as 0
                 }
-            } else if (k0 + KC > p.K) {                 // only the last chunk can cross K
+            } else if (k0 + KC > p.K && !(PREC == PREC_F16X3 && p.x16)) {   // only the last chunk can cross K
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = (k + c < p.K) ? v[c] : 0.f;
             }
             if (PREC == PREC_F32) {
                 *reinterpret_cast<f32x4*>(&sA[(lrow + i * RPP) * LDK + 4 * lkq]) = v;
+            } else if (LOAD == LOAD_DENSE && p.x16) {
+                // the producer already wrote [32 halves hi | 32 halves lo] per 32-column chunk: plain copy
+                *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 16 * lkq) = ra[i];
             } else {
                 // hi = fp16(x) (round-toward-zero, 2 per instruction), lo = fp16(x - hi): x - hi is exact in fp32
                 const f16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
@@ -293,7 +297,18 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
                         float v = acc[mt][nt][r] + b;
                         if (p.rowbias) v += p.rowbias[(size_t)sseg[rl] * p.ld_rowbias + col];
                         if (p.relu) v = v > 0.f ? v : 0.f;
-                        p.Y[(size_t)row * p.ldy + col] = v * sc + sh;
+                        v = v * sc + sh;
+                        if (PREC == PREC_F16X3 && p.y16) {
+                            // split-fp16 layout for the next layer's loader: chunk (col/32) = [32 hi | 32 lo]
+                            const f16x2 hl = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
+                            const f16x2 ll = __builtin_amdgcn_cvt_pkrtz(v - (float)hl[0], 0.f);
+                            if (!(fabsf(v) < 65000.f)) *p.ovf = 1;
+                            __fp16* yh = reinterpret_cast<__fp16*>(p.Y + (size_t)row * p.ldy) + (col >> 5) * 64 + (col & 31);
+                            yh[0] = hl[0];
+                            yh[32] = ll[0];
+                        } else {
+                            p.Y[(size_t)row * p.ldy + col] = v;
+                        }
                     }
                 }
             }
@@ -480,6 +495,12 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         if (!a->overflow || !aligned16(a->W_split)) return MORIG_E_INVALID;
         p.W = static_cast<const float*>(a->W_split); p.ovf = a->overflow;
     }
+    if (a->x_split || a->y_split) {
+        if (!f16) return MORIG_E_INVALID;                        // split activations only exist on the split-fp16 path
+        if (a->x_split && ((a->ldx & 31) || (reinterpret_cast<uintptr_t>(a->X) & 127))) return MORIG_E_INVALID;
+        if (a->y_split && (pool || (a->ldy & 31) || (reinterpret_cast<uintptr_t>(a->Y) & 127))) return MORIG_E_INVALID;
+        p.x16 = a->x_split ? 1 : 0; p.y16 = a->y_split ? 1 : 0;
+    }
     if (pool) {
         if (a->n_seg <= 0 || a->ld_pool < a->N) return MORIG_E_INVALID;
         // identity of the integer-atomic float max
@@ -491,7 +512,7 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
                    : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
     }
     p.Y = a->Y; p.ldy = a->ldy;
-    if (f16 && a->N >= 256 && a->N % 256 == 0 && !getenv("MORIG_NO_BN256")) {
+    if (f16 && a->N >= 256 && a->N % 256 == 0 && getenv("MORIG_BN256")) {     // experiment: slower (1 wave/SIMD)
         // wide layers: 128 x 256 tile -- the on-the-fly operand split is amortised over twice the columns
         p.tiles_n = a->N / 256;
         ProfScope ps(K_GEMM16_BN256, s, flops, bytes);

@@ -87,8 +87,9 @@ class TemporalAttn(NativeModule):
 class GCNRig(NativeModule):
     """models/rignet.py:49-67."""
 
-    X1, X2, X3, POS = 0, 64, 320, 832          # column offsets in the wide activation buffer
-    FEAT = 836                                  # pos occupies 832..834, 835 is a zero pad
+    # wide activation buffer: [x_1 64 | x_2 256 | x_3 512 | pos slot 32 (xyz, zeros) | feature slot roundup32(F)];
+    # every window starts on a 32-column chunk so the buffer can be kept in the split-fp16 layout
+    X1, X2, X3, POS, FEAT = 0, 64, 320, 832, 864
 
     def __init__(self, chn_feature, chn_output, aggr="max"):
         super().__init__()
@@ -100,8 +101,12 @@ class GCNRig(NativeModule):
         self.mlp_transform = Sequential(MLP([1024 + 3 + chn_feature + 64 + 256 + 512, 1024, 256]), Linear(256, chn_output))
 
     @property
+    def feat_slot(self):
+        return (self.chn_feature + 31) // 32 * 32
+
+    @property
     def wide_ld(self):
-        return (self.FEAT + self.chn_feature + 3) // 4 * 4
+        return self.FEAT + self.feat_slot
 
     def _pack(self):
         F = self.chn_feature
@@ -120,29 +125,31 @@ class GCNRig(NativeModule):
 
     def run(self, ops, pos4: torch.Tensor, write_feature, csr_tpl, csr_geo, seg: torch.Tensor, n_graphs: int,
             replicas: int, out: Mat):
-        """pos4: [n, 4] (pos, 0); write_feature(Mat window [R*n, F]) fills the feature columns;
-        seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window."""
+        """pos4: [n, 4] (pos, 0); write_feature(window Mat [R*n, feat_slot], split) fills the feature slot
+        (zero padded); seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window."""
         dev = pos4.device
         pk = self.packed(dev)
         n, R, F = pos4.shape[0], replicas, self.chn_feature
         M = n * R
+        sp = ops.split_activations                    # GEMM -> GEMM activations in the split-fp16 layout
         wide = ops.empty(M, self.wide_ld, dev)
         for r in range(R):
-            ops.copy2d(Mat.of(pos4), Mat.of(wide, self.POS, 4, r * n, n))
-        write_feature(Mat.of(wide, self.FEAT, F))
+            ops.copy2d_pad(Mat.of(pos4), Mat.of(wide, self.POS, 32, r * n, n), split=sp)
+        write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
-        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, 64), R)
-        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, 64), csr_tpl, csr_geo, Mat.of(wide, self.X2, 256), R)
-        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, 256), csr_tpl, csr_geo, Mat.of(wide, self.X3, 512), R)
+        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, 64), R, split=sp)
+        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, 64), csr_tpl, csr_geo, Mat.of(wide, self.X2, 256), R, split=sp)
+        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, 256), csr_tpl, csr_geo, Mat.of(wide, self.X3, 512), R, split=sp)
         pooled = ops.empty(R * n_graphs, 1024, dev)
-        ops.gemm(Mat.of(wide, 0, 832), pk["glb"], relu=True, seg=seg, pool=pooled)
+        ops.gemm(Mat.of(wide, 0, 832), pk["glb"], relu=True, seg=seg, pool=pooled, x_split=sp)
         gb = ops.empty(R * n_graphs, 1024, dev)
         ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
         h1 = ops.empty(M, 1024, dev)
-        ops.gemm(Mat.of(wide, 0, self.FEAT + F), pk["t1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg)
+        ops.gemm(Mat.of(wide, 0, self.FEAT + F), pk["t1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg,
+                 x_split=sp, y_split=sp)
         h2 = ops.empty(M, 256, dev)
-        ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2))
-        ops.gemm(Mat.of(h2), pk["t3"], relu=False, Y=out)
+        ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2), x_split=sp, y_split=sp)
+        ops.gemm(Mat.of(h2), pk["t3"], relu=False, Y=out, x_split=sp)
 
     def _forward(self, pos, feature, tpl_edge_index, geo_edge_index, batch):
         ops = get_ops()
@@ -154,7 +161,7 @@ class GCNRig(NativeModule):
         feature = feature.unsqueeze(-1) if feature.dim() == 1 else feature
         feat = feature.float().contiguous()
         out = ops.empty(n, self.chn_output, dev)
-        self.run(ops, pos4, lambda w: ops.copy2d(Mat.of(feat), w), ops.csr_build(tpl_edge_index, n),
+        self.run(ops, pos4, lambda w, sp: ops.copy2d_pad(Mat.of(feat), w, split=sp), ops.csr_build(tpl_edge_index, n),
                  ops.csr_build(geo_edge_index, n), ops.make_seg(batch, ng, 1), ng, 1, Mat.of(out))
         return out
 
@@ -176,9 +183,9 @@ class _MotionBackbone(NativeModule):
         csr_geo = ops.csr_build(data.geo_edge_index, n)
         seg_T = ops.make_seg(data.batch, ng, T)
 
-        def write_flow(w: Mat):                       # feature of replica t = input_flow[:, 3t:3t+3]  (:86)
+        def write_flow(w: Mat, sp: bool):             # feature of replica t = input_flow[:, 3t:3t+3]  (:86)
             for t in range(T):
-                ops.copy2d(Mat.of(flow, 3 * t, 3), Mat.of(w.base, w.col0, 3, t * n, n))
+                ops.copy2d_pad(Mat.of(flow, 3 * t, 3), Mat.of(w.base, w.col0, w.cols, t * n, n), split=sp)
 
         C = self.motionNet.chn_output
         raw = ops.empty(T * n, C, dev)
@@ -221,8 +228,8 @@ class _MotionHead(_MotionBackbone):
         n = data.pos.shape[0]
         aggr = st["motion_aggr"]
         out = torch.empty((n, head.chn_output), dtype=torch.float32, device=aggr.device)
-        head.run(ops, st["pos4"], lambda w: ops.copy2d(Mat.of(aggr), w), st["csr_tpl"], st["csr_geo"], st["seg"],
-                 st["ng"], 1, Mat.of(out))
+        head.run(ops, st["pos4"], lambda w, sp: ops.copy2d_pad(Mat.of(aggr), w, split=sp), st["csr_tpl"], st["csr_geo"],
+                 st["seg"], st["ng"], 1, Mat.of(out))
         return st["motion_all"], aggr, out
 
 

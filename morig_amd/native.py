@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("Y", c_f32p), ("ldy", C.c_int32),
         ("pool", c_f32p), ("ld_pool", C.c_int32), ("n_seg", C.c_int32),
         ("W_split", C.c_void_p), ("overflow", c_i32p),
+        ("x_split", C.c_int32), ("y_split", C.c_int32),
     ]
 
 
@@ -85,6 +86,7 @@ _SIGNATURES = {
     "morig_gather_rows": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_copy2d": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "morig_copy2d_pad": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_gather_cols": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
     "morig_make_seg": (C.c_int, [c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_rownorm": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -212,6 +214,11 @@ class NativeOps:
     def fast(self) -> bool:
         return self.precision == "f16x3" and not self._force_f32
 
+    @property
+    def split_activations(self) -> bool:
+        """plans keep GEMM->GEMM activations in the split-fp16 layout while the fast path is active"""
+        return self.fast and os.environ.get("MORIG_SPLIT_ACT", "1") != "0"
+
     def _flag(self, device) -> torch.Tensor:
         key = (device.type, device.index)
         if key not in self._ovf:
@@ -266,8 +273,17 @@ class NativeOps:
 
     # -- dense ----------------------------------------------------------------------------------
     def gemm(self, X: Mat, lin, relu: bool, Y: Optional[Mat] = None, rowbias: Optional[Mat] = None,
-             seg: Optional[torch.Tensor] = None, pool: Optional[torch.Tensor] = None, affine: bool = True):
+             seg: Optional[torch.Tensor] = None, pool: Optional[torch.Tensor] = None, affine: bool = True,
+             x_split: bool = False, y_split: bool = False):
+        """x_split / y_split: the X window is / the Y window shall be in the split-fp16 activation layout
+        (include/morig_hip.h); only meaningful while ``self.fast``."""
         _need_gpu(X.base, lin.W)
+        if x_split or y_split:
+            if not self.fast:
+                raise MorigNativeError("split-fp16 activations requested on the fp32 path (plan bug)")
+            if lin.Wsplit is None:                    # weights outside the fp16 range: force the fp32 redo
+                self._flag(X.base.device).fill_(1)
+                return
         a = GemmArgs()
         a.M, a.N, a.K = X.rows, lin.N, lin.K
         assert X.cols == lin.K, (X.cols, lin.K)
@@ -288,6 +304,7 @@ class NativeOps:
             a.pool, a.ld_pool, a.n_seg = pool.data_ptr(), pool.stride(0), pool.shape[0]
         if self.fast and lin.Wsplit is not None:
             a.W_split, a.overflow = lin.Wsplit.data_ptr(), self._flag(X.base.device).data_ptr()
+        a.x_split, a.y_split = int(x_split), int(y_split)
         check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")
 
     # -- fused edge conv ----------------------------------------------------------------------------
@@ -389,6 +406,15 @@ class NativeOps:
         _need_gpu(src.base, dst.base)
         assert src.rows == dst.rows and src.cols == dst.cols
         check(self.lib.morig_copy2d(src.ptr, src.ld, dst.ptr, dst.ld, src.rows, src.cols, _stream()), "morig_copy2d")
+
+    def copy2d_pad(self, src: Mat, dst: Mat, split: bool = False):
+        """dst window (wider than src) = [src | zeros]; split: written in the split-fp16 activation layout."""
+        _need_gpu(src.base, dst.base)
+        assert src.rows == dst.rows and dst.cols >= src.cols
+        if split and not self.fast:
+            raise MorigNativeError("split-fp16 activations requested on the fp32 path (plan bug)")
+        check(self.lib.morig_copy2d_pad(src.ptr, src.ld, src.rows, src.cols, dst.ptr, dst.ld, dst.cols, int(split),
+                                        _p(self._flag(src.base.device)), _stream()), "morig_copy2d_pad")
 
     def gather_cols(self, src: Mat, cols: torch.Tensor, dst: Mat):
         _need_gpu(src.base, cols, dst.base)

@@ -85,6 +85,14 @@ def _pad_vec(v: Optional[torch.Tensor], n: int, fill: float = 0.0) -> Optional[t
     return out.contiguous()
 
 
+def unsplit_f16(buf: torch.Tensor, cols: int) -> torch.Tensor:
+    """inverse of the split-fp16 activation layout (tests / debugging): fp32 values hi + lo of the first ``cols``
+    logical columns of a [rows, ld] float32-typed buffer (ld % 32 == 0)."""
+    rows, ld = buf.shape
+    h = buf.contiguous().view(torch.float16).view(rows, ld // 32, 2, 32).float()
+    return (h[:, :, 0, :] + h[:, :, 1, :]).reshape(rows, ld)[:, :cols]
+
+
 def fold_hidden_affine(W2: torch.Tensor, b2: torch.Tensor, s1: torch.Tensor, t1: torch.Tensor):
     """W2 (s1*h + t1) + b2 = (W2 diag(s1)) h + (b2 + W2 t1): the BatchNorm that follows the FIRST edge ReLU is a
     linear map in front of Linear2, so it folds into Linear2 exactly (evaluated in fp64, rounded once)."""

@@ -20,6 +20,10 @@ class EmuOps:
     def guarded(self, device, fn):
         return fn()
 
+    @property
+    def split_activations(self):
+        return self.emulate_split
+
     def empty(self, rows, cols, device, dtype=torch.float32):
         # poison, so a plan that reads something it never wrote fails loudly
         return torch.full((rows, cols), float("nan"), dtype=dtype, device=device)
@@ -55,7 +59,24 @@ class EmuOps:
         assert not torch.isnan(v).any(), "GEMM reads uninitialised memory"
         return v
 
-    def gemm(self, X: Mat, lin, relu, Y=None, rowbias=None, seg=None, pool=None, affine=True):
+    fast = False
+    emulate_split = False       # tests set this to exercise the split-activation plan wiring (alignment rules only)
+
+    def copy2d_pad(self, src: Mat, dst: Mat, split=False):
+        if split:
+            assert dst.col0 % 32 == 0 and dst.cols % 32 == 0 and dst.ld % 32 == 0, "split slot alignment"
+        d = dst.view()
+        d.zero_()
+        d[:, : src.cols] = src.view()
+
+    def gemm(self, X: Mat, lin, relu, Y=None, rowbias=None, seg=None, pool=None, affine=True, x_split=False, y_split=False):
+        if x_split:
+            assert X.col0 % 32 == 0 and X.ld % 32 == 0, "split-fp16 X window must be chunk aligned"
+            # logical K may end inside a chunk: the remaining columns of that chunk must hold finite data
+            tail = X.base[X.row0:X.row0 + X.rows, X.col0 + X.cols: X.col0 + (X.cols + 31) // 32 * 32]
+            assert not torch.isnan(tail).any(), "split-fp16 X: chunk tail uninitialised"
+        if y_split:
+            assert Y.col0 % 32 == 0 and Y.ld % 32 == 0 and pool is None
         x = self._x(X, lin.K)
         acc = x @ lin.W[: lin.N, : lin.K].t()
         assert float(lin.W[lin.N:].abs().sum()) == 0 and float(lin.W[:, lin.K:].abs().sum()) == 0, "padding must be zero"

@@ -353,3 +353,52 @@ def test_split_fp16_overflow_is_flagged_and_forward_falls_back():
     got = ours(feat.to(DEV), batch.tpl_edge_index.to(DEV), batch.geo_edge_index.to(DEV))
     assert torch.isfinite(got).all()
     assert maxdiff(got, want) <= 1e-4 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 512, 544), (1000, 1024, 867), (129, 64, 64), (4096, 256, 1024)])
+def test_gemm_split_fp16_activation_layout(M, N, K):
+    """X consumed and Y produced in the split-fp16 activation layout (chunk = [32 hi | 32 lo])."""
+    from morig_amd import native
+    o = native.get_ops()
+    o.precision = "f16x3"
+    g = torch.Generator().manual_seed(M + K)
+    Kp, Np = (K + 31) // 32 * 32, (N + 31) // 32 * 32
+    x = torch.zeros(M, Kp + 32)
+    x[:, :K] = torch.randn(M, K, generator=g)
+    lin = _lin(N, K, 4)
+    want = torch.zeros(M, N)
+    EmuOps().gemm(Mat.of(x, 0, K), lin, True, Y=Mat.of(want))
+    xs = packing.split_f16(x).to(DEV)                           # same function that pre-splits the weights
+    ys = torch.zeros(M, Np + 32, device=DEV)
+    o.gemm(Mat.of(xs, 0, K), packing.to_device(lin, DEV), True, Y=Mat.of(ys, 32, N), x_split=True, y_split=True)
+    torch.cuda.synchronize()
+    got = packing.unsplit_f16(ys.cpu(), Np + 32)[:, 32:32 + N]
+    assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
+    # x fp32 -> y split, and x split -> y fp32
+    y2 = torch.zeros(M, N, device=DEV)
+    o.gemm(Mat.of(xs, 0, K), packing.to_device(lin, DEV), True, Y=Mat.of(y2), x_split=True)
+    assert maxdiff(y2, want) <= 2e-5 * max(1.0, want.abs().max().item())
+    # pooled consumer of a split X
+    seg = torch.sort(torch.randint(0, 5, (M,), generator=g))[0].int()
+    pw = torch.zeros(5, N)
+    EmuOps().gemm(Mat.of(x, 0, K), lin, True, seg=seg, pool=pw)
+    pg = torch.zeros(5, N, device=DEV)
+    o.gemm(Mat.of(xs, 0, K), packing.to_device(lin, DEV), True, seg=seg.to(DEV), pool=pg, x_split=True)
+    present = torch.unique(seg.long())
+    assert maxdiff(pg[present.to(DEV)], pw[present]) <= 2e-5 * max(1.0, pw[present].abs().max().item())
+
+
+def test_copy2d_pad_plain_and_split():
+    from morig_amd import native
+    o = native.get_ops()
+    o.precision = "f16x3"
+    src = torch.randn(77, 15)
+    dst = torch.full((80, 96), 7.0, device=DEV)
+    o.copy2d_pad(Mat.of(src.to(DEV), 3, 5), Mat.of(dst, 32, 32, 2, 77))
+    d = dst.cpu()
+    assert torch.equal(d[2:79, 32:37], src[:, 3:8]) and float(d[2:79, 37:64].abs().sum()) == 0
+    assert float((d[:, :32] - 7).abs().sum()) == 0 and float((d[:, 64:] - 7).abs().sum()) == 0
+    dst2 = torch.zeros(77, 96, device=DEV)
+    o.copy2d_pad(Mat.of(src.to(DEV), 3, 5), Mat.of(dst2, 32, 64), split=True)
+    dec = packing.unsplit_f16(dst2.cpu(), 96)
+    assert maxdiff(dec[:, 32:37], src[:, 3:8]) <= 1e-6 and float(dec[:, 37:].abs().sum()) == 0

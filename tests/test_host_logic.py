@@ -14,9 +14,13 @@ from morig_amd.models import basic_modules as bm, rignet as rn
 TOL = 2e-5
 
 
-@pytest.fixture(autouse=True)
-def emulated_ops():
-    runtime._test_ops = EmuOps()
+@pytest.fixture(autouse=True, params=["fp32-activations", "split-activations"])
+def emulated_ops(request):
+    """every host-logic test runs twice: plain fp32 hand-offs, and with the split-fp16 activation layout requested
+    (the emulation then checks the chunk-alignment / zero-tail rules the HIP loader relies on)."""
+    ops = EmuOps()
+    ops.emulate_split = request.param == "split-activations"
+    runtime._test_ops = ops
     yield
     runtime._test_ops = None
 
