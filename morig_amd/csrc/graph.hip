@@ -127,12 +127,12 @@ __global__ void copy2d_pad_kernel(const float* __restrict__ src, int lds, int ro
         const int64_t r = i / slot; const int c = (int)(i - r * slot);
         const float v = c < cols ? src[r * lds + c] : 0.f;
         if (!split) { dst[r * ldd + c] = v; continue; }
-        const f16x2_t h = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
-        const f16x2_t l = __builtin_amdgcn_cvt_pkrtz(v - (float)h[0], 0.f);
+        const __fp16 h = (__fp16)v;
+        const __fp16 l = (__fp16)(v - (float)h);
         if (!(fabsf(v) < 65000.f)) *ovf = 1;
         __fp16* yh = reinterpret_cast<__fp16*>(dst + r * ldd) + (c >> 5) * 64 + (c & 31);
-        yh[0] = h[0];
-        yh[32] = l[0];
+        yh[0] = h;
+        yh[32] = l;
     }
 }
 

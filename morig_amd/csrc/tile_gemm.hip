@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     constexpr int SM_Z = (MODE == MODE_STORE) ? 0 : BM * ZLD;
     constexpr int SM = SM_MAIN > SM_Z ? SM_MAIN : SM_Z;
     static_assert(BN % 32 == 0 && KC % 8 == 0, "tile shape");
-    static_assert(PREC == PREC_F32 || KC == 32, "the split-fp16 LDS image is [hi 32 halves | lo 32 halves] per row chunk");
+    static_assert(PREC == PREC_F32 || KC % 32 == 0, "the split-fp16 LDS image is [hi 32 halves | lo 32 halves] per 32-column chunk");
 
     __shared__ __attribute__((aligned(16))) float smem[SM + BM];
     float* sA = smem;
@@ -151,7 +151,8 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         for (int i = 0; i < PA; ++i) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             ra[i] = z; rb[i] = z;
-            const int k = k0 + 4 * lkq;
+            // split-fp16 X: a 16-byte piece holds halves of its whole 32-column chunk -> guard per chunk
+            const int k = (PREC == PREC_F16X3 && LOAD == LOAD_DENSE && p.x16) ? ((k0 + 4 * lkq) & ~31) : (k0 + 4 * lkq);
             if (va[i] && k < p.K && !(p.dbg & DBG_NO_GATHER)) {
                 ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
                 if (LOAD == LOAD_EDGE) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + k0);
@@ -193,16 +194,18 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
                 // hi = fp16(x) (round-toward-zero, 2 per instruction), lo = fp16(x - hi): x - hi is exact in fp32
                 const f16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
                 const f16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                const f16x2 l01 = __builtin_amdgcn_cvt_pkrtz(v[0] - (float)h01[0], v[1] - (float)h01[1]);
-                const f16x2 l23 = __builtin_amdgcn_cvt_pkrtz(v[2] - (float)h23[0], v[3] - (float)h23[1]);
+                // (hi may truncate: lo absorbs it exactly; lo itself is rounded to nearest-even so the split is unbiased)
+                f16x2 l01, l23;
+                l01[0] = (__fp16)(v[0] - (float)h01[0]); l01[1] = (__fp16)(v[1] - (float)h01[1]);
+                l23[0] = (__fp16)(v[2] - (float)h23[0]); l23[1] = (__fp16)(v[3] - (float)h23[1]);
                 const float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 if (!(amax < 65000.f)) *p.ovf = 1;                     // also catches NaN
                 f16x4 h, l;
                 h[0] = (_Float16)h01[0]; h[1] = (_Float16)h01[1]; h[2] = (_Float16)h23[0]; h[3] = (_Float16)h23[1];
                 l[0] = (_Float16)l01[0]; l[1] = (_Float16)l01[1]; l[2] = (_Float16)l23[0]; l[3] = (_Float16)l23[1];
-                char* rowp = reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4);
-                *reinterpret_cast<f16x4*>(rowp + 8 * lkq) = h;
-                *reinterpret_cast<f16x4*>(rowp + 64 + 8 * lkq) = l;
+                char* rowp = reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 128 * (lkq >> 3) + 8 * (lkq & 7);
+                *reinterpret_cast<f16x4*>(rowp) = h;
+                *reinterpret_cast<f16x4*>(rowp + 64) = l;
             }
         }
 #pragma unroll
@@ -233,17 +236,18 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
             const char* a0 = reinterpret_cast<const char*>(sA) + (wm * MT * 32 + l31) * (LDK * 4) + 16 * hi;
             const char* b0 = reinterpret_cast<const char*>(sB) + (wn * NT * 32 + l31) * (LDK * 4) + 16 * hi;
 #pragma unroll
-            for (int st = 0; st < KC / 16; ++st) {
+            for (int st2 = 0; st2 < KC / 16; ++st2) {
+                const int off = 128 * (st2 >> 1) + 32 * (st2 & 1);     // 32-column chunk, 16-k step inside it
                 f16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    ah[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDK * 4 + 32 * st);
-                    al[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDK * 4 + 32 * st + 64);
+                    ah[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDK * 4 + off);
+                    al[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDK * 4 + off + 64);
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    bh[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDK * 4 + 32 * st);
-                    bl[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDK * 4 + 32 * st + 64);
+                    bh[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDK * 4 + off);
+                    bl[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDK * 4 + off + 64);
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
@@ -300,12 +304,12 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
                         v = v * sc + sh;
                         if (PREC == PREC_F16X3 && p.y16) {
                             // split-fp16 layout for the next layer's loader: chunk (col/32) = [32 hi | 32 lo]
-                            const f16x2 hl = __builtin_amdgcn_cvt_pkrtz(v, 0.f);
-                            const f16x2 ll = __builtin_amdgcn_cvt_pkrtz(v - (float)hl[0], 0.f);
+                            const __fp16 hv = (__fp16)v;                       // round-to-nearest-even, both parts
+                            const __fp16 lv = (__fp16)(v - (float)hv);
                             if (!(fabsf(v) < 65000.f)) *p.ovf = 1;
                             __fp16* yh = reinterpret_cast<__fp16*>(p.Y + (size_t)row * p.ldy) + (col >> 5) * 64 + (col & 31);
-                            yh[0] = hl[0];
-                            yh[32] = ll[0];
+                            yh[0] = hv;
+                            yh[32] = lv;
                         } else {
                             p.Y[(size_t)row * p.ldy + col] = v;
                         }
@@ -495,9 +499,11 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         if (!a->overflow || !aligned16(a->W_split)) return MORIG_E_INVALID;
         p.W = static_cast<const float*>(a->W_split); p.ovf = a->overflow;
     }
+    // 64-deep K chunks halve the barriers per MFMA on the split-fp16 path (needs weights padded to 64 in K)
+    const bool kc64 = f16 && a->K >= 64 && (a->ldw & 63) == 0 && a->ldw >= ((a->K + 63) & ~63) && !getenv("MORIG_KC32");
     if (a->x_split || a->y_split) {
         if (!f16) return MORIG_E_INVALID;                        // split activations only exist on the split-fp16 path
-        if (a->x_split && ((a->ldx & 31) || (reinterpret_cast<uintptr_t>(a->X) & 127))) return MORIG_E_INVALID;
+        if (a->x_split && ((a->ldx & 31) || a->ldx < ((a->K + 31) & ~31) || (reinterpret_cast<uintptr_t>(a->X) & 127))) return MORIG_E_INVALID;
         if (a->y_split && (pool || (a->ldy & 31) || (reinterpret_cast<uintptr_t>(a->Y) & 127))) return MORIG_E_INVALID;
         p.x16 = a->x_split ? 1 : 0; p.y16 = a->y_split ? 1 : 0;
     }
@@ -508,6 +514,7 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         p.Y = a->pool; p.ldy = a->ld_pool;
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_POOL : K_GEMM_POOL, s, flops, bytes);
+        if (f16 && kc64) return launch_tile<128, 64, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
         return f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
                    : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
     }
@@ -521,6 +528,7 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
     if (a->N > 64) {
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_BN128 : K_GEMM_BN128, s, flops, bytes);
+        if (f16 && kc64) return launch_tile<128, 64, LOAD_DENSE, MODE_STORE, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
         return f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_STORE, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
                    : launch_tile<128, 32, LOAD_DENSE, MODE_STORE>(p, tiles_m * p.tiles_n, s);
     } else if (a->N > 32) {

@@ -111,7 +111,7 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: O
         in_cols = list(range(Ksrc))
     K = max(in_cols) + 1 if k_total is None else k_total
     Npad = _roundup(N, row_tile or col_tile(N))
-    Kpad = _roundup(K, 32)
+    Kpad = _roundup(K, 64)                      # 64: the split-fp16 dense kernel stages 64-deep K chunks
     Wp = torch.zeros((Npad, Kpad), dtype=torch.float32, device=W.device)
     Wp[:N, torch.as_tensor(list(in_cols), device=W.device)] = W
     s = t = None
