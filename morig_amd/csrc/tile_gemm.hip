@@ -466,6 +466,17 @@ static int launch_tile(const TileParams& p0, int nblocks, hipStream_t s) {
     return MORIG_OK;
 }
 
+struct EdgePcParams {
+    int H;
+    const float* W; int ldw;
+    const float* bias; const float* scale; const float* shift;
+    const float* A; int lda; const float* B; int ldb;
+    const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
+    float* Y; int ldy;
+    int* ovf;
+};
+int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);      // edge_pc.hip
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace morig
@@ -646,6 +657,18 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
     const double flops = 2.0 * E * a->H * (double)a->H;
     const double bytes = 4.0 * (2.0 * E * a->H) ;    // gathered operand rows (mostly L2 hits)
+    // H = 256: wave-specialised kernel (1.35x). H = 128 keeps the symmetric kernel (two workgroups per CU win there).
+    if (f16 && (a->H == 256 || (a->H == 128 && getenv("MORIG_EDGE_PC128"))) && a->s1 == nullptr && !getenv("MORIG_NO_EDGE_PC")) {
+        // wave-specialised producer/consumer kernel (edge_pc.hip)
+        EdgePcParams q = {};
+        q.H = a->H; q.W = p.W; q.ldw = p.ldw; q.bias = p.bias; q.scale = p.scale; q.shift = p.shift;
+        q.A = p.A; q.lda = p.lda; q.B = p.B; q.ldb = p.ldb;
+        q.rowptr = p.rowptr; q.srcS = p.srcS; q.dstS = p.dstS; q.n_nodes = p.n_nodes;
+        q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep;
+        q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf;
+        ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
+        return launch_edge_pc(q, nblocks, s);
+    }
     if (f16) {
         switch (a->H) {
             case 32:  { ProfScope ps(K_EDGE16_H32, s, flops, bytes);  return launch_tile<32, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }

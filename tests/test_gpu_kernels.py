@@ -129,7 +129,9 @@ def test_gemm_pool_and_rowbias(ops, M, N, K, nseg):
     assert maxdiff(y, y_ref) <= 2e-5 * max(1.0, y_ref.abs().max().item())
 
 
-def _edge_pack(H, seed):
+def _edge_pack(H, seed, folded=False):
+    """folded=True: hidden affine absent (s1 = t1 = None), the form morig_amd.packing produces and the only
+    one the wave-specialised kernel (edge_pc.hip) takes."""
     g = torch.Generator().manual_seed(seed)
     Hp, Kp = max(H, 32), (H + 31) // 32 * 32
     W2 = torch.zeros(Hp, Kp)
@@ -140,18 +142,23 @@ def _edge_pack(H, seed):
         v[:H] = f(H)
         return v
     rn = lambda k: torch.randn(k, generator=g)
-    return packing.PackedEdge(H, vec(Kp, 1.0, rn), vec(Kp, 0.0, lambda k: rn(k) * 0.2), W2, vec(Hp, 0.0, lambda k: rn(k) * 0.1),
-                              vec(Hp, 1.0, rn), vec(Hp, 0.0, lambda k: rn(k) * 0.2))
+    s1, t1 = vec(Kp, 1.0, rn), vec(Kp, 0.0, lambda k: rn(k) * 0.2)
+    pe = packing.PackedEdge(H, s1, t1, W2, vec(Hp, 0.0, lambda k: rn(k) * 0.1), vec(Hp, 1.0, rn), vec(Hp, 0.0, lambda k: rn(k) * 0.2))
+    if folded:
+        pe.s1 = pe.t1 = None
+    pe.W2split = packing.split_f16(W2) if H >= 32 else None
+    return pe
 
 
+@pytest.mark.parametrize("folded", [False, True])
 @pytest.mark.parametrize("H", [16, 32, 64, 128, 256])
 @pytest.mark.parametrize("n,e,hub,reps,shared", [(300, 2500, 5, 1, False), (1500, 9000, None, 3, False), (700, 5000, 3, 2, True)])
-def test_edgeconv(ops, H, n, e, hub, reps, shared):
+def test_edgeconv(ops, H, n, e, hub, reps, shared, folded):
     g = torch.Generator().manual_seed(H + n)
     ei = _rand_graph(n, e, 9, hub)
     rows_in = n if shared else n * reps
     ab = torch.randn(rows_in, 2 * H + 4, generator=g)
-    ec = _edge_pack(H, 21)
+    ec = _edge_pack(H, 21, folded)
     emu = EmuOps()
     csr_ref = emu.csr_build(ei, n)
     out_ref = torch.zeros(n * reps, H + 3)

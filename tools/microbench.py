@@ -41,7 +41,7 @@ def main():
         for H in (256, 128):
             g = torch.Generator().manual_seed(H)
             W = torch.randn(H, H, generator=g) / H ** 0.5
-            ec = packing.PackedEdge(H, torch.ones(H), torch.zeros(H), W.contiguous(), torch.zeros(H), torch.ones(H), torch.zeros(H),
+            ec = packing.PackedEdge(H, None, None, W.contiguous(), torch.zeros(H), torch.ones(H), torch.zeros(H),
                                     packing.split_f16(W.contiguous()))
             ec = packing.to_device(ec, DEV)
             ab = torch.randn(R * n, 4 * H, device=DEV)
