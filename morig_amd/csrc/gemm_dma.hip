@@ -1,0 +1,209 @@
+// Dense vertex layer on the split-fp16 path when BOTH operands are already in the split layout (X from the
+// producing layer's epilogue, W pre-split by the host): the operand tiles need no VALU work at all, so they are
+// streamed HBM/L2 -> LDS with global_load_lds (LDS-DMA, 16 bytes per lane, no VGPR round trip) into a 4-stage
+// ring, three K-chunks ahead of the MFMAs, with ONE raw s_barrier and a COUNTED s_waitcnt vmcnt per chunk
+// (cdna_hip_programming.md section 5: "Pipelining across barriers", rule 21 for the swizzle).
+//
+// LDS image of a stage: [128 rows][128 B] for X then the same for W, a row = [32 hi | 32 lo] halves of one
+// 32-column chunk = 8 slots of 16 B. DMA writes are lane-linear (wave base + lane*16), so the bank-conflict fix
+// is an XOR swizzle applied on the SOURCE side: LDS slot p of row r holds logical slot p ^ ((r >> 1) & 7); fragment
+// reads apply the same involution. A 16-lane read group (16 distinct rows mod 16) then hits 16 distinct slots.
+#include "common.h"
+#include <stdlib.h>
+
+namespace morig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+struct GemmDmaParams {
+    int M, N, K;
+    const float* X; int ldx;                     // split-fp16 layout
+    const float* W; int ldw;                     // split-fp16 layout, rows padded to 128
+    const float* bias; const float* scale; const float* shift; int relu;
+    const float* rowbias; int ld_rowbias; const int* seg;
+    float* Y; int ldy; int y16;
+    int tiles_n;
+    int* ovf;
+};
+
+// Tile shapes. The split layout doubles the operand bytes per MFMA (hi and lo fragments), so LDS bandwidth --
+// fragment reads plus the DMA writes -- is what binds a 128x128 / 64x64-per-wave tile (measured plateau
+// ~260 TFLOP/s for every staging scheme). BIG = 256x256 block, 8 waves of 64x128: 3x fewer LDS bytes per MFMA.
+template <int BM, int BN, int NT, int DMA_NS>
+__global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_kernel(const GemmDmaParams p) {
+    constexpr int MT = 2;
+    constexpr int WNW = BN / (32 * NT);          // waves along N
+    constexpr int NW = (BM / 64) * WNW;          // waves per block
+    constexpr int DMA_STAGE = (BM + BN) * 128;   // bytes: X tile + W tile of one 32-column chunk
+    constexpr int XJ = BM / 8 / NW, WJ = BN / 8 / NW;     // 1-KiB DMA instructions per wave per chunk (X, W)
+    constexpr int PER_CHUNK = XJ + WJ;
+    __shared__ __attribute__((aligned(128))) char smem[DMA_NS * DMA_STAGE + BM * 4];
+    int* sseg = reinterpret_cast<int*>(smem + DMA_NS * DMA_STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
+    const int row0 = tm * BM;
+
+    if (p.seg != nullptr && tid < BM) sseg[tid] = (row0 + tid < p.M) ? p.seg[row0 + tid] : 0;
+
+    // ---- per-lane DMA source pointers: wave w moves row blocks (8 rows x 128 B = 1 KiB per instruction) 4w..4w+3 ----
+    const float* gx[XJ]; const float* gw[WJ];
+    const int rsub = lane >> 3;                  // row inside the 8-row block
+    const int pslot = lane & 7;                  // physical 16-byte slot inside the row
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+        const int r = (wave * XJ + j) * 8 + rsub;
+        const int lslot = pslot ^ ((r >> 1) & 7);  // rule 21: swizzle the SOURCE, keep the LDS destination linear
+        int xr = row0 + r; if (xr >= p.M) xr = p.M - 1;      // clamp: rows past M are never stored
+        gx[j] = p.X + (size_t)xr * p.ldx + 4 * lslot;
+    }
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+        const int r = (wave * WJ + j) * 8 + rsub;
+        gw[j] = p.W + (size_t)(tn * BN + r) * p.ldw + 4 * (pslot ^ ((r >> 1) & 7));
+    }
+    auto issue = [&](int c) {
+        char* st = smem + (c % DMA_NS) * DMA_STAGE;
+        const int k0 = c * 32;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gx[j] + k0), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(gw[j] + k0), (lds_void_t*)(st + BM * 128 + (wave * WJ + j) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int nchunk = (p.K + 31) / 32;
+    // prologue: NS-1 chunks in flight (PER_CHUNK DMA instructions per chunk per wave)
+#pragma unroll
+    for (int c = 0; c < DMA_NS - 1; ++c) if (c < nchunk) issue(c);
+
+    const int x7 = (l31 >> 1) & 7;               // 128-B rows: slot position in the 256-B bank window = 8*(r&1) + slot,
+                                                 // so XOR-ing with (r>>1)&7 makes any 16 consecutive rows conflict-free
+    const int aoff = (wm * 64 + l31) * 128, boff = BM * 128 + (wn * NT * 32 + l31) * 128;
+    // software pipeline: the fragments of the NEXT 16-k step are always in flight (ds_read) while the 12 MFMAs
+    // of the current step issue, and the wait + barrier for chunk c+1 sit in the MIDDLE of chunk c
+    struct Frag { f16x8 ah[MT], al[MT], bh[NT], bl[NT]; };
+    auto load_frag = [&](Frag& f, int c, int s2) {
+        const char* st = smem + (c % DMA_NS) * DMA_STAGE;
+        const int sh = ((2 * s2 + hi) ^ x7) * 16, sl = ((4 + 2 * s2 + hi) ^ x7) * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            f.ah[mt] = *reinterpret_cast<const f16x8*>(st + aoff + mt * 32 * 128 + sh);
+            f.al[mt] = *reinterpret_cast<const f16x8*>(st + aoff + mt * 32 * 128 + sl);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            f.bh[nt] = *reinterpret_cast<const f16x8*>(st + boff + nt * 32 * 128 + sh);
+            f.bl[nt] = *reinterpret_cast<const f16x8*>(st + boff + nt * 32 * 128 + sl);
+        }
+    };
+    auto mma = [&](const Frag& f) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+            }
+    };
+    auto wait_chunk = [&](int c) {               // chunk c landed for this wave: only younger chunks' DMAs outstanding
+        int younger = nchunk - 1 - c;
+        if (younger > DMA_NS - 2) younger = DMA_NS - 2;
+        static_assert(DMA_NS >= 2 && DMA_NS <= 4, "ring depth");
+        if (younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER_CHUNK) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    Frag f0, f1;
+    wait_chunk(0);
+    __builtin_amdgcn_s_barrier();
+    if (DMA_NS - 1 < nchunk) issue(DMA_NS - 1);
+    load_frag(f0, 0, 0);
+    for (int c = 0; c < nchunk; ++c) {
+        load_frag(f1, c, 1);
+        mma(f0);
+        if (c + 1 < nchunk) {
+            wait_chunk(c + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my own reads of chunk c have returned ...
+            __builtin_amdgcn_s_barrier();        // ... and everyone's: chunk c lives in registers, stage c%NS is free
+            if (c + DMA_NS < nchunk) issue(c + DMA_NS);
+            load_frag(f0, c + 1, 0);
+        }
+        mma(f1);
+    }
+
+    // ---- epilogue: bias / per-mesh row bias / ReLU / BN affine, fp32 or split-fp16 store ----
+    __syncthreads();                             // sseg visible
+    const int colw0 = tn * BN + wn * NT * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int col = colw0 + nt * 32 + l31;
+        if (col >= p.N) continue;
+        const float b = p.bias ? p.bias[col] : 0.f;
+        const float sc = p.scale ? p.scale[col] : 1.f;
+        const float shf = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int row = row0 + rl;
+                if (row < p.M) {
+                    float v = acc[mt][nt][r] + b;
+                    if (p.rowbias) v += p.rowbias[(size_t)sseg[rl] * p.ld_rowbias + col];
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    v = v * sc + shf;
+                    if (p.y16) {
+                        // neighbouring lanes hold neighbouring columns: trade halves so that every lane writes ONE dword
+                        // (even lane: hi(c),hi(c+1); odd lane: lo(c-1),lo(c)) instead of two 2-byte stores
+                        const __fp16 hv = (__fp16)v;
+                        const __fp16 lv = (__fp16)(v - (float)hv);
+                        if (!(fabsf(v) < 65000.f)) *p.ovf = 1;
+                        const unsigned hb = __builtin_bit_cast(unsigned short, hv), lb = __builtin_bit_cast(unsigned short, lv);
+                        const bool odd = lane & 1;
+                        // quad_perm [1,0,3,2] = swap with the xor-1 neighbour: one v_mov_dpp, no LDS crossbar
+                        const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hb : lb), 0xB1, 0xF, 0xF, false);
+                        const unsigned word = odd ? (got | (lb << 16)) : (hb | (got << 16));
+                        unsigned* yw = reinterpret_cast<unsigned*>(p.Y + (size_t)row * p.ldy) + (col >> 5) * 32 + ((col & 31) >> 1) + (odd ? 16 : 0);
+                        *yw = word;
+                    } else {
+                        p.Y[(size_t)row * p.ldy + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
+    GemmDmaParams p = p0;
+    static const int mode = [] { const char* e = getenv("MORIG_DMA_TILE"); return e ? atoi(e) : 256; }();
+    if (mode == 256 && p.N % 256 == 0) {
+        p.tiles_n = p.N / 256;
+        const int nb = cdiv(p.M, 256) * p.tiles_n;
+        hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2>), dim3(nb), dim3(512), 0, s, p);
+    } else {
+        p.tiles_n = cdiv(p.N, 128);
+        hipLaunchKernelGGL((gemm16_dma_kernel<128, 128, 2, 4>), dim3(tiles_m128 * p.tiles_n), dim3(256), 0, s, p);
+    }
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+}  // namespace morig

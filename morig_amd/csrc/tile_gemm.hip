@@ -476,6 +476,17 @@ struct EdgePcParams {
     int* ovf;
 };
 int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);      // edge_pc.hip
+struct GemmDmaParams {
+    int M, N, K;
+    const float* X; int ldx;
+    const float* W; int ldw;
+    const float* bias; const float* scale; const float* shift; int relu;
+    const float* rowbias; int ld_rowbias; const int* seg;
+    float* Y; int ldy; int y16;
+    int tiles_n;
+    int* ovf;
+};
+int launch_gemm16_dma(const GemmDmaParams& p, int nblocks, hipStream_t s);   // gemm_dma.hip
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -530,6 +541,16 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
                    : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
     }
     p.Y = a->Y; p.ldy = a->ldy;
+    if (f16 && a->x_split && a->N > 64 && !getenv("MORIG_NO_DMA")) {
+        // both operands pre-split: LDS-DMA pipeline (gemm_dma.hip)
+        GemmDmaParams q = {};
+        q.M = a->M; q.N = a->N; q.K = a->K; q.X = a->X; q.ldx = a->ldx; q.W = p.W; q.ldw = p.ldw;
+        q.bias = a->bias; q.scale = a->scale; q.shift = a->shift; q.relu = a->relu;
+        q.rowbias = a->rowbias; q.ld_rowbias = a->ld_rowbias; q.seg = a->seg;
+        q.Y = a->Y; q.ldy = a->ldy; q.y16 = a->y_split ? 1 : 0; q.tiles_n = cdiv(a->N, 128); q.ovf = a->overflow;
+        ProfScope ps(K_GEMM16_DMA, s, flops, bytes);
+        return launch_gemm16_dma(q, tiles_m, s);
+    }
     if (f16 && a->N >= 256 && a->N % 256 == 0 && getenv("MORIG_BN256")) {     // experiment: slower (1 wave/SIMD)
         // wide layers: 128 x 256 tile -- the on-the-fly operand split is amortised over twice the columns
         p.tiles_n = a->N / 256;

@@ -58,6 +58,11 @@ def main():
         y = torch.empty(M, N, device=DEV)
         ms = timed(lambda: ops.gemm(Mat.of(x, 0, K), lin, True, Y=Mat.of(y)), reps=3)
         out[f"gemm_M{M}_K{K}_N{N}"] = (ms, 2.0 * M * K * N / ms / 1e9)
+        if prec == "f16x3":
+            xs = torch.randn(M, (K + 31) // 32 * 32, device=DEV)          # bit pattern irrelevant for timing? no: use a real split
+            xs = packing.split_f16(xs.cpu()).to(DEV) if M * K < 2e8 else xs.half().float()
+            ms = timed(lambda: ops.gemm(Mat.of(xs, 0, K), lin, True, Y=Mat.of(y), x_split=True, y_split=True), reps=3)
+            out[f"gemm16_M{M}_K{K}_N{N}"] = (ms, 2.0 * M * K * N / ms / 1e9)
     flags = os.environ.get("MORIG_DEBUG_FLAGS", "0")
     for k, (ms, tf) in out.items():
         print(f"prec={prec} dbg={flags:>2} {k:28s} {ms:9.3f} ms  {tf:8.1f} TFLOP/s")
