@@ -62,9 +62,13 @@ int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes,
 /* bipartite form used by PointConv (PyG applies remove_self_loops/add_self_loops(num_nodes =
  * min(N_src, N_dst)) to the raw (source, target) index pairs even though they index different sets):
  * sources in [0, n_src_nodes), targets in [0, n_nodes), n_src_nodes >= n_nodes; pairs with a negative
- * index (unused ball-query slots) are skipped when skip_negative != 0. */
+ * index (unused ball-query slots) are skipped with MORIG_CSR_SKIP_NEGATIVE. */
+#define MORIG_CSR_SKIP_NEGATIVE 1   /* pairs with a negative index are skipped instead of flagged            */
+#define MORIG_CSR_PAD4          2   /* every target's segment is padded to a multiple of 4 entries by repeating
+                                       its self loop (max-aggregation is idempotent); capacity n_edges + 4*n_nodes.
+                                       morig_edgeconv's `quad_aligned` fast epilogue requires it.              */
 int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_t n_src_nodes, int32_t n_nodes,
-                              int32_t skip_negative, int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
+                              int32_t flags, int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
                               int32_t* cursor, int32_t* status, void* stream);
 
 /* --------------------------------------------------------------------------------------------
@@ -138,6 +142,7 @@ typedef struct morig_edgeconv_args {
     const float* b2; const float* s2; const float* t2;   /* [Hpad]                        */
     float* out; int32_t ldo;           /* out[row][0..H)                                  */
     const void* W2_split; int32_t* overflow;   /* optional split-fp16 fast path (H >= 32), as in morig_gemm_args */
+    int32_t quad_aligned;              /* the CSR was built with MORIG_CSR_PAD4: segments are 4-aligned */
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 

@@ -34,6 +34,31 @@ inline int check_hip(hipError_t e) {
 #define MORIG_HIP_TRY(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { ::morig::set_hip_error(_e); return MORIG_E_HIP; } } while (0)
 #define MORIG_LAUNCH_CHECK() MORIG_HIP_TRY(hipGetLastError())
 
+// parameter blocks of the specialised kernels (edge_pc.hip, gemm_dma.hip), filled by the launchers in tile_gemm.hip
+struct EdgePcParams {
+    int H;
+    const float* W; int ldw;                     // split-fp16 image of W2 [H][ldw]
+    const float* bias; const float* scale; const float* shift;
+    const float* A; int lda; const float* B; int ldb;
+    const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
+    float* Y; int ldy;
+    int* ovf;
+    int quad;                                    // CSR segments are 4-aligned (MORIG_CSR_PAD4)
+};
+struct GemmDmaParams {
+    int M, N, K;
+    const float* X; int ldx;                     // split-fp16 layout
+    const float* W; int ldw;                     // split-fp16 layout, rows padded to the column tile
+    const float* bias; const float* scale; const float* shift; int relu;
+    const float* rowbias; int ld_rowbias; const int* seg;
+    float* Y; int ldy; int y16;
+    float* pool; int ld_pool;                    // column max per segment instead of a store (seg sorted)
+    int tiles_n;
+    int* ovf;
+};
+int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pc.hip
+int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); // gemm_dma.hip
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device helpers -------------------------------------------------------------------

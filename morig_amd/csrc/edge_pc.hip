@@ -21,16 +21,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));
 
-struct EdgePcParams {
-    int H;
-    const float* W; int ldw;                     // split-fp16 image of W2 [H][ldw]
-    const float* bias; const float* scale; const float* shift;
-    const float* A; int lda; const float* B; int ldb;
-    const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
-    float* Y; int ldy;
-    int* ovf;
-};
-
 template <int H>
 __global__ __launch_bounds__(512, 2) void edge_pc_kernel(const EdgePcParams p) {
     constexpr int BM = 128, KC = 32, LDB = 144;         // LDB: bytes per LDS row = [32 hi | 32 lo | 16 pad]
@@ -177,6 +167,66 @@ __global__ __launch_bounds__(512, 2) void edge_pc_kernel(const EdgePcParams p) {
     const bool first_cont = p.rowptr[sseg[0]] < row0;
     bool last_cont = false;
     if (row0 + BM < Etot) last_cont = p.rowptr[sseg[BM - 1] + 1] > row0 + BM;
+    if (p.quad) {
+        // ---- 4-aligned segments (MORIG_CSR_PAD4): every lane's 4 consecutive accumulator rows (r&3) belong to one
+        // segment, so they are reduced in registers first; the LDS tile holds 32 quad-rows x H columns in ONE pass ----
+        constexpr int ZQ = H + 1;
+        constexpr int G = 512 / H, RGQ = 32 / G, EXTQ = 8;
+        if (!producer) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = wn * NT * 32 + nt * 32 + l31;
+                const float b = p.bias[col], sc = p.scale[col], sh = p.shift[col];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float m = fmaxf(acc[mt][nt][4 * q] + b, 0.f) * sc + sh;
+#pragma unroll
+                        for (int r = 1; r < 4; ++r) m = fmaxf(m, fmaxf(acc[mt][nt][4 * q + r] + b, 0.f) * sc + sh);
+                        Z[(wm * 16 + mt * 8 + 2 * q + hi) * ZQ + col] = m;
+                    }
+            }
+        }
+        __syncthreads();
+        const int col = tid % H, zg = tid / H;              // zg is wave-uniform (H is a multiple of 64)
+        const int q0 = __builtin_amdgcn_readfirstlane(zg * RGQ);
+        const float* zcolp = Z + col;
+        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
+        auto flush = [&](int sg, float m, int qs, int qend) {
+            float* o = obase + (size_t)sg * p.ldy;
+            const bool partial = (qs == 0 && first_cont) || (qend == 32 && last_cont);
+            if (partial) atomic_max_f32(o, m); else *o = m;
+        };
+        int cur = __builtin_amdgcn_readfirstlane((zg > 0) ? sseg[4 * q0 - 1] : -2);
+        bool open = false, done = false;
+        float m = 0.f; int qs = 0, qnext = q0;
+#pragma unroll
+        for (int bt = 0; bt < (RGQ + EXTQ) / 8; ++bt) {
+            const int qb0 = q0 + bt * 8;
+            if (done || qb0 >= 32) break;
+            float zv[8]; int sv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sv[i] = __builtin_amdgcn_readfirstlane(sseg[4 * (qb0 + i)]); zv[i] = zcolp[(qb0 + i) * ZQ]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (!done) {
+                    if (sv[i] != cur) {
+                        if (open) flush(cur, m, qs, qb0 + i);
+                        if (bt * 8 + i >= RGQ) { open = false; done = true; }
+                        else { cur = sv[i]; open = cur >= 0; m = zv[i]; qs = qb0 + i; }
+                    } else if (open) m = fmaxf(m, zv[i]);
+                }
+            }
+            qnext = qb0 + 8;
+        }
+        if (open && !done) {
+            int q = qnext;
+            while (q < 32 && sseg[4 * q] == cur) { m = fmaxf(m, zcolp[q * ZQ]); ++q; }
+            flush(cur, m, qs, q);
+        }
+        return;
+    }
     constexpr int NPASS = NT;                           // one fragment column (2 consumer column-waves x 32) per pass
     constexpr int RG = 16, EXT = 32;                    // 8 row groups of 16
     const int zc = tid & 63, zg = tid >> 6;

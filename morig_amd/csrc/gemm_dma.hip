@@ -18,17 +18,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
-struct GemmDmaParams {
-    int M, N, K;
-    const float* X; int ldx;                     // split-fp16 layout
-    const float* W; int ldw;                     // split-fp16 layout, rows padded to 128
-    const float* bias; const float* scale; const float* shift; int relu;
-    const float* rowbias; int ld_rowbias; const int* seg;
-    float* Y; int ldy; int y16;
-    int tiles_n;
-    int* ovf;
-};
-
 // Tile shapes. The split layout doubles the operand bytes per MFMA (hi and lo fragments), so LDS bandwidth --
 // fragment reads plus the DMA writes -- is what binds a 128x128 / 64x64-per-wave tile (measured plateau
 // ~260 TFLOP/s for every staging scheme). BIG = 256x256 block, 8 waves of 64x128: 3x fewer LDS bytes per MFMA.
@@ -148,9 +137,46 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
         mma(f1);
     }
 
+    const int colw0 = tn * BN + wn * NT * 32;
+    if (p.pool != nullptr) {
+        // ---- pooled epilogue (scatter_max over meshes): `seg` is sorted, so the 64 rows of a wave tile almost always
+        // belong to ONE mesh: reduce them in registers (32 values per lane, then the two half-waves) and issue one
+        // integer-atomic float max per column; a wave tile that straddles meshes falls back to per-element atomics ----
+        const int rfirst = row0 + wm * 64;
+        if (rfirst >= p.M) return;
+        const int rlast = min(rfirst + 63, p.M - 1);
+        const int s0 = p.seg[rfirst];
+        const bool uni = s0 == p.seg[rlast];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = colw0 + nt * 32 + l31;
+            const bool cok = col < p.N;
+            const float b = (p.bias && cok) ? p.bias[col] : 0.f;
+            const float sc = (p.scale && cok) ? p.scale[col] : 1.f;
+            const float shf = (p.shift && cok) ? p.shift[col] : 0.f;
+            float m = -INFINITY;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rfirst + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = acc[mt][nt][r] + b;
+                    if (p.relu) v = v > 0.f ? v : 0.f;
+                    v = v * sc + shf;
+                    if (row < p.M) {
+                        if (uni) m = fmaxf(m, v);
+                        else if (cok) atomic_max_f32(p.pool + (size_t)p.seg[row] * p.ld_pool + col, v);
+                    }
+                }
+            if (uni) {
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                if (hi == 0 && cok && m > -INFINITY) atomic_max_f32(p.pool + (size_t)s0 * p.ld_pool + col, m);
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias / per-mesh row bias / ReLU / BN affine, fp32 or split-fp16 store ----
     __syncthreads();                             // sseg visible
-    const int colw0 = tn * BN + wn * NT * 32;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int col = colw0 + nt * 32 + l31;

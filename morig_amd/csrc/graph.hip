@@ -47,12 +47,17 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /* >= SCAN_T/64 + 
     return woff + inc - v;
 }
 
-__global__ __launch_bounds__(SCAN_T) void scan_reduce_kernel(const int* __restrict__ cnt, int n, int* __restrict__ bsum) {
+// segment length of a target: its non-loop in-edges + one self loop, optionally rounded up to a multiple of 4
+// (the padding slots repeat the self loop: max-aggregation is idempotent, and 4-aligned segments let the
+// EdgeConv epilogue reduce each lane's 4 consecutive accumulator rows in registers)
+__device__ __forceinline__ int seg_len(int cnt, int pad4) { const int d = cnt + 1; return pad4 ? ((d + 3) & ~3) : d; }
+
+__global__ __launch_bounds__(SCAN_T) void scan_reduce_kernel(const int* __restrict__ cnt, int n, int pad4, int* __restrict__ bsum) {
     __shared__ int sh[SCAN_T / 64 + 1];
     const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
     int v = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_I; ++i) if (base + i < n) v += cnt[base + i] + 1;
+    for (int i = 0; i < SCAN_I; ++i) if (base + i < n) v += seg_len(cnt[base + i], pad4);
     int tot;
     (void)block_excl_scan(v, sh, &tot);
     if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
@@ -73,14 +78,14 @@ __global__ __launch_bounds__(SCAN_T) void scan_blocksums_kernel(int* bsum, int n
     if (threadIdx.x == 0) *total_out = carry;
 }
 
-__global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const int* cnt_in, int n, const int* __restrict__ bsum,
+__global__ __launch_bounds__(SCAN_T) void scan_apply_kernel(const int* cnt_in, int n, int pad4, const int* __restrict__ bsum,
                                                            int* __restrict__ rowptr, int* cursor) {   // cursor may alias cnt_in
     __shared__ int sh[SCAN_T / 64 + 1];
     const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
     int item[SCAN_I];
     int v = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_I; ++i) { item[i] = (base + i < n) ? cnt_in[base + i] + 1 : 0; v += item[i]; }
+    for (int i = 0; i < SCAN_I; ++i) { item[i] = (base + i < n) ? seg_len(cnt_in[base + i], pad4) : 0; v += item[i]; }
     int tot;
     int run = bsum[blockIdx.x] + block_excl_scan(v, sh, &tot);
 #pragma unroll
@@ -106,6 +111,16 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E, int n
         const int pos = atomicAdd(&cursor[d], 1);
         srcS[pos] = s;
         dstS[pos] = d;
+    }
+}
+
+// after the fill pass cursor[i] = end of node i's real entries: repeat the self loop up to rowptr[i+1]
+__global__ void csr_pad_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ cursor,
+                               int* __restrict__ srcS, int* __restrict__ dstS) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int e1 = rowptr[i + 1];
+        for (int pos = cursor[i]; pos < e1; ++pos) { srcS[pos] = (int)i; dstS[pos] = (int)i; }
     }
 }
 
@@ -172,12 +187,14 @@ extern "C" int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32
 }
 
 extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_t n_src_nodes, int32_t n_nodes,
-                                         int32_t skip_negative, int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
+                                         int32_t flags, int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
                                          int32_t* cursor, int32_t* status, void* stream) {
     if (n_src_nodes < n_nodes) return MORIG_E_INVALID;
+    const int skip_negative = flags & MORIG_CSR_SKIP_NEGATIVE ? 1 : 0;
+    const int pad4 = flags & MORIG_CSR_PAD4 ? 1 : 0;
     if (!rowptr || !src_sorted || !dst_sorted || !cursor || !status) return MORIG_E_INVALID;
     if (n_edges < 0 || n_nodes <= 0 || (n_edges > 0 && !edge_index)) return MORIG_E_INVALID;
-    if (n_edges + (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;   // int32 edge ids
+    if (n_edges + 4 * (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;   // int32 edge ids
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nb = cdiv(n_nodes, SCAN_B);
     int* bsum = dst_sorted;                       // scratch until the fill pass (capacity >= n_nodes >= nb)
@@ -188,15 +205,19 @@ extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_ed
         hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, edge_index, n_edges, n_src_nodes, n_nodes, skip_negative, cursor, status);
         MORIG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, bsum);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, pad4, bsum);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nb, rowptr + n_nodes);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, bsum, rowptr, cursor);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, pad4, bsum, rowptr, cursor);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_fill_kernel, dim3(grid_for(n_edges + n_nodes)), dim3(256), 0, s, edge_index, n_edges, n_src_nodes, n_nodes,
                        cursor, src_sorted, dst_sorted);
     MORIG_LAUNCH_CHECK();
+    if (pad4) {
+        hipLaunchKernelGGL(csr_pad_kernel, dim3(grid_for(n_nodes)), dim3(256), 0, s, n_nodes, rowptr, cursor, src_sorted, dst_sorted);
+        MORIG_LAUNCH_CHECK();
+    }
     return MORIG_OK;
 }
 

@@ -466,28 +466,6 @@ static int launch_tile(const TileParams& p0, int nblocks, hipStream_t s) {
     return MORIG_OK;
 }
 
-struct EdgePcParams {
-    int H;
-    const float* W; int ldw;
-    const float* bias; const float* scale; const float* shift;
-    const float* A; int lda; const float* B; int ldb;
-    const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
-    float* Y; int ldy;
-    int* ovf;
-};
-int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);      // edge_pc.hip
-struct GemmDmaParams {
-    int M, N, K;
-    const float* X; int ldx;
-    const float* W; int ldw;
-    const float* bias; const float* scale; const float* shift; int relu;
-    const float* rowbias; int ld_rowbias; const int* seg;
-    float* Y; int ldy; int y16;
-    int tiles_n;
-    int* ovf;
-};
-int launch_gemm16_dma(const GemmDmaParams& p, int nblocks, hipStream_t s);   // gemm_dma.hip
-
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace morig
@@ -533,6 +511,15 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         if (a->n_seg <= 0 || a->ld_pool < a->N) return MORIG_E_INVALID;
         // identity of the integer-atomic float max
         MORIG_HIP_TRY(hipMemsetAsync(a->pool, 0xFF, (size_t)a->n_seg * a->ld_pool * sizeof(float), s));
+        if (f16 && a->x_split && a->N > 64 && !getenv("MORIG_NO_DMA")) {
+            // requires `seg` sorted within the matrix (PyG batch vectors are): see gemm_dma.hip
+            GemmDmaParams q = {};
+            q.M = a->M; q.N = a->N; q.K = a->K; q.X = a->X; q.ldx = a->ldx; q.W = p.W; q.ldw = p.ldw;
+            q.bias = a->bias; q.scale = a->scale; q.shift = a->shift; q.relu = a->relu; q.seg = a->seg;
+            q.pool = a->pool; q.ld_pool = a->ld_pool; q.ovf = a->overflow;
+            ProfScope ps(K_GEMM16_POOL, s, flops, bytes);
+            return launch_gemm16_dma(q, tiles_m, s);
+        }
         p.Y = a->pool; p.ldy = a->ld_pool;
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_POOL : K_GEMM_POOL, s, flops, bytes);
@@ -686,7 +673,7 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.A = p.A; q.lda = p.lda; q.B = p.B; q.ldb = p.ldb;
         q.rowptr = p.rowptr; q.srcS = p.srcS; q.dstS = p.dstS; q.n_nodes = p.n_nodes;
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep;
-        q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf;
+        q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
         return launch_edge_pc(q, nblocks, s);
     }

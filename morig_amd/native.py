@@ -52,6 +52,7 @@ class EdgeConvArgs(C.Structure):
         ("b2", c_f32p), ("s2", c_f32p), ("t2", c_f32p),
         ("out", c_f32p), ("ldo", C.c_int32),
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
+        ("quad_aligned", C.c_int32),
     ]
 
 
@@ -179,6 +180,7 @@ class CSR:
     capacity: int
     status: torch.Tensor      # int32 [1], non-zero = index out of range (checked lazily)
     edge_count: int = 0       # exact E' when known (accounting only)
+    quad: bool = False        # segments padded to multiples of 4 (MORIG_CSR_PAD4)
 
 
 def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -251,25 +253,27 @@ class NativeOps:
 
     # -- graph --------------------------------------------------------------------------------
     def csr_build(self, edge_index: torch.Tensor, n_nodes: int, n_src: Optional[int] = None,
-                  skip_negative: bool = False) -> CSR:
+                  skip_negative: bool = False, pad4: bool = False) -> CSR:
+        """pad4: pad every target's segment to a multiple of 4 by repeating its self loop (exact for
+        max-aggregation); enables the in-register quad reduction of the EdgeConv epilogue."""
         _need_gpu(edge_index)
         ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
         E = ei.shape[1]
         dev = ei.device
-        cap = E + n_nodes
+        cap = E + (4 if pad4 else 1) * n_nodes
         rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
         src = torch.empty(cap, dtype=torch.int32, device=dev)
         dst = torch.empty(cap, dtype=torch.int32, device=dev)
         cursor = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
         status = torch.empty(1, dtype=torch.int32, device=dev)
-        if n_src is None and not skip_negative:
+        if n_src is None and not skip_negative and not pad4:
             check(self.lib.morig_csr_build(_p(ei), E, n_nodes, _p(rowptr), _p(src), _p(dst), _p(cursor), _p(status), _stream()),
                   "morig_csr_build")
         else:
             check(self.lib.morig_csr_build_bipartite(_p(ei), E, n_nodes if n_src is None else n_src, n_nodes,
-                                                     1 if skip_negative else 0, _p(rowptr), _p(src), _p(dst), _p(cursor),
-                                                     _p(status), _stream()), "morig_csr_build_bipartite")
-        return CSR(rowptr, src, dst, n_nodes, cap, status)
+                                                     (1 if skip_negative else 0) | (2 if pad4 else 0), _p(rowptr), _p(src),
+                                                     _p(dst), _p(cursor), _p(status), _stream()), "morig_csr_build_bipartite")
+        return CSR(rowptr, src, dst, n_nodes, cap, status, quad=pad4)
 
     # -- dense ----------------------------------------------------------------------------------
     def gemm(self, X: Mat, lin, relu: bool, Y: Optional[Mat] = None, rowbias: Optional[Mat] = None,
@@ -328,6 +332,7 @@ class NativeOps:
         a.W2, a.ldw = ec.W2.data_ptr(), ec.W2.stride(0)
         a.b2, a.s2, a.t2 = ec.b2.data_ptr(), ec.s2.data_ptr(), ec.t2.data_ptr()
         a.out, a.ldo = out.ptr, out.ld
+        a.quad_aligned = 1 if csr.quad else 0
         if self.fast and ec.W2split is not None:
             a.W2_split, a.overflow = ec.W2split.data_ptr(), self._flag(A.base.device).data_ptr()
         return a

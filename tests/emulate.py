@@ -29,7 +29,7 @@ class EmuOps:
         return torch.full((rows, cols), float("nan"), dtype=dtype, device=device)
 
     # -- graph ----------------------------------------------------------------------------------
-    def csr_build(self, edge_index, n_nodes, n_src=None, skip_negative=False):
+    def csr_build(self, edge_index, n_nodes, n_src=None, skip_negative=False, pad4=False):
         src, dst = edge_index[0].long(), edge_index[1].long()
         if skip_negative:
             keep = (src >= 0) & (dst >= 0)
@@ -40,15 +40,19 @@ class EmuOps:
         loop = torch.arange(n_nodes)
         src = torch.cat([src[keep], loop])
         dst = torch.cat([dst[keep], loop])
+        if pad4:        # pad every target's segment to a multiple of 4 with copies of its self loop
+            deg = torch.bincount(dst, minlength=n_nodes)
+            extra = torch.repeat_interleave(loop, (-deg) % 4)
+            src, dst = torch.cat([src, extra]), torch.cat([dst, extra])
         order = torch.sort(dst, stable=True)[1]
         src, dst = src[order], dst[order]
         rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64)
         rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
-        cap = edge_index.shape[1] + n_nodes
+        cap = edge_index.shape[1] + (4 if pad4 else 1) * n_nodes
         pad = cap - src.numel()
         junk = torch.full((pad,), -12345, dtype=torch.int32)
         return CSR(rowptr.int(), torch.cat([src.int(), junk]), torch.cat([dst.int(), junk]), n_nodes, cap,
-                   torch.zeros(1, dtype=torch.int32), edge_count=int(src.numel()))
+                   torch.zeros(1, dtype=torch.int32), edge_count=int(src.numel()), quad=pad4)
 
     # -- dense -------------------------------------------------------------------------------------
     @staticmethod

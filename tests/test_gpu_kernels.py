@@ -41,21 +41,25 @@ def _segments(csr, E):
     return [sorted(src[rp[i]:rp[i + 1]].tolist()) for i in range(csr.n_nodes)]
 
 
+@pytest.mark.parametrize("pad4", [False, True])
 @pytest.mark.parametrize("n,e,hub", [(50, 400, None), (3000, 40000, 17), (5000, 0, None), (1, 5, None)])
-def test_csr_build(ops, n, e, hub):
+def test_csr_build(ops, n, e, hub, pad4):
     ei = _rand_graph(n, e, 3, hub) if e else torch.zeros((2, 0), dtype=torch.long)
-    ref = EmuOps().csr_build(ei, n) if e else None
-    got = ops.csr_build(ei.to(DEV), n)
+    ref = EmuOps().csr_build(ei, n, pad4=pad4) if e else None
+    got = ops.csr_build(ei.to(DEV), n, pad4=pad4)
     torch.cuda.synchronize()
     assert int(got.status.item()) == 0
     if e == 0:
-        assert got.rowptr.cpu().tolist() == list(range(n + 1))
-        assert got.src.cpu()[:n].tolist() == list(range(n))
+        k = 4 if pad4 else 1
+        assert got.rowptr.cpu().tolist() == list(range(0, k * (n + 1), k))
+        assert got.src.cpu()[:k * n].tolist() == [i // k for i in range(k * n)]
         return
     assert torch.equal(got.rowptr.cpu(), ref.rowptr)
     E = int(ref.rowptr[-1])
     assert torch.equal(got.dst.cpu()[:E], ref.dst[:E])
     assert _segments(got, E) == _segments(ref, E)
+    if pad4:
+        assert int((got.rowptr.cpu() % 4).abs().sum()) == 0
 
 
 def test_csr_build_flags_bad_index(ops):
@@ -150,10 +154,10 @@ def _edge_pack(H, seed, folded=False):
     return pe
 
 
-@pytest.mark.parametrize("folded", [False, True])
+@pytest.mark.parametrize("folded,pad4", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("H", [16, 32, 64, 128, 256])
 @pytest.mark.parametrize("n,e,hub,reps,shared", [(300, 2500, 5, 1, False), (1500, 9000, None, 3, False), (700, 5000, 3, 2, True)])
-def test_edgeconv(ops, H, n, e, hub, reps, shared, folded):
+def test_edgeconv(ops, H, n, e, hub, reps, shared, folded, pad4):
     g = torch.Generator().manual_seed(H + n)
     ei = _rand_graph(n, e, 9, hub)
     rows_in = n if shared else n * reps
@@ -164,7 +168,7 @@ def test_edgeconv(ops, H, n, e, hub, reps, shared, folded):
     out_ref = torch.zeros(n * reps, H + 3)
     emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_ref, ec, Mat.of(out_ref, 0, H), replicas=reps,
                  in_rep_stride=0 if shared else n, out_rep_stride=n)
-    csr = ops.csr_build(ei.to(DEV), n)
+    csr = ops.csr_build(ei.to(DEV), n, pad4=pad4)
     abg = ab.to(DEV)
     out = torch.zeros(n * reps, H + 3, device=DEV)
     ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), csr, packing.to_device(ec, DEV), Mat.of(out, 0, H), replicas=reps,

@@ -34,10 +34,10 @@ def main():
     R = 5
     out = {}
     for gname, ei in (("tpl", batch.tpl_edge_index), ("geo", batch.geo_edge_index)):
-        csr = ops.csr_build(ei, n)
+        E = int(ops.csr_build(ei, n).rowptr[-1].item())          # algorithmic edge count (no padding)
+        csr = ops.csr_build(ei, n, pad4=os.environ.get("MB_PAD4", "1") == "1")
         torch.cuda.synchronize()
-        E = int(csr.rowptr[-1].item())
-        csr.edge_count = E
+        csr.edge_count = int(csr.rowptr[-1].item())
         for H in (256, 128):
             g = torch.Generator().manual_seed(H)
             W = torch.randn(H, H, generator=g) / H ** 0.5
