@@ -26,6 +26,22 @@ PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/FP16 MFMA, den
 PEAK_HBM_GBS = 8000.0
 
 
+def measured_traffic(kernel_kind):
+    """HBM bytes per launch of a kernel kind from the committed rocprofv3 PMC pass (profiles/traffic_latest.json,
+    produced by tools/gpu_pmc_bench.sh on the same command), corrected as MI355X_MICROARCH.md prescribes."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(path):
+        return None
+    symbol = {"edgeconv_f16x3_h256": "edge_pc_kernel<256>", "gemm_f16x3_dma": "gemm16_dma_kernel<256, 256, 4, 2>",
+              "edgeconv_h256": "tile_kernel<256, 16, 1, 2, 0>", "gemm_f32_bn128": "tile_kernel<128, 32, 0, 0, 0>"}.get(kernel_kind)
+    if symbol is None:
+        return None
+    for name, v in json.load(open(path))["kernels"].items():
+        if symbol in name and "FETCH_SIZE_KiB_per_dispatch" in v and "WRITE_SIZE_KiB_per_dispatch" in v:
+            return round((2.0 * v["FETCH_SIZE_KiB_per_dispatch"] + v["WRITE_SIZE_KiB_per_dispatch"]) * 1024.0)
+    return None
+
+
 def _mesh(args):
     from morig_amd import synth
     return synth.make_mesh(args[0], n_side=args[1], with_skin=args[2])
@@ -164,8 +180,11 @@ def main():
             torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        ops = native.get_ops()
+        ops.learn_edge_counts = True                  # warm-up only: exact E' per graph for the FLOP accounting
+        for _ in range(max(1, args.warmup)):
             step()
+        ops.learn_edge_counts = False
         fence()
         native.prof_reset()
         native.prof_enable(True)                      # HIP events around every launch, on the launch stream
@@ -194,7 +213,8 @@ def main():
         split = "f16x3" in dom_name
         peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         roof = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=None,
+                    frac=round(achieved / peak, 4), traffic=measured_traffic(dom_name),
+                    traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/traffic_latest.json)",
                     mfma_issued_per_product=3 if split else 1,
                     frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
                     launches_per_step=dom["launches"] / args.steps,

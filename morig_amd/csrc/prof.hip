@@ -54,7 +54,7 @@ static const char* kNames[K_COUNT] = {
     "csr_build", "copy", "rownorm", "cls_attention", "misc",
     "fps", "ball_query", "pointconv", "knn_interpolate", "cosine_nn",
     "gemm_f16x3_bn128", "gemm_f16x3_bn64", "gemm_f16x3_bn32", "gemm_f16x3_pool",
-    "edgeconv_f16x3_h32", "edgeconv_f16x3_h64", "edgeconv_f16x3_h128", "edgeconv_f16x3_h256", "pointconv_f16x3", "gemm_f16x3_bn256", "gemm_f16x3_dma",
+    "edgeconv_f16x3_h32", "edgeconv_f16x3_h64", "edgeconv_f16x3_h128", "edgeconv_f16x3_h256", "pointconv_f16x3", "gemm_f16x3_dma",
 };
 
 }  // namespace morig

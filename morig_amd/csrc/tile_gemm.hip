@@ -538,12 +538,6 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         ProfScope ps(K_GEMM16_DMA, s, flops, bytes);
         return launch_gemm16_dma(q, tiles_m, s);
     }
-    if (f16 && a->N >= 256 && a->N % 256 == 0 && getenv("MORIG_BN256")) {     // experiment: slower (1 wave/SIMD)
-        // wide layers: 128 x 256 tile -- the on-the-fly operand split is amortised over twice the columns
-        p.tiles_n = a->N / 256;
-        ProfScope ps(K_GEMM16_BN256, s, flops, bytes);
-        return launch_tile<256, 32, LOAD_DENSE, MODE_STORE, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
-    }
     if (a->N > 64) {
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_BN128 : K_GEMM_BN128, s, flops, bytes);

@@ -210,6 +210,10 @@ class NativeOps:
         self._ovf = {}
         self._depth = 0
         self._force_f32 = False
+        # accounting only (bench.py): exact self-loop-normalised edge counts E' per input graph, learned during
+        # warm-up with one host read each, so the live FLOP counters use ALGORITHMIC edges (no capacity, no padding)
+        self.learn_edge_counts = False
+        self._edge_counts = {}
 
     # -- split-fp16 guard -------------------------------------------------------------------------
     @property
@@ -273,7 +277,12 @@ class NativeOps:
             check(self.lib.morig_csr_build_bipartite(_p(ei), E, n_nodes if n_src is None else n_src, n_nodes,
                                                      (1 if skip_negative else 0) | (2 if pad4 else 0), _p(rowptr), _p(src),
                                                      _p(dst), _p(cursor), _p(status), _stream()), "morig_csr_build_bipartite")
-        return CSR(rowptr, src, dst, n_nodes, cap, status, quad=pad4)
+        csr = CSR(rowptr, src, dst, n_nodes, cap, status, quad=pad4)
+        key = (ei.data_ptr(), E, n_nodes)
+        if self.learn_edge_counts and not pad4 and key not in self._edge_counts:
+            self._edge_counts[key] = int(rowptr[-1].item())
+        csr.edge_count = self._edge_counts.get(key, 0)
+        return csr
 
     # -- dense ----------------------------------------------------------------------------------
     def gemm(self, X: Mat, lin, relu: bool, Y: Optional[Mat] = None, rowbias: Optional[Mat] = None,
