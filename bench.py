@@ -51,6 +51,8 @@ def build_batch(seeds, n_side, with_skin=False, n_pts=0):
     from morig_amd import synth
     import multiprocessing as mp
     nproc = max(1, min(len(seeds), (os.cpu_count() or 8) // 4, 32))
+    if os.environ.get("MORIG_BENCH_NPROC"):
+        nproc = int(os.environ["MORIG_BENCH_NPROC"])     # profilers dislike forked workers: set to 1 under rocprofv3 --pmc
     if nproc > 1:
         torch.set_num_threads(1)
         with mp.get_context("fork").Pool(nproc) as pool:
