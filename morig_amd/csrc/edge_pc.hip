@@ -22,7 +22,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));
 
 template <int H>
-__global__ __launch_bounds__(512, 2) void edge_pc_kernel(const EdgePcParams p) {
+__global__ __launch_bounds__(512, (H == 128 ? 4 : 2)) void edge_pc_kernel(const EdgePcParams p) {   // H=128: two workgroups per CU
     constexpr int BM = 128, KC = 32, LDB = 144;         // LDB: bytes per LDS row = [32 hi | 32 lo | 16 pad]
     constexpr int NT = H / 64;                          // consumer wave tile: 64 rows x H/2 cols
     constexpr int MT = 2;

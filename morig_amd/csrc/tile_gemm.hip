@@ -659,8 +659,8 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
     const double flops = 2.0 * E * a->H * (double)a->H;
     const double bytes = 4.0 * (2.0 * E * a->H) ;    // gathered operand rows (mostly L2 hits)
-    // H = 256: wave-specialised kernel (1.35x). H = 128 keeps the symmetric kernel (two workgroups per CU win there).
-    if (f16 && (a->H == 256 || (a->H == 128 && getenv("MORIG_EDGE_PC128"))) && a->s1 == nullptr && !getenv("MORIG_NO_EDGE_PC")) {
+    // H = 256 / 128: wave-specialised kernel (1.35x / 1.25x over the symmetric one; H = 128 runs two workgroups per CU)
+    if (f16 && (a->H == 256 || a->H == 128) && a->s1 == nullptr && !getenv("MORIG_NO_EDGE_PC")) {
         // wave-specialised producer/consumer kernel (edge_pc.hip)
         EdgePcParams q = {};
         q.H = a->H; q.W = p.W; q.ldw = p.ldw; q.bias = p.bias; q.scale = p.scale; q.shift = p.shift;

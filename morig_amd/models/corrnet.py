@@ -99,13 +99,13 @@ class CorrNet(NativeModule):
         ops.copy2d(Mat.of(v4), Mat.of(wide, self.VTX, 4))
         csr_tpl = ops.csr_build(data.tpl_edge_index, n)
         csr_geo = ops.csr_build(data.geo_edge_index, n)
-        csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)      # 4-aligned segments for the 256-wide layer
+        csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)      # 4-aligned segments for the 128/256-wide layers
         gcus = (self.vtx_gcu_1, self.vtx_gcu_2, self.vtx_gcu_3, self.vtx_gcu_4)
         widths = (32, 64, 256, 512)
         x_in = Mat.of(wide, self.VTX, 3)
         for g, off, w in zip(gcus, self.X, widths):
             out = Mat.of(wide, off, w)
-            g.run(ops, x_in, csr_tpl, csr_geo4 if w == 512 else csr_geo, out)
+            g.run(ops, x_in, csr_tpl, csr_geo4 if w >= 256 else csr_geo, out)
             x_in = out
         pooled = ops.empty(n_graphs, 1024, dev)
         ops.gemm(Mat.of(wide, 0, 864), pk["glb"], relu=True, seg=seg, pool=pooled)

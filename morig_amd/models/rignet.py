@@ -138,10 +138,12 @@ class GCNRig(NativeModule):
         write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
         self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, 64), R, split=sp)
-        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, 64), csr_tpl, csr_geo, Mat.of(wide, self.X2, 256), R, split=sp)
-        # the 256-wide layer takes the geo graph with 4-aligned segments (quad-reduced epilogue: measured +18 % there;
-        # on the tpl graph, in-degree 7 -> 8, and on the narrower layers the padding costs more than it saves)
-        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, 256), csr_tpl, csr_geo_wide or csr_geo, Mat.of(wide, self.X3, 512), R, split=sp)
+        # the 128- and 256-wide layers take the geo graph with 4-aligned segments (quad-reduced epilogue of the
+        # wave-specialised kernel: measured +12..18 % there; on the tpl graph, in-degree 7 -> 8, and on the narrow
+        # layers the padding costs more than it saves)
+        cg = csr_geo_wide or csr_geo
+        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, 64), csr_tpl, cg, Mat.of(wide, self.X2, 256), R, split=sp)
+        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, 256), csr_tpl, cg, Mat.of(wide, self.X3, 512), R, split=sp)
         pooled = ops.empty(R * n_graphs, 1024, dev)
         ops.gemm(Mat.of(wide, 0, 832), pk["glb"], relu=True, seg=seg, pool=pooled, x_split=sp)
         gb = ops.empty(R * n_graphs, 1024, dev)
@@ -341,7 +343,7 @@ class SkinMotion(_MotionBackbone):
         n = data.pos.shape[0]
         aggr = st["motion_aggr"]
         out = torch.empty((n, self.skinNet.num_nearest_bone), dtype=torch.float32, device=aggr.device)
-        self.skinNet.run(ops, data, aggr, st["csr_tpl"], st["csr_geo"], st["seg"], st["ng"], Mat.of(out))
+        self.skinNet.run(ops, data, aggr, st["csr_tpl"], st["csr_geo4"], st["seg"], st["ng"], Mat.of(out))
         return st["motion_all"], aggr, out
 
 
