@@ -87,17 +87,6 @@ class CorrNet(NativeModule):
             vis_out=packing.pack_linear(self.lin_vismask[1].weight, self.lin_vismask[1].bias),
         )
 
-    def _side_stream(self, dev):
-        """a second HIP stream per device for the point branch (None on the CPU test double / when disabled)"""
-        import os
-        if dev.type != "cuda" or os.environ.get("MORIG_SINGLE_STREAM"):
-            return None
-        cache = self.__dict__.setdefault("_streams", {})
-        key = dev.index if dev.index is not None else torch.cuda.current_device()
-        if key not in cache:
-            cache[key] = torch.cuda.Stream(device=dev)
-        return cache[key]
-
     # ------------------------------------------------------------------------------------------
     def _vertex_branch(self, ops, data, seg, n_graphs):
         dev = data.vtx.device
@@ -241,22 +230,8 @@ class CorrNet(NativeModule):
         counts = torch.stack([torch.bincount(vb, minlength=B), torch.bincount(pb, minlength=B)]).tolist()   # one sync
         vcounts, pcounts = counts
         seg = ops.make_seg(vb, B, 1)
-        # The two branches are independent until the matching step. The point branch is latency-bound (farthest
-        # point sampling is one workgroup per cloud, thousands of dependent steps) and leaves most CUs idle, so it
-        # runs on a side HIP stream underneath the MFMA-bound vertex branch.
-        side = self._side_stream(dev)
-        if side is not None:
-            main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                out_pts, ptr_p = self._point_branch(ops, data, pcounts, random_start)
-            out_vtx = self._vertex_branch(ops, data, seg, B)
-            main.wait_stream(side)
-            out_pts.record_stream(main)
-            ptr_p.record_stream(main)
-        else:
-            out_vtx = self._vertex_branch(ops, data, seg, B)
-            out_pts, ptr_p = self._point_branch(ops, data, pcounts, random_start)
+        out_vtx = self._vertex_branch(ops, data, seg, B)
+        out_pts, ptr_p = self._point_branch(ops, data, pcounts, random_start)
         out_vismask = None
         if train_vismask:
             n, C = out_vtx.shape
