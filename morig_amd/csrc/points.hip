@@ -27,7 +27,6 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ po
     __shared__ float s_val[FPS_T / 64];
     __shared__ int s_idx[FPS_T / 64];
     __shared__ float s_cur[3];
-    __shared__ int s_sel;
     const int b = blockIdx.x;
     const int p0 = ptr[b], n = ptr[b + 1] - p0;
     const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
@@ -46,10 +45,15 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ po
     int cur = start ? start[b] : 0;
     if (cur < 0 || cur >= n) cur = 0;
     for (int s = 0; s < m; ++s) {
-        if (tid == 0) {
+        // the thread that holds point `cur` in registers broadcasts its coordinates through LDS (a global load
+        // of the selected point would put an L2 round trip on the critical path of every one of the m steps)
+        if (tid == (cur & (FPS_T - 1))) {
+            const int slot = cur / FPS_T;
+            float cx = px[0], cy = py[0], cz = pz[0];
+#pragma unroll
+            for (int i = 1; i < PPT; ++i) if (slot == i) { cx = px[i]; cy = py[i]; cz = pz[i]; }
+            s_cur[0] = cx; s_cur[1] = cy; s_cur[2] = cz;
             idx_out[o0 + s] = p0 + cur;
-            const float* q = pos + (size_t)(p0 + cur) * ldp;
-            s_cur[0] = q[0]; s_cur[1] = q[1]; s_cur[2] = q[2];
         }
         __syncthreads();
         if (s + 1 == m) break;
@@ -72,19 +76,16 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ po
         }
         if (lane == 0) { s_val[w] = bv; s_idx[w] = bi; }
         __syncthreads();
-        if (w == 0) {
-            float v = lane < FPS_T / 64 ? s_val[lane] : -2.f;
-            int ix = lane < FPS_T / 64 ? s_idx[lane] : 0x7fffffff;
+        // every wave reduces the 16 per-wave candidates itself: no third barrier, no single-wave bottleneck
+        float v = lane < FPS_T / 64 ? s_val[lane] : -2.f;
+        int ix = lane < FPS_T / 64 ? s_idx[lane] : 0x7fffffff;
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) {
-                const float ov = __shfl_xor(v, o, 64);
-                const int oi = __shfl_xor(ix, o, 64);
-                if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-            }
-            if (lane == 0) s_sel = ix;
+        for (int o = 8; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(v, o, 64);
+            const int oi = __shfl_xor(ix, o, 64);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
         }
-        __syncthreads();
-        cur = s_sel;
+        cur = __shfl(ix, 0, 64);
     }
 }
 
