@@ -14,6 +14,29 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
 
+// Wave-wide max of a non-negative float / min of an int WITHOUT the LDS crossbar: 4 DPP steps give every lane its
+// 16-lane row's result (quad swaps, half-row mirror, row mirror), 4 readlanes + scalar ops combine the rows.
+// (__shfl_xor is a ds_bpermute, ~100 cycles of latency per level: 12 dependent levels per FPS sample.)
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+    int x = __float_as_int(v);                              // v >= 0: integer order == float order
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false));    // row_half_mirror
+    x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false));    // row_mirror
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const int c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return __int_as_float(max(max(a, b), max(c, d)));
+}
+__device__ __forceinline__ int wave_min_int(int x) {
+    x = min(x, __builtin_amdgcn_update_dpp(0x7fffffff, x, 0xB1, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(0x7fffffff, x, 0x4E, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(0x7fffffff, x, 0x141, 0xF, 0xF, false));
+    x = min(x, __builtin_amdgcn_update_dpp(0x7fffffff, x, 0x140, 0xF, 0xF, false));
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const int c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    return min(min(a, b), min(c, d));
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Farthest point sampling: one 1024-thread workgroup per cloud; every thread keeps PPT points and their
 // running min-distance in registers; per sample one block-wide arg-max (value desc, index asc).
@@ -58,34 +81,26 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ po
         __syncthreads();
         if (s + 1 == m) break;
         const float cx = s_cur[0], cy = s_cur[1], cz = s_cur[2];
-        float bv = -1.f; int bi = 0x7fffffff;
+        float bv = 0.f; int bi = 0x7fffffff;               // distances are >= 0; lanes without points keep (0, INT_MAX)
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
             const int j = tid + i * FPS_T;
             if (j < n) {
                 const float d = sqdist3(px[i], py[i], pz[i], cx, cy, cz);
                 dist[i] = fminf(dist[i], d);
-                if (dist[i] > bv) { bv = dist[i]; bi = j; }        // j ascending within a thread: first max kept
+                if (dist[i] > bv || bi == 0x7fffffff) { bv = dist[i]; bi = j; }   // j ascending: first max kept
             }
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int oi = __shfl_xor(bi, o, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { s_val[w] = bv; s_idx[w] = bi; }
+        // arg-max as (max value, then lowest index among the lanes that hold it), both wave-wide via DPP
+        const float wv = wave_max_nonneg(bv);
+        const int wi = wave_min_int(bv == wv ? bi : 0x7fffffff);
+        if (lane == 0) { s_val[w] = wv; s_idx[w] = wi; }
         __syncthreads();
-        // every wave reduces the 16 per-wave candidates itself: no third barrier, no single-wave bottleneck
-        float v = lane < FPS_T / 64 ? s_val[lane] : -2.f;
-        int ix = lane < FPS_T / 64 ? s_idx[lane] : 0x7fffffff;
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(v, o, 64);
-            const int oi = __shfl_xor(ix, o, 64);
-            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-        }
-        cur = __shfl(ix, 0, 64);
+        // every wave combines the 16 per-wave candidates itself: no third barrier
+        const float v = lane < FPS_T / 64 ? s_val[lane] : 0.f;
+        const int ix = lane < FPS_T / 64 ? s_idx[lane] : 0x7fffffff;
+        const float gv = wave_max_nonneg(v);
+        cur = wave_min_int((v == gv) ? ix : 0x7fffffff);
     }
 }
 
