@@ -41,9 +41,12 @@ struct EdgePcParams {
     const float* bias; const float* scale; const float* shift;
     const float* A; int lda; const float* B; int ldb;
     const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
+    int replicas;
     float* Y; int ldy;
     int* ovf;
     int quad;                                    // CSR segments are 4-aligned (MORIG_CSR_PAD4)
+    unsigned long long* trace;                   // -DMORIG_PP_TRACE builds only
+    int dbg;                                     // ablation (tools/microbench.py): 1 no epilogue, 2 no MFMA, 4 no gathers, 8 no W loads
 };
 struct GemmDmaParams {
     int M, N, K;
@@ -57,6 +60,7 @@ struct GemmDmaParams {
     int* ovf;
 };
 int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pc.hip
+int launch_edge_pp(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pp.hip (persistent)
 int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); // gemm_dma.hip
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

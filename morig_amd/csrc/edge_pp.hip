@@ -1,0 +1,428 @@
+// Fused EdgeConv, PERSISTENT wave-specialised kernel for the wide layers (H = 128, 256) on the split-fp16 path.
+//
+// Same arithmetic and tile shape as edge_pc.hip (128 edge rows x H columns per tile, waves 0-3 consume with MFMA,
+// waves 4-7 produce the operand tile: gather A[dst] + B[src], add, ReLU, split into fp16 hi/lo), but ONE workgroup
+// per CU walks a list of tiles, so that
+//   * the per-tile start-up chain (index loads -> row pointers -> first gathers, ~5 us with nothing to overlap it
+//     when a 110 KB-LDS workgroup owns the CU) runs during the previous tile's MFMAs: the producers always hold the
+//     next two K-chunks in registers, across tile boundaries, and load the next tile's indices half a tile ahead;
+//   * the segmented-max scan of tile t has its own LDS region (Z), so chunk 0 of tile t+1 is already staged when
+//     the scan ends and the consumers restart at once.
+// Measured on MI355X (tools/ubench/overlap.hip, gaps.hip; MI355X_MICROARCH.md "LDS-DMA piece issue cost"): every VMEM
+// wave-instruction issued on a SIMD whose matrix pipe is busy costs ~60-180 cycles, whichever wave issues it: a sibling
+// wave's loads starve behind back-to-back MFMAs, and loads/LDS-DMA issued from inside the MFMA stream stall it instead
+// (consumer-issued W2 LDS-DMA measured 13 % SLOWER than this version). What counts is the NUMBER of VMEM
+// wave-instructions per MFMA: the producers use 16-byte loads only, fetch W2 one chunk ahead and the gathered rows two.
+//
+// Barrier protocol (all 8 waves, same count in both roles), per tile:  B_0 .. B_7, E1
+//   consumers:  for c: { B_c; consume chunk c }   write Z;  E1;  scan
+//   producers:  B_0;  for c = 1..7: { stage chunk c; B_c }   stage chunk 0 of the NEXT tile;  E1;  scan
+// Chunk c lives in ring stage c & 1; it is overwritten only after the barrier that follows its consumption.
+#include "common.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace morig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int C> using IC = std::integral_constant<int, C>;
+
+// Workgroup barrier that only drains this wave's LDS traffic (lgkmcnt): global loads in flight and the scan's global
+// stores must not be waited for here (__syncthreads() adds vmcnt(0) once stores are pending).
+__device__ __forceinline__ void pp_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Build with -DMORIG_PP_TRACE to record s_memtime stamps of workgroup 8, tile 3 (wave 0 = a consumer, wave 4 = a
+// producer) into p.trace[role][32]; launch_edge_pp prints the deltas. Diagnostic only.
+#ifdef MORIG_PP_TRACE
+#define PP_TS(k) do { if (j == 3 && blockIdx.x == 8 && lane == 0 && (wave & 3) == 0) p.trace[(wave >> 2) * 32 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PP_TS(k) do { } while (0)
+#endif
+
+template <int H, bool QUAD>
+__global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
+    constexpr int BM = 128, KC = 32, LDB = 144;         // LDB: bytes per LDS row = [32 hi | 32 lo | 16 pad]
+    constexpr int NT = H / 64;                          // consumer wave tile: 64 rows x H/2 cols
+    constexpr int MT = 2;
+    constexpr int NCHUNK = H / KC;
+    static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "ring/register-set parity");
+    constexpr int STAGE = (BM + H) * LDB;               // bytes per ring stage: operand rows, then W2 rows
+    constexpr int ZQ = H + 1;                           // quad mode: 32 quad-rows x H columns
+    constexpr int ZC = 64, ZLD = ZC + 1;                // general mode: 128 rows x 64 columns per pass
+    constexpr int ZB = (32 * ZQ > BM * ZLD ? 32 * ZQ : BM * ZLD) * 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + ZB + 2 * BM * 4 + 32 + 3 * H * 4];
+    char* aring = smem;
+    float* Z = reinterpret_cast<float*>(aring + 2 * STAGE);
+    int* sseg_all = reinterpret_cast<int*>(aring + 2 * STAGE + ZB);         // [2][BM] destination id per tile row
+    int* sflag = sseg_all + 2 * BM;                                         // [2][2] first/last segment continues
+    float* sbias = reinterpret_cast<float*>(sflag + 8);                     // [3][H] bias, BN scale, BN shift
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const bool producer = wave >= 4;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = (wave & 3) >> 1, wn = wave & 1;
+
+    // ---- this workgroup's tile list: XCD x (= blockIdx & 7 under round-robin dispatch) owns a contiguous range ----
+    const int Etot = p.rowptr[p.n_nodes];
+    const int tpr = (Etot + BM - 1) / BM;
+    const int T = tpr * p.replicas;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const int t_lo = (int)((long long)T * xcd / 8), t_hi = (int)((long long)T * (xcd + 1) / 8);
+    const int n_my = (t_hi - t_lo - bi + nbx - 1) / nbx;                     // tiles t_lo + bi + j * nbx < t_hi
+    if (n_my <= 0) return;                                                   // block-uniform
+    auto tile_of = [&](int j) __attribute__((always_inline)) { return t_lo + bi + (j < n_my ? j : n_my - 1) * nbx; };
+    if (tid < H) { sbias[tid] = p.bias[tid]; sbias[H + tid] = p.scale[tid]; sbias[2 * H + tid] = p.shift[tid]; }   // visible after B_0
+
+    // ---- segmented max of one finished tile (Z already holds pass 0); all 8 waves scan ----
+    f32x16 acc[MT][NT];
+    auto write_z_quad = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = wn * NT * 32 + nt * 32 + l31;
+            const float b = sbias[col], sc = sbias[H + col], sh = sbias[2 * H + col];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float m = fmaxf(acc[mt][nt][4 * q] + b, 0.f) * sc + sh;
+#pragma unroll
+                    for (int r = 1; r < 4; ++r) m = fmaxf(m, fmaxf(acc[mt][nt][4 * q + r] + b, 0.f) * sc + sh);
+                    Z[(wm * 16 + mt * 8 + 2 * q + hi) * ZQ + col] = m;
+                }
+        }
+    };
+    auto write_z_pass = [&](auto cb_const) __attribute__((always_inline)) {
+        constexpr int cb = decltype(cb_const)::value;
+        const int col = wn * NT * 32 + cb * 32 + l31;
+        const float b = sbias[col], sc = sbias[H + col], sh = sbias[2 * H + col];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                Z[rl * ZLD + wn * 32 + l31] = fmaxf(acc[mt][cb][r] + b, 0.f) * sc + sh;
+            }
+    };
+    auto scan_quad = [&](int rep, const int* sseg, bool first_cont, bool last_cont) __attribute__((always_inline)) {
+        constexpr int G = 512 / H, RGQ = 32 / G, EXTQ = 8;
+        const int col = tid % H, zg = tid / H;              // zg is wave-uniform (H is a multiple of 64)
+        const int q0 = __builtin_amdgcn_readfirstlane(zg * RGQ);
+        const float* zcolp = Z + col;
+        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
+        auto flush = [&](int sg, float m, int qs, int qend) __attribute__((always_inline)) {
+            float* o = obase + (size_t)sg * p.ldy;
+            const bool partial = (qs == 0 && first_cont) || (qend == 32 && last_cont);
+            if (partial) atomic_max_f32(o, m); else *o = m;
+        };
+        int cur = __builtin_amdgcn_readfirstlane((zg > 0) ? sseg[4 * q0 - 1] : -2);
+        bool open = false, done = false;
+        float m = 0.f; int qs = 0, qnext = q0;
+#pragma unroll
+        for (int bt = 0; bt < (RGQ + EXTQ) / 8; ++bt) {
+            const int qb0 = q0 + bt * 8;
+            if (done || qb0 >= 32) break;
+            float zv[8]; int sv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { sv[i] = __builtin_amdgcn_readfirstlane(sseg[4 * (qb0 + i)]); zv[i] = zcolp[(qb0 + i) * ZQ]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (!done) {
+                    if (sv[i] != cur) {
+                        if (open) flush(cur, m, qs, qb0 + i);
+                        if (bt * 8 + i >= RGQ) { open = false; done = true; }
+                        else { cur = sv[i]; open = cur >= 0; m = zv[i]; qs = qb0 + i; }
+                    } else if (open) m = fmaxf(m, zv[i]);
+                }
+            }
+            qnext = qb0 + 8;
+        }
+        if (open && !done) {
+            int q = qnext;
+            while (q < 32 && sseg[4 * q] == cur) { m = fmaxf(m, zcolp[q * ZQ]); ++q; }
+            flush(cur, m, qs, q);
+        }
+    };
+    auto scan_pass = [&](int cb, int rep, const int* sseg, bool first_cont, bool last_cont) __attribute__((always_inline)) {
+        constexpr int RG = 16, EXT = 32;                    // 8 row groups of 16
+        const int zc = tid & 63, zg = tid >> 6;
+        const int r0 = __builtin_amdgcn_readfirstlane(zg * RG);
+        const int col = (zc >> 5) * NT * 32 + cb * 32 + (zc & 31);
+        const float* zcolp = Z + zc;
+        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
+        auto flush = [&](int sg, float m, int rs, int rend) __attribute__((always_inline)) {
+            float* o = obase + (size_t)sg * p.ldy;
+            const bool partial = (rs == 0 && first_cont) || (rend == BM && last_cont);
+            if (partial) atomic_max_f32(o, m); else *o = m;
+        };
+        int cur = __builtin_amdgcn_readfirstlane((zg > 0) ? sseg[r0 - 1] : -2);
+        bool open = false, done = false;
+        float m = 0.f; int rs = 0, rnext = r0;
+#pragma unroll
+        for (int bt = 0; bt < (RG + EXT) / 16; ++bt) {
+            const int rb0 = r0 + bt * 16;
+            if (done || rb0 >= BM) break;
+            float zv[16]; int sv[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_readfirstlane(sseg[rb0 + i]); zv[i] = zcolp[(rb0 + i) * ZLD]; }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (!done) {
+                    if (sv[i] != cur) {
+                        if (open) flush(cur, m, rs, rb0 + i);
+                        if (bt * 16 + i >= RG) { open = false; done = true; }
+                        else { cur = sv[i]; open = cur >= 0; m = zv[i]; rs = rb0 + i; }
+                    } else if (open) m = fmaxf(m, zv[i]);
+                }
+            }
+            rnext = rb0 + 16;
+        }
+        if (open && !done) {
+            int r = rnext;
+            while (r < BM && sseg[r] == cur) { m = fmaxf(m, zcolp[r * ZLD]); ++r; }
+            flush(cur, m, rs, r);
+        }
+    };
+    // everything after E1 for tile j (both roles; the general mode re-stages Z per 64-column pass)
+    auto finish_tile = [&](int j, auto role) __attribute__((always_inline)) {
+        constexpr bool is_producer = decltype(role)::value != 0;
+        const int t = tile_of(j);
+        const int rep = t / tpr;
+        const int* sseg = sseg_all + (j & 1) * BM;
+        const bool fc = sflag[(j & 1) * 2] != 0, lc = sflag[(j & 1) * 2 + 1] != 0;
+        if (p.dbg & 1) return;
+        if constexpr (QUAD) { scan_quad(rep, sseg, fc, lc); return; }
+        scan_pass(0, rep, sseg, fc, lc);
+        auto more = [&](auto cbc) __attribute__((always_inline)) {
+            pp_barrier();                            // previous pass scanned
+            if constexpr (!is_producer) write_z_pass(cbc);
+            pp_barrier();
+            scan_pass(decltype(cbc)::value, rep, sseg, fc, lc);
+        };
+        if constexpr (!QUAD && NT > 1) more(IC<1>{});
+        if constexpr (!QUAD && NT > 2) more(IC<2>{});
+        if constexpr (!QUAD && NT > 3) more(IC<3>{});
+    };
+
+    if (producer) {
+        // ---------------- producers: 256 threads, thread (row = pt/8 + 32 i, 16-byte piece = pt%8) ----------------
+        const int pt = tid - 256;
+        const int lrow = pt >> 3, lkq = pt & 7;
+        unsigned oa[4], ob[4];                               // byte offsets of this thread's 4 gathered rows (< 4 GB per replica)
+        const char* abase = reinterpret_cast<const char*>(p.A);             // + replica offset: wave-uniform, lives in SGPRs
+        const char* bbase = reinterpret_cast<const char*>(p.B);
+        int nd[4], ns[4], nprev, nlast, nafter;             // next tile's indices, in flight
+        int nrow0 = 0, nrep = 0;
+        auto load_indices = [&](int j) __attribute__((always_inline)) {
+            const int t = tile_of(j);
+            nrep = t / tpr; nrow0 = (t - nrep * tpr) * BM;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = min(nrow0 + lrow + 32 * i, Etot - 1);
+                nd[i] = p.dstS[row]; ns[i] = p.srcS[row];
+            }
+            nprev = p.dstS[max(nrow0 - 1, 0)];
+            nlast = p.dstS[min(nrow0 + BM - 1, Etot - 1)];
+            nafter = p.dstS[min(nrow0 + BM, Etot - 1)];
+        };
+        auto switch_tile = [&](int j) __attribute__((always_inline)) {   // make tile j (indices loaded) the one fetched from
+            abase = reinterpret_cast<const char*>(p.A + (size_t)nrep * p.rep_in * p.lda);
+            bbase = reinterpret_cast<const char*>(p.B + (size_t)nrep * p.rep_in * p.ldb);
+            int* sseg = sseg_all + (j & 1) * BM;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool valid = nrow0 + lrow + 32 * i < Etot;
+                oa[i] = ((unsigned)nd[i] * (unsigned)p.lda + 4u * lkq) * 4u;          // rows past the end re-read the last edge:
+                ob[i] = ((unsigned)ns[i] * (unsigned)p.ldb + 4u * lkq) * 4u;          // finite, and ignored by the scan (id -1)
+                if (p.dbg & 4) oa[i] = ob[i] = 16u * lkq;                              // ablation: every gather hits row 0
+                if (lkq == 0) sseg[lrow + 32 * i] = valid ? nd[i] : -1;
+            }
+            if (pt == 0) {
+                sflag[(j & 1) * 2] = (nrow0 > 0 && nprev == nd[0]) ? 1 : 0;       // lrow == 0: nd[0] is row nrow0
+                sflag[(j & 1) * 2 + 1] = (nrow0 + BM < Etot && nlast == nafter) ? 1 : 0;
+            }
+        };
+        const unsigned ow = ((unsigned)lrow * (unsigned)p.ldw + 4u * lkq) * 4u;
+        const char* wbase = reinterpret_cast<const char*>(p.W);
+        constexpr int PW = H / 32;                          // W2 passes of 32 rows
+        f32x4 ra[2][4], rb[2][4], rw[PW];                   // gathers: two chunks in flight; W2 (L2-resident): one
+        auto fetch_w = [&](int c) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < PW; ++i) {
+                unsigned o = ow;
+                asm volatile("" : "+v"(o));                 // keep the (scalar base + 32-bit lane offset) form: no hoisted 64-bit VGPR pairs
+                rw[i] = *reinterpret_cast<const f32x4*>(wbase + (size_t)i * 32 * p.ldw * 4 + c * KC * 4 + o);
+            }
+        };
+        auto stage_w = [&](int c) __attribute__((always_inline)) {
+            char* sB = aring + (c & 1) * STAGE + BM * LDB;
+#pragma unroll
+            for (int i = 0; i < PW; ++i) *reinterpret_cast<f32x4*>(sB + (lrow + 32 * i) * LDB + 16 * lkq) = rw[i];
+        };
+        float amax = 0.f;
+        auto fetch_g = [&](int c, auto setc) __attribute__((always_inline)) {
+            constexpr int S = decltype(setc)::value;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ra[S][i] = *reinterpret_cast<const f32x4*>(abase + c * KC * 4 + oa[i]);
+                rb[S][i] = *reinterpret_cast<const f32x4*>(bbase + c * KC * 4 + ob[i]);
+            }
+        };
+        auto stage_a = [&](int c, auto setc) __attribute__((always_inline)) {
+            constexpr int S = decltype(setc)::value;
+            char* sA = aring + (c & 1) * STAGE;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf(ra[S][i][q] + rb[S][i][q], 0.f);
+                const f16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
+                const f16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
+                f16x4 h, l;
+                h[0] = (_Float16)h01[0]; h[1] = (_Float16)h01[1]; h[2] = (_Float16)h23[0]; h[3] = (_Float16)h23[1];
+                l[0] = (_Float16)(v[0] - (float)h01[0]); l[1] = (_Float16)(v[1] - (float)h01[1]);
+                l[2] = (_Float16)(v[2] - (float)h23[0]); l[3] = (_Float16)(v[3] - (float)h23[1]);
+                amax = fmaxf(amax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));               // v >= 0 after the ReLU
+                char* rowp = sA + (lrow + 32 * i) * LDB + 8 * lkq;
+                *reinterpret_cast<f16x4*>(rowp) = h;
+                *reinterpret_cast<f16x4*>(rowp + 64) = l;
+            }
+        };
+        // one producer interval: stage chunk c from register set c & 1, then refill that set with chunk c + 2
+        auto interval = [&](auto cc, int j, auto refill) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;          // chunk staged (0 = next tile's chunk 0)
+            constexpr bool fill = decltype(refill)::value != 0;
+            constexpr int cn = (c + 2) % NCHUNK;            // chunk fetched
+            using S = IC<(c & 1)>;
+            stage_w(c);
+            fetch_w((c + 1) % NCHUNK);                      // W2 loads first: they issue while the consumers wait for their ds_reads
+            stage_a(c, S{});
+            if constexpr (c == NCHUNK - 2) switch_tile(j + 1);     // chunks 0, 1, ... fetched from here on are the next tile's
+            if constexpr (fill) fetch_g(cn, S{});
+            // indices for the next switch_tile: loaded well ahead, but (H = 256) not held across the scan
+            if constexpr (NCHUNK == 8 && c == 1) load_indices(j + 1);
+            if constexpr (NCHUNK == 4 && c == NCHUNK - 1) load_indices(j + 2);
+        };
+
+        load_indices(0);
+        switch_tile(0);
+        fetch_w(0); fetch_g(0, IC<0>{});
+        fetch_g(1, IC<1>{});
+        if constexpr (NCHUNK == 4) load_indices(1);
+        interval(IC<0>{}, -1000, IC<1>{});                  // stages chunk 0 of tile 0, fetches chunk 2 (no switch: c != NCHUNK-2)
+#pragma unroll 1
+        for (int j = 0; j < n_my; ++j) {
+            PP_TS(0); pp_barrier();                      // B_0
+            PP_TS(1); interval(IC<1>{}, j, IC<1>{}); PP_TS(2); pp_barrier();
+            PP_TS(3); interval(IC<2>{}, j, IC<1>{}); PP_TS(4); pp_barrier();
+            PP_TS(5); interval(IC<3>{}, j, IC<1>{}); PP_TS(6); pp_barrier();
+            if constexpr (NCHUNK == 8) {
+                PP_TS(7); interval(IC<4>{}, j, IC<1>{}); PP_TS(8); pp_barrier();
+                PP_TS(9); interval(IC<5>{}, j, IC<1>{}); PP_TS(10); pp_barrier();
+                PP_TS(11); interval(IC<6>{}, j, IC<1>{}); PP_TS(12); pp_barrier();
+                PP_TS(13); interval(IC<7>{}, j, IC<1>{}); PP_TS(14); pp_barrier();
+            }
+            PP_TS(15); interval(IC<0>{}, j, IC<0>{});       // next tile's chunk 0 (the last tile re-stages itself, unused)
+            PP_TS(16); pp_barrier();                     // E1
+            PP_TS(17); finish_tile(j, IC<1>{});
+            PP_TS(18); fetch_g(2, IC<0>{});                            // register set 0 refilled AFTER the scan (keeps it out of the scan's way)
+        }
+        if (!(amax < 65000.f)) *p.ovf = 1;
+    } else {
+        // ---------------- consumers: 4 waves as 2 (rows) x 2 (cols), fragments + MFMA only ----------------
+#pragma unroll 1
+        for (int j = 0; j < n_my; ++j) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+#pragma unroll 1
+            for (int c = 0; c < NCHUNK; ++c) {
+                PP_TS(2 * c); pp_barrier();                 // B_c: chunk c is in stage c&1
+                PP_TS(2 * c + 1);
+                if (p.dbg & 2) continue;
+                const char* sA = aring + (c & 1) * STAGE;
+                const char* sB = sA + BM * LDB;
+                const char* a0 = sA + (wm * 64 + l31) * LDB + 16 * hi;
+                const char* b0 = sB + (wn * NT * 32 + l31) * LDB + 16 * hi;
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        ah[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDB + 32 * st);
+                        al[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDB + 32 * st + 64);
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        bh[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDB + 32 * st);
+                        bl[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDB + 32 * st + 64);
+                    }
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        }
+                }
+            }
+            PP_TS(16);
+            if (!(p.dbg & 1)) { if constexpr (QUAD) write_z_quad(); else write_z_pass(IC<0>{}); }
+            PP_TS(17); pp_barrier();                     // E1: Z visible; next tile's chunk 0 staged
+            PP_TS(18); finish_tile(j, IC<0>{});
+            PP_TS(19);
+        }
+    }
+}
+
+int launch_edge_pp(const EdgePcParams& p0, int nblocks, hipStream_t s) {
+    EdgePcParams p = p0;
+    static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n > 8 ? (n / 8) * 8 : 8;
+    }();
+    p.dbg = dbg;
+#ifdef MORIG_PP_TRACE
+    static unsigned long long* trace_buf = [] { void* b = nullptr; return hipMalloc(&b, 64 * 8) == hipSuccess ? (unsigned long long*)b : nullptr; }();
+    p.trace = trace_buf;
+#endif
+    const int grid = nblocks < ncu ? ((nblocks + 7) / 8) * 8 : ncu;     // one persistent workgroup per CU, multiple of 8 (XCDs)
+#define PP_LAUNCH(HH, QQ) hipLaunchKernelGGL((edge_pp_kernel<HH, QQ>), dim3(grid), dim3(512), 0, s, p)
+    if (p.H == 256 && p.quad) PP_LAUNCH(256, true);
+    else if (p.H == 256) PP_LAUNCH(256, false);
+    else if (p.H == 128 && p.quad) PP_LAUNCH(128, true);
+    else if (p.H == 128) PP_LAUNCH(128, false);
+    else return MORIG_E_UNSUPPORTED;
+    MORIG_LAUNCH_CHECK();
+#ifdef MORIG_PP_TRACE
+    {
+        unsigned long long h[64];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, p.trace, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int r = 0; r < 2; ++r) {
+                fprintf(stderr, "PP_TRACE H=%d quad=%d %s:", p.H, p.quad, r ? "producer" : "consumer");
+                for (int q = 1; q < 20; ++q) fprintf(stderr, " %lld", (long long)(h[r * 32 + q] - h[r * 32 + q - 1]));
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
+    return MORIG_OK;
+}
+
+}  // namespace morig

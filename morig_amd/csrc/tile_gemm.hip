@@ -666,10 +666,11 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.H = a->H; q.W = p.W; q.ldw = p.ldw; q.bias = p.bias; q.scale = p.scale; q.shift = p.shift;
         q.A = p.A; q.lda = p.lda; q.B = p.B; q.ldb = p.ldb;
         q.rowptr = p.rowptr; q.srcS = p.srcS; q.dstS = p.dstS; q.n_nodes = p.n_nodes;
-        q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep;
+        q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
-        return launch_edge_pc(q, nblocks, s);
+        static const bool one_shot = [] { const char* e = getenv("MORIG_EDGE_KERNEL"); return e && e[0] == 'p' && e[1] == 'c'; }();
+        return one_shot ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
     }
     if (f16) {
         switch (a->H) {
