@@ -56,16 +56,21 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
     constexpr int MT = 2;
     constexpr int NCHUNK = H / KC;
     static_assert(NCHUNK % 2 == 0 && NCHUNK >= 4, "ring/register-set parity");
-    constexpr int STAGE = (BM + H) * LDB;               // bytes per ring stage: operand rows, then W2 rows
-    constexpr int ZQ = H + 1;                           // quad mode: 32 quad-rows x H columns
+    constexpr bool WRES = (H == 128);                   // H = 128: all of W2 (4 chunks, 72 KB padded) stays resident in LDS
+    constexpr int STAGE = (BM + (WRES ? 0 : H)) * LDB;  // bytes per ring stage: operand rows, then (streamed) W2 rows
+    constexpr int WRESB = WRES ? NCHUNK * H * LDB : 0;
+    constexpr int ZQ = H + 4;                           // quad mode: 32 quad-rows x H columns (+4: 16-byte rows, 2-way store conflicts only)
     constexpr int ZC = 64, ZLD = ZC + 1;                // general mode: 128 rows x 64 columns per pass
     constexpr int ZB = (32 * ZQ > BM * ZLD ? 32 * ZQ : BM * ZLD) * 4;
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + ZB + 2 * BM * 4 + 32 + 3 * H * 4];
-    char* aring = smem;
+    constexpr int ATAB = QUAD ? 4 * 1024 : 0;           // quad mode: per producer wave, 8 quads x 128 B of A rows for one chunk
+    __shared__ __attribute__((aligned(16))) char smem[WRESB + 2 * STAGE + ZB + 2 * BM * 4 + 32 + 3 * H * 4 + ATAB];
+    char* wres = smem;                                  // [chunk][row][LDB]
+    char* aring = smem + WRESB;
     float* Z = reinterpret_cast<float*>(aring + 2 * STAGE);
     int* sseg_all = reinterpret_cast<int*>(aring + 2 * STAGE + ZB);         // [2][BM] destination id per tile row
     int* sflag = sseg_all + 2 * BM;                                         // [2][2] first/last segment continues
     float* sbias = reinterpret_cast<float*>(sflag + 8);                     // [3][H] bias, BN scale, BN shift
+    char* atab = reinterpret_cast<char*>(sbias + 3 * H);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -86,19 +91,23 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 
     // ---- segmented max of one finished tile (Z already holds pass 0); all 8 waves scan ----
     f32x16 acc[MT][NT];
+    // y = relu(acc + b) * sc + sh is monotone in acc (rising for sc >= 0, falling for sc < 0), so the max over a quad's
+    // four rows is f(max acc) or f(min acc): two 3-input min/max per quad instead of the affine on every element
     auto write_z_quad = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = wn * NT * 32 + nt * 32 + l31;
             const float b = sbias[col], sc = sbias[H + col], sh = sbias[2 * H + col];
+            const bool rising = sc >= 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float m = fmaxf(acc[mt][nt][4 * q] + b, 0.f) * sc + sh;
-#pragma unroll
-                    for (int r = 1; r < 4; ++r) m = fmaxf(m, fmaxf(acc[mt][nt][4 * q + r] + b, 0.f) * sc + sh);
-                    Z[(wm * 16 + mt * 8 + 2 * q + hi) * ZQ + col] = m;
+                    const float a0 = acc[mt][nt][4 * q], a1 = acc[mt][nt][4 * q + 1], a2 = acc[mt][nt][4 * q + 2], a3 = acc[mt][nt][4 * q + 3];
+                    const float hi4 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3);
+                    const float lo4 = fminf(__builtin_fminf(__builtin_fminf(a0, a1), a2), a3);
+                    const float x = rising ? hi4 : lo4;
+                    Z[(wm * 16 + mt * 8 + 2 * q + hi) * ZQ + col] = fmaxf(x + b, 0.f) * sc + sh;
                 }
         }
     };
@@ -114,42 +123,51 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
                 Z[rl * ZLD + wn * 32 + l31] = fmaxf(acc[mt][cb][r] + b, 0.f) * sc + sh;
             }
     };
+    // quad mode scan: wave w owns quad-rows [4w, 4w+4) and every segment that STARTS there (following it into later
+    // rows); a lane holds VEC = H/64 adjacent columns, so a segment's result leaves as one 16-byte (8-byte) store per lane
     auto scan_quad = [&](int rep, const int* sseg, bool first_cont, bool last_cont) __attribute__((always_inline)) {
-        constexpr int G = 512 / H, RGQ = 32 / G, EXTQ = 8;
-        const int col = tid % H, zg = tid / H;              // zg is wave-uniform (H is a multiple of 64)
-        const int q0 = __builtin_amdgcn_readfirstlane(zg * RGQ);
-        const float* zcolp = Z + col;
-        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
-        auto flush = [&](int sg, float m, int qs, int qend) __attribute__((always_inline)) {
+        constexpr int VEC = H / 64;
+        typedef float fvec __attribute__((ext_vector_type(VEC)));
+        const int q0 = __builtin_amdgcn_readfirstlane(wave * 4);
+        const float* zl = Z + VEC * lane;
+        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + VEC * lane;
+        auto flush = [&](int sg, fvec m, int qs, int qend) __attribute__((always_inline)) {
             float* o = obase + (size_t)sg * p.ldy;
             const bool partial = (qs == 0 && first_cont) || (qend == 32 && last_cont);
-            if (partial) atomic_max_f32(o, m); else *o = m;
-        };
-        int cur = __builtin_amdgcn_readfirstlane((zg > 0) ? sseg[4 * q0 - 1] : -2);
-        bool open = false, done = false;
-        float m = 0.f; int qs = 0, qnext = q0;
+            if (partial) {
 #pragma unroll
-        for (int bt = 0; bt < (RGQ + EXTQ) / 8; ++bt) {
-            const int qb0 = q0 + bt * 8;
-            if (done || qb0 >= 32) break;
-            float zv[8]; int sv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { sv[i] = __builtin_amdgcn_readfirstlane(sseg[4 * (qb0 + i)]); zv[i] = zcolp[(qb0 + i) * ZQ]; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (!done) {
-                    if (sv[i] != cur) {
-                        if (open) flush(cur, m, qs, qb0 + i);
-                        if (bt * 8 + i >= RGQ) { open = false; done = true; }
-                        else { cur = sv[i]; open = cur >= 0; m = zv[i]; qs = qb0 + i; }
-                    } else if (open) m = fmaxf(m, zv[i]);
-                }
+                for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
+            } else {
+                *reinterpret_cast<fvec*>(o) = m;
             }
-            qnext = qb0 + 8;
+        };
+        fvec zv[4]; int sv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            zv[i] = *reinterpret_cast<const fvec*>(zl + (q0 + i) * ZQ);
+            sv[i] = __builtin_amdgcn_readfirstlane(sseg[4 * (q0 + i)]);
         }
-        if (open && !done) {
-            int q = qnext;
-            while (q < 32 && sseg[4 * q] == cur) { m = fmaxf(m, zcolp[q * ZQ]); ++q; }
+        int cur = __builtin_amdgcn_readfirstlane((q0 > 0) ? sseg[4 * q0 - 1] : -2);
+        bool open = false;
+        fvec m = zv[0]; int qs = q0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (sv[i] != cur) {
+                if (open) flush(cur, m, qs, q0 + i);
+                cur = sv[i]; open = cur >= 0; m = zv[i]; qs = q0 + i;
+            } else if (open) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], zv[i][v]);
+            }
+        }
+        if (open) {                                         // the last segment may run on into later waves' rows
+            int q = q0 + 4;
+            while (q < 32 && __builtin_amdgcn_readfirstlane(sseg[4 * q]) == cur) {
+                const fvec z = *reinterpret_cast<const fvec*>(zl + q * ZQ);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], z[v]);
+                ++q;
+            }
             flush(cur, m, qs, q);
         }
     };
@@ -219,6 +237,16 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
         const int pt = tid - 256;
         const int lrow = pt >> 3, lkq = pt & 7;
         unsigned oa[4], ob[4];                               // byte offsets of this thread's 4 gathered rows (< 4 GB per replica)
+        // quad mode (4-aligned segments): the four rows of a quad share their destination, so A[dst] is fetched once
+        // per QUAD: this lane loads piece (lane & 7) of quad qe of its own wave's 8 quads into a 1 KB per-wave LDS
+        // table, from which the wave's threads take the A piece of each of their 4 rows (1 gather + 4 ds_reads
+        // instead of 4 gathers per chunk)
+        const int pw4 = pt >> 6;
+        const int qe = 8 * ((lane >> 4) & 3) + 2 * pw4 + ((lane >> 3) & 1);
+        char* atab_w = atab + pw4 * 1024;
+        const char* atab_r = atab_w + ((pt >> 5) & 1) * 128 + lkq * 16;      // + 256 i
+        unsigned oq = 0; int nq = 0;
+        f32x4 ta[2];
         const char* abase = reinterpret_cast<const char*>(p.A);             // + replica offset: wave-uniform, lives in SGPRs
         const char* bbase = reinterpret_cast<const char*>(p.B);
         int nd[4], ns[4], nprev, nlast, nafter;             // next tile's indices, in flight
@@ -229,8 +257,10 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = min(nrow0 + lrow + 32 * i, Etot - 1);
-                nd[i] = p.dstS[row]; ns[i] = p.srcS[row];
+                if constexpr (!QUAD) nd[i] = p.dstS[row];
+                ns[i] = p.srcS[row];
             }
+            if constexpr (QUAD) nq = p.dstS[min(nrow0 + 4 * qe, Etot - 1)];
             nprev = p.dstS[max(nrow0 - 1, 0)];
             nlast = p.dstS[min(nrow0 + BM - 1, Etot - 1)];
             nafter = p.dstS[min(nrow0 + BM, Etot - 1)];
@@ -242,13 +272,22 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const bool valid = nrow0 + lrow + 32 * i < Etot;
-                oa[i] = ((unsigned)nd[i] * (unsigned)p.lda + 4u * lkq) * 4u;          // rows past the end re-read the last edge:
-                ob[i] = ((unsigned)ns[i] * (unsigned)p.ldb + 4u * lkq) * 4u;          // finite, and ignored by the scan (id -1)
+                if constexpr (!QUAD) oa[i] = ((unsigned)nd[i] * (unsigned)p.lda + 4u * lkq) * 4u;   // rows past the end re-read the
+                ob[i] = ((unsigned)ns[i] * (unsigned)p.ldb + 4u * lkq) * 4u;          // last edge: finite, ignored by the scan (id -1)
                 if (p.dbg & 4) oa[i] = ob[i] = 16u * lkq;                              // ablation: every gather hits row 0
-                if (lkq == 0) sseg[lrow + 32 * i] = valid ? nd[i] : -1;
+                if constexpr (!QUAD) { if (lkq == 0) sseg[lrow + 32 * i] = valid ? nd[i] : -1; }
+            }
+            if constexpr (QUAD) {
+                oq = ((unsigned)nq * (unsigned)p.lda + 4u * lkq) * 4u;
+                if (lkq == 0) {                             // Etot is a multiple of 4 here: a quad is valid or not as a whole
+                    const int d = (nrow0 + 4 * qe < Etot) ? nq : -1;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sseg[4 * qe + k] = d;
+                }
             }
             if (pt == 0) {
-                sflag[(j & 1) * 2] = (nrow0 > 0 && nprev == nd[0]) ? 1 : 0;       // lrow == 0: nd[0] is row nrow0
+                const int first = QUAD ? nq : nd[0];                               // pt == 0 holds row nrow0 / quad 0
+                sflag[(j & 1) * 2] = (nrow0 > 0 && nprev == first) ? 1 : 0;
                 sflag[(j & 1) * 2 + 1] = (nrow0 + BM < Etot && nlast == nafter) ? 1 : 0;
             }
         };
@@ -265,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
             }
         };
         auto stage_w = [&](int c) __attribute__((always_inline)) {
-            char* sB = aring + (c & 1) * STAGE + BM * LDB;
+            char* sB = WRES ? wres + c * (H * LDB) : aring + (c & 1) * STAGE + BM * LDB;
 #pragma unroll
             for (int i = 0; i < PW; ++i) *reinterpret_cast<f32x4*>(sB + (lrow + 32 * i) * LDB + 16 * lkq) = rw[i];
         };
@@ -274,18 +313,25 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
             constexpr int S = decltype(setc)::value;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ra[S][i] = *reinterpret_cast<const f32x4*>(abase + c * KC * 4 + oa[i]);
+                if constexpr (!QUAD) ra[S][i] = *reinterpret_cast<const f32x4*>(abase + c * KC * 4 + oa[i]);
                 rb[S][i] = *reinterpret_cast<const f32x4*>(bbase + c * KC * 4 + ob[i]);
             }
+            if constexpr (QUAD) ta[S] = *reinterpret_cast<const f32x4*>(abase + c * KC * 4 + oq);
         };
         auto stage_a = [&](int c, auto setc) __attribute__((always_inline)) {
             constexpr int S = decltype(setc)::value;
             char* sA = aring + (c & 1) * STAGE;
+            f32x4 qa[4];
+            if constexpr (QUAD) {                           // same-wave LDS hand-over: the LDS executes a wave's operations in order
+                *reinterpret_cast<f32x4*>(atab_w + lane * 16) = ta[S];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) qa[i] = *reinterpret_cast<const f32x4*>(atab_r + 256 * i);
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 f32x4 v;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = fmaxf(ra[S][i][q] + rb[S][i][q], 0.f);
+                for (int q = 0; q < 4; ++q) v[q] = fmaxf((QUAD ? qa[i][q] : ra[S][i][q]) + rb[S][i][q], 0.f);
                 const f16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
                 const f16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
                 f16x4 h, l;
@@ -304,8 +350,10 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
             constexpr bool fill = decltype(refill)::value != 0;
             constexpr int cn = (c + 2) % NCHUNK;            // chunk fetched
             using S = IC<(c & 1)>;
-            stage_w(c);
-            fetch_w((c + 1) % NCHUNK);                      // W2 loads first: they issue while the consumers wait for their ds_reads
+            if constexpr (!WRES) {
+                stage_w(c);
+                fetch_w((c + 1) % NCHUNK);                  // W2 loads first: they issue while the consumers wait for their ds_reads
+            }
             stage_a(c, S{});
             if constexpr (c == NCHUNK - 2) switch_tile(j + 1);     // chunks 0, 1, ... fetched from here on are the next tile's
             if constexpr (fill) fetch_g(cn, S{});
@@ -316,7 +364,13 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 
         load_indices(0);
         switch_tile(0);
-        fetch_w(0); fetch_g(0, IC<0>{});
+        if constexpr (WRES) {
+#pragma unroll
+            for (int c = 0; c < NCHUNK; ++c) { fetch_w(c); stage_w(c); }                   // visible after B_0
+        } else {
+            fetch_w(0);
+        }
+        fetch_g(0, IC<0>{});
         fetch_g(1, IC<1>{});
         if constexpr (NCHUNK == 4) load_indices(1);
         interval(IC<0>{}, -1000, IC<1>{});                  // stages chunk 0 of tile 0, fetches chunk 2 (no switch: c != NCHUNK-2)
@@ -354,7 +408,7 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
                 PP_TS(2 * c + 1);
                 if (p.dbg & 2) continue;
                 const char* sA = aring + (c & 1) * STAGE;
-                const char* sB = sA + BM * LDB;
+                const char* sB = WRES ? wres + c * (H * LDB) : sA + BM * LDB;
                 const char* a0 = sA + (wm * 64 + l31) * LDB + 16 * hi;
                 const char* b0 = sB + (wn * NT * 32 + l31) * LDB + 16 * hi;
 #pragma unroll

@@ -17,6 +17,7 @@
 //   * LDS rows are padded to KC+4 floats: for ds_read_b128 the 16-lane service groups then touch
 //     16 distinct 16-byte slots (36*r mod 64 and 20*r mod 64 are 4*(odd*r mod 16)) -> conflict-free.
 #include "common.h"
+#include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -670,7 +671,10 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
         static const bool one_shot = [] { const char* e = getenv("MORIG_EDGE_KERNEL"); return e && e[0] == 'p' && e[1] == 'c'; }();
-        return one_shot ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
+        // the persistent kernel stores 16-byte result vectors and addresses gathered rows with 32-bit byte offsets
+        const bool pp_ok = (reinterpret_cast<uintptr_t>(a->out) & 15) == 0 && (a->ldo & 3) == 0 &&
+                           (double)a->n_nodes * a->lda * 4.0 < 4.0e9 && (double)a->n_nodes * a->ldb * 4.0 < 4.0e9;
+        return (one_shot || !pp_ok) ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
     }
     if (f16) {
         switch (a->H) {
