@@ -58,6 +58,7 @@ struct GemmDmaParams {
     float* pool; int ld_pool;                    // column max per segment instead of a store (seg sorted)
     int tiles_n;
     int* ovf;
+    int dbg;                                     // ablation: 1 = no epilogue
 };
 int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pc.hip
 int launch_edge_pp(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pp.hip (persistent)

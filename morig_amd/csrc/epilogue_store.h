@@ -1,0 +1,117 @@
+// Store epilogue shared by the GEMM kernels (tile_gemm.hip MODE_STORE, gemm_dma.hip): bias / per-mesh row bias / ReLU /
+// BN affine, then an fp32 or split-fp16 store.
+//
+// A lane owns one COLUMN of an MFMA result tile, so storing straight from the accumulators costs one 4-byte (or two
+// 2-byte) store instruction per element: 128 per lane for a 64x128 wave tile, measured at 25-57 % of the whole GEMM.
+// Here every wave transposes its tile through a private LDS region, 32 rows at a time (the operand ring is dead by
+// then; same-wave LDS traffic executes in order, so no barrier is involved). A lane then owns 4 (fp32) or 8 (split)
+// ADJACENT columns of a row: the per-column constants live in registers, the row bias is re-read only when the mesh id
+// changes, and the result leaves as 16-byte stores, 1 KB per wave instruction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace morig {
+
+typedef float ep_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ep_f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 ep_f16x8 __attribute__((ext_vector_type(8)));
+
+template <int NT> struct EpilogueTile { static constexpr int CW = NT * 32, LDT = CW + 4, FLOATS = 32 * LDT; };
+
+// acc: the wave's MT x NT accumulator tiles (C/D layout of v_mfma_f32_32x32x*: col = lane & 31,
+// row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); T: this wave's EpilogueTile<NT>::FLOATS floats of LDS;
+// rl_base: block-local row of the wave tile's first row (index into sseg); row0: global row of block-local row 0.
+template <int MT, int NT, bool ALLOW16, class P>
+__device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&acc)[MT][NT], float* T, const int* sseg,
+                                                      int rl_base, int row0, int Mlim, int colw0, int lane) {
+    constexpr int CW = EpilogueTile<NT>::CW, LDT = EpilogueTile<NT>::LDT;
+    constexpr int VW = 4, LPR = CW / VW, RPI = 64 / LPR;            // fp32: 4 columns per lane
+    constexpr int VW16 = 8, LPR16 = CW / VW16, RPI16 = 64 / LPR16;  // split: 8 columns = 16 B of hi + 16 B of lo
+    constexpr int NV = ALLOW16 ? 8 : 4;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bool y16 = ALLOW16 && p.y16 != 0;
+    const bool vec_ok = (reinterpret_cast<size_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0;
+    const int cg = y16 ? (lane % LPR16) * VW16 : (lane % LPR) * VW;   // first of my columns inside the wave tile
+    const int rsel = y16 ? lane / LPR16 : lane / LPR;
+    const int col0 = colw0 + cg;
+    const int nv = y16 ? VW16 : VW;
+    float cb[NV], cs[NV], ch[NV], rbv[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const bool ok = v < nv && col0 + v < p.N;
+        cb[v] = (ok && p.bias) ? p.bias[col0 + v] : 0.f;
+        cs[v] = (ok && p.scale) ? p.scale[col0 + v] : 1.f;
+        ch[v] = (ok && p.shift) ? p.shift[col0 + v] : 0.f;
+        rbv[v] = 0.f;
+    }
+    int rb_seg = -1;
+    bool ovf = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDT + nt * 32 + l31] = acc[mt][nt][r];
+        const int nit = y16 ? 32 / RPI16 : 32 / RPI;
+        for (int it = 0; it < nit; ++it) {
+            const int rloc = it * (y16 ? RPI16 : RPI) + rsel;         // row inside the 32-row slab
+            const int rl = rl_base + mt * 32 + rloc;                  // row inside the block tile
+            const int row = row0 + rl;
+            float v[NV];
+            const ep_f32x4 t0 = *reinterpret_cast<const ep_f32x4*>(T + rloc * LDT + cg);
+            v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3];
+            if constexpr (ALLOW16) {
+                if (y16) {
+                    const ep_f32x4 t1 = *reinterpret_cast<const ep_f32x4*>(T + rloc * LDT + cg + 4);
+                    v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
+                }
+            }
+            if (row >= Mlim) continue;
+            if (p.rowbias) {
+                const int sg = sseg[rl];
+                if (sg != rb_seg) {
+                    rb_seg = sg;
+#pragma unroll
+                    for (int q = 0; q < NV; ++q)
+                        rbv[q] = (q < nv && col0 + q < p.N) ? p.rowbias[(size_t)sg * p.ld_rowbias + col0 + q] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                float x = v[q] + cb[q];
+                if (p.rowbias) x += rbv[q];
+                if (p.relu) x = x > 0.f ? x : 0.f;
+                v[q] = x * cs[q] + ch[q];
+            }
+            if (!y16) {
+                float* o = p.Y + (size_t)row * p.ldy + col0;
+                if (vec_ok && col0 + VW <= p.N) { ep_f32x4 w = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<ep_f32x4*>(o) = w; }
+                else { for (int q = 0; q < VW; ++q) if (col0 + q < p.N) o[q] = v[q]; }
+            } else if constexpr (ALLOW16) {
+                // split layout: each 32-column chunk is [32 hi halves | 32 lo halves]; my 8 columns never straddle a chunk.
+                // Both parts round to nearest even (as the loaders of the next layer expect)
+                ep_f16x8 hv, lv;
+                float am = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const __fp16 h = (__fp16)v[q];
+                    hv[q] = (_Float16)h; lv[q] = (_Float16)(__fp16)(v[q] - (float)h);
+                    am = fmaxf(am, fabsf(v[q]));
+                }
+                if (!(am < 65000.f)) ovf = true;
+                char* o = reinterpret_cast<char*>(p.Y + (size_t)row * p.ldy) + (col0 >> 5) * 128 + (col0 & 31) * 2;
+                if (vec_ok && col0 + VW16 <= p.N) {
+                    *reinterpret_cast<ep_f16x8*>(o) = hv;
+                    *reinterpret_cast<ep_f16x8*>(o + 64) = lv;
+                } else {
+                    for (int q = 0; q < 8; ++q) if (col0 + q < p.N) {
+                        reinterpret_cast<_Float16*>(o)[q] = hv[q]; reinterpret_cast<_Float16*>(o + 64)[q] = lv[q];
+                    }
+                }
+            }
+        }
+    }
+    if (ovf) *p.ovf = 1;
+}
+
+}  // namespace morig

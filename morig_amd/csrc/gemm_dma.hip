@@ -9,6 +9,8 @@
 // is an XOR swizzle applied on the SOURCE side: LDS slot p of row r holds logical slot p ^ ((r >> 1) & 7); fragment
 // reads apply the same involution. A 16-lane read group (16 distinct rows mod 16) then hits 16 distinct slots.
 #include "common.h"
+#include "epilogue_store.h"
+#include <stdlib.h>
 #include <stdlib.h>
 
 namespace morig {
@@ -29,8 +31,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     constexpr int DMA_STAGE = (BM + BN) * 128;   // bytes: X tile + W tile of one 32-column chunk
     constexpr int XJ = BM / 8 / NW, WJ = BN / 8 / NW;     // 1-KiB DMA instructions per wave per chunk (X, W)
     constexpr int PER_CHUNK = XJ + WJ;
-    __shared__ __attribute__((aligned(128))) char smem[DMA_NS * DMA_STAGE + BM * 4];
-    int* sseg = reinterpret_cast<int*>(smem + DMA_NS * DMA_STAGE);
+    constexpr int TBYTES = NW * EpilogueTile<NT>::FLOATS * 4;     // per-wave transposition tiles of the store epilogue
+    constexpr int RING = DMA_NS * DMA_STAGE;
+    constexpr int SM0 = RING > TBYTES ? RING : TBYTES;
+    __shared__ __attribute__((aligned(128))) char smem[SM0 + BM * 4];
+    int* sseg = reinterpret_cast<int*>(smem + SM0);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -175,50 +180,17 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
         }
         return;
     }
-    // ---- epilogue: bias / per-mesh row bias / ReLU / BN affine, fp32 or split-fp16 store ----
-    __syncthreads();                             // sseg visible
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int col = colw0 + nt * 32 + l31;
-        if (col >= p.N) continue;
-        const float b = p.bias ? p.bias[col] : 0.f;
-        const float sc = p.scale ? p.scale[col] : 1.f;
-        const float shf = p.shift ? p.shift[col] : 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rl = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int row = row0 + rl;
-                if (row < p.M) {
-                    float v = acc[mt][nt][r] + b;
-                    if (p.rowbias) v += p.rowbias[(size_t)sseg[rl] * p.ld_rowbias + col];
-                    if (p.relu) v = v > 0.f ? v : 0.f;
-                    v = v * sc + shf;
-                    if (p.y16) {
-                        // neighbouring lanes hold neighbouring columns: trade halves so that every lane writes ONE dword
-                        // (even lane: hi(c),hi(c+1); odd lane: lo(c-1),lo(c)) instead of two 2-byte stores
-                        const __fp16 hv = (__fp16)v;
-                        const __fp16 lv = (__fp16)(v - (float)hv);
-                        if (!(fabsf(v) < 65000.f)) *p.ovf = 1;
-                        const unsigned hb = __builtin_bit_cast(unsigned short, hv), lb = __builtin_bit_cast(unsigned short, lv);
-                        const bool odd = lane & 1;
-                        // quad_perm [1,0,3,2] = swap with the xor-1 neighbour: one v_mov_dpp, no LDS crossbar
-                        const unsigned got = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(odd ? hb : lb), 0xB1, 0xF, 0xF, false);
-                        const unsigned word = odd ? (got | (lb << 16)) : (hb | (got << 16));
-                        unsigned* yw = reinterpret_cast<unsigned*>(p.Y + (size_t)row * p.ldy) + (col >> 5) * 32 + ((col & 31) >> 1) + (odd ? 16 : 0);
-                        *yw = word;
-                    } else {
-                        p.Y[(size_t)row * p.ldy + col] = v;
-                    }
-                }
-            }
-        }
-    }
+    // ---- epilogue: bias / per-mesh row bias / ReLU / BN affine, fp32 or split-fp16 store (epilogue_store.h) ----
+    __syncthreads();                             // every wave is done with the ring; sseg visible
+    if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
+    store_tile_transposed<MT, NT, true>(p, acc, reinterpret_cast<float*>(smem) + wave * EpilogueTile<NT>::FLOATS, sseg,
+                                        wm * 64, row0, p.M, colw0, lane);
 }
 
 int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
     GemmDmaParams p = p0;
+    static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
     static const int mode = [] { const char* e = getenv("MORIG_DMA_TILE"); return e ? atoi(e) : 256; }();
     if (mode == 256 && p.N % 256 == 0) {
         p.tiles_n = p.N / 256;

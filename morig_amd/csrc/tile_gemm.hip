@@ -17,6 +17,7 @@
 //   * LDS rows are padded to KC+4 floats: for ds_read_b128 the 16-lane service groups then touch
 //     16 distinct 16-byte slots (36*r mod 64 and 20*r mod 64 are 4*(odd*r mod 16)) -> conflict-free.
 #include "common.h"
+#include "epilogue_store.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     constexpr int ZC = BN < 64 ? BN : 64;       // epilogue column block
     constexpr int ZLD = ZC + 1;
     constexpr int SM_MAIN = (BM + BN) * LDK;
-    constexpr int SM_Z = (MODE == MODE_STORE) ? 0 : BM * ZLD;
+    constexpr int SM_Z = (MODE == MODE_STORE) ? 4 * EpilogueTile<NT>::FLOATS : BM * ZLD;    // store: per-wave transposition tiles
     constexpr int SM = SM_MAIN > SM_Z ? SM_MAIN : SM_Z;
     static_assert(BN % 32 == 0 && KC % 8 == 0, "tile shape");
     static_assert(PREC == PREC_F32 || KC % 32 == 0, "the split-fp16 LDS image is [hi 32 halves | lo 32 halves] per 32-column chunk");
@@ -284,40 +285,9 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     if (p.dbg & DBG_NO_EPILOGUE) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
     const int colw0 = tn * BN + wn * NT * 32;   // first global column of this wave
     if (MODE == MODE_STORE) {
-        __syncthreads();                        // sseg visible (written before the loop; harmless otherwise)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = colw0 + nt * 32 + l31;
-            if (col >= p.N) continue;
-            const float b = p.bias ? p.bias[col] : 0.f;
-            const float sc = p.scale ? p.scale[col] : 1.f;
-            const float sh = p.shift ? p.shift[col] : 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rl = wm * MT * 32 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    const int row = row0 + rl;
-                    if (row < Mlim) {
-                        float v = acc[mt][nt][r] + b;
-                        if (p.rowbias) v += p.rowbias[(size_t)sseg[rl] * p.ld_rowbias + col];
-                        if (p.relu) v = v > 0.f ? v : 0.f;
-                        v = v * sc + sh;
-                        if (PREC == PREC_F16X3 && p.y16) {
-                            // split-fp16 layout for the next layer's loader: chunk (col/32) = [32 hi | 32 lo]
-                            const __fp16 hv = (__fp16)v;                       // round-to-nearest-even, both parts
-                            const __fp16 lv = (__fp16)(v - (float)hv);
-                            if (!(fabsf(v) < 65000.f)) *p.ovf = 1;
-                            __fp16* yh = reinterpret_cast<__fp16*>(p.Y + (size_t)row * p.ldy) + (col >> 5) * 64 + (col & 31);
-                            yh[0] = hv;
-                            yh[32] = lv;
-                        } else {
-                            p.Y[(size_t)row * p.ldy + col] = v;
-                        }
-                    }
-                }
-            }
-        }
+        __syncthreads();                        // all waves are done with the operand tiles; sseg visible
+        store_tile_transposed<MT, NT, PREC == PREC_F16X3>(p, acc, smem + wave * EpilogueTile<NT>::FLOATS, sseg,
+                                                          wm * MT * 32, row0, Mlim, colw0, lane);
         return;
     }
 
