@@ -46,32 +46,44 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
 
     if (p.seg != nullptr && tid < BM) sseg[tid] = (row0 + tid < p.M) ? p.seg[row0 + tid] : 0;
 
-    // ---- per-lane DMA source pointers: wave w moves row blocks (8 rows x 128 B = 1 KiB per instruction) 4w..4w+3 ----
-    const float* gx[XJ]; const float* gw[WJ];
+    // ---- per-lane DMA sources: wave w moves row blocks (8 rows x 128 B = 1 KiB per instruction) XJ*w .. XJ*w+XJ-1.
+    // Addresses are (block-uniform base in SGPRs) + (32-bit per-lane byte offset): half the address VGPRs of pointers ----
+    unsigned ox[XJ], ow[WJ];
     const int rsub = lane >> 3;                  // row inside the 8-row block
     const int pslot = lane & 7;                  // physical 16-byte slot inside the row
+    const char* xbase = reinterpret_cast<const char*>(p.X + (size_t)row0 * p.ldx);
+    const char* wbase = reinterpret_cast<const char*>(p.W + (size_t)(tn * BN) * p.ldw);
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
         const int r = (wave * XJ + j) * 8 + rsub;
         const int lslot = pslot ^ ((r >> 1) & 7);  // rule 21: swizzle the SOURCE, keep the LDS destination linear
-        int xr = row0 + r; if (xr >= p.M) xr = p.M - 1;      // clamp: rows past M are never stored
-        gx[j] = p.X + (size_t)xr * p.ldx + 4 * lslot;
+        int xr = r; if (row0 + xr >= p.M) xr = p.M - 1 - row0;   // clamp: rows past M are never stored
+        ox[j] = ((unsigned)xr * (unsigned)p.ldx + 4u * lslot) * 4u;
     }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
         const int r = (wave * WJ + j) * 8 + rsub;
-        gw[j] = p.W + (size_t)(tn * BN + r) * p.ldw + 4 * (pslot ^ ((r >> 1) & 7));
+        ow[j] = ((unsigned)r * (unsigned)p.ldw + 4u * (pslot ^ ((r >> 1) & 7))) * 4u;
     }
-    auto issue = [&](int c) {
+    auto issue_x = [&](int c) {
         char* st = smem + (c % DMA_NS) * DMA_STAGE;
-        const int k0 = c * 32;
 #pragma unroll
-        for (int j = 0; j < XJ; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(gx[j] + k0), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
-#pragma unroll
-        for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(gw[j] + k0), (lds_void_t*)(st + BM * 128 + (wave * WJ + j) * 1024), 16, 0, 0);
+        for (int j = 0; j < XJ; ++j) {
+            unsigned o = ox[j];
+            asm volatile("" : "+v"(o));              // keep (scalar base + lane offset) addressing
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(xbase + c * 128 + o), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
+        }
     };
+    auto issue_w = [&](int c) {
+        char* st = smem + (c % DMA_NS) * DMA_STAGE;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            unsigned o = ow[j];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(wbase + c * 128 + o), (lds_void_t*)(st + BM * 128 + (wave * WJ + j) * 1024), 16, 0, 0);
+        }
+    };
+    auto issue = [&](int c) { issue_x(c); issue_w(c); };
 
     f32x16 acc[MT][NT];
 #pragma unroll

@@ -15,7 +15,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmorig_hip.so")
+LIB_PATH = os.environ.get("MORIG_HIP_LIB") or os.path.join(_HERE, "lib", "libmorig_hip.so")   # env: A/B builds
 
 c_f32p = C.c_void_p
 c_i32p = C.c_void_p
