@@ -32,14 +32,18 @@ def measured_traffic(kernel_kind):
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if not os.path.exists(path):
         return None
-    symbol = {"edgeconv_f16x3_h256": "edge_pc_kernel<256>", "gemm_f16x3_dma": "gemm16_dma_kernel<256, 256, 4, 2>",
+    symbol = {"edgeconv_f16x3_h256": "edge_pp_kernel<256", "edgeconv_f16x3_h128": "edge_pp_kernel<128",
+              "gemm_f16x3_dma": "gemm16_dma_kernel<256, 256, 4, 2>",
               "edgeconv_h256": "tile_kernel<256, 16, 1, 2, 0>", "gemm_f32_bn128": "tile_kernel<128, 32, 0, 0, 0>"}.get(kernel_kind)
     if symbol is None:
         return None
+    tot, n = 0.0, 0            # a kind may cover several instantiations (4-aligned / general CSR): dispatch-weighted mean
     for name, v in json.load(open(path))["kernels"].items():
         if symbol in name and "FETCH_SIZE_KiB_per_dispatch" in v and "WRITE_SIZE_KiB_per_dispatch" in v:
-            return round((2.0 * v["FETCH_SIZE_KiB_per_dispatch"] + v["WRITE_SIZE_KiB_per_dispatch"]) * 1024.0)
-    return None
+            d = v.get("dispatches", 1)
+            tot += (2.0 * v["FETCH_SIZE_KiB_per_dispatch"] + v["WRITE_SIZE_KiB_per_dispatch"]) * 1024.0 * d
+            n += d
+    return round(tot / n) if n else None
 
 
 def _mesh(args):

@@ -155,9 +155,11 @@ def _edge_pack(H, seed, folded=False):
 
 
 @pytest.mark.parametrize("folded,pad4", [(False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("H", [16, 32, 64, 128, 256])
+@pytest.mark.parametrize("H,ld_extra", [(16, 3), (32, 3), (64, 3), (128, 3), (256, 3), (128, 4), (256, 4)])
 @pytest.mark.parametrize("n,e,hub,reps,shared", [(300, 2500, 5, 1, False), (1500, 9000, None, 3, False), (700, 5000, 3, 2, True)])
-def test_edgeconv(ops, H, n, e, hub, reps, shared, folded, pad4):
+def test_edgeconv(ops, H, ld_extra, n, e, hub, reps, shared, folded, pad4):
+    """ld_extra = 4: 16-byte aligned output rows, the layout the persistent kernel (edge_pp.hip) needs; 3: misaligned
+    rows, which H = 128 / 256 serve with the one-shot kernel (edge_pc.hip)."""
     g = torch.Generator().manual_seed(H + n)
     ei = _rand_graph(n, e, 9, hub)
     rows_in = n if shared else n * reps
@@ -165,18 +167,45 @@ def test_edgeconv(ops, H, n, e, hub, reps, shared, folded, pad4):
     ec = _edge_pack(H, 21, folded)
     emu = EmuOps()
     csr_ref = emu.csr_build(ei, n)
-    out_ref = torch.zeros(n * reps, H + 3)
+    out_ref = torch.zeros(n * reps, H + ld_extra)
     emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_ref, ec, Mat.of(out_ref, 0, H), replicas=reps,
                  in_rep_stride=0 if shared else n, out_rep_stride=n)
     csr = ops.csr_build(ei.to(DEV), n, pad4=pad4)
     abg = ab.to(DEV)
-    out = torch.zeros(n * reps, H + 3, device=DEV)
+    out = torch.zeros(n * reps, H + ld_extra, device=DEV)
     ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), csr, packing.to_device(ec, DEV), Mat.of(out, 0, H), replicas=reps,
                  in_rep_stride=0 if shared else n, out_rep_stride=n)
     torch.cuda.synchronize()
     assert not torch.isnan(out).any()
     assert maxdiff(out, out_ref) <= 2e-5 * max(1.0, out_ref.abs().max().item())
     assert float(out[:, H:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("pad4", [False, True])
+@pytest.mark.parametrize("H", [128, 256])
+def test_edgeconv_persistent_many_tiles(ops, H, pad4):
+    """~20 tiles per workgroup of the persistent kernel (cross-tile prefetch, double-buffered segment ids, tile-straddling
+    segments incl. one hub longer than several tiles), two replicas reading the same input."""
+    n, e, reps = 20000, 300000, 2
+    g = torch.Generator().manual_seed(H)
+    ei = _rand_graph(n, e, 31, hub=777)
+    extra = torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 1234)])      # a 700-edge destination
+    ei = torch.cat([ei, extra], dim=1)
+    ab = torch.randn(n, 2 * H, generator=g)
+    ec = _edge_pack(H, 5, folded=True)
+    emu = EmuOps()
+    out_ref = torch.zeros(n * reps, H)
+    emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), emu.csr_build(ei, n), ec, Mat.of(out_ref), replicas=reps,
+                 in_rep_stride=0, out_rep_stride=n)
+    csr = ops.csr_build(ei.to(DEV), n, pad4=pad4)
+    abg = ab.to(DEV)
+    out = torch.full((n * reps, H), float("nan"), device=DEV)
+    ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), csr, packing.to_device(ec, DEV), Mat.of(out), replicas=reps,
+                 in_rep_stride=0, out_rep_stride=n)
+    torch.cuda.synchronize()
+    assert not torch.isnan(out).any()
+    assert maxdiff(out, out_ref) <= 2e-5 * max(1.0, out_ref.abs().max().item())
+    assert torch.equal(out[:n], out[n:])                      # replicas of one input: identical bits
 
 
 def test_edgeconv_sign_cases(ops):
