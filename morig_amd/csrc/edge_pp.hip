@@ -104,8 +104,11 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float a0 = acc[mt][nt][4 * q], a1 = acc[mt][nt][4 * q + 1], a2 = acc[mt][nt][4 * q + 2], a3 = acc[mt][nt][4 * q + 3];
-                    const float hi4 = fmaxf(__builtin_fmaxf(__builtin_fmaxf(a0, a1), a2), a3);
-                    const float lo4 = fminf(__builtin_fminf(__builtin_fminf(a0, a1), a2), a3);
+                    float hi4, lo4, t3;                    // raw v_max3/v_min3: fmaxf() would first canonicalise every input
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(hi4) : "v"(t3), "v"(a3));
+                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
+                    asm("v_min_f32 %0, %1, %2" : "=v"(lo4) : "v"(t3), "v"(a3));
                     const float x = rising ? hi4 : lo4;
                     Z[(wm * 16 + mt * 8 + 2 * q + hi) * ZQ + col] = fmaxf(x + b, 0.f) * sc + sh;
                 }
@@ -394,45 +397,54 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
         if (!(amax < 65000.f)) *p.ovf = 1;
     } else {
         // ---------------- consumers: 4 waves as 2 (rows) x 2 (cols), fragments + MFMA only ----------------
-#pragma unroll 1
-        for (int j = 0; j < n_my; ++j) {
+        // one K-chunk: fragments of both 16-k steps, 3 MFMAs per (mt, nt) and step. `first`: the accumulators start from
+        // the inline constant 0 (no 128 v_mov per tile)
+        auto consume = [&](int c, auto firstc) __attribute__((always_inline)) {
+            constexpr bool first = decltype(firstc)::value != 0;
+            const char* sA = aring + (c & 1) * STAGE;
+            const char* sB = WRES ? wres + c * (H * LDB) : sA + BM * LDB;
+            const char* a0 = sA + (wm * 64 + l31) * LDB + 16 * hi;
+            const char* b0 = sB + (wn * NT * 32 + l31) * LDB + 16 * hi;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int st = 0; st < 2; ++st) {
+                f16x8 ah[MT], al[MT], bh[NT], bl[NT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    ah[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDB + 32 * st);
+                    al[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDB + 32 * st + 64);
+                }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-#pragma unroll 1
-            for (int c = 0; c < NCHUNK; ++c) {
-                PP_TS(2 * c); pp_barrier();                 // B_c: chunk c is in stage c&1
-                PP_TS(2 * c + 1);
-                if (p.dbg & 2) continue;
-                const char* sA = aring + (c & 1) * STAGE;
-                const char* sB = WRES ? wres + c * (H * LDB) : sA + BM * LDB;
-                const char* a0 = sA + (wm * 64 + l31) * LDB + 16 * hi;
-                const char* b0 = sB + (wn * NT * 32 + l31) * LDB + 16 * hi;
+                for (int nt = 0; nt < NT; ++nt) {
+                    bh[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDB + 32 * st);
+                    bl[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDB + 32 * st + 64);
+                }
 #pragma unroll
-                for (int st = 0; st < 2; ++st) {
-                    f16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        ah[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDB + 32 * st);
-                        al[mt] = *reinterpret_cast<const f16x8*>(a0 + mt * 32 * LDB + 32 * st + 64);
-                    }
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        bh[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDB + 32 * st);
-                        bl[nt] = *reinterpret_cast<const f16x8*>(b0 + nt * 32 * LDB + 32 * st + 64);
-                    }
+                        if (first && st == 0) {
+                            f32x16 z;
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) {
+                            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], z, 0, 0, 0);
+                        } else {
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                         }
-                }
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        };
+#pragma unroll 1
+        for (int j = 0; j < n_my; ++j) {
+            PP_TS(0); pp_barrier();                         // B_0: chunk 0 is in stage 0
+            PP_TS(1);
+            if (!(p.dbg & 2)) consume(0, IC<1>{});
+#pragma unroll 1
+            for (int c = 1; c < NCHUNK; ++c) {
+                PP_TS(2 * c); pp_barrier();                 // B_c: chunk c is in stage c&1
+                PP_TS(2 * c + 1);
+                if (!(p.dbg & 2)) consume(c, IC<0>{});
             }
             PP_TS(16);
             if (!(p.dbg & 1)) { if constexpr (QUAD) write_z_quad(); else write_z_pass(IC<0>{}); }
