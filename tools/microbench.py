@@ -38,11 +38,13 @@ def main():
         csr = ops.csr_build(ei, n, pad4=os.environ.get("MB_PAD4", "1") == "1")
         torch.cuda.synchronize()
         csr.edge_count = int(csr.rowptr[-1].item())
-        for H in (256, 128):
+        for H in [int(h) for h in os.environ.get("MB_HS", "256,128").split(",")]:
             g = torch.Generator().manual_seed(H)
-            W = torch.randn(H, H, generator=g) / H ** 0.5
-            ec = packing.PackedEdge(H, None, None, W.contiguous(), torch.zeros(H), torch.ones(H), torch.zeros(H),
-                                    packing.split_f16(W.contiguous()))
+            Hp = max(H, 32)
+            W = torch.zeros(Hp, Hp)
+            W[:H, :H] = torch.randn(H, H, generator=g) / H ** 0.5
+            ec = packing.PackedEdge(H, None, None, W.contiguous(), torch.zeros(Hp), torch.ones(Hp), torch.zeros(Hp),
+                                    packing.split_f16(W.contiguous()) if H >= 32 else None)
             ec = packing.to_device(ec, DEV)
             ab = torch.randn(R * n, 4 * H, device=DEV)
             o = torch.empty(R * n, 2 * H + 32, device=DEV)
@@ -51,7 +53,7 @@ def main():
             fl = 2.0 * E * R * H * H
             out[f"edge_{gname}_H{H}"] = (ms, fl / ms / 1e9)
     M = R * n
-    for (K, N) in ((1862, 1024), (544, 512), (256, 1024), (1024, 256), (832, 1024)):
+    for (K, N) in (() if os.environ.get("MB_NOGEMM") else ((1862, 1024), (544, 512), (256, 1024), (1024, 256), (832, 1024))):
         g = torch.Generator().manual_seed(K)
         lin = packing.to_device(packing.pack_linear(torch.randn(N, K, generator=g) / K ** 0.5, torch.zeros(N)), DEV)
         x = torch.randn(M, (K + 3) // 4 * 4, device=DEV)
