@@ -208,9 +208,13 @@ class GCUMotion(NativeModule):
         vp, (pt, pg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_pos, self.edge_conv_geo.nn_pos])
         return dict(vx=vx, xt=xt, xg=xg, vp=vp, pt=pt, pg=pg, mlp=packing.pack_mlp_layer(self.mlp[0]))
 
-    def run(self, ops, pos: Mat, x: Mat, csr_tpl, csr_geo, out: Mat, replicas: int = 1, split: bool = False):
+    def run(self, ops, pos: Mat, x: Mat, csr_tpl, csr_geo, out: Mat, replicas: int = 1, split: bool = False,
+            split_in=None, split_out=None):
         """pos: [n, P] window; x: [R*n, C] window (replica-major); out: [R*n, O] window.
-        split: x and out are windows in the split-fp16 activation layout (GEMM -> GEMM hand-off)."""
+        split: x and out are windows in the split-fp16 activation layout (GEMM -> GEMM hand-off);
+        split_in / split_out override it for one side."""
+        split_in = split if split_in is None else split_in
+        split_out = split if split_out is None else split_out
         dev = x.base.device
         pk = self.packed(dev)
         n, M = pos.rows, x.rows
@@ -218,7 +222,7 @@ class GCUMotion(NativeModule):
         H, D = pk["xt"].H, pk["pt"].H
         ldo = 2 * H + 2 * D
         ab = ops.empty(M, 4 * H, dev)
-        ops.gemm(x, pk["vx"], relu=False, Y=Mat.of(ab), x_split=split)
+        ops.gemm(x, pk["vx"], relu=False, Y=Mat.of(ab), x_split=split_in)
         pab = ops.empty(n, 4 * D, dev)
         ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
@@ -232,7 +236,7 @@ class GCUMotion(NativeModule):
         for r in range(1, replicas):
             ops.copy2d(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, r * n, n))
             ops.copy2d(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, r * n, n))
-        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split)
+        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split_out)
 
     def _forward(self, pos, x, tpl_edge_index, geo_edge_index):
         ops = get_ops()

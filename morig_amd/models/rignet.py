@@ -296,23 +296,24 @@ class SkinNet_inner(NativeModule):
         cols = torch.tensor(self.sample_columns(skin.shape[1]), dtype=torch.int32, device=dev)
         ops.gather_cols(Mat.of(skin), cols, Mat.of(raw, 3, P - 3))
         posm = Mat.of(raw, 0, P)
+        sp = ops.split_activations                    # GEMM -> GEMM activations in the split-fp16 layout
         x1 = ops.empty(n, 256, dev)
-        self.gcu1.run(ops, posm, Mat.of(motion, 0, mdim), csr_tpl, csr_geo, Mat.of(x1))
+        self.gcu1.run(ops, posm, Mat.of(motion, 0, mdim), csr_tpl, csr_geo, Mat.of(x1), split_in=False, split_out=sp)
         g1 = ops.empty(n, 512, dev)
-        ops.gemm(Mat.of(x1), pk["m1"], relu=True, Y=Mat.of(g1))
+        ops.gemm(Mat.of(x1), pk["m1"], relu=True, Y=Mat.of(g1), x_split=sp, y_split=sp)
         pooled = ops.empty(n_graphs, 1024, dev)
-        ops.gemm(Mat.of(g1), pk["m2"], relu=True, seg=seg, pool=pooled)
+        ops.gemm(Mat.of(g1), pk["m2"], relu=True, seg=seg, pool=pooled, x_split=sp)
         x2 = ops.empty(n, 256, dev)
-        self.gcu2.run(ops, posm, Mat.of(x1), csr_tpl, csr_geo, Mat.of(x2))
+        self.gcu2.run(ops, posm, Mat.of(x1), csr_tpl, csr_geo, Mat.of(x2), split=sp)
         x3 = ops.empty(n, 256, dev)
-        self.gcu3.run(ops, posm, Mat.of(x2), csr_tpl, csr_geo, Mat.of(x3))
+        self.gcu3.run(ops, posm, Mat.of(x2), csr_tpl, csr_geo, Mat.of(x3), split=sp)
         gb = ops.empty(n_graphs, 1024, dev)
         ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
         h1 = ops.empty(n, 1024, dev)
-        ops.gemm(Mat.of(x3), pk["c1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg)
+        ops.gemm(Mat.of(x3), pk["c1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg, x_split=sp, y_split=sp)
         h2 = ops.empty(n, 512, dev)
-        ops.gemm(Mat.of(h1), pk["c2"], relu=True, Y=Mat.of(h2))
-        ops.gemm(Mat.of(h2), pk["c3"], relu=False, Y=out)
+        ops.gemm(Mat.of(h1), pk["c2"], relu=True, Y=Mat.of(h2), x_split=sp, y_split=sp)
+        ops.gemm(Mat.of(h2), pk["c3"], relu=False, Y=out, x_split=sp)
 
     def _forward(self, data, motion):
         ops = get_ops()
