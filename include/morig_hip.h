@@ -207,6 +207,13 @@ int morig_frame_reduce(const float* x, int32_t n, int32_t T, int32_t C, int32_t 
  * CorrNet point branch (models/corrnet.py:50-73, models/basic_modules.py:66-138). Clouds are contiguous
  * row ranges given by int32 offset arrays ptr[n_clouds + 1] (PyG's sorted `batch` vector).
  */
+/* The same normalised CSR as morig_csr_build_bipartite(MORIG_CSR_SKIP_NEGATIVE) for the slot table morig_ball_query
+ * writes (target k owns slots [k*max_nbrs, (k+1)*max_nbrs) of row 0 of `coo`, max_nbrs <= 64, unused = -1): counted
+ * and filled per target without atomics (replaces torch_cluster.radius -> PointConv's remove/add_self_loops,
+ * basic_modules.py:77-84). Capacity of src_sorted / dst_sorted: n_nodes * (max_nbrs + 1); cursor: n_nodes + 1 ints. */
+int morig_csr_from_slots(const int64_t* coo, int32_t n_nodes, int32_t max_nbrs, int32_t n_src_nodes,
+                         int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted, int32_t* cursor, int32_t* status,
+                         void* stream);
 /* torch_cluster.fps (basic_modules.py:75): per cloud out_ptr[b+1]-out_ptr[b] samples, first = ptr[b] +
  * start[b] (start == NULL: first point), then repeatedly the point farthest from the chosen set
  * (lowest index on ties). idx_out: GLOBAL row indices, clouds concatenated. */

@@ -221,6 +221,62 @@ extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_ed
     return MORIG_OK;
 }
 
+// ---- CSR straight from a ball-query slot table: target k owns slots [k * max_nbrs, (k+1) * max_nbrs) of row 0 of the COO
+// (unused = -1), so counting and filling need neither row 1 nor atomics: one wave per target, ballot + popcount ranks.
+// Same normalisation as morig_csr_build_bipartite(MORIG_CSR_SKIP_NEGATIVE): pairs with source == target index dropped,
+// one self loop (k, k) appended last.
+__global__ __launch_bounds__(256) void csr_slots_count_kernel(const int64_t* __restrict__ src_slots, int n, int max_nbrs, int nsrc,
+                                                              int* __restrict__ cnt, int* status) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int64_t v = lane < max_nbrs ? src_slots[(int64_t)k * max_nbrs + lane] : -1;
+    if (v >= nsrc) *status = 1;
+    const bool keep = v >= 0 && v < nsrc && v != k;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) cnt[k] = __popcll(mask);
+}
+
+__global__ __launch_bounds__(256) void csr_slots_fill_kernel(const int64_t* __restrict__ src_slots, int n, int max_nbrs, int nsrc,
+                                                             const int* __restrict__ rowptr, int* __restrict__ srcS, int* __restrict__ dstS) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (k >= n) return;
+    const int64_t v = lane < max_nbrs ? src_slots[(int64_t)k * max_nbrs + lane] : -1;
+    const bool keep = v >= 0 && v < nsrc && v != k;
+    const unsigned long long mask = __ballot(keep);
+    const int base = rowptr[k];
+    if (keep) {
+        const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+        srcS[pos] = (int)v; dstS[pos] = k;
+    }
+    if (lane == 0) { const int pos = base + __popcll(mask); srcS[pos] = k; dstS[pos] = k; }
+}
+
+extern "C" int morig_csr_from_slots(const int64_t* coo, int32_t n_nodes, int32_t max_nbrs, int32_t n_src_nodes,
+                                    int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted, int32_t* cursor, int32_t* status,
+                                    void* stream) {
+    if (!coo || !rowptr || !src_sorted || !dst_sorted || !cursor || !status) return MORIG_E_INVALID;
+    if (n_nodes <= 0 || max_nbrs <= 0 || max_nbrs > 64 || n_src_nodes < n_nodes) return MORIG_E_INVALID;
+    if ((int64_t)n_nodes * (max_nbrs + 1) > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nb = cdiv(n_nodes, SCAN_B);
+    int* bsum = dst_sorted;                       // scratch until the fill pass (capacity >= n_nodes >= nb)
+    ProfScope ps(K_CSR, s, 0.0, 16.0 * n_nodes * (double)max_nbrs + 8.0 * n_nodes * (double)max_nbrs);
+    MORIG_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), s));
+    hipLaunchKernelGGL(csr_slots_count_kernel, dim3(cdiv(n_nodes, 4)), dim3(256), 0, s, coo, n_nodes, max_nbrs, n_src_nodes, cursor, status);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, 0, bsum);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, nb, rowptr + n_nodes);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, 0, bsum, rowptr, cursor);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_slots_fill_kernel, dim3(cdiv(n_nodes, 4)), dim3(256), 0, s, coo, n_nodes, max_nbrs, n_src_nodes, rowptr, src_sorted, dst_sorted);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
 extern "C" int morig_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t rows, int32_t cols, void* stream) {
     if (!src || !dst || rows < 0 || cols < 0 || lds < cols || ldd < cols) return MORIG_E_INVALID;
     if (rows == 0 || cols == 0) return MORIG_OK;

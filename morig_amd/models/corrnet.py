@@ -137,7 +137,7 @@ class CorrNet(NativeModule):
         pos_new = torch.zeros((M, 4), dtype=torch.float32, device=dev)
         ops.gather_rows(posm, idx, Mat.of(pos_new, 0, 3))
         coo = ops.ball_query(posm, ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, sa.r, sa.max_num_neighbors)
-        csr = ops.csr_build(coo, M, n_src=N, skip_negative=True)
+        csr = ops.csr_from_slots(coo, M, sa.max_num_neighbors, N)
         H = pk["edge"].H
         bsrc = ops.empty(N, H, dev)
         ops.gemm(Mat.of(xp, 0, cx + 3), pk["src"], relu=False, Y=Mat.of(bsrc))

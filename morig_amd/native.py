@@ -76,6 +76,7 @@ _SIGNATURES = {
     "morig_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "morig_csr_build": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_csr_build_bipartite": (C.c_int, [c_i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
+    "morig_csr_from_slots": (C.c_int, [c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "morig_edge_hidden": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_segmax_gemm": (C.c_int, [C.POINTER(SegmaxArgs), C.c_void_p]),
@@ -283,6 +284,22 @@ class NativeOps:
             self._edge_counts[key] = int(rowptr[-1].item())
         csr.edge_count = self._edge_counts.get(key, 0)
         return csr
+
+    def csr_from_slots(self, coo: torch.Tensor, n_nodes: int, max_nbrs: int, n_src: int) -> CSR:
+        """the bipartite CSR of a ball-query slot table (``ball_query`` output): same result as
+        ``csr_build(coo, n_nodes, n_src=n_src, skip_negative=True)``, built per target without atomics."""
+        _need_gpu(coo)
+        assert coo.dtype == torch.int64 and coo.is_contiguous() and coo.shape == (2, n_nodes * max_nbrs)
+        dev = coo.device
+        cap = n_nodes * (max_nbrs + 1)
+        rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        src = torch.empty(cap, dtype=torch.int32, device=dev)
+        dst = torch.empty(cap, dtype=torch.int32, device=dev)
+        cursor = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        check(self.lib.morig_csr_from_slots(_p(coo), n_nodes, max_nbrs, n_src, _p(rowptr), _p(src), _p(dst), _p(cursor),
+                                            _p(status), _stream()), "morig_csr_from_slots")
+        return CSR(rowptr, src, dst, n_nodes, cap, status)
 
     # -- dense ----------------------------------------------------------------------------------
     def gemm(self, X: Mat, lin, relu: bool, Y: Optional[Mat] = None, rowbias: Optional[Mat] = None,

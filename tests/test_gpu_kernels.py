@@ -310,6 +310,11 @@ def test_ball_query_and_bipartite_csr_bit_exact(ops):
         assert int(cg.status.item()) == 0 and torch.equal(cg.rowptr.cpu(), cw.rowptr)
         E = int(cw.rowptr[-1])
         assert _segments(cg, E) == _segments(cw, E)
+        cs = ops.csr_from_slots(got, cen.shape[0], mx, pos4.shape[0])          # the atomics-free builder for slot tables
+        torch.cuda.synchronize()
+        assert int(cs.status.item()) == 0 and torch.equal(cs.rowptr.cpu(), cw.rowptr)
+        assert _segments(cs, E) == _segments(cw, E)
+        assert torch.equal(cs.dst.cpu()[:E].long(), torch.repeat_interleave(torch.arange(cen.shape[0]), (cw.rowptr[1:] - cw.rowptr[:-1]).long()))
 
 
 @pytest.mark.parametrize("H,N3", [(32, 64), (64, 128), (256, 256)])
