@@ -128,10 +128,11 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
     };
     // quad mode scan: wave w owns quad-rows [4w, 4w+4) and every segment that STARTS there (following it into later
     // rows); a lane holds VEC = H/64 adjacent columns, so a segment's result leaves as one 16-byte (8-byte) store per lane
-    auto scan_quad = [&](int rep, const int* sseg, bool first_cont, bool last_cont) __attribute__((always_inline)) {
+    auto scan_quad = [&](int rep, const int* sseg, bool first_cont, bool last_cont, auto nownc, int wslot) __attribute__((always_inline)) {
         constexpr int VEC = H / 64;
+        constexpr int NOWN = decltype(nownc)::value;   // quad rows owned per scanning wave
         typedef float fvec __attribute__((ext_vector_type(VEC)));
-        const int q0 = __builtin_amdgcn_readfirstlane(wave * 4);
+        const int q0 = __builtin_amdgcn_readfirstlane(wslot * NOWN);
         const float* zl = Z + VEC * lane;
         float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + VEC * lane;
         auto flush = [&](int sg, fvec m, int qs, int qend) __attribute__((always_inline)) {
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
                 *reinterpret_cast<fvec*>(o) = m;
             }
         };
-        fvec zv[4]; int sv[4];
+        fvec zv[NOWN]; int sv[NOWN];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NOWN; ++i) {
             zv[i] = *reinterpret_cast<const fvec*>(zl + (q0 + i) * ZQ);
             sv[i] = __builtin_amdgcn_readfirstlane(sseg[4 * (q0 + i)]);
         }
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
         bool open = false;
         fvec m = zv[0]; int qs = q0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NOWN; ++i) {
             if (sv[i] != cur) {
                 if (open) flush(cur, m, qs, q0 + i);
                 cur = sv[i]; open = cur >= 0; m = zv[i]; qs = q0 + i;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
             }
         }
         if (open) {                                         // the last segment may run on into later waves' rows
-            int q = q0 + 4;
+            int q = q0 + NOWN;
             while (q < 32 && __builtin_amdgcn_readfirstlane(sseg[4 * q]) == cur) {
                 const fvec z = *reinterpret_cast<const fvec*>(zl + q * ZQ);
 #pragma unroll
@@ -222,7 +223,10 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
         const int* sseg = sseg_all + (j & 1) * BM;
         const bool fc = sflag[(j & 1) * 2] != 0, lc = sflag[(j & 1) * 2 + 1] != 0;
         if (p.dbg & 1) return;
-        if constexpr (QUAD) { scan_quad(rep, sseg, fc, lc); return; }
+        if constexpr (QUAD) {                               // quad mode: the four CONSUMER waves scan (8 quad-rows each); the producers,
+            if constexpr (!is_producer) scan_quad(rep, sseg, fc, lc, IC<8>{}, wave);     // which are the critical path, go on staging
+            return;
+        }
         scan_pass(0, rep, sseg, fc, lc);
         auto more = [&](auto cbc) __attribute__((always_inline)) {
             pp_barrier();                            // previous pass scanned
@@ -380,7 +384,9 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 #pragma unroll 1
         for (int j = 0; j < n_my; ++j) {
             PP_TS(0); pp_barrier();                      // B_0
-            PP_TS(1); interval(IC<1>{}, j, IC<1>{}); PP_TS(2); pp_barrier();
+            // quad mode: chunk 1 of every tile but the first was staged while the consumers scanned the previous tile
+            if (!QUAD || j == 0) { PP_TS(1); interval(IC<1>{}, j, IC<1>{}); PP_TS(2); }
+            pp_barrier();
             PP_TS(3); interval(IC<2>{}, j, IC<1>{}); PP_TS(4); pp_barrier();
             PP_TS(5); interval(IC<3>{}, j, IC<1>{}); PP_TS(6); pp_barrier();
             if constexpr (NCHUNK == 8) {
@@ -389,10 +395,17 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
                 PP_TS(11); interval(IC<6>{}, j, IC<1>{}); PP_TS(12); pp_barrier();
                 PP_TS(13); interval(IC<7>{}, j, IC<1>{}); PP_TS(14); pp_barrier();
             }
-            PP_TS(15); interval(IC<0>{}, j, IC<0>{});       // next tile's chunk 0 (the last tile re-stages itself, unused)
-            PP_TS(16); pp_barrier();                     // E1
-            PP_TS(17); finish_tile(j, IC<1>{});
-            PP_TS(18); fetch_g(2, IC<0>{});                            // register set 0 refilled AFTER the scan (keeps it out of the scan's way)
+            if constexpr (QUAD) {
+                PP_TS(15); interval(IC<0>{}, j, IC<1>{});   // next tile's chunk 0 (the last tile re-stages itself, unused)
+                PP_TS(16); pp_barrier();                 // E1: chunk 7 is consumed, ring stage 1 is free
+                PP_TS(17); interval(IC<1>{}, j + 1, IC<1>{});          // next tile's chunk 1, under the consumers' scan
+                PP_TS(18);
+            } else {
+                PP_TS(15); interval(IC<0>{}, j, IC<0>{});
+                PP_TS(16); pp_barrier();                 // E1
+                PP_TS(17); finish_tile(j, IC<1>{});
+                PP_TS(18); fetch_g(2, IC<0>{});             // register set 0 refilled AFTER the scan (keeps it out of the scan's way)
+            }
         }
         if (!(amax < 65000.f)) *p.ovf = 1;
     } else {
