@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     constexpr int ZC = BN < 64 ? BN : 64;       // epilogue column block
     constexpr int ZLD = ZC + 1;
     constexpr int SM_MAIN = (BM + BN) * LDK;
-    constexpr int SM_Z = (MODE == MODE_STORE) ? 4 * EpilogueTile<NT>::FLOATS : BM * ZLD;    // store: per-wave transposition tiles
+    constexpr int SM_Z = (MODE == MODE_STORE) ? 4 * EpilogueTile<NT>::FLOATS      // store: per-wave transposition tiles
+                       : (MODE == MODE_EDGEMAX && BN == 32) ? BM * 36 : BM * ZLD;      // narrow EdgeConv: 16-byte Z rows
     constexpr int SM = SM_MAIN > SM_Z ? SM_MAIN : SM_Z;
     static_assert(BN % 32 == 0 && KC % 8 == 0, "tile shape");
     static_assert(PREC == PREC_F32 || KC % 32 == 0, "the split-fp16 LDS image is [hi 32 halves | lo 32 halves] per 32-column chunk");
@@ -301,6 +302,69 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         const int d0 = sseg[0];
         first_cont = p.rowptr[d0] < row0;
         if (row0 + BM < Etot) last_cont = p.rowptr[sseg[BM - 1] + 1] > row0 + BM;
+    }
+    if constexpr (MODE == MODE_EDGEMAX && BN == 32) {
+        // ---- narrow layers (H = 16, 32): the scan is half of the kernel if every thread walks a row group plus the tail
+        // of its last segment (17-row segments over 16-row groups: ~3x redundant reads). Here wave 0 lists the segment
+        // starts of the tile (two ballots over the 128 destination ids), and a slot of 8 threads -- 4 adjacent columns
+        // each, 16-byte LDS reads -- reduces exactly the rows of one segment, slots taking segments round-robin.
+        constexpr int ZL = 36;                      // floats per Z row (16-byte rows)
+        __shared__ int sstart[BM + 2];              // start row of segment k; [nseg] = BM
+        __shared__ int snseg;
+        __syncthreads();                            // main-loop reads done
+        {
+            const int col = tn * BN + l31;
+            const float b = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+            const float sc = (p.scale && col < p.N) ? p.scale[col] : 1.f;
+            const float sh = (p.shift && col < p.N) ? p.shift[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;     // MT = NT = 1 for BN = 32
+                float v = acc[0][0][r] + b;
+                if (p.relu) v = v > 0.f ? v : 0.f;
+                Z[rl * ZL + l31] = v * sc + sh;
+            }
+        }
+        if (wave == 0) {
+            const int r0 = lane, r1 = lane + 64;
+            const bool f0 = r0 == 0 || sseg[r0] != sseg[r0 - 1];
+            const bool f1 = sseg[r1] != sseg[r1 - 1];
+            const unsigned long long m0 = __ballot(f0), m1 = __ballot(f1);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (f0) sstart[__popcll(m0 & below)] = r0;
+            if (f1) sstart[__popcll(m0) + __popcll(m1 & below)] = r1;
+            if (lane == 0) { const int ns = __popcll(m0) + __popcll(m1); snseg = ns; sstart[ns] = BM; }
+        }
+        __syncthreads();
+        const int c4 = (tid & 7) * 4, slot = tid >> 3;                          // 8 threads x 4 columns per segment, 32 slots
+        const int col0 = tn * BN + c4;
+        if (col0 >= p.N) return;
+        const int nseg = snseg;
+        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col0;
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0 && col0 + 4 <= p.N;
+        for (int k = slot; k < nseg; k += 32) {
+            const int rs = sstart[k], re = sstart[k + 1];
+            const int sg = sseg[rs];
+            if (sg < 0) continue;                                               // rows past the last edge
+            f32x4 m = *reinterpret_cast<const f32x4*>(Z + rs * ZL + c4);
+            for (int r = rs + 1; r < re; ++r) {
+                const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ZL + c4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], z[q]);
+            }
+            float* o = obase + (size_t)sg * p.ldy;
+            const bool partial = (rs == 0 && first_cont) || (re == BM && last_cont);
+            if (partial) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (col0 + q < p.N) atomic_max_f32(o + q, m[q]);
+            } else if (vec_ok) {
+                *reinterpret_cast<f32x4*>(o) = m;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (col0 + q < p.N) o[q] = m[q];
+            }
+        }
+        return;
     }
     constexpr int NTP = ((ZC / 32) / WN) >= 1 ? ((ZC / 32) / WN) : 1;    // fragments per wave per pass
     constexpr int NPASS = NT / NTP;
