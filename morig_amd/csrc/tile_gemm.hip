@@ -112,6 +112,13 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
         if (row0 >= Etot) return;               // block-uniform
     }
     const int Mlim = EDGE_ROWS ? Etot : p.M;
+    // destination ids just outside the tile, fetched NOW (they decide in the epilogue whether the first / last segment
+    // is shared with a neighbouring tile; rowptr look-ups there would put two dependent global loads on its critical path)
+    int dprev = -2, dafter = -3;
+    if (MODE == MODE_EDGEMAX) {
+        if (row0 > 0) dprev = p.dstS[row0 - 1];
+        if (row0 + BM < Etot) dafter = p.dstS[row0 + BM];
+    }
 
     // ---- loader set-up -------------------------------------------------------------------
     const int lrow = tid / TPR, lkq = tid % TPR;
@@ -299,9 +306,8 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     bool first_cont = false, last_cont = false;
     if (MODE == MODE_EDGEMAX) {
         // sseg was written before the main loop; every thread passed >= 1 barrier since
-        const int d0 = sseg[0];
-        first_cont = p.rowptr[d0] < row0;
-        if (row0 + BM < Etot) last_cont = p.rowptr[sseg[BM - 1] + 1] > row0 + BM;
+        first_cont = sseg[0] == dprev;
+        last_cont = sseg[BM - 1] == dafter;
     }
     if constexpr (MODE == MODE_EDGEMAX && BN == 32) {
         // ---- narrow layers (H = 16, 32): the scan is half of the kernel if every thread walks a row group plus the tail
