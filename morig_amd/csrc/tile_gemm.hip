@@ -353,10 +353,14 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
             const int sg = sseg[rs];
             if (sg < 0) continue;                                               // rows past the last edge
             f32x4 m = *reinterpret_cast<const f32x4*>(Z + rs * ZL + c4);
-            for (int r = rs + 1; r < re; ++r) {
-                const f32x4 z = *reinterpret_cast<const f32x4*>(Z + r * ZL + c4);
+            for (int r = rs + 1; r < re; r += 4) {          // four independent reads in flight (rows past the end repeat the last)
+                f32x4 z[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], z[q]);
+                for (int u = 0; u < 4; ++u) z[u] = *reinterpret_cast<const f32x4*>(Z + min(r + u, re - 1) * ZL + c4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) m[q] = fmaxf(m[q], z[u][q]);
             }
             float* o = obase + (size_t)sg * p.ldy;
             const bool partial = (rs == 0 && first_cont) || (re == BM && last_cont);
