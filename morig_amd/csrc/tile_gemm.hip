@@ -106,19 +106,30 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
     const int row0 = tm * BM;
 
     constexpr bool EDGE_ROWS = (LOAD == LOAD_EDGE) || (MODE == MODE_EDGEMAX);   // tile rows = sorted edges
+    // Edge tiles: the edge count, this thread's edge ids and the ids just outside the tile are all fetched before anything
+    // waits (rows are clamped to the arrays' capacity p.M, validity is applied afterwards): ONE memory latency at tile
+    // start instead of a chain of two or three. The neighbour ids decide in the epilogue whether the first / last
+    // segment is shared with another tile (rowptr look-ups there were two dependent global loads on its critical path).
     int Etot = 0;
+    int dprev = -2, dafter = -3;
+    int ld_d[BM / (256 / (KC / 4))], ld_s[BM / (256 / (KC / 4))];
     if (EDGE_ROWS) {
         Etot = p.rowptr[p.n_nodes];
+        const int lr = tid / (KC / 4);
+#pragma unroll
+        for (int i = 0; i < BM / (256 / (KC / 4)); ++i) {
+            const int rc = min(row0 + lr + i * (256 / (KC / 4)), p.M - 1);
+            ld_d[i] = p.dstS[rc];
+            ld_s[i] = (LOAD == LOAD_EDGE) ? p.srcS[rc] : 0;
+        }
+        if (MODE == MODE_EDGEMAX) {
+            const int dp = p.dstS[max(row0 - 1, 0)], da = p.dstS[min(row0 + BM, p.M - 1)];
+            if (row0 > 0) dprev = dp;
+            if (row0 + BM < Etot) dafter = da;
+        }
         if (row0 >= Etot) return;               // block-uniform
     }
     const int Mlim = EDGE_ROWS ? Etot : p.M;
-    // destination ids just outside the tile, fetched NOW (they decide in the epilogue whether the first / last segment
-    // is shared with a neighbouring tile; rowptr look-ups there would put two dependent global loads on its critical path)
-    int dprev = -2, dafter = -3;
-    if (MODE == MODE_EDGEMAX) {
-        if (row0 > 0) dprev = p.dstS[row0 - 1];
-        if (row0 + BM < Etot) dafter = p.dstS[row0 + BM];
-    }
 
     // ---- loader set-up -------------------------------------------------------------------
     const int lrow = tid / TPR, lkq = tid % TPR;
@@ -134,14 +145,14 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : 1)) voi
             pa[i] = p.X + (size_t)(va[i] ? row : 0) * p.ldx + 4 * lkq;
             pb[i] = nullptr;
             if (MODE == MODE_EDGEMAX) {
-                if (lkq == 0) sseg[r] = va[i] ? p.dstS[row] : -1;
+                if (lkq == 0) sseg[r] = va[i] ? ld_d[i] : -1;
             } else if (MODE != MODE_STORE || p.seg != nullptr) {
                 if (lkq == 0) sseg[r] = (va[i] && p.seg) ? p.seg[row] : -1;
             }
         } else {
             va[i] = row < Etot;
-            const int d = va[i] ? p.dstS[row] : -1;
-            const int s = va[i] ? p.srcS[row] : 0;
+            const int d = va[i] ? ld_d[i] : -1;
+            const int s = va[i] ? ld_s[i] : 0;
             const size_t base = (size_t)rep * p.rep_in;
             pa[i] = p.A + (base + (va[i] ? d : 0)) * p.lda + 4 * lkq;
             pb[i] = p.B + (base + s) * p.ldb + 4 * lkq;
