@@ -71,7 +71,7 @@ static int debug_flags() {
 // The narrow EdgeConv tiles are latency chains (ids -> gathers -> one or two K-chunks -> scan): occupancy is what hides
 // them, so their register budget is capped for 4 (fp32, KC = 16: 6) waves per SIMD (measured -17..21 % at H = 32).
 template <int BN, int KC, int LOAD, int MODE, int PREC>
-__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD == LOAD_EDGE) ? (PREC == PREC_F16X3 ? 4 : 6) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : 1)) void tile_kernel(const TileParams p) {
+__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD == LOAD_EDGE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : 1)) void tile_kernel(const TileParams p) {
     constexpr int BM = 128;
     constexpr int WN = (BN >= 128) ? 2 : 1;
     constexpr int WM = 4 / WN;
