@@ -72,7 +72,8 @@ static int debug_flags() {
 // them, so their register budget is capped for 4 (fp32, KC = 16: 6) waves per SIMD (measured -17..21 % at H = 32).
 // The dense fp32-X GEMM tile (BN = 128, KC = 32) likewise runs better at 3 waves per SIMD than at 2.
 template <int BN, int KC, int LOAD, int MODE, int PREC>
-__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD == LOAD_EDGE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE == MODE_STORE && PREC == PREC_F16X3) ? 3 : 1)) void tile_kernel(const TileParams p) {
+__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD == LOAD_EDGE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC == PREC_F16X3) ? 3 :
+                               (BN == 64 && LOAD == LOAD_DENSE && MODE == MODE_STORE && PREC == PREC_F16X3) ? 4 : 1)) void tile_kernel(const TileParams p) {
     constexpr int BM = 128;
     constexpr int WN = (BN >= 128) ? 2 : 1;
     constexpr int WM = 4 / WN;
@@ -582,7 +583,7 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         p.Y = a->pool; p.ldy = a->ld_pool;
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_POOL : K_GEMM_POOL, s, flops, bytes);
-        if (f16 && kc64) return launch_tile<128, 64, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
+        if (f16 && kc64 && getenv("MORIG_KC64")) return launch_tile<128, 64, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
         return f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
                    : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
     }
