@@ -9,6 +9,7 @@
 // changes, and the result leaves as 16-byte stores, 1 KB per wave instruction.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 namespace morig {
 
@@ -53,8 +54,25 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDT + nt * 32 + l31] = acc[mt][nt][r];
         const int nit = y16 ? 32 / RPI16 : 32 / RPI;
-        for (int it = 0; it < nit; ++it) {
-            const int rloc = it * (y16 ? RPI16 : RPI) + rsel;         // row inside the 32-row slab
+        const int rstep = y16 ? RPI16 : RPI;
+        // The copy-out loop must contain NO global load: vmcnt counts loads and stores in order, so waiting for a row-bias
+        // load issued after the previous row's stores waits for those stores too (measured: ~0.7 us per row pass, the whole
+        // cost of this epilogue). `seg` is sorted, so the rows of a slab share one mesh id unless the slab straddles a mesh
+        // boundary: the row bias is fetched once, before the loop; only straddling slabs take the per-row path.
+        bool per_row = false;
+        if (p.rowbias) {
+            const int rl0 = rl_base + mt * 32 + rsel;
+            const int sg0 = sseg[rl0], sg1 = sseg[rl0 + (nit - 1) * rstep];
+            if (sg0 != sg1) per_row = true;
+            else if (sg0 != rb_seg) {
+                rb_seg = sg0;
+#pragma unroll
+                for (int q = 0; q < NV; ++q)
+                    rbv[q] = (q < nv && col0 + q < p.N) ? p.rowbias[(size_t)sg0 * p.ld_rowbias + col0 + q] : 0.f;
+            }
+        }
+        auto pass = [&](int it, auto check_seg) __attribute__((always_inline)) {
+            const int rloc = it * rstep + rsel;                       // row inside the 32-row slab
             const int rl = rl_base + mt * 32 + rloc;                  // row inside the block tile
             const int row = row0 + rl;
             float v[NV];
@@ -66,8 +84,8 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
                     v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
                 }
             }
-            if (row >= Mlim) continue;
-            if (p.rowbias) {
+            if (row >= Mlim) return;
+            if constexpr (decltype(check_seg)::value) {
                 const int sg = sseg[rl];
                 if (sg != rb_seg) {
                     rb_seg = sg;
@@ -78,8 +96,7 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
             }
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                float x = v[q] + cb[q];
-                if (p.rowbias) x += rbv[q];
+                float x = v[q] + cb[q] + rbv[q];                     // rbv stays 0 without a row bias
                 if (p.relu) x = x > 0.f ? x : 0.f;
                 v[q] = x * cs[q] + ch[q];
             }
@@ -109,7 +126,9 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
                     }
                 }
             }
-        }
+        };
+        if (!per_row) { for (int it = 0; it < nit; ++it) pass(it, std::false_type{}); }
+        else          { for (int it = 0; it < nit; ++it) pass(it, std::true_type{}); }
     }
     if (ovf) *p.ovf = 1;
 }
