@@ -210,7 +210,9 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
         hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2>), dim3(nb), dim3(512), 0, s, p);
     } else {
         p.tiles_n = cdiv(p.N, 128);
-        hipLaunchKernelGGL((gemm16_dma_kernel<128, 128, 2, 4>), dim3(tiles_m128 * p.tiles_n), dim3(256), 0, s, p);
+        // 2-stage ring = 64 KB: TWO workgroups per CU, one's prologue / epilogue under the other's main loop
+        // (measured 25 % faster than a 4-stage ring at one workgroup per CU)
+        hipLaunchKernelGGL((gemm16_dma_kernel<128, 128, 2, 2>), dim3(tiles_m128 * p.tiles_n), dim3(256), 0, s, p);
     }
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
