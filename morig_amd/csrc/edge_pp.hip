@@ -223,8 +223,13 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
         const int* sseg = sseg_all + (j & 1) * BM;
         const bool fc = sflag[(j & 1) * 2] != 0, lc = sflag[(j & 1) * 2 + 1] != 0;
         if (p.dbg & 1) return;
-        if constexpr (QUAD) {                               // quad mode: the four CONSUMER waves scan (8 quad-rows each); the producers,
-            if constexpr (!is_producer) scan_quad(rep, sseg, fc, lc, IC<8>{}, wave);     // which are the critical path, go on staging
+        if constexpr (QUAD && H == 128) {                   // the consumer waves scan 6 quad-rows each; the producers, which are the
+            if constexpr (!is_producer) scan_quad(rep, sseg, fc, lc, IC<6>{}, wave);     // critical path, stage the next tile's
+            else scan_quad(rep, sseg, fc, lc, IC<2>{}, 12 + (wave - 4));                 // chunk 1 first and then take 2 each
+            return;
+        }
+        if constexpr (QUAD) {                               // H = 256: the consumers scan alone (8 each), the producers only stage
+            if constexpr (!is_producer) scan_quad(rep, sseg, fc, lc, IC<8>{}, wave);
             return;
         }
         scan_pass(0, rep, sseg, fc, lc);
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
                 PP_TS(15); interval(IC<0>{}, j, IC<1>{});   // next tile's chunk 0 (the last tile re-stages itself, unused)
                 PP_TS(16); pp_barrier();                 // E1: chunk 7 is consumed, ring stage 1 is free
                 PP_TS(17); interval(IC<1>{}, j + 1, IC<1>{});          // next tile's chunk 1, under the consumers' scan
-                PP_TS(18);
+                PP_TS(18); if constexpr (H == 128) finish_tile(j, IC<1>{});
             } else {
                 PP_TS(15); interval(IC<0>{}, j, IC<0>{});
                 PP_TS(16); pp_barrier();                 // E1
