@@ -47,6 +47,7 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
     }
     int rb_seg = -1;
     bool ovf = false;
+    const float lo_bound = p.relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -71,6 +72,9 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
                     rbv[q] = (q < nv && col0 + q < p.N) ? p.rowbias[(size_t)sg0 * p.ld_rowbias + col0 + q] : 0.f;
             }
         }
+        float cbr[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) cbr[q] = cb[q] + rbv[q];        // rbv stays 0 without a row bias
         auto pass = [&](int it, auto check_seg) __attribute__((always_inline)) {
             const int rloc = it * rstep + rsel;                       // row inside the 32-row slab
             const int rl = rl_base + mt * 32 + rloc;                  // row inside the block tile
@@ -96,9 +100,9 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
             }
 #pragma unroll
             for (int q = 0; q < NV; ++q) {
-                float x = v[q] + cb[q] + rbv[q];                     // rbv stays 0 without a row bias
-                if (p.relu) x = x > 0.f ? x : 0.f;
-                v[q] = x * cs[q] + ch[q];
+                float add = cb[q];
+                if constexpr (decltype(check_seg)::value) add += rbv[q]; else add = cbr[q];   // bias + row bias, pre-added per slab
+                v[q] = fmaxf(v[q] + add, lo_bound) * cs[q] + ch[q];                          // ReLU as a lower bound (-inf: none)
             }
             if (!y16) {
                 float* o = p.Y + (size_t)row * p.ldy + col0;
@@ -106,14 +110,16 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
                 else { for (int q = 0; q < VW; ++q) if (col0 + q < p.N) o[q] = v[q]; }
             } else if constexpr (ALLOW16) {
                 // split layout: each 32-column chunk is [32 hi halves | 32 lo halves]; my 8 columns never straddle a chunk.
-                // Both parts round to nearest even (as the loaders of the next layer expect)
+                // hi = fp16(v) truncated (one v_cvt_pkrtz per pair), lo = fp16(v - hi) rounded to nearest: hi + lo == v to ~2^-22
+                typedef __fp16 ep_h2 __attribute__((ext_vector_type(2)));
                 ep_f16x8 hv, lv;
                 float am = 0.f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const __fp16 h = (__fp16)v[q];
-                    hv[q] = (_Float16)h; lv[q] = (_Float16)(__fp16)(v[q] - (float)h);
-                    am = fmaxf(am, fabsf(v[q]));
+                for (int q = 0; q < 8; q += 2) {
+                    const ep_h2 h = __builtin_amdgcn_cvt_pkrtz(v[q], v[q + 1]);
+                    hv[q] = (_Float16)h[0]; hv[q + 1] = (_Float16)h[1];
+                    lv[q] = (_Float16)(v[q] - (float)h[0]); lv[q + 1] = (_Float16)(v[q + 1] - (float)h[1]);
+                    am = fmaxf(am, fmaxf(fabsf(v[q]), fabsf(v[q + 1])));
                 }
                 if (!(am < 65000.f)) ovf = true;
                 char* o = reinterpret_cast<char*>(p.Y + (size_t)row * p.ldy) + (col0 >> 5) * 128 + (col0 & 31) * 2;
