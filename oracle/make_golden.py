@@ -55,10 +55,41 @@ def ragged_batch(seeds_sides, n_pts=0):
     return synth.collate(meshes, clouds)
 
 
+def deformnet_fixtures(ref):
+    """DeformNet (models/deformnet.py) -- SURVEY 8(f-1). The reference calls its CorrNet with the default
+    random_start=True (:41): the FPS start indices come from torch's global RNG, one draw per cloud per SA level
+    in order, so the fixture records the seed set right before the forward."""
+    print("deformnet fixtures")
+    kw = dict(tau_nce=0.07, num_interp=5)
+    for name, spec, n_pts, rseed in (("deformnet_ragged", [(41, 16), (42, 12)], 768, 501),
+                                     ("deformnet_three", [(43, 10), (44, 14), (45, 8)], 512, 502)):
+        cb = ragged_batch(spec, n_pts=n_pts)
+        m = ref.__dict__["deformnet"](**kw).eval()
+        # The visible / invisible split (mask >= 0.5, :57-58) is a discrete decision: keep fixtures whose masks stay
+        # clear of the threshold by more than the product's fp32 tolerance, so parity does not hinge on one rounding.
+        for attempt in range(32):
+            synth.load_recipe(m, rseed, mild=True)
+            rng_seed = 1000 + rseed
+            with shim.pretend_cuda_available():
+                torch.manual_seed(rng_seed)
+                pf, vf, ptf, vis, tau = m(cb)
+            if float((vis - 0.5).abs().min()) > 5e-4:
+                break
+            rseed += 10
+        else:
+            raise RuntimeError("no recipe seed with a clear visibility split")
+        inputs = _batch_arrays(cb, with_pts=True)
+        inputs.pop("pred_flow")                              # the synthetic jointnet input; DeformNet PRODUCES pred_flow
+        _save(name, dict(recipe_seed=rseed, mild=True, arch="deformnet", kwargs=kw, rng_seed=rng_seed),
+              out_pred_flow=pf, vtx_feature=vf, pts_feature=ptf, pred_vismask=vis, tau=tau, **inputs)
+
+
 def main():
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     ref = shim.import_reference_models()
+    if len(sys.argv) > 1 and sys.argv[1] == "deformnet":      # only the (f-1) fixtures; the others stay byte-identical
+        return deformnet_fixtures(ref)
     bm = sys.modules["models.basic_modules"]
     rn = sys.modules["models.rignet"]
 
@@ -177,6 +208,8 @@ def main():
     _save("jointnet_4k", dict(recipe_seed=401, mild=True, arch="jointnet_motion", kwargs=kw, mesh_seed=31,
                               n_side=64), motion_aggr=mg, pred_shift=ps,
           pos_check=big.pos[:8], geo_check=big.geo_edge_index[:, :32])
+
+    deformnet_fixtures(ref)
 
     # ---- writers (utils/io_utils.py:41-55, training/train_rig.py:253-258) ---------------
     print("writer fixtures")

@@ -360,6 +360,65 @@ class CorrNet(nn.Module):
         return out_vtx, out_pts, vis, self.temprature
 
 
+class DeformGCN(nn.Module):
+    """``GCNDeform`` (models/deformnet.py:13-32): GCNRig's wiring at widths 128/256/512; note the
+    argument order (geo before tpl) and the attribute name ``mlp_tramsform`` (sic)."""
+
+    def __init__(self, chn_in: int, chn_output: int):
+        super().__init__()
+        self.gcu_1 = GraphConvUnitMotion(chn_in, 128)
+        self.gcu_2 = GraphConvUnitMotion(128, 256)
+        self.gcu_3 = GraphConvUnitMotion(256, 512)
+        self.mlp_glb = mlp_stack([128 + 256 + 512, 1024])
+        self.mlp_tramsform = nn.Sequential(mlp_stack([1024 + 3 + chn_in + 896, 1024, 256]), nn.Linear(256, chn_output))
+
+    def forward(self, pos, feature, geo, tpl, batch):
+        a = self.gcu_1(pos, feature, tpl, geo)
+        b = self.gcu_2(pos, a, tpl, geo)
+        c = self.gcu_3(pos, b, tpl, geo)
+        g = _pool_and_broadcast(self.mlp_glb(torch.cat([a, b, c], dim=1)), batch)
+        return self.mlp_tramsform(torch.cat([g, pos, feature, a, b, c], dim=1))
+
+
+def _vote(values: torch.Tensor, weights: torch.Tensor, target: torch.Tensor, n: int) -> torch.Tensor:
+    """scatter_add(values * w) / scatter_add(w) over the neighbours of every target (deformnet.py:54,94);
+    a target without neighbours (or whose weights sum to 0) gets 0/0 = NaN, as in the reference."""
+    return P.scatter_add(values * weights, target, dim=0, dim_size=n) / P.scatter_add(weights, target, dim=0, dim_size=n)
+
+
+class DeformNet(nn.Module):
+    """models/deformnet.py:35-99: CorrNet features -> sigmoid visibility, min-max normalised per mesh (:42-46) ->
+    flow of visible vertices voted from their ``num_interp`` most similar points (:49-54) -> flow of invisible
+    vertices voted from their most similar *visible* vertices (:57-95) -> GCNDeform on [flow_init | vismask] (:97-98)."""
+
+    def __init__(self, tau_nce, num_interp):
+        super().__init__()
+        self.corr_extractor = CorrNet(3, 64, temprature=tau_nce)
+        self.completing = DeformGCN(chn_in=4, chn_output=3)
+        self.num_interp = num_interp
+
+    def forward(self, data):
+        vtx_f, pts_f, vis, tau = self.corr_extractor(data, True)          # random_start defaults to True (:41)
+        vis = torch.sigmoid(vis)
+        for s, e in P._segments(data.vtx_batch):
+            m = vis[s:e]
+            vis[s:e] = (m - m.min()) / (m.max() - m.min())
+        n, k = vtx_f.shape[0], self.num_interp
+        yi, xi = P.knn(pts_f, vtx_f, k, data.pts_batch, data.vtx_batch, cosine=True)
+        sim = (pts_f[xi] * vtx_f[yi]).sum(dim=-1, keepdim=True) * vis[yi]
+        flow = _vote(data.pts[xi] - data.vtx[yi], sim, yi, n)
+        seen = (vis >= 0.5).squeeze(1)
+        hidden = (vis < 0.5).squeeze(1)                                   # NaN masks fall in neither set
+        seen_ids, hidden_ids = torch.nonzero(seen).squeeze(1), torch.nonzero(hidden).squeeze(1)
+        if hidden_ids.numel():
+            yi2, xi2 = P.knn(vtx_f[seen], vtx_f[hidden], k, data.vtx_batch[seen], data.vtx_batch[hidden], cosine=True)
+            sim2 = (vtx_f[seen][xi2] * vtx_f[hidden][yi2]).sum(dim=-1, keepdim=True)
+            flow[hidden_ids] = _vote(flow[seen_ids][xi2], sim2, yi2, hidden_ids.numel())
+        pred = self.completing(data.vtx, torch.cat([flow, vis], dim=-1), data.geo_edge_index, data.tpl_edge_index,
+                               data.vtx_batch)
+        return pred, vtx_f, pts_f, vis, tau
+
+
 # ----------------------------------------------------------------------------- factories
 def jointnet_motion(**kw):
     return JointNetMotion(kw["num_keyframes"], kw["chn_output"], kw["aggr_method"])
@@ -376,3 +435,7 @@ def skinnet_motion(**kw):
 
 def corrnet(**kw):
     return CorrNet(kw["input_feature"], kw["output_feature"], kw["temprature"])
+
+
+def deformnet(**kw):
+    return DeformNet(kw["tau_nce"], kw["num_interp"])

@@ -124,3 +124,32 @@ def test_headline_size_fixture_inputs_regenerate():
     assert torch.equal(mesh.pos[:8], a["pos_check"])
     assert torch.equal(mesh.geo_edge_index[:, :32], a["geo_check"])
     assert mesh.pos.shape[0] == 4096 and mesh.tpl_edge_index.shape[1] == 24576 + 4096
+
+
+@pytest.mark.parametrize("name", ["deformnet_ragged", "deformnet_three"])
+def test_deformnet(name):
+    """models/deformnet.py. The reference's CorrNet call uses random FPS starts (default
+    random_start=True, deformnet.py:41): the fixture records the torch seed set right before its forward."""
+    meta, a = load_golden(name)
+    m = _net(meta)
+    d = data_from(a)
+    torch.manual_seed(meta["rng_seed"])
+    pf, vf, ptf, vis, tau = m(d)
+    assert maxdiff(vf, a["vtx_feature"]) <= TOL and maxdiff(ptf, a["pts_feature"]) <= TOL
+    assert maxdiff(vis, a["pred_vismask"]) <= 1e-5
+    # every mesh: the normalised mask spans [0, 1] exactly, and the fixture keeps a margin around the 0.5 split
+    for b in range(int(a["batch"].max()) + 1):
+        v = a["pred_vismask"][a["batch"] == b]
+        assert float(v.min()) == 0.0 and float(v.max()) == 1.0
+    assert float((a["pred_vismask"] - 0.5).abs().min()) > 5e-4
+    assert maxdiff(pf, a["out_pred_flow"]) <= 2e-5
+    assert float(tau) == pytest.approx(0.07)
+
+
+def test_deformnet_state_dict_contract():
+    m = nets.deformnet(tau_nce=0.07, num_interp=5)
+    sd = m.state_dict()
+    assert len([k for k in sd if k.startswith("corr_extractor.")]) == 336
+    assert tuple(sd["completing.gcu_1.edge_conv_tpl.nn_x.0.0.weight"].shape) == (64, 8)
+    assert tuple(sd["completing.mlp_tramsform.0.0.0.weight"].shape) == (1024, 1024 + 3 + 4 + 896)
+    assert tuple(sd["completing.mlp_tramsform.1.weight"].shape) == (3, 256)
