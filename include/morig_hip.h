@@ -236,6 +236,26 @@ int morig_knn_interpolate(const float* feat, int32_t ldf, int32_t C, const float
 int morig_cosine_nn(const float* v, int32_t ldv, const int32_t* ptr_v, const float* p, int32_t ldp,
                     const int32_t* ptr_p, int32_t n_clouds, int32_t max_rows_per_cloud, int32_t C,
                     int32_t* nn, float* sim, void* stream);
+/* ---- DeformNet glue (/root/reference/models/deformnet.py) ----
+ * pred_vismask = sigmoid(logit), then (m - min) / (max - min) per mesh (deformnet.py:42-46). ptr: [n_meshes + 1]
+ * vertex offsets. A constant mask gives 0/0 = NaN, as the reference. */
+int morig_sigmoid_minmax(const float* x, int32_t ldx, const int32_t* ptr, int32_t n_meshes, float* out, int32_t ldo,
+                         void* stream);
+/* knn(x, y, k, batch_x, batch_y, cosine=True) on L2-normalised rows (deformnet.py:49 and :92), 1 <= k <= 8, C must
+ * be 64: idx[i][t] = global x row of the t-th most similar candidate of the same cloud (lowest index on ties), -1 where
+ * there are fewer than k. split = 1 (x == y, ptr_x == ptr_y, vis required): rows with vis < 0.5 query the rows with
+ * vis >= 0.5 -- the visible / invisible partition of :57-63 without the compaction; other rows get -1. */
+int morig_cosine_knn(const float* y, int32_t ldy, const int32_t* ptr_y, const float* x, int32_t ldx,
+                     const int32_t* ptr_x, int32_t n_clouds, int32_t max_rows_per_cloud, int32_t C, int32_t k,
+                     const float* vis, int32_t ld_vis, int32_t split, int32_t* idx, void* stream);
+/* scatter_add(v * w) / scatter_add(w) over the k neighbours of every vertex (deformnet.py:50-54 and :93-95); l1 rows
+ * are [flow(3) | vis] = the feature of GCNDeform (:97).
+ *   mode 0: every vertex i, w = <feat_s[j], feat_q[i]> * vis[i], v = pos_s[j] - pos_q[i]; also writes l1[i][3] = vis[i]
+ *   mode 1: vertices with vis < 0.5, w = <feat_s[j], feat_q[i]>, v = l1[j][0:3] (the flow of visible vertex j). */
+int morig_flow_vote(int32_t mode, const int32_t* idx, int32_t k, int32_t n, const float* feat_q, int32_t ldq,
+                    const float* feat_s, int32_t lds, int32_t C, const float* pos_q, int32_t ldpq,
+                    const float* pos_s, int32_t ldps, const float* vis, int32_t ld_vis, float* l1, int32_t ld_l1,
+                    void* stream);
 /* dst[r] = src[idx[r]] (pos[idx], out_pts[nn]); idx < 0 -> zeros */
 int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t rows, int32_t cols,
                       float* dst, int32_t ldd, void* stream);

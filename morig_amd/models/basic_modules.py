@@ -71,7 +71,12 @@ class NativeModule(torch.nn.Module):
         self._require_eval()
         ops = get_ops()
         dev = next(self.parameters()).device
-        return ops.guarded(dev, lambda: self._forward(*args, **kwargs))
+        rng = torch.get_rng_state()                    # random FPS starts: a repeated attempt draws the same ones
+
+        def attempt():
+            torch.set_rng_state(rng)
+            return self._forward(*args, **kwargs)
+        return ops.guarded(dev, attempt)
 
     def _forward(self, *args, **kwargs):
         raise NotImplementedError

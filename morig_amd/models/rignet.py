@@ -85,20 +85,36 @@ class TemporalAttn(NativeModule):
 
 
 class GCNRig(NativeModule):
-    """models/rignet.py:49-67."""
+    """models/rignet.py:49-67 (and, through ``WIDTHS`` / ``TRANSFORM``, the identically wired
+    ``GCNDeform`` of models/deformnet.py:13-32, see morig_amd/models/deformnet.py)."""
 
-    # wide activation buffer: [x_1 64 | x_2 256 | x_3 512 | pos slot 32 (xyz, zeros) | feature slot roundup32(F)];
+    # wide activation buffer: [x_1 | x_2 | x_3 | pos slot 32 (xyz, zeros) | feature slot roundup32(F)];
     # every window starts on a 32-column chunk so the buffer can be kept in the split-fp16 layout
-    X1, X2, X3, POS, FEAT = 0, 64, 320, 832, 864
+    WIDTHS = (64, 256, 512)
+    TRANSFORM = "mlp_transform"
 
     def __init__(self, chn_feature, chn_output, aggr="max"):
         super().__init__()
         self.chn_feature, self.chn_output = chn_feature, chn_output
-        self.gcu_1 = GCUMotion(in_channels=chn_feature, out_channels=64, dim_pos_feat=16, aggr=aggr)
-        self.gcu_2 = GCUMotion(in_channels=64, out_channels=256, dim_pos_feat=16, aggr=aggr)
-        self.gcu_3 = GCUMotion(in_channels=256, out_channels=512, dim_pos_feat=16, aggr=aggr)
-        self.mlp_glb = MLP([(64 + 256 + 512), 1024])
-        self.mlp_transform = Sequential(MLP([1024 + 3 + chn_feature + 64 + 256 + 512, 1024, 256]), Linear(256, chn_output))
+        w1, w2, w3 = self.WIDTHS
+        self.gcu_1 = GCUMotion(in_channels=chn_feature, out_channels=w1, dim_pos_feat=16, aggr=aggr)
+        self.gcu_2 = GCUMotion(in_channels=w1, out_channels=w2, dim_pos_feat=16, aggr=aggr)
+        self.gcu_3 = GCUMotion(in_channels=w2, out_channels=w3, dim_pos_feat=16, aggr=aggr)
+        self.mlp_glb = MLP([(w1 + w2 + w3), 1024])
+        setattr(self, self.TRANSFORM,
+                Sequential(MLP([1024 + 3 + chn_feature + w1 + w2 + w3, 1024, 256]), Linear(256, chn_output)))
+
+    # column offsets inside the wide buffer
+    @property
+    def X1(self): return 0
+    @property
+    def X2(self): return self.WIDTHS[0]
+    @property
+    def X3(self): return self.WIDTHS[0] + self.WIDTHS[1]
+    @property
+    def POS(self): return sum(self.WIDTHS)
+    @property
+    def FEAT(self): return sum(self.WIDTHS) + 32
 
     @property
     def feat_slot(self):
@@ -110,17 +126,18 @@ class GCNRig(NativeModule):
 
     def _pack(self):
         F = self.chn_feature
-        l1 = self.mlp_transform[0][0]
+        tr = getattr(self, self.TRANSFORM)
+        l1 = tr[0][0]
         W = l1[0].weight.detach()
-        # reference column order of mlp_transform's input (:65): [x_global(1024) | pos(3) | feature(F) | x_1 x_2 x_3(832)]
+        # reference column order of the transform's input (:65): [x_global(1024) | pos(3) | feature(F) | x_1 x_2 x_3]
         Wg, Wrest = W[:, :1024], W[:, 1024:]
-        in_cols = ([self.POS + i for i in range(3)] + [self.FEAT + i for i in range(F)] + list(range(832)))
+        in_cols = ([self.POS + i for i in range(3)] + [self.FEAT + i for i in range(F)] + list(range(self.POS)))
         return dict(
             glb=packing.pack_mlp_layer(self.mlp_glb[0]),
             g=packing.pack_linear(Wg),                                   # x_global @ Wg^T  -> per-mesh row bias
             t1=packing.pack_linear(Wrest, l1[0].bias, l1[2], in_cols=in_cols, k_total=self.FEAT + F),
-            t2=packing.pack_mlp_layer(self.mlp_transform[0][1]),
-            t3=packing.pack_linear(self.mlp_transform[1].weight, self.mlp_transform[1].bias),
+            t2=packing.pack_mlp_layer(tr[0][1]),
+            t3=packing.pack_linear(tr[1].weight, tr[1].bias),
         )
 
     def run(self, ops, pos4: torch.Tensor, write_feature, csr_tpl, csr_geo, seg: torch.Tensor, n_graphs: int,
@@ -137,15 +154,15 @@ class GCNRig(NativeModule):
             ops.copy2d_pad(Mat.of(pos4), Mat.of(wide, self.POS, 32, r * n, n), split=sp)
         write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
-        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, 64), R, split=sp)
+        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp)
         # the 128- and 256-wide layers take the geo graph with 4-aligned segments (quad-reduced epilogue of the
         # wave-specialised kernel: measured +12..18 % there; on the tpl graph, in-degree 7 -> 8, and on the narrow
         # layers the padding costs more than it saves)
         cg = csr_geo_wide or csr_geo
-        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, 64), csr_tpl, cg, Mat.of(wide, self.X2, 256), R, split=sp)
-        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, 256), csr_tpl, cg, Mat.of(wide, self.X3, 512), R, split=sp)
+        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, self.WIDTHS[0]), csr_tpl, cg, Mat.of(wide, self.X2, self.WIDTHS[1]), R, split=sp)
+        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, self.WIDTHS[1]), csr_tpl, cg, Mat.of(wide, self.X3, self.WIDTHS[2]), R, split=sp)
         pooled = ops.empty(R * n_graphs, 1024, dev)
-        ops.gemm(Mat.of(wide, 0, 832), pk["glb"], relu=True, seg=seg, pool=pooled, x_split=sp)
+        ops.gemm(Mat.of(wide, 0, self.POS), pk["glb"], relu=True, seg=seg, pool=pooled, x_split=sp)
         gb = ops.empty(R * n_graphs, 1024, dev)
         ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
         h1 = ops.empty(M, 1024, dev)

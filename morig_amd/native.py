@@ -85,6 +85,11 @@ _SIGNATURES = {
     "morig_knn_interpolate": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_cosine_nn": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
+    "morig_sigmoid_minmax": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_cosine_knn": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
+    "morig_flow_vote": (C.c_int, [C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
+                                   c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_gather_rows": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_copy2d": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -425,6 +430,38 @@ class NativeOps:
         check(self.lib.morig_cosine_nn(v.ptr, v.ld, _p(ptr_v), p.ptr, p.ld, _p(ptr_p), n_clouds, max_rows_per_cloud, v.cols,
                                        _p(nn), _p(sim), _stream()), "morig_cosine_nn")
         return nn, sim
+
+    # -- DeformNet glue (csrc/deform.hip) ----------------------------------------------------------------
+    def sigmoid_minmax(self, x: Mat, ptr: torch.Tensor, n_meshes: int, out: Mat):
+        """out = per-mesh min-max normalised sigmoid(x) (one column)."""
+        _need_gpu(x.base, ptr, out.base)
+        assert x.cols == 1 and out.cols == 1 and x.rows == out.rows and ptr.dtype == torch.int32
+        check(self.lib.morig_sigmoid_minmax(x.ptr, x.ld, _p(ptr), n_meshes, out.ptr, out.ld, _stream()), "morig_sigmoid_minmax")
+
+    def cosine_knn(self, y: Mat, ptr_y: torch.Tensor, x: Mat, ptr_x: torch.Tensor, n_clouds: int, max_rows_per_cloud: int,
+                   k: int, vis: Mat = None, split: bool = False):
+        """idx [y.rows, k] int32: the k most similar x rows of the same cloud per y row (-1 padded);
+        split: rows with vis < 0.5 query rows with vis >= 0.5 of the same matrix."""
+        _need_gpu(y.base, x.base, ptr_y, ptr_x)
+        assert ptr_y.dtype == torch.int32 and ptr_x.dtype == torch.int32 and y.cols == x.cols
+        idx = torch.empty((y.rows, k), dtype=torch.int32, device=y.base.device)
+        if split:
+            assert vis is not None and x.ptr == y.ptr
+            ptr_x = ptr_y
+        check(self.lib.morig_cosine_knn(y.ptr, y.ld, _p(ptr_y), x.ptr, x.ld, _p(ptr_x), n_clouds, max_rows_per_cloud, y.cols, k,
+                                        vis.ptr if vis is not None else None, vis.ld if vis is not None else 0, int(split),
+                                        _p(idx), _stream()), "morig_cosine_knn")
+        return idx
+
+    def flow_vote(self, mode: int, idx: torch.Tensor, feat_q: Mat, feat_s: Mat, pos_q, pos_s, vis: Mat, l1: Mat):
+        """similarity-weighted voting into l1 = [flow(3) | vis]; mode 0: from points (pos_s - pos_q), all vertices;
+        mode 1: invisible vertices from the flow of their visible neighbours."""
+        _need_gpu(idx, feat_q.base, feat_s.base, vis.base, l1.base)
+        assert idx.dtype == torch.int32 and idx.dim() == 2 and idx.shape[0] == feat_q.rows and l1.cols >= 4
+        check(self.lib.morig_flow_vote(mode, _p(idx), idx.shape[1], feat_q.rows, feat_q.ptr, feat_q.ld, feat_s.ptr, feat_s.ld,
+                                       feat_q.cols, pos_q.ptr if pos_q is not None else None, pos_q.ld if pos_q is not None else 0,
+                                       pos_s.ptr if pos_s is not None else None, pos_s.ld if pos_s is not None else 0,
+                                       vis.ptr, vis.ld, l1.ptr, l1.ld, _stream()), "morig_flow_vote")
 
     def gather_rows(self, src: Mat, idx: torch.Tensor, dst: Mat):
         _need_gpu(src.base, idx, dst.base)

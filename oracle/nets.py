@@ -397,13 +397,24 @@ class DeformNet(nn.Module):
         self.completing = DeformGCN(chn_in=4, chn_output=3)
         self.num_interp = num_interp
 
-    def forward(self, data):
+    @staticmethod
+    def _pairs(lists: torch.Tensor):
+        """[n, k] neighbour table (-1 padded) -> (query, neighbour) index vectors in knn's order."""
+        q, t = torch.nonzero(lists >= 0, as_tuple=True)
+        return q, lists[q, t].long()
+
+    def forward(self, data, neighbours=None):
+        """neighbours (tests only): (points of every vertex [n, k], visible vertices of every vertex [n, k]; global
+        indices, -1 padded) to use instead of the two knn calls -- similarity near-ties make the k-NN choice
+        ill-conditioned on symmetric meshes, so large-size parity is checked downstream of a fixed choice."""
         vtx_f, pts_f, vis, tau = self.corr_extractor(data, True)          # random_start defaults to True (:41)
         vis = torch.sigmoid(vis)
         for s, e in P._segments(data.vtx_batch):
             m = vis[s:e]
             vis[s:e] = (m - m.min()) / (m.max() - m.min())
         n, k = vtx_f.shape[0], self.num_interp
+        if neighbours is not None:
+            return self._with_neighbours(data, vtx_f, pts_f, vis, tau, *neighbours)
         yi, xi = P.knn(pts_f, vtx_f, k, data.pts_batch, data.vtx_batch, cosine=True)
         sim = (pts_f[xi] * vtx_f[yi]).sum(dim=-1, keepdim=True) * vis[yi]
         flow = _vote(data.pts[xi] - data.vtx[yi], sim, yi, n)
@@ -414,6 +425,21 @@ class DeformNet(nn.Module):
             yi2, xi2 = P.knn(vtx_f[seen], vtx_f[hidden], k, data.vtx_batch[seen], data.vtx_batch[hidden], cosine=True)
             sim2 = (vtx_f[seen][xi2] * vtx_f[hidden][yi2]).sum(dim=-1, keepdim=True)
             flow[hidden_ids] = _vote(flow[seen_ids][xi2], sim2, yi2, hidden_ids.numel())
+        pred = self.completing(data.vtx, torch.cat([flow, vis], dim=-1), data.geo_edge_index, data.tpl_edge_index,
+                               data.vtx_batch)
+        return pred, vtx_f, pts_f, vis, tau
+
+    def _with_neighbours(self, data, vtx_f, pts_f, vis, tau, to_points, to_visible):
+        n = vtx_f.shape[0]
+        yi, xi = self._pairs(to_points)
+        sim = (pts_f[xi] * vtx_f[yi]).sum(dim=-1, keepdim=True) * vis[yi]
+        flow = _vote(data.pts[xi] - data.vtx[yi], sim, yi, n)
+        hidden_ids = torch.nonzero((vis < 0.5).squeeze(1)).squeeze(1)
+        yi2, xi2 = self._pairs(to_visible)
+        assert bool((vis[yi2] < 0.5).all()) and bool((vis[xi2] >= 0.5).all())
+        sim2 = (vtx_f[xi2] * vtx_f[yi2]).sum(dim=-1, keepdim=True)
+        voted = _vote(flow[xi2], sim2, yi2, n)
+        flow[hidden_ids] = voted[hidden_ids]
         pred = self.completing(data.vtx, torch.cat([flow, vis], dim=-1), data.geo_edge_index, data.tpl_edge_index,
                                data.vtx_batch)
         return pred, vtx_f, pts_f, vis, tau

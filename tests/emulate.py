@@ -244,6 +244,58 @@ def _emu_cosine_nn(self, v: Mat, ptr_v, p: Mat, ptr_p, n_clouds, max_rows_per_cl
     return nn, sim
 
 
+def _emu_sigmoid_minmax(self, x: Mat, ptr, n_meshes, out: Mat):
+    s = torch.sigmoid(x.view())
+    p = ptr.long().tolist()
+    o = out.view()
+    for b in range(n_meshes):
+        m = s[p[b]:p[b + 1]]
+        o[p[b]:p[b + 1]] = (m - m.min()) / (m.max() - m.min())
+
+
+def _emu_cosine_knn(self, y: Mat, ptr_y, x: Mat, ptr_x, n_clouds, max_rows_per_cloud, k, vis: Mat = None, split=False):
+    yy, xx = y.view(), x.view()
+    py, px = ptr_y.long().tolist(), (ptr_y if split else ptr_x).long().tolist()
+    idx = torch.full((y.rows, k), -1, dtype=torch.int32)
+    vv = vis.view().reshape(-1) if vis is not None else None
+    for c in range(n_clouds):
+        ys, ye, xs, xe = py[c], py[c + 1], px[c], px[c + 1]
+        if ye == ys or xe == xs:
+            continue
+        s = yy[ys:ye] @ xx[xs:xe].t()
+        if split:
+            s = s.masked_fill(~(vv[xs:xe] >= 0.5)[None, :], float("-inf"))
+        order = torch.sort(s, dim=1, descending=True, stable=True)
+        kk = min(k, xe - xs)
+        sel = order[1][:, :kk] + xs
+        sel = torch.where(torch.isinf(order[0][:, :kk]), torch.full_like(sel, -1), sel)
+        if split:
+            sel = torch.where((vv[ys:ye] < 0.5)[:, None], sel, torch.full_like(sel, -1))
+        idx[ys:ye, :kk] = sel.int()
+    return idx
+
+
+def _emu_flow_vote(self, mode, idx, feat_q: Mat, feat_s: Mat, pos_q, pos_s, vis: Mat, l1: Mat):
+    fq, fs, vv, out = feat_q.view(), feat_s.view(), vis.view().reshape(-1), l1.view()
+    n, k = idx.shape
+    j = idx.long().clamp(min=0)
+    ok = (idx >= 0).float()
+    dot = (fs[j] * fq[:, None, :]).sum(-1)                       # [n, k]
+    if mode == 0:
+        w = dot * vv[:, None] * ok
+        val = pos_s.view()[j] - pos_q.view()[:, None, :]
+        rows = torch.ones(n, dtype=torch.bool)
+    else:
+        w = dot * ok
+        val = out[:, :3][j]
+        rows = vv < 0.5
+    val = torch.where(ok[..., None] > 0, val, torch.zeros_like(val))      # skipped neighbours add nothing (not NaN * 0)
+    flow = (val * w[..., None]).sum(1) / w.sum(1, keepdim=True)
+    out[rows, :3] = flow[rows]
+    if mode == 0:
+        out[:, 3] = vv
+
+
 def _emu_gather_rows(self, src: Mat, idx, dst: Mat):
     dst.view().copy_(src.view()[idx.long()])
 
@@ -255,3 +307,6 @@ EmuOps.ball_query = _emu_ball_query
 EmuOps.knn_interpolate = _emu_knn_interpolate
 EmuOps.cosine_nn = _emu_cosine_nn
 EmuOps.gather_rows = _emu_gather_rows
+EmuOps.sigmoid_minmax = _emu_sigmoid_minmax
+EmuOps.cosine_knn = _emu_cosine_knn
+EmuOps.flow_vote = _emu_flow_vote

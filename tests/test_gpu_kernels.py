@@ -374,6 +374,90 @@ def test_cosine_nn_and_gather_rows(ops):
     assert torch.equal(out.cpu()[0, 3:67], p[5]) and float(out[2].abs().sum()) == 0 and torch.equal(out.cpu()[3, 3:67], p[1899])
 
 
+def test_sigmoid_minmax(ops):
+    """deformnet.py:42-46: sigmoid, then per-mesh min-max normalisation (ragged meshes, one single-vertex-pair mesh)."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1000, 3, generator=g) * 2.0
+    ptr = torch.tensor([0, 2, 300, 1000], dtype=torch.int32)
+    want = torch.full((1000, 1), float("nan"))
+    EmuOps().sigmoid_minmax(Mat.of(x, 1, 1), ptr, 3, Mat.of(want))
+    got = torch.zeros(1000, 2, device=DEV)
+    ops.sigmoid_minmax(Mat.of(x.to(DEV), 1, 1), ptr.to(DEV), 3, Mat.of(got, 1, 1))
+    assert maxdiff(got[:, 1:2], want) <= 2e-6
+    assert float(got[:, 0].abs().sum()) == 0
+    for b in range(3):
+        seg = got[int(ptr[b]):int(ptr[b + 1]), 1]
+        assert float(seg.min()) == 0.0 and float(seg.max()) == 1.0
+
+
+@pytest.mark.parametrize("k", [1, 5, 8])
+def test_cosine_knn_all_rows(ops, k):
+    """knn(pts_f, vtx_f, k, cosine=True) (deformnet.py:49): order, lowest index on ties, -1 padding in a cloud with < k candidates."""
+    from oracle import pyg_primitives as P
+    g = torch.Generator().manual_seed(9)
+    y = torch.nn.functional.normalize(torch.randn(700, 64, generator=g), dim=1)
+    x = torch.nn.functional.normalize(torch.randn(1203, 64, generator=g), dim=1)
+    x[40] = x[7]; x[41] = x[7]; y[3] = x[7]                        # exact ties -> lowest index first
+    py = torch.tensor([0, 300, 650, 700], dtype=torch.int32)
+    px = torch.tensor([0, 900, 1200, 1203], dtype=torch.int32)    # last cloud: 3 candidates only
+    got = ops.cosine_knn(Mat.of(y.to(DEV)), py.to(DEV), Mat.of(x.to(DEV)), px.to(DEV), 3, 350, k).cpu()
+    emu = EmuOps().cosine_knn(Mat.of(y), py, Mat.of(x), px, 3, 350, k)
+    # primitive of the oracle: [y_idx ; x_idx] pairs, nearest first
+    by = torch.repeat_interleave(torch.arange(3), torch.tensor([300, 350, 50]))
+    bx = torch.repeat_interleave(torch.arange(3), torch.tensor([900, 300, 3]))
+    yi, xi = P.knn(x, y, k, bx, by, cosine=True)
+    want = torch.full((700, k), -1, dtype=torch.int32)
+    pos = torch.zeros(700, dtype=torch.long)
+    for a, b in zip(yi.tolist(), xi.tolist()):
+        want[a, pos[a]] = b; pos[a] += 1
+    assert torch.equal(emu, want)
+    sim = lambda idx: torch.where(idx >= 0, (y[:, None, :] * x[idx.long().clamp(min=0)]).sum(-1), torch.full(idx.shape, -9.0))
+    assert maxdiff(sim(got), sim(want)) <= 2e-6                   # same similarity profile
+    assert (got != want).float().mean().item() <= 0.005           # only fp-order near-ties may differ
+    assert torch.equal(got < 0, want < 0)
+    if k >= 3:
+        tied = (want == 7).any(1) & (want == 40).any(1) & (want == 41).any(1)
+        assert bool(tied[3])
+        for r in torch.nonzero(tied).flatten().tolist():
+            row = got[r].tolist()
+            assert row.index(7) < row.index(40) < row.index(41)
+
+
+def test_cosine_knn_visible_invisible_split_and_votes(ops):
+    """deformnet.py:57-95: rows with mask < 0.5 query rows with mask >= 0.5 of their own mesh; then both votes."""
+    g = torch.Generator().manual_seed(10)
+    n, k = 900, 5
+    f = torch.nn.functional.normalize(torch.randn(n, 64, generator=g), dim=1)
+    pf = torch.nn.functional.normalize(torch.randn(1500, 64, generator=g), dim=1)
+    vis = torch.rand(n, 1, generator=g)
+    ptr = torch.tensor([0, 400, 897, 900], dtype=torch.int32)
+    pptr = torch.tensor([0, 700, 1400, 1500], dtype=torch.int32)
+    vis[0:400] = (vis[0:400] > 0.3).float() * 0.8 + 0.1            # plenty of both kinds
+    vis[897:900] = torch.tensor([[0.9], [0.2], [0.1]])             # mesh 2: ONE visible vertex -> 1 neighbour, -1 padding
+    pos = torch.randn(n, 3, generator=g); ppos = torch.randn(1500, 3, generator=g)
+    e = EmuOps()
+    want_idx = e.cosine_knn(Mat.of(f), ptr, Mat.of(f), ptr, 3, 500, k, vis=Mat.of(vis), split=True)
+    fd, vd = f.to(DEV), vis.to(DEV)
+    got_idx = ops.cosine_knn(Mat.of(fd), ptr.to(DEV), Mat.of(fd), ptr.to(DEV), 3, 500, k, vis=Mat.of(vd), split=True).cpu()
+    assert torch.equal(got_idx < 0, want_idx < 0)
+    assert (got_idx != want_idx).float().mean().item() <= 0.005
+    assert bool((got_idx[(vis >= 0.5).squeeze(1)] == -1).all())
+    assert got_idx[898].tolist() == [897, -1, -1, -1, -1]
+    sel = got_idx[got_idx >= 0].long()
+    assert bool((vis[sel] >= 0.5).all())
+    # votes (same neighbour lists on both sides)
+    idx1 = e.cosine_knn(Mat.of(f), ptr, Mat.of(pf), pptr, 3, 500, k)
+    want = torch.full((n, 4), float("nan"))
+    e.flow_vote(0, idx1, Mat.of(f), Mat.of(pf), Mat.of(pos), Mat.of(ppos), Mat.of(vis), Mat.of(want))
+    e.flow_vote(1, want_idx, Mat.of(f), Mat.of(f), None, None, Mat.of(vis), Mat.of(want))
+    got = torch.full((n, 6), 7.0, device=DEV)
+    l1 = Mat.of(got, 1, 4)
+    ops.flow_vote(0, idx1.to(DEV), Mat.of(fd), Mat.of(pf.to(DEV)), Mat.of(pos.to(DEV)), Mat.of(ppos.to(DEV)), Mat.of(vd), l1)
+    ops.flow_vote(1, want_idx.to(DEV), Mat.of(fd), Mat.of(fd), None, None, Mat.of(vd), l1)
+    assert maxdiff(got[:, 1:5], want) <= 1e-4 * max(1.0, want.abs().max().item())
+    assert bool((got[:, 0] == 7.0).all()) and bool((got[:, 5] == 7.0).all())
+
+
 def test_split_fp16_overflow_is_flagged_and_forward_falls_back():
     """operands beyond the fp16 range: the fast kernels raise the flag, NativeOps.guarded re-runs in fp32."""
     from morig_amd import native, synth

@@ -146,6 +146,64 @@ def test_corrnet_against_reference_golden():
     assert m(d, False, True)[2] is None
 
 
+@pytest.mark.parametrize("name", ["deformnet_ragged", "deformnet_three"])
+def test_deformnet_against_reference_golden(name):
+    """SURVEY 8(f-1): CorrNet -> mask normalisation -> k-NN votes -> GCNDeform, against the reference's own outputs;
+    FPS starts from the recorded torch seed (the reference's default random_start=True, deformnet.py:41)."""
+    meta, a = load_golden(name)
+    m = models.deformnet(**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
+    d = data_from(a, DEV)
+    torch.manual_seed(meta["rng_seed"])
+    pf, vf, ptf, vis, tau = m(d)
+    torch.cuda.synchronize()
+    assert rel_excess(vf, a["vtx_feature"], TOL) <= 0 and rel_excess(ptf, a["pts_feature"], TOL) <= 0
+    assert rel_excess(vis, a["pred_vismask"], TOL) <= 0
+    assert torch.equal(vis.cpu() >= 0.5, a["pred_vismask"] >= 0.5)
+    assert rel_excess(pf, a["out_pred_flow"], TOL) <= 0
+    assert float(tau) == pytest.approx(0.07)
+
+
+def test_deformnet_larger_clouds_against_oracle():
+    """At larger sizes the k-NN choice is ill-conditioned (symmetric meshes give vertex features whose similarities tie
+    to ~1e-7, and one swapped neighbour moves pred_flow through the global max-pool), so: (1) features and mask against
+    the oracle, (2) the product's neighbour tables have the oracle's similarity profile, (3) everything downstream of
+    the neighbour choice against the oracle evaluated on the SAME tables."""
+    from oracle import nets, pyg_primitives as P
+    kw = dict(tau_nce=0.07, num_interp=5)
+    ours = synth.load_recipe(models.deformnet(**kw).eval(), 61, mild=True)
+    ref = synth.load_recipe(nets.deformnet(**kw).eval(), 61, mild=True)
+    batch = synth.make_batch([91, 92], n_side=24, n_pts=2048)
+    torch.manual_seed(5)
+    want = ref(batch)
+    torch.manual_seed(5)
+    got = ours.to(DEV)(batch.to(DEV))
+    for g, w in zip(got[1:4], want[1:4]):
+        assert rel_excess(g, w, TOL) <= 0
+    assert float((want[3] - 0.5).abs().min()) > 2e-4                 # the split itself is not decided by a rounding
+    assert torch.equal(got[3].cpu() >= 0.5, want[3] >= 0.5)
+    to_pts, to_vis = [t.cpu() for t in ours.last_neighbours]
+    vf, pf, vis = want[1], want[2], want[3]
+    k = 5
+    # (2) similarity profiles
+    yi, xi = P.knn(pf, vf, k, batch.pts_batch, batch.vtx_batch, cosine=True)
+    want_sim = (pf[xi] * vf[yi]).sum(-1).view(-1, k)
+    got_sim = (pf[to_pts.long()] * vf[:, None, :]).sum(-1)
+    assert bool((to_pts >= 0).all()) and (got_sim - want_sim).abs().max().item() <= 2e-6
+    seen = (vis >= 0.5).squeeze(1); hid = (vis < 0.5).squeeze(1)
+    assert bool((to_vis[seen] == -1).all()) and bool((to_vis[hid] >= 0).all())
+    yi2, xi2 = P.knn(vf[seen], vf[hid], k, batch.vtx_batch[seen], batch.vtx_batch[hid], cosine=True)
+    want_sim2 = (vf[seen][xi2] * vf[hid][yi2]).sum(-1).view(-1, k)
+    got_sim2 = (vf[to_vis[hid].long()] * vf[hid][:, None, :]).sum(-1)
+    assert (got_sim2 - want_sim2).abs().max().item() <= 2e-6
+    assert bool(seen[to_vis[hid].long()].all())
+    assert bool((batch.vtx_batch[to_vis[hid].long()] == batch.vtx_batch[hid][:, None]).all())
+    # (3) downstream of the neighbour choice
+    torch.manual_seed(5)
+    want_same = ref(batch, neighbours=(to_pts, to_vis))
+    assert rel_excess(got[0], want_same[0], TOL) <= 0
+
+
 def test_corrnet_larger_clouds_against_oracle():
     from oracle import nets
     kw = dict(input_feature=3, output_feature=64, temprature=0.07)

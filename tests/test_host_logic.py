@@ -140,3 +140,38 @@ def test_corrnet_state_dict_and_forward():
     assert tau is m.temprature
     assert m(d, False, False)[2] is None
     m(d, False, True)       # random FPS start runs
+
+
+@pytest.mark.parametrize("name", ["deformnet_ragged", "deformnet_three"])
+def test_deformnet_state_dict_and_forward(name):
+    """the DeformNet plan (CorrNet -> mask normalisation -> k-NN votes -> GCNDeform) on the emulated op
+    layer against the reference-generated fixture; FPS starts come from the recorded torch seed (deformnet.py:41)."""
+    from oracle import nets
+    meta, a = load_golden(name)
+    m = models.deformnet(**meta["kwargs"]).eval()
+    ref = nets.deformnet(**meta["kwargs"])
+    assert list(m.state_dict().keys()) == list(ref.state_dict().keys())
+    assert [tuple(v.shape) for v in m.state_dict().values()] == [tuple(v.shape) for v in ref.state_dict().values()]
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"])
+    d = data_from(a)
+    torch.manual_seed(meta["rng_seed"])
+    pf, vf, ptf, vis, tau = m(d)
+    assert rel_excess(vf, a["vtx_feature"], TOL) <= 0 and rel_excess(ptf, a["pts_feature"], TOL) <= 0
+    assert rel_excess(vis, a["pred_vismask"], 1e-4) <= 0
+    assert torch.equal(vis >= 0.5, a["pred_vismask"] >= 0.5)
+    assert pf.shape == a["out_pred_flow"].shape and rel_excess(pf, a["out_pred_flow"], 1e-4) <= 0
+    assert tau is m.corr_extractor.temprature
+
+
+def test_gcndeform_argument_order():
+    """GCNDeform.forward takes (pos, feature, geo_edge_index, tpl_edge_index, batch) -- geo first (deformnet.py:23)."""
+    from oracle import nets
+    from morig_amd.models.deformnet import GCNDeform
+    _, a = load_golden("gcnrig_f3_o32")
+    m = GCNDeform(chn_in=3, chn_output=3).eval()
+    ref = nets.DeformGCN(3, 3).eval()
+    synth.load_recipe(m, 77); synth.load_recipe(ref, 77)
+    with torch.no_grad():
+        want = ref(a["pos"], a["feature"], a["geo_edge_index"], a["tpl_edge_index"], a["batch"])
+    got = m(a["pos"], a["feature"], a["geo_edge_index"], a["tpl_edge_index"], a["batch"])
+    assert rel_excess(got, want, TOL) <= 0
