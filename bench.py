@@ -121,9 +121,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="meshes per GPU")
     ap.add_argument("--n-side", type=int, default=64, help="mesh grid side (64 -> 4096 vertices)")
-    ap.add_argument("--workload", default="jointnet", choices=["jointnet", "mask_skin", "corrnet"],
+    ap.add_argument("--workload", default="jointnet", choices=["jointnet", "mask_skin", "corrnet", "deformnet"],
                     help="jointnet = BASELINE.json configs[1] (the headline metric); mask_skin = configs[2]; "
-                         "corrnet = configs[3] (8192-point clouds, 32 pairs per GPU)")
+                         "corrnet = configs[3] (8192-point clouds, 32 pairs per GPU); deformnet = the producer of pred_flow "
+                         "(SURVEY 8 f-1), same pairs as corrnet")
     ap.add_argument("--n-pts", type=int, default=8192)
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline leg (0 = skip)")
     args = ap.parse_args()
@@ -134,12 +135,12 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     B = args.batch
-    if args.workload == "corrnet" and args.batch == 64:
+    if args.workload in ("corrnet", "deformnet") and args.batch == 64:
         B = 32                                         # configs[3]: 256 pairs over 8 GPUs
     with_skin = args.workload == "mask_skin"
     # synthetic batch on the host FIRST (forked workers), before this process touches the GPU runtime
     host_batch = build_batch([1000 + rank * B + i for i in range(B)], args.n_side, with_skin=with_skin,
-                             n_pts=args.n_pts if args.workload == "corrnet" else 0)
+                             n_pts=args.n_pts if args.workload in ("corrnet", "deformnet") else 0)
 
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -172,6 +173,14 @@ def main():
             sk = skin(data, data.pred_flow)[2]
             gather(mask)
             return gather(sk)
+    elif args.workload == "deformnet":
+        model = models.deformnet(tau_nce=0.07, num_interp=5).eval()
+        synth.load_recipe(model, 0, mild=True).to(dev)
+
+        def step():
+            pred_flow, _, _, vis, _ = model(data)
+            gather(vis)
+            return gather(pred_flow)
     else:
         model = models.corrnet(input_feature=3, output_feature=64, temprature=0.07).eval()
         synth.load_recipe(model, 0, mild=True).to(dev)
@@ -240,10 +249,13 @@ def main():
                                "masknet_motion + skinnet_motion(nearest_bone=5) eval forwards", "BASELINE.json configs[2]"),
                  "corrnet": ("pairs/sec corrnet forward, 4 k-vert mesh + 8 k-point cloud",
                              f"corrnet(train_vismask=True, random_start=False) eval forward, {args.n_pts}-point clouds",
-                             "BASELINE.json configs[3]")}[args.workload]
+                             "BASELINE.json configs[3]"),
+                 "deformnet": ("pairs/sec deformnet forward, 4 k-vert mesh + 8 k-point cloud",
+                               f"deformnet(tau_nce=0.07, num_interp=5) eval forward (CorrNet + votes + GCNDeform), "
+                               f"{args.n_pts}-point clouds", "SURVEY 8(f-1), pairs of BASELINE.json configs[3]")}[args.workload]
         res = {
             "metric": names[0],
-            "value": round(world * B * args.steps / dt, 2), "unit": "pairs/s" if args.workload == "corrnet" else "meshes/s",
+            "value": round(world * B * args.steps / dt, 2), "unit": "pairs/s" if args.workload in ("corrnet", "deformnet") else "meshes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

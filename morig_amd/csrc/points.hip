@@ -1,5 +1,5 @@
 // CorrNet point-branch operators (models/corrnet.py:50-73, models/basic_modules.py:66-138): farthest point
-// sampling, ball query, k-NN (k<=3) inverse-distance interpolation, cosine 1-NN, row gather.
+// sampling, ball query, k-NN (k<=3) inverse-distance interpolation, row gather (cosine k-NN: deform.hip).
 // All are distance scans over one cloud at a time: HBM/LDS-bound integer+fp32 work, no GEMM shape.
 //
 // Squared distances are evaluated as ((dx*dx + dy*dy) + dz*dz) with every product and sum rounded to
@@ -213,51 +213,6 @@ __global__ __launch_bounds__(256) void knn_interp_kernel(const float* __restrict
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// cosine 1-NN (models/corrnet.py:64 / :68-73): for every vertex the point of the same cloud with the
-// largest dot product (rows are already L2-normalised). One thread per vertex (its C-vector in
-// registers), points streamed through LDS. Ties -> lowest index.
-// ---------------------------------------------------------------------------------------------------
-constexpr int COS_C = 64;
-constexpr int COS_TILE = 128;
-__global__ __launch_bounds__(256) void cosine_nn_kernel(const float* __restrict__ v, int ldv, const int* __restrict__ ptr_v,
-                                                        const float* __restrict__ p, int ldp, const int* __restrict__ ptr_p,
-                                                        int* __restrict__ nn, float* __restrict__ sim) {
-    __shared__ float sp[COS_TILE * COS_C];
-    const int c = blockIdx.y;
-    const int vs = ptr_v[c], ve = ptr_v[c + 1];
-    const int ps = ptr_p[c], pe = ptr_p[c + 1];
-    if (vs + (int)(blockIdx.x * blockDim.x) >= ve) return;
-    const int t = vs + blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = t < ve;
-    float q[COS_C];
-#pragma unroll
-    for (int i = 0; i < COS_C; ++i) q[i] = live ? v[(size_t)t * ldv + i] : 0.f;
-    float best = -INFINITY; int bi = -1;
-    for (int base = ps; base < pe; base += COS_TILE) {
-        const int cnt = min(COS_TILE, pe - base);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt * COS_C; i += blockDim.x) {
-            const int r = i / COS_C, cc = i - r * COS_C;
-            sp[i] = p[(size_t)(base + r) * ldp + cc];
-        }
-        __syncthreads();
-        for (int r = 0; r < cnt; ++r) {
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll
-            for (int i = 0; i < COS_C; i += 4) {
-                a0 += q[i] * sp[r * COS_C + i];
-                a1 += q[i + 1] * sp[r * COS_C + i + 1];
-                a2 += q[i + 2] * sp[r * COS_C + i + 2];
-                a3 += q[i + 3] * sp[r * COS_C + i + 3];
-            }
-            const float s = (a0 + a1) + (a2 + a3);
-            if (s > best) { best = s; bi = base + r; }
-        }
-    }
-    if (live) { nn[t] = bi; sim[t] = best; }
-}
-
 __global__ void gather_rows_kernel(const float* __restrict__ src, int lds, const int* __restrict__ idx, int rows, int cols,
                                    float* __restrict__ dst, int ldd) {
     const int64_t total = (int64_t)rows * cols;
@@ -322,19 +277,6 @@ extern "C" int morig_knn_interpolate(const float* feat, int32_t ldf, int32_t C, 
     int64_t blocks = ((int64_t)n_targets * C + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(knn_interp_kernel, dim3((int)blocks), dim3(256), 0, s, feat, ldf, C, idx_ws, wgt_ws, n_targets, out, ldo);
-    MORIG_LAUNCH_CHECK();
-    return MORIG_OK;
-}
-
-extern "C" int morig_cosine_nn(const float* v, int32_t ldv, const int32_t* ptr_v, const float* p, int32_t ldp,
-                               const int32_t* ptr_p, int32_t n_clouds, int32_t max_rows_per_cloud, int32_t C,
-                               int32_t* nn, float* sim, void* stream) {
-    if (!v || !p || !ptr_v || !ptr_p || !nn || !sim || n_clouds <= 0 || max_rows_per_cloud <= 0) return MORIG_E_INVALID;
-    if (C != COS_C) return MORIG_E_UNSUPPORTED;
-    if (ldv < C || ldp < C) return MORIG_E_INVALID;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    ProfScope ps(K_COSINE_NN, s, 0.0, 0.0);
-    hipLaunchKernelGGL(cosine_nn_kernel, dim3(cdiv(max_rows_per_cloud, 256), n_clouds), dim3(256), 0, s, v, ldv, ptr_v, p, ldp, ptr_p, nn, sim);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
