@@ -105,6 +105,75 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ po
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Clouds of up to 8192 points (every CorrNet level at the benchmark sizes). A cloud's scan is bound by the VALU rate of
+// the ONE CU it runs on (~12 ops per point per sample in the kernel above), so this variant spends fewer instructions:
+//   * coordinates of all points also sit in LDS (96 KB): the selected point is a broadcast LDS read, no owner thread,
+//     no barrier for the hand-over -- ONE barrier per sample;
+//   * the distance update runs on pairs of points in packed fp32 math (v_pk_add/mul_f32 round every component exactly
+//     like the scalar ops; contraction is off, so the value is sqdist3's);
+//   * threads track only their max VALUE (max3); the index is worked out by the few lanes that hold the wave's max and
+//     merged across waves by one 64-bit LDS atomic max on (value bits, ~index): value descending, index ascending.
+// Three key slots rotate so a slot is cleared one barrier after its last read and one barrier before its next use.
+// ---------------------------------------------------------------------------------------------------
+typedef float fps_f2 __attribute__((ext_vector_type(2)));
+
+template <int PPT>                                        // even, <= 8
+__global__ __launch_bounds__(FPS_T) void fps_lds_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
+                                                        const int* __restrict__ out_ptr, const int* __restrict__ start,
+                                                        int* __restrict__ idx_out) {
+    constexpr int NP = PPT * FPS_T, H = PPT / 2;
+    __shared__ float sx[NP], sy[NP], sz[NP];
+    __shared__ unsigned long long s_key[3];
+    const int b = blockIdx.x;
+    const int p0 = ptr[b], n = ptr[b + 1] - p0;
+    const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
+    if (n <= 0 || m <= 0) return;
+    const int tid = threadIdx.x;
+    fps_f2 px[H], py[H], pz[H], dist[H];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = tid + i * FPS_T;
+        float x = 0.f, y = 0.f, z = 0.f, d = -1.f;                     // d = -1: never selected
+        if (j < n) {
+            const float* q = pos + (size_t)(p0 + j) * ldp;
+            x = q[0]; y = q[1]; z = q[2]; d = INFINITY;
+        }
+        px[i >> 1][i & 1] = x; py[i >> 1][i & 1] = y; pz[i >> 1][i & 1] = z; dist[i >> 1][i & 1] = d;
+        sx[j] = x; sy[j] = y; sz[j] = z;
+    }
+    if (tid < 3) s_key[tid] = 0ull;
+    int cur = start ? start[b] : 0;
+    if (cur < 0 || cur >= n) cur = 0;
+    __syncthreads();
+    for (int s = 0; s < m; ++s) {
+        if (tid == 0) { idx_out[o0 + s] = p0 + cur; s_key[(s + 1) % 3] = 0ull; }
+        if (s + 1 == m) break;
+        const float cx = sx[cur], cy = sy[cur], cz = sz[cur];
+        const fps_f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+        float best = -1.f;
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const fps_f2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
+                const fps_f2 d = (dx * dx + dy * dy) + dz * dz;
+                dist[h][0] = fminf(dist[h][0], d[0]); dist[h][1] = fminf(dist[h][1], d[1]);
+                best = fmaxf(best, fmaxf(dist[h][0], dist[h][1]));
+            }
+        }
+        const float wv = wave_max_nonneg(best);            // int-ordered max: correct as soon as one lane is >= 0
+        if (best == wv && wv >= 0.f) {
+            unsigned loc = 0x7fffffffu;
+#pragma unroll
+            for (int i = PPT - 1; i >= 0; --i) if (dist[i >> 1][i & 1] == wv) loc = (unsigned)(tid + i * FPS_T);
+            atomicMax(&s_key[s % 3], ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)(0xffffffffu - loc));
+        }
+        __syncthreads();
+        cur = (int)(0xffffffffu - (unsigned)(s_key[s % 3] & 0xffffffffull));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Ball query (torch_cluster.radius CUDA semantics): one wave per centre scans its cloud in index order,
 // 64 points per step; ballot + popcount keeps the first `max_nbrs` hits with d^2 < r^2 in order.
 // Writes an int64 COO (row 0 = source point, row 1 = centre), unused slots = -1, ready for morig_csr_build.
@@ -235,7 +304,14 @@ extern "C" int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, cons
     const int ppt = cdiv(max_cloud_points, FPS_T);
     ProfScope ps(K_FPS, s, 0.0, 0.0);
 #define MORIG_FPS_CASE(P) hipLaunchKernelGGL((fps_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
-    if (ppt <= 1) MORIG_FPS_CASE(1);
+#define MORIG_FPS_LDS_CASE(P) hipLaunchKernelGGL((fps_lds_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
+    static const bool old_fps = getenv("MORIG_FPS_OLD") != nullptr;
+    if (ppt <= 8 && !old_fps) {
+        if (ppt <= 2) MORIG_FPS_LDS_CASE(2);
+        else if (ppt <= 4) MORIG_FPS_LDS_CASE(4);
+        else MORIG_FPS_LDS_CASE(8);
+    }
+    else if (ppt <= 1) MORIG_FPS_CASE(1);
     else if (ppt <= 2) MORIG_FPS_CASE(2);
     else if (ppt <= 4) MORIG_FPS_CASE(4);
     else if (ppt <= 8) MORIG_FPS_CASE(8);
@@ -243,6 +319,7 @@ extern "C" int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, cons
     else if (ppt <= 32) MORIG_FPS_CASE(32);
     else return MORIG_E_UNSUPPORTED;               // > 32768 points per cloud
 #undef MORIG_FPS_CASE
+#undef MORIG_FPS_LDS_CASE
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
