@@ -84,12 +84,65 @@ def deformnet_fixtures(ref):
               out_pred_flow=pf, vtx_feature=vf, pts_feature=ptf, pred_vismask=vis, tau=tau, **inputs)
 
 
+def joints_fixtures():
+    """Joint extraction after the hot path: the reference's own utils/cluster_utils.py, utils/mst_utils.py
+    functions and sklearn's estimate_bandwidth on seeded point sets, in the sequence of evaluate/eval_rigging.py:72-95."""
+    print("joint-extraction fixtures")
+    import types
+    from sklearn.cluster import estimate_bandwidth
+    sys.path.insert(0, shim.REFERENCE_ROOT)
+    for name in ("open3d", "cv2"):                      # imported at module level by utils/, unused by these functions
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if not hasattr(np, "bool"):
+        np.bool = bool                                  # utils/cluster_utils.py:53 predates numpy 1.24
+    if not hasattr(np, "int"):
+        np.int = int
+    cu = __import__("utils.cluster_utils", fromlist=["meanshift_cluster"])
+    mu = __import__("utils.mst_utils", fromlist=["flip"])
+    for name, seed, n_side in (("joints_small", 7, 12), ("joints_medium", 8, 20)):
+        rng = np.random.default_rng(seed)
+        mesh = synth.make_mesh(seed, n_side=n_side)
+        pos = mesh.pos.numpy().astype(np.float64)
+        # "shifted" vertices: pulled towards a few interior joints, as the attention-weighted shifts do
+        centres = pos[rng.choice(len(pos), 9, replace=False)] * 0.8
+        near = np.argmin(((pos[:, None, :] - centres[None]) ** 2).sum(-1), axis=1)
+        shifted = pos + 0.85 * (centres[near] - pos) + rng.normal(0, 0.004, pos.shape)
+        shifted = np.round(shifted, 6)                   # the .ply hand-over prints %f (utils/io_utils.py:41-55)
+        attn_raw = rng.random((len(pos), 1)).astype(np.float32) ** 2
+        # voxel grid: a filled box that drops a slab of the points
+        vox_data = np.zeros((88, 88, 88), dtype=bool)
+        vox_data[4:84, 2:86, 4:52] = True
+        vox = types.SimpleNamespace(data=vox_data, translate=[-0.6, -0.1, -0.6], scale=1.2, dims=[88, 88, 88])
+        # ---- evaluate/eval_rigging.py:72-95 with the reference's functions ----
+        attn = (attn_raw - np.min(attn_raw)) / (np.max(attn_raw) - np.min(attn_raw))
+        pts_in, index_inside = mu.inside_check(shifted, vox)
+        attn_in = attn[index_inside, :]
+        pts_t = pts_in[attn_in.squeeze() > 0.1]
+        attn_t = attn_in[attn_in.squeeze() > 0.1]
+        pts_m = np.concatenate((pts_t, pts_t * np.array([[-1, 1, 1]])), axis=0)
+        attn_m = np.tile(attn_t, (2, 1))
+        bandwidth = estimate_bandwidth(pts_m, quantile=0.04)
+        modes = cu.meanshift_cluster(pts_m, bandwidth, attn_m, max_iter=30)
+        joints_nms = cu.nms_meanshift(modes, attn=attn_m, bandwidth=bandwidth, thrd_density=0.02)
+        joints, side = mu.flip(joints_nms)
+        # two steps of the iteration alone, and the unweighted form
+        two = cu.meanshift_cluster(pts_m, bandwidth, attn_m, max_iter=3)
+        plain = cu.meanshift_cluster(pts_m, bandwidth, None, max_iter=5)
+        _save(name, dict(seed=seed, n_side=n_side, quantile=0.04, threshold1=0.1, threshold2=0.02, max_iter=30,
+                         vox_translate=vox.translate, vox_scale=vox.scale, vox_dims=vox.dims),
+              shifted=shifted, attn_raw=attn_raw, vox_data=np.packbits(vox_data), index_inside=index_inside.astype(np.int64),
+              pts_mirrored=pts_m, attn_mirrored=attn_m, bandwidth=np.array([bandwidth]), modes=modes, modes_two_steps=two,
+              modes_unweighted=plain, joints_nms=joints_nms, joints=joints, side=side)
+
+
 def main():
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
     ref = shim.import_reference_models()
     if len(sys.argv) > 1 and sys.argv[1] == "deformnet":      # only the (f-1) fixtures; the others stay byte-identical
         return deformnet_fixtures(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "joints":
+        return joints_fixtures()
     bm = sys.modules["models.basic_modules"]
     rn = sys.modules["models.rignet"]
 
@@ -210,6 +263,7 @@ def main():
           pos_check=big.pos[:8], geo_check=big.geo_edge_index[:, :32])
 
     deformnet_fixtures(ref)
+    joints_fixtures()
 
     # ---- writers (utils/io_utils.py:41-55, training/train_rig.py:253-258) ---------------
     print("writer fixtures")
