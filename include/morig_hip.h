@@ -256,6 +256,29 @@ int morig_flow_vote(int32_t mode, const int32_t* idx, int32_t k, int32_t n, cons
                     const float* feat_s, int32_t lds, int32_t C, const float* pos_q, int32_t ldpq,
                     const float* pos_s, int32_t ldps, const float* vis, int32_t ld_vis, float* l1, int32_t ld_l1,
                     void* stream);
+/* ---- joint extraction after the path (/root/reference/evaluate/eval_rigging.py:80-95). The reference
+ * runs these steps in numpy float64, one mesh at a time; all point arrays here are float64 [n][3], contiguous. ----
+ * inside_check (utils/mst_utils.py:15-29): keep[i] = 1 when round((p - translate) / scale * dims0) (half to even) lies
+ * inside the 88^3 grid (hard-coded there) on a filled voxel. vox88: [88][88][88] bytes; translate: 3 HOST doubles. */
+int morig_inside_check(const double* pts, int32_t n, const uint8_t* vox88, const double* translate, double scale,
+                       double dims0, uint8_t* keep, void* stream);
+/* sklearn.cluster.estimate_bandwidth (eval_rigging.py:89): *bandwidth (device) = mean over points of the distance to
+ * the k-th nearest neighbour, the point itself included; the caller passes k = max(int(n * quantile), 1).
+ * kth_ws: scratch [n] doubles. */
+int morig_knn_bandwidth(const double* pts, int32_t n, int32_t k, double* kth_ws, double* bandwidth, void* stream);
+/* meanshift_cluster (utils/cluster_utils.py:14-38): at most max_iter - 1 steps of p_j += 0.3 (weighted mean - p_j) with
+ * kernel max(h^2 - d^2, 0) * weights[source] (weights may be NULL); the loop condition "total displacement > 1e-3" is
+ * evaluated on the device (state: [max_iter] doubles, step t accumulates its squared displacement in state[t]), so the
+ * call enqueues max_iter - 1 launches and never synchronises. bandwidth: device pointer to one double.
+ * The result is in buf_a when *result_in_a (HOST int, written before return) is 1, else in buf_b. */
+int morig_meanshift(const double* pts, const float* weights, int32_t n, const double* bandwidth, int32_t max_iter,
+                    double* buf_a, double* buf_b, double* state, int32_t* result_in_a, void* stream);
+/* nms_meanshift (utils/cluster_utils.py:41-66), two steps around the caller's np.argsort(counts)[::-1] (numpy's
+ * unstable sort fixes the visiting order among equal counts, so it stays in numpy):
+ * counts[j] = #{i : |p_i - p_j| <= bandwidth}; then the greedy pass over `order` writes alive[n]. */
+int morig_nms_counts(const double* pts, int32_t n, const double* bandwidth, int32_t* counts, void* stream);
+int morig_nms_greedy(const double* pts, const float* attn, int32_t n, const double* bandwidth, const int32_t* order,
+                     double thrd_density, float thrd_attn, uint8_t* alive, void* stream);
 /* dst[r] = src[idx[r]] (pos[idx], out_pts[nn]); idx < 0 -> zeros */
 int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t rows, int32_t cols,
                       float* dst, int32_t ldd, void* stream);

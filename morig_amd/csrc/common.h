@@ -14,7 +14,7 @@ enum Kind : int {
     K_FPS, K_BALL, K_POINTCONV, K_KNN_INTERP, K_COSINE_NN,
     K_GEMM16_BN128, K_GEMM16_BN64, K_GEMM16_BN32, K_GEMM16_POOL,
     K_EDGE16_H32, K_EDGE16_H64, K_EDGE16_H128, K_EDGE16_H256, K_POINTCONV16, K_GEMM16_DMA,
-    K_COSINE_KNN, K_FLOW_VOTE,
+    K_COSINE_KNN, K_FLOW_VOTE, K_JOINTS,
     K_COUNT
 };
 static_assert(K_COUNT <= MORIG_PROF_KINDS, "raise MORIG_PROF_KINDS");

@@ -1,0 +1,258 @@
+// Joint extraction that follows the hot path (evaluate/eval_rigging.py:80-95): voxel inside-test
+// (utils/mst_utils.py:15-29), bandwidth = mean distance to the k-th nearest neighbour (sklearn estimate_bandwidth),
+// weighted mean-shift (utils/cluster_utils.py:14-38), non-maximum suppression (utils/cluster_utils.py:41-66).
+// The reference runs these in numpy float64 on a few thousand points per mesh; every kernel here is an O(n^2) fp64
+// scan of one point set (VALU fp64, candidates streamed through LDS) and keeps numpy's operation order where a
+// discrete decision depends on it (distance = ((dx^2 + dy^2) + dz^2), no FMA contraction; sqrt before "<= bandwidth").
+#include "common.h"
+
+namespace morig {
+
+__device__ __forceinline__ double sqdist3d(double ax, double ay, double az, double bx, double by, double bz) {
+    const double dx = __dsub_rn(ax, bx), dy = __dsub_rn(ay, by), dz = __dsub_rn(az, bz);
+    return __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+}
+
+// ---- inside_check (mst_utils.py:15-29): vc = round((p - translate) / scale * dims0) half-to-even; inside the
+// hard-coded 88^3 grid and on a filled voxel ----
+__global__ void inside_check_kernel(const double* __restrict__ pts, int n, const unsigned char* __restrict__ vox, double tx, double ty,
+                                    double tz, double scale, double dims0, unsigned char* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double t[3] = {tx, ty, tz};
+    long vc[3]; bool in_grid = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double v = __dmul_rn(__ddiv_rn(__dsub_rn(pts[(size_t)i * 3 + a], t[a]), scale), dims0);
+        vc[a] = (long)rint(v);
+        in_grid = in_grid && vc[a] >= 0 && vc[a] < 88;
+        vc[a] = vc[a] < 0 ? 0 : (vc[a] > 87 ? 87 : vc[a]);
+    }
+    keep[i] = (in_grid && vox[(vc[0] * 88 + vc[1]) * 88 + vc[2]]) ? 1 : 0;
+}
+
+// ---- distance to the k-th nearest neighbour (the point itself included), one workgroup per point: radix select over
+// the bit pattern of the squared distances (non-negative doubles order like their bits), 8 bits per pass, distances
+// recomputed in every pass instead of stored ----
+__global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ pts, int n, int k, double* __restrict__ kth) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_k;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const double px = pts[(size_t)row * 3], py = pts[(size_t)row * 3 + 1], pz = pts[(size_t)row * 3 + 2];
+    if (tid == 0) { s_prefix = 0ull; s_k = k; }
+    for (int pass = 7; pass >= 0; --pass) {
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        const unsigned long long hi_mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+        for (int j = tid; j < n; j += 256) {
+            const unsigned long long key = (unsigned long long)__double_as_longlong(
+                sqdist3d(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], px, py, pz));
+            if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 0xffu], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int need = s_k; unsigned b = 0;
+            while (b < 255u && (int)hist[b] < need) { need -= (int)hist[b]; ++b; }
+            s_k = need; s_prefix = prefix | ((unsigned long long)b << (8 * pass));
+        }
+        __syncthreads();
+    }
+    if (tid == 0) kth[row] = sqrt(__longlong_as_double((long long)s_prefix));
+}
+
+// fixed-order sum (one workgroup): the bandwidth is deterministic from run to run
+__global__ __launch_bounds__(256) void sum_f64_kernel(const double* __restrict__ x, int n, double scale, double* __restrict__ out) {
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = part[0] * scale;
+}
+
+// ---- one mean-shift step (cluster_utils.py:24-35), sources i streamed through LDS: moved_j = p_j + 0.3 (sum_i k_ij w_i p_i / (sum_i k_ij w_i + 1e-10) - p_j), k_ij = max(h^2 - d_ij^2, 0).
+// state[t] accumulates sum |moved - p|^2 of step t; a step runs only while sqrt(state[t-1]) > 1e-3 (the reference's
+// loop condition evaluated on the device: no host round trip per step), otherwise it passes the points through ----
+// A workgroup owns 32 targets; its 256 threads are 8 source slices x 32 targets (one thread alone would walk all n sources:
+// a dependent fp64 chain of ~n x 20 operations, 0.4 ms per step at n = 8192). Slice s takes sources 32 s .. 32 s + 31 of
+// every 256-source tile; the 8 partial sums of a target are added in slice order (deterministic).
+constexpr int MS_TILE = 256, MS_TGT = 32, MS_SL = MS_TILE / MS_TGT;
+__global__ __launch_bounds__(MS_TILE) void meanshift_step_kernel(const double* __restrict__ src, const float* __restrict__ w, int n,
+                                                                 const double* __restrict__ bandwidth, int t,
+                                                                 double* __restrict__ state, double* __restrict__ dst) {
+    __shared__ double sx[MS_TILE], sy[MS_TILE], sz[MS_TILE], sw[MS_TILE];
+    __shared__ double part[MS_SL][4][MS_TGT];
+    const int tg = threadIdx.x & (MS_TGT - 1), sl = threadIdx.x / MS_TGT;
+    const int j = blockIdx.x * MS_TGT + tg;
+    const bool live = j < n;
+    const bool active = sqrt(state[t - 1]) > 1e-3;              // block-uniform
+    const double px = live ? src[(size_t)j * 3] : 0.0, py = live ? src[(size_t)j * 3 + 1] : 0.0, pz = live ? src[(size_t)j * 3 + 2] : 0.0;
+    if (!active) {
+        if (live && sl == 0) { dst[(size_t)j * 3] = px; dst[(size_t)j * 3 + 1] = py; dst[(size_t)j * 3 + 2] = pz; }
+        return;
+    }
+    const double h = bandwidth[0], h2 = __dmul_rn(h, h);
+    double ax = 0.0, ay = 0.0, az = 0.0, aw = 0.0;
+    for (int base = 0; base < n; base += MS_TILE) {
+        const int i = base + threadIdx.x;
+        __syncthreads();
+        if (i < n) { sx[threadIdx.x] = src[(size_t)i * 3]; sy[threadIdx.x] = src[(size_t)i * 3 + 1]; sz[threadIdx.x] = src[(size_t)i * 3 + 2];
+                     sw[threadIdx.x] = w ? (double)w[i] : 1.0; }
+        __syncthreads();
+        const int lo = sl * MS_TGT, hi = min(lo + MS_TGT, n - base);
+        for (int r = lo; r < hi; ++r) {
+            double kk = __dsub_rn(h2, sqdist3d(sx[r], sy[r], sz[r], px, py, pz));
+            kk = kk > 0.0 ? kk : 0.0;
+            kk = __dmul_rn(kk, sw[r]);
+            aw = __dadd_rn(aw, kk);
+            ax = __dadd_rn(ax, __dmul_rn(kk, sx[r])); ay = __dadd_rn(ay, __dmul_rn(kk, sy[r])); az = __dadd_rn(az, __dmul_rn(kk, sz[r]));
+        }
+    }
+    part[sl][0][tg] = ax; part[sl][1][tg] = ay; part[sl][2][tg] = az; part[sl][3][tg] = aw;
+    __syncthreads();
+    double d2 = 0.0;
+    if (sl == 0) {
+        ax = ay = az = aw = 0.0;
+#pragma unroll
+        for (int q = 0; q < MS_SL; ++q) { ax += part[q][0][tg]; ay += part[q][1][tg]; az += part[q][2][tg]; aw += part[q][3][tg]; }
+        if (live) {
+            const double den = aw + 1e-10;
+            const double mx = 0.3 * (ax / den - px) + px, my = 0.3 * (ay / den - py) + py, mz = 0.3 * (az / den - pz) + pz;
+            dst[(size_t)j * 3] = mx; dst[(size_t)j * 3 + 1] = my; dst[(size_t)j * 3 + 2] = mz;
+            d2 = (mx - px) * (mx - px) + (my - py) * (my - py) + (mz - pz) * (mz - pz);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) d2 += __shfl_xor(d2, o);
+        if (tg == 0) atomicAdd(&state[t], d2);
+    }
+}
+
+// ---- NMS (cluster_utils.py:48-51): neighbour counts within the bandwidth (the point itself included) ----
+__global__ __launch_bounds__(256) void nms_counts_kernel(const double* __restrict__ pts, int n, const double* __restrict__ bandwidth,
+                                                         int* __restrict__ counts) {
+    __shared__ double sx[256], sy[256], sz[256];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < n;
+    const double px = live ? pts[(size_t)j * 3] : 0.0, py = live ? pts[(size_t)j * 3 + 1] : 0.0, pz = live ? pts[(size_t)j * 3 + 2] : 0.0;
+    const double h = bandwidth[0];
+    int c = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        __syncthreads();
+        if (i < n) { sx[threadIdx.x] = pts[(size_t)i * 3]; sy[threadIdx.x] = pts[(size_t)i * 3 + 1]; sz[threadIdx.x] = pts[(size_t)i * 3 + 2]; }
+        __syncthreads();
+        const int cnt = min(256, n - base);
+        for (int r = 0; r < cnt; ++r) c += sqrt(sqdist3d(sx[r], sy[r], sz[r], px, py, pz)) <= h ? 1 : 0;
+    }
+    if (live) counts[j] = c;
+}
+
+// ---- NMS greedy pass (cluster_utils.py:54-64), one 1024-thread workgroup: points visited in `order`; a point still
+// alive suppresses everything within the bandwidth (itself included) and is restored only if its neighbourhood is
+// well attended (float32 compare, as numpy compares a float32 with a Python float) or dense ----
+constexpr int NMS_T = 1024;
+__global__ __launch_bounds__(NMS_T) void nms_greedy_kernel(const double* __restrict__ pts, const float* __restrict__ attn, int n,
+                                                           const double* __restrict__ bandwidth, const int* __restrict__ order,
+                                                           double thrd_density, float thrd_attn, unsigned char* __restrict__ alive) {
+    __shared__ int s_cnt[NMS_T / 64];
+    __shared__ float s_att[NMS_T / 64];
+    __shared__ int s_alive_i;
+    const int tid = threadIdx.x;
+    const double h = bandwidth[0];
+    for (int r = tid; r < n; r += NMS_T) alive[r] = 1;
+    __syncthreads();
+    for (int s = 0; s < n; ++s) {
+        const int i = order[s];
+        if (tid == 0) s_alive_i = alive[i];
+        __syncthreads();
+        const bool go = s_alive_i != 0;
+        __syncthreads();                                   // s_alive_i is rewritten by the next iteration
+        if (!go) continue;
+        const double cx = pts[(size_t)i * 3], cy = pts[(size_t)i * 3 + 1], cz = pts[(size_t)i * 3 + 2];
+        int c = 0; float am = -INFINITY;
+        for (int r = tid; r < n; r += NMS_T) {
+            if (sqrt(sqdist3d(pts[(size_t)r * 3], pts[(size_t)r * 3 + 1], pts[(size_t)r * 3 + 2], cx, cy, cz)) <= h) {
+                ++c; am = fmaxf(am, attn[r]); alive[r] = 0;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); am = fmaxf(am, __shfl_xor(am, o)); }
+        if ((tid & 63) == 0) { s_cnt[tid >> 6] = c; s_att[tid >> 6] = am; }
+        __syncthreads();
+        if (tid == 0) {
+            int ct = 0; float at = -INFINITY;
+            for (int q = 0; q < NMS_T / 64; ++q) { ct += s_cnt[q]; at = fmaxf(at, s_att[q]); }
+            if (at > thrd_attn || (double)ct / (double)n > thrd_density) alive[i] = 1;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace morig
+
+using namespace morig;
+
+extern "C" int morig_inside_check(const double* pts, int32_t n, const uint8_t* vox88, const double* translate, double scale,
+                                  double dims0, uint8_t* keep, void* stream) {
+    if (!pts || !vox88 || !translate || !keep || n < 0 || !(scale != 0.0)) return MORIG_E_INVALID;
+    if (n == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(inside_check_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, pts, n, vox88, translate[0], translate[1], translate[2],
+                       scale, dims0, keep);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_knn_bandwidth(const double* pts, int32_t n, int32_t k, double* kth_ws, double* bandwidth, void* stream) {
+    if (!pts || !kth_ws || !bandwidth || n <= 0 || k < 1 || k > n) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(kth_nn_kernel, dim3(n), dim3(256), 0, s, pts, n, k, kth_ws);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, s, kth_ws, n, 1.0 / (double)n, bandwidth);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_meanshift(const double* pts, const float* weights, int32_t n, const double* bandwidth, int32_t max_iter,
+                               double* buf_a, double* buf_b, double* state, int32_t* result_in_a, void* stream) {
+    if (!pts || !bandwidth || !buf_a || !buf_b || !state || !result_in_a || n <= 0 || max_iter < 1) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    // state[0] = 1e20 (the reference's diff = 1e10, squared), state[1 .. max_iter-1] = 0
+    MORIG_HIP_TRY(hipMemsetAsync(state, 0, sizeof(double) * (size_t)max_iter, s));
+    const double first = 1e20;
+    MORIG_HIP_TRY(hipMemcpyAsync(state, &first, sizeof(double), hipMemcpyHostToDevice, s));
+    MORIG_HIP_TRY(hipMemcpyAsync(buf_a, pts, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, s));
+    double* cur = buf_a; double* nxt = buf_b;
+    for (int t = 1; t < max_iter; ++t) {                  // num_iter runs 1 .. max_iter - 1 (cluster_utils.py:23)
+        hipLaunchKernelGGL(meanshift_step_kernel, dim3(cdiv(n, MS_TGT)), dim3(MS_TILE), 0, s, cur, weights, n, bandwidth, t, state, nxt);
+        MORIG_LAUNCH_CHECK();
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *result_in_a = (cur == buf_a) ? 1 : 0;
+    return MORIG_OK;
+}
+
+extern "C" int morig_nms_counts(const double* pts, int32_t n, const double* bandwidth, int32_t* counts, void* stream) {
+    if (!pts || !bandwidth || !counts || n <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(nms_counts_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, pts, n, bandwidth, counts);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_nms_greedy(const double* pts, const float* attn, int32_t n, const double* bandwidth, const int32_t* order,
+                                double thrd_density, float thrd_attn, uint8_t* alive, void* stream) {
+    if (!pts || !attn || !bandwidth || !order || !alive || n <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(1), dim3(NMS_T), 0, s, pts, attn, n, bandwidth, order, thrd_density, thrd_attn, alive);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}

@@ -55,7 +55,7 @@ static const char* kNames[K_COUNT] = {
     "fps", "ball_query", "pointconv", "knn_interpolate", "cosine_nn",
     "gemm_f16x3_bn128", "gemm_f16x3_bn64", "gemm_f16x3_bn32", "gemm_f16x3_pool",
     "edgeconv_f16x3_h32", "edgeconv_f16x3_h64", "edgeconv_f16x3_h128", "edgeconv_f16x3_h256", "pointconv_f16x3", "gemm_f16x3_dma",
-    "cosine_knn", "flow_vote",
+    "cosine_knn", "flow_vote", "joint_extraction",
 };
 
 }  // namespace morig

@@ -1,0 +1,100 @@
+"""Joint extraction after the hot path on the MI355X-native op layer: the functions of
+/root/reference/utils/cluster_utils.py (``meanshift_cluster`` :14-38, ``nms_meanshift`` :41-66),
+/root/reference/utils/mst_utils.py (``inside_check`` :15-29, ``flip`` :294-313) and sklearn's
+``estimate_bandwidth`` as evaluate/eval_rigging.py:89 calls it, with the reference's names and argument meaning, and
+``extract_joints`` = the sequence of evaluate/eval_rigging.py:72-95.
+
+The reference computes in numpy float64 on the host; here the O(n^2) scans (k-th nearest neighbour, mean-shift steps,
+neighbour counts, the greedy suppression) are float64 HIP kernels (csrc/joints.hip) on device tensors. Point sets are
+``torch.float64 [n, 3]`` CUDA tensors (numpy input is uploaded); ``attn`` is ``float32 [n, 1]`` as the reference
+loads it from ``*_attn.npy``. There is no CPU fallback: without the HIP library or a GPU the op layer raises.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .runtime import get_ops
+
+
+def _dev_pts(pts, device) -> torch.Tensor:
+    t = torch.as_tensor(pts) if not torch.is_tensor(pts) else pts
+    return t.to(device=device, dtype=torch.float64).contiguous()
+
+
+def _dev_attn(attn, device) -> torch.Tensor:
+    t = torch.as_tensor(attn) if not torch.is_tensor(attn) else attn
+    return t.to(device=device, dtype=torch.float32).reshape(-1, 1).contiguous()
+
+
+def inside_check(pts: torch.Tensor, vox):
+    """utils/mst_utils.py:15-29. vox: object with ``data`` (88^3 bool), ``translate``, ``scale``, ``dims`` (a binvox
+    ``Voxels``). Returns (pts[inside], indices of the inside points)."""
+    ops = get_ops()
+    data = torch.as_tensor(np.ascontiguousarray(np.asarray(vox.data, dtype=np.uint8))).to(pts.device).reshape(-1)
+    keep = ops.inside_mask(pts, data, vox.translate, vox.scale, vox.dims[0])
+    return pts[keep], torch.nonzero(keep).squeeze(1)
+
+
+def estimate_bandwidth(pts: torch.Tensor, quantile: float = 0.3) -> torch.Tensor:
+    """sklearn.cluster.estimate_bandwidth(X, quantile): device tensor [1] (float64)."""
+    n = pts.shape[0]
+    return get_ops().knn_bandwidth(pts, max(int(n * quantile), 1))
+
+
+def meanshift_cluster(pts_in: torch.Tensor, bandwidth, weights: Optional[torch.Tensor] = None, max_iter: int = 20) -> torch.Tensor:
+    """utils/cluster_utils.py:14-38. bandwidth: device tensor [1] or a float."""
+    bw = bandwidth if torch.is_tensor(bandwidth) else torch.tensor([float(bandwidth)], dtype=torch.float64, device=pts_in.device)
+    w = None if weights is None else weights.reshape(-1).contiguous()
+    return get_ops().meanshift(pts_in, w, bw, max_iter)
+
+
+def nms_meanshift(pts_in: torch.Tensor, attn: torch.Tensor, bandwidth, thrd_density: float, thrd_attn: float = 0.7) -> torch.Tensor:
+    """utils/cluster_utils.py:41-66. The visiting order is numpy's ``argsort(counts)[::-1]`` (:52) on the host -- its
+    unstable sort decides the order among equal counts -- everything else runs on the device."""
+    ops = get_ops()
+    bw = bandwidth if torch.is_tensor(bandwidth) else torch.tensor([float(bandwidth)], dtype=torch.float64, device=pts_in.device)
+    counts = ops.nms_counts(pts_in, bw)
+    order = np.argsort(counts.cpu().numpy().astype(np.int64))[::-1]
+    order_d = torch.as_tensor(np.ascontiguousarray(order).astype(np.int32)).to(pts_in.device)
+    alive = ops.nms_greedy(pts_in, attn.reshape(-1).contiguous(), bw, order_d, thrd_density, thrd_attn)
+    return pts_in[alive]
+
+
+def flip(pred_joints):
+    """utils/mst_utils.py:294-313 on the (small) joint array; returns numpy (joints, side_indicator)."""
+    j = pred_joints.detach().cpu().numpy() if torch.is_tensor(pred_joints) else np.asarray(pred_joints)
+    left = j[j[:, 0] < -2e-2].reshape(-1, 3)
+    middle = j[np.abs(j[:, 0]) <= 2e-2].reshape(-1, 3).copy()
+    middle[:, 0] = 0.0
+    right = left.copy()
+    right[:, 0] = -right[:, 0]
+    side = np.concatenate((-np.ones(len(left)), np.zeros(len(middle)), np.ones(len(right))), axis=0)
+    return np.concatenate((left, middle, right), axis=0), side
+
+
+def extract_joints(shifted_pts, attn, vox=None, bandwidth_quantile: float = 0.04, threshold1: float = 0.1,
+                   threshold2: float = 0.02, max_iter: int = 30, device=None):
+    """evaluate/eval_rigging.py:72-95 from the loaded arrays on: attention min-max normalised (:72), inside test (:80),
+    attention threshold (:82-83), x-mirror (:86-88), bandwidth (:89), mean-shift (:91), NMS (:94), flip (:95).
+    Returns dict(joints numpy [J, 3], side, bandwidth float, modes device [2m, 3], attn device [2m, 1])."""
+    if device is None:
+        device = shifted_pts.device if torch.is_tensor(shifted_pts) and shifted_pts.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    pts = _dev_pts(shifted_pts, device)
+    a = _dev_attn(attn, device)
+    a = (a - a.min()) / (a.max() - a.min())                               # float32, as numpy does on the loaded array
+    if vox is not None:
+        pts, inside = inside_check(pts, vox)
+        a = a[inside, :]
+    sel = a.squeeze(1) > threshold1
+    pts, a = pts[sel], a[sel]
+    mirror = torch.tensor([[-1.0, 1.0, 1.0]], dtype=torch.float64, device=device)
+    pts = torch.cat((pts, pts * mirror), dim=0).contiguous()
+    a = a.repeat(2, 1).contiguous()
+    bw = estimate_bandwidth(pts, bandwidth_quantile)
+    modes = meanshift_cluster(pts, bw, a, max_iter=max_iter)
+    kept = nms_meanshift(modes, a, bw, threshold2)
+    joints, side = flip(kept)
+    return dict(joints=joints, side=side, bandwidth=float(bw.item()), modes=modes, attn=a)

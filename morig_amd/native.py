@@ -20,6 +20,8 @@ LIB_PATH = os.environ.get("MORIG_HIP_LIB") or os.path.join(_HERE, "lib", "libmor
 c_f32p = C.c_void_p
 c_i32p = C.c_void_p
 c_i64p = C.c_void_p
+c_f64p = C.c_void_p
+c_u8p = C.c_void_p
 
 
 class GemmArgs(C.Structure):
@@ -90,6 +92,11 @@ _SIGNATURES = {
                                     c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_flow_vote": (C.c_int, [C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
                                    c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_inside_check": (C.c_int, [c_f64p, C.c_int32, c_u8p, c_f64p, C.c_double, C.c_double, c_u8p, C.c_void_p]),
+    "morig_knn_bandwidth": (C.c_int, [c_f64p, C.c_int32, C.c_int32, c_f64p, c_f64p, C.c_void_p]),
+    "morig_meanshift": (C.c_int, [c_f64p, c_f32p, C.c_int32, c_f64p, C.c_int32, c_f64p, c_f64p, c_f64p, c_i32p, C.c_void_p]),
+    "morig_nms_counts": (C.c_int, [c_f64p, C.c_int32, c_f64p, c_i32p, C.c_void_p]),
+    "morig_nms_greedy": (C.c_int, [c_f64p, c_f32p, C.c_int32, c_f64p, c_i32p, C.c_double, C.c_float, c_u8p, C.c_void_p]),
     "morig_gather_rows": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_copy2d": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -462,6 +469,62 @@ class NativeOps:
                                        feat_q.cols, pos_q.ptr if pos_q is not None else None, pos_q.ld if pos_q is not None else 0,
                                        pos_s.ptr if pos_s is not None else None, pos_s.ld if pos_s is not None else 0,
                                        vis.ptr, vis.ld, l1.ptr, l1.ld, _stream()), "morig_flow_vote")
+
+    # -- joint extraction (csrc/joints.hip): float64 [n, 3] contiguous point sets -----------------------------
+    @staticmethod
+    def _pts64(pts: torch.Tensor):
+        assert pts.dtype == torch.float64 and pts.dim() == 2 and pts.shape[1] == 3 and pts.is_contiguous()
+
+    def inside_mask(self, pts: torch.Tensor, vox88: torch.Tensor, translate, scale: float, dims0: float) -> torch.Tensor:
+        _need_gpu(pts, vox88)
+        self._pts64(pts)
+        assert vox88.dtype == torch.uint8 and vox88.numel() == 88 ** 3 and vox88.is_contiguous()
+        keep = torch.empty(pts.shape[0], dtype=torch.uint8, device=pts.device)
+        t = (C.c_double * 3)(*[float(v) for v in translate])
+        check(self.lib.morig_inside_check(_p(pts), pts.shape[0], _p(vox88), t, float(scale), float(dims0), _p(keep), _stream()),
+              "morig_inside_check")
+        return keep.bool()
+
+    def knn_bandwidth(self, pts: torch.Tensor, k: int) -> torch.Tensor:
+        """device tensor [1] float64: mean distance to the k-th nearest neighbour (self included)."""
+        _need_gpu(pts)
+        self._pts64(pts)
+        n = pts.shape[0]
+        ws = torch.empty(n, dtype=torch.float64, device=pts.device)
+        bw = torch.empty(1, dtype=torch.float64, device=pts.device)
+        check(self.lib.morig_knn_bandwidth(_p(pts), n, k, _p(ws), _p(bw), _stream()), "morig_knn_bandwidth")
+        return bw
+
+    def meanshift(self, pts: torch.Tensor, weights: Optional[torch.Tensor], bandwidth: torch.Tensor, max_iter: int) -> torch.Tensor:
+        _need_gpu(pts, bandwidth)
+        self._pts64(pts)
+        n = pts.shape[0]
+        if weights is not None:
+            assert weights.dtype == torch.float32 and weights.numel() == n and weights.is_contiguous()
+        a, b = torch.empty_like(pts), torch.empty_like(pts)
+        state = torch.empty(max(max_iter, 1), dtype=torch.float64, device=pts.device)
+        in_a = C.c_int32(0)
+        check(self.lib.morig_meanshift(_p(pts), _p(weights), n, _p(bandwidth), max_iter, _p(a), _p(b), _p(state), C.byref(in_a),
+                                       _stream()), "morig_meanshift")
+        return a if in_a.value else b
+
+    def nms_counts(self, pts: torch.Tensor, bandwidth: torch.Tensor) -> torch.Tensor:
+        _need_gpu(pts, bandwidth)
+        self._pts64(pts)
+        counts = torch.empty(pts.shape[0], dtype=torch.int32, device=pts.device)
+        check(self.lib.morig_nms_counts(_p(pts), pts.shape[0], _p(bandwidth), _p(counts), _stream()), "morig_nms_counts")
+        return counts
+
+    def nms_greedy(self, pts: torch.Tensor, attn: torch.Tensor, bandwidth: torch.Tensor, order: torch.Tensor, thrd_density: float,
+                   thrd_attn: float) -> torch.Tensor:
+        _need_gpu(pts, attn, bandwidth, order)
+        self._pts64(pts)
+        n = pts.shape[0]
+        assert attn.dtype == torch.float32 and attn.numel() == n and order.dtype == torch.int32 and order.numel() == n
+        alive = torch.empty(n, dtype=torch.uint8, device=pts.device)
+        check(self.lib.morig_nms_greedy(_p(pts), _p(attn), n, _p(bandwidth), _p(order), float(thrd_density), float(thrd_attn),
+                                        _p(alive), _stream()), "morig_nms_greedy")
+        return alive.bool()
 
     def gather_rows(self, src: Mat, idx: torch.Tensor, dst: Mat):
         _need_gpu(src.base, idx, dst.base)

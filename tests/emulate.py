@@ -310,3 +310,75 @@ EmuOps.gather_rows = _emu_gather_rows
 EmuOps.sigmoid_minmax = _emu_sigmoid_minmax
 EmuOps.cosine_knn = _emu_cosine_knn
 EmuOps.flow_vote = _emu_flow_vote
+
+
+# ---- joint extraction (csrc/joints.hip): numpy float64, same operation order as the kernels -------------------------
+def _np64(t):
+    return t.detach().cpu().numpy().astype("float64")
+
+
+def _emu_inside_mask(self, pts, vox88, translate, scale, dims0):
+    import numpy as np
+    p = _np64(pts)
+    vc = np.round((p - np.asarray(translate, dtype=np.float64)) / float(scale) * float(dims0)).astype(np.int64)
+    ok = np.logical_and(np.all(vc >= 0, axis=1), np.all(vc < 88, axis=1))
+    vc = np.clip(vc, 0, 87)
+    v = vox88.cpu().numpy().reshape(88, 88, 88)
+    return torch.from_numpy(np.logical_and(ok, v[vc[:, 0], vc[:, 1], vc[:, 2]] != 0))
+
+
+def _emu_knn_bandwidth(self, pts, k):
+    import numpy as np
+    p = _np64(pts)
+    d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)
+    kth = np.sqrt(np.partition(d2, k - 1, axis=1)[:, k - 1])
+    return torch.tensor([kth.sum() / len(p)], dtype=torch.float64)
+
+
+def _emu_meanshift(self, pts, weights, bandwidth, max_iter):
+    import numpy as np
+    p = _np64(pts)
+    h2 = float(bandwidth.item()) ** 2
+    w = None if weights is None else weights.cpu().numpy().astype(np.float64).reshape(-1)
+    diff2, t = 1e20, 1
+    while np.sqrt(diff2) > 1e-3 and t < max_iter:
+        d2 = ((p[:, None, :] - p[None, :, :]) ** 2).sum(-1)            # [target j, source i]
+        k = np.maximum(h2 - d2, 0.0)
+        if w is not None:
+            k = k * w[None, :]
+        moved = 0.3 * ((k @ p) / (k.sum(1, keepdims=True) + 1e-10) - p) + p
+        diff2 = ((moved - p) ** 2).sum()
+        p = moved
+        t += 1
+    return torch.from_numpy(p)
+
+
+def _emu_nms_counts(self, pts, bandwidth):
+    import numpy as np
+    p = _np64(pts)
+    d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))
+    return torch.from_numpy((d <= float(bandwidth.item())).sum(0).astype(np.int32))
+
+
+def _emu_nms_greedy(self, pts, attn, bandwidth, order, thrd_density, thrd_attn):
+    import numpy as np
+    p = _np64(pts)
+    a = attn.cpu().numpy().astype(np.float32).reshape(-1)
+    n = len(p)
+    d = np.sqrt(((p[:, None, :] - p[None, :, :]) ** 2).sum(-1))
+    h = float(bandwidth.item())
+    alive = np.ones(n, dtype=bool)
+    for i in order.cpu().numpy().tolist():
+        if alive[i]:
+            nb = d[:, i] <= h
+            alive[nb] = False
+            if a[nb].max() > np.float32(thrd_attn) or nb.sum() / n > thrd_density:
+                alive[i] = True
+    return torch.from_numpy(alive)
+
+
+EmuOps.inside_mask = _emu_inside_mask
+EmuOps.knn_bandwidth = _emu_knn_bandwidth
+EmuOps.meanshift = _emu_meanshift
+EmuOps.nms_counts = _emu_nms_counts
+EmuOps.nms_greedy = _emu_nms_greedy

@@ -1,0 +1,98 @@
+"""CPU: host logic of morig_amd/joints.py (thresholds, mirror, k from the quantile, numpy visiting order, flip) on the
+emulated op layer against the reference-generated fixtures; GPU: the same through the HIP kernels (float64)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import morig_amd.runtime as runtime
+from conftest import load_golden
+from emulate import EmuOps
+from morig_amd import joints as J
+
+
+def _load(name):
+    meta, a = load_golden(name)
+    a = {k: v.numpy() for k, v in a.items()}
+    vox = types.SimpleNamespace(data=np.unpackbits(a["vox_data"])[:88 ** 3].reshape(88, 88, 88).astype(bool),
+                                translate=meta["vox_translate"], scale=meta["vox_scale"], dims=meta["vox_dims"])
+    return meta, a, vox
+
+
+def _check_against_fixture(name, device, tol):
+    meta, a, vox = _load(name)
+    out = J.extract_joints(a["shifted"], a["attn_raw"], vox, meta["quantile"], meta["threshold1"], meta["threshold2"],
+                           meta["max_iter"], device=device)
+    assert out["bandwidth"] == pytest.approx(float(a["bandwidth"][0]), rel=1e-12)
+    assert np.array_equal(out["attn"].cpu().numpy(), a["attn_mirrored"])
+    assert np.abs(out["modes"].cpu().numpy() - a["modes"]).max() <= tol
+    assert out["joints"].shape == a["joints"].shape and np.abs(out["joints"] - a["joints"]).max() <= tol
+    assert np.array_equal(out["side"], a["side"])
+    # the pieces, through the reference-named functions
+    dev = torch.device(device)
+    pm = torch.from_numpy(a["pts_mirrored"]).to(dev)
+    am = torch.from_numpy(a["attn_mirrored"]).to(dev)
+    bw = float(a["bandwidth"][0])
+    assert np.abs(J.meanshift_cluster(pm, bw, am, 3).cpu().numpy() - a["modes_two_steps"]).max() <= tol
+    assert np.abs(J.meanshift_cluster(pm, bw, None, 5).cpu().numpy() - a["modes_unweighted"]).max() <= tol
+    kept = J.nms_meanshift(torch.from_numpy(a["modes"]).to(dev), am, bw, meta["threshold2"])
+    assert np.array_equal(kept.cpu().numpy(), a["joints_nms"])
+    pts_in, idx = J.inside_check(torch.from_numpy(a["shifted"]).to(dev), vox)
+    assert np.array_equal(idx.cpu().numpy(), a["index_inside"])
+
+
+@pytest.fixture
+def emulated_ops():
+    runtime._test_ops = EmuOps()
+    yield
+    runtime._test_ops = None
+
+
+@pytest.mark.parametrize("name", ["joints_small", "joints_medium"])
+def test_extract_joints_host_logic(emulated_ops, name):
+    _check_against_fixture(name, "cpu", 1e-11)
+
+
+def test_flip_known_answer():
+    j, side = J.flip(np.array([[-0.3, 1, 2], [0.01, 3, 4], [0.4, 5, 6], [-0.02, 7, 8]]))
+    assert j.tolist() == [[-0.3, 1, 2], [0.0, 3, 4], [0.0, 7, 8], [0.3, 1, 2]] and side.tolist() == [-1, 0, 0, 1]
+
+
+def test_no_cpu_fallback():
+    """without the emulation seam the product path refuses CPU tensors / a missing GPU"""
+    from morig_amd import native
+    with pytest.raises((native.MorigNativeError, RuntimeError, AssertionError, OSError)):
+        J.estimate_bandwidth(torch.zeros(10, 3, dtype=torch.float64), 0.3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["joints_small", "joints_medium"])
+def test_extract_joints_on_gpu(name):
+    _check_against_fixture(name, "cuda:0", 1e-11)
+
+
+@pytest.mark.gpu
+def test_joint_kernels_larger_set_against_oracle():
+    """6144 mirrored points: bandwidth (k = 245), 29 mean-shift steps with device-side convergence, NMS."""
+    from oracle import joints as O
+    rng = np.random.default_rng(3)
+    centres = rng.uniform(-0.4, 0.4, (12, 3)); centres[:, 0] = -np.abs(centres[:, 0])
+    half = centres[rng.integers(0, 12, 3072)] + rng.normal(0, 0.03, (3072, 3))
+    pts = np.concatenate([half, half * np.array([[-1, 1, 1]])])
+    attn = np.tile((rng.random((3072, 1)) ** 2).astype(np.float32), (2, 1))
+    dev = torch.device("cuda:0")
+    p = torch.from_numpy(pts).to(dev)
+    a = torch.from_numpy(attn).to(dev)
+    bw = J.estimate_bandwidth(p, 0.04)
+    want_bw = O.estimate_bandwidth(pts, 0.04)
+    assert float(bw.item()) == pytest.approx(want_bw, rel=1e-12)
+    modes = J.meanshift_cluster(p, bw, a, max_iter=30)
+    want_modes = O.meanshift_cluster(pts, want_bw, attn, max_iter=30)
+    assert np.abs(modes.cpu().numpy() - want_modes).max() <= 1e-10
+    kept = J.nms_meanshift(torch.from_numpy(want_modes).to(dev), a, want_bw, 0.02)
+    want_kept, _, _ = O.nms_meanshift(want_modes, attn, want_bw, 0.02)
+    assert np.array_equal(kept.cpu().numpy(), want_kept) and 4 <= len(want_kept) <= 200
+    # early exit: a generous bandwidth converges well before max_iter; later launches must pass the points through
+    quick = J.meanshift_cluster(p, 10.0, None, max_iter=200)
+    assert np.abs(quick.cpu().numpy() - O.meanshift_cluster(pts, 10.0, None, max_iter=200)).max() <= 1e-10
