@@ -135,6 +135,98 @@ def joints_fixtures():
               modes_unweighted=plain, joints_nms=joints_nms, joints=joints, side=side)
 
 
+def write_rig_sample(folder, name, seed, n_side=6, n_joints=7, n_bones=24):
+    """A synthetic model in the reference's raw file formats (datasets/dataset_rig.py:82-115); returns the file map
+    {relative path: bytes} so a test can lay the same files down again anywhere."""
+    rng = np.random.default_rng(seed)
+    mesh = synth.make_mesh(seed, n_side=n_side)
+    V = mesh.pos.shape[0]
+    os.makedirs(os.path.join(folder, "pred_flow"), exist_ok=True)
+    traj = mesh.pos.numpy()[:, None, :].astype(np.float64) + np.cumsum(rng.normal(0, 0.004, (V, 101, 3)), axis=1)
+    np.save(os.path.join(folder, f"{name}_vtx_traj.npy"), traj)
+    np.savetxt(os.path.join(folder, f"{name}_attn.txt"), rng.random(V))
+    strip = lambda e: e[:, e[0] != e[1]].numpy().T                  # the raw files carry no self loops
+    np.savetxt(os.path.join(folder, f"{name}_tpl_e.txt"), strip(mesh.tpl_edge_index), fmt="%d")
+    np.savetxt(os.path.join(folder, f"{name}_geo_e.txt"), strip(mesh.geo_edge_index), fmt="%d")
+    jn = [f"joint{j}" for j in range(n_joints)]
+    jp = rng.uniform(-0.4, 0.4, (n_joints, 3))
+    with open(os.path.join(folder, f"{name}_rig.txt"), "w") as f:
+        for n_, p_ in zip(jn, jp):
+            f.write("joints {0} {1:.8f} {2:.8f} {3:.8f}\n".format(n_, *p_))
+        f.write(f"root {jn[2]}\n")
+        for v in range(V):
+            js = rng.choice(n_joints, 3, replace=False)
+            ws = rng.dirichlet(np.ones(3))
+            f.write(f"skin {v} " + " ".join(f"{jn[j]} {w:.4f}" for j, w in zip(js, ws)) + "\n")
+        order = [2] + [j for j in range(n_joints) if j != 2]
+        for k in range(1, n_joints):                                   # a random tree rooted at joint2
+            f.write(f"hier {jn[order[rng.integers(0, k)]]} {jn[order[k]]}\n")
+    with open(os.path.join(folder, f"{name}_skin.txt"), "w") as f:
+        for b in range(n_bones):
+            a, c = rng.choice(n_joints, 2, replace=False)
+            f.write(f"bones {jn[a]} {jn[c]} " + " ".join(f"{x:.6f}" for x in np.concatenate([jp[a], jp[c]])) + "\n")
+        for v in range(V):
+            near = rng.choice(n_bones, 20, replace=False)
+            n_valid = 20 if v % 5 else 14                              # some vertices see fewer than 20 bones: -1 slots
+            words = [str(v)]
+            for i in range(20):
+                if i < n_valid:
+                    words += [str(int(near[i])), f"{rng.uniform(1, 50):.6f}", str(int(rng.integers(0, 2)))]
+                else:
+                    words += ["-1", "0.000000", "0"]
+            f.write("bind " + " ".join(words) + "\n")
+            f.write("influence " + " ".join(f"{x:.6f}" for x in rng.dirichlet(np.ones(5))) + "\n")
+    for t in range(1, 6):
+        np.save(os.path.join(folder, "pred_flow", f"{name}_{t}_pred_flow.npy"), rng.normal(0, 0.05, (V, 3)))
+    files = {}
+    for dirpath, _, fns in os.walk(folder):
+        for fn in fns:
+            full = os.path.join(dirpath, fn)
+            files[os.path.relpath(full, folder)] = open(full, "rb").read()
+    return files
+
+
+def dataset_fixtures():
+    """On-disk formats: the reference's own RigDataset.process (datasets/dataset_rig.py:78-140) and
+    readPly (utils/io_utils.py:18-26) on synthetic raw files; the fixture holds the raw files' bytes and every tensor of
+    the resulting Data."""
+    print("dataset-format fixtures")
+    import tempfile, types
+    shim.install()
+    sys.path.insert(0, shim.REFERENCE_ROOT)
+    for name in ("open3d", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if not hasattr(np, "int"):
+        np.int = int
+    dr = __import__("datasets.dataset_rig", fromlist=["RigDataset"])
+    iou = __import__("utils.io_utils", fromlist=["readPly"])
+    with tempfile.TemporaryDirectory() as td:
+        root = os.path.join(td, "val")
+        os.makedirs(root)
+        files = {}
+        for name, seed in ((1401, 51), (27, 52)):
+            files.update(write_rig_sample(root, name, seed))
+        raw = {k: v for k, v in files.items() if not k.startswith("processed")}
+        from oracle import pyg_primitives as P
+        torch.serialization.add_safe_globals([P.Data])               # the reference's __init__ torch.load()s its own file
+        ds = dr.RigDataset(root)
+        data_list, _ = torch.load(ds.processed_paths[0], weights_only=False)
+        out = {}
+        for d in data_list:
+            for k, v in d.__dict__.items():
+                if torch.is_tensor(v):
+                    out[f"m{d.name}__{k}"] = v
+        ply = "ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\nend_header\n" \
+              "0.100000 0.250000 -0.300000\n1.000000 2.000000 3.000000\n0.000000 -0.000000 0.500000\n"
+        with open(os.path.join(td, "kat.ply"), "w") as f:
+            f.write(ply)
+        out["ply_points"] = iou.readPly(os.path.join(td, "kat.ply"))
+    names = sorted(raw)
+    blob = b"".join(raw[n] for n in names)
+    _save("rig_dataset_files", dict(models=[1401, 27], file_names=names, file_sizes=[len(raw[n]) for n in names], ply_text=ply),
+          file_blob=np.frombuffer(blob, dtype=np.uint8), **out)
+
+
 def main():
     torch.set_grad_enabled(False)
     torch.manual_seed(0)
@@ -143,6 +235,8 @@ def main():
         return deformnet_fixtures(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "joints":
         return joints_fixtures()
+    if len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        return dataset_fixtures()
     bm = sys.modules["models.basic_modules"]
     rn = sys.modules["models.rignet"]
 
@@ -264,6 +358,7 @@ def main():
 
     deformnet_fixtures(ref)
     joints_fixtures()
+    dataset_fixtures()
 
     # ---- writers (utils/io_utils.py:41-55, training/train_rig.py:253-258) ---------------
     print("writer fixtures")

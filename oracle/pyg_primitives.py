@@ -249,3 +249,44 @@ class PointConv(MessagePassing):
         if self.local_nn is not None:
             msg = self.local_nn(msg)
         return msg
+
+
+# ---------------------------------------------------------------------------------------------------
+# torch_geometric.data stand-ins, just enough for datasets/dataset_rig.py to run its own process()
+# ---------------------------------------------------------------------------------------------------
+class Data:
+    """attribute bag: Data(pos=..., tpl_edge_index=..., ...) (datasets/dataset_rig.py:134-138)."""
+
+    def __init__(self, **kwargs):
+        self.__dict__.update(kwargs)
+
+    def keys(self):
+        return list(self.__dict__.keys())
+
+
+class InMemoryDataset:
+    """PyG's life cycle as dataset_rig.py relies on it: ``raw_paths`` from ``raw_file_names`` (the reference returns
+    absolute glob results), ``processed_paths`` under ``root/processed``, ``process()`` run once when the processed
+    file is missing, ``collate`` -> (data, slices). Here collate keeps the per-model list (no concatenation)."""
+
+    def __init__(self, root=None, transform=None, pre_transform=None):
+        import os
+        self.root = root
+        os.makedirs(os.path.join(root, "processed"), exist_ok=True)
+        if not os.path.exists(self.processed_paths[0]):
+            self.process()
+
+    @property
+    def raw_paths(self):
+        return sorted(self.raw_file_names)
+
+    @property
+    def processed_paths(self):
+        import os
+        names = self.processed_file_names
+        names = [names] if isinstance(names, str) else list(names)
+        return [os.path.join(self.root, "processed", n) for n in names]
+
+    @staticmethod
+    def collate(data_list):
+        return data_list, None

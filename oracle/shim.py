@@ -9,6 +9,7 @@ into ``sys.modules``:
     torch_geometric.utils.{remove_self_loops, add_self_loops}        models/basic_modules.py:5
     torch_geometric.nn.{knn_interpolate, fps, radius, global_max_pool,
                         PointConv, knn}                              models/basic_modules.py:6, corrnet.py:3
+    torch_geometric.data.{Data, InMemoryDataset}                     datasets/dataset_rig.py:6
 
 Nothing of the reference is copied; it is imported from /root/reference where it lies.
 """
@@ -44,6 +45,10 @@ def install() -> None:
     tgu.remove_self_loops, tgu.add_self_loops = P.remove_self_loops, P.add_self_loops
     for name in ("knn_interpolate", "fps", "radius", "global_max_pool", "PointConv", "knn"):
         setattr(tgn, name, getattr(P, name))
+    # torch_geometric.data.{Data, InMemoryDataset}: datasets/dataset_rig.py:6
+    tgd = mod("torch_geometric.data")
+    tg.data = tgd
+    tgd.Data, tgd.InMemoryDataset, tgd.Dataset = P.Data, P.InMemoryDataset, P.InMemoryDataset
 
 
 def import_reference_models():
