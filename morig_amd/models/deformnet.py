@@ -20,7 +20,7 @@ import torch
 from ..native import Mat
 from ..runtime import get_ops
 from .basic_modules import NativeModule
-from .corrnet import CorrNet, _ptr
+from .corrnet import CorrNet
 from .rignet import GCNRig
 
 __all__ = ["deformnet"]
@@ -59,12 +59,10 @@ class DeformNet(NativeModule):
         # CorrNet with its defaults: train_vismask=True, random_start=True (:41)
         vtx_f, pts_f, logit, tau = self.corr_extractor._forward(data, True)
         n = vtx_f.shape[0]
-        B = getattr(data, "num_graphs", None)
-        vb, pb = data.vtx_batch, data.pts_batch
-        if B is None:
-            B = int(max(int(vb.max().item()), int(pb.max().item()))) + 1
-        vcounts, pcounts = torch.stack([torch.bincount(vb, minlength=B), torch.bincount(pb, minlength=B)]).tolist()
-        ptr_v, ptr_p = _ptr(vcounts, dev), _ptr(pcounts, dev)
+        plan = self.corr_extractor.last_plan              # offsets / counts of this very forward: no second count, no sync
+        B, vcounts = plan.B, plan.vcounts
+        vb = data.vtx_batch
+        ptr_v, ptr_p = plan.ptr_v, plan.ptr[0]
 
         vis = torch.empty((n, 1), dtype=torch.float32, device=dev)
         ops.sigmoid_minmax(Mat.of(logit), ptr_v, B, Mat.of(vis))                      # :42-46
