@@ -36,6 +36,9 @@ extern "C" {
 #define MORIG_E_NODEVICE     -4   /* no gfx950 device visible                                   */
 
 int         morig_abi_version(void);
+/* Scheduling hint, process-wide: leave n CUs (rounded up to 8) free of the persistent EdgeConv workgroups launched from now
+ * on. The host sets it while single-CU-per-cloud kernels (FPS) run on a second stream, and back to 0 afterwards. */
+int         morig_reserve_cus(int n);
 const char* morig_strerror(int status);
 int         morig_last_hip_error(void);            /* raw hipError_t of the last MORIG_E_HIP   */
 /* device facts used by the host side for roofline arithmetic; arch must start with "gfx950" */

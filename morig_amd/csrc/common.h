@@ -62,6 +62,7 @@ struct GemmDmaParams {
     int dbg;                                     // ablation: 1 = no epilogue
 };
 int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pc.hip
+void set_reserved_cus(int n);
 int launch_edge_pp(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pp.hip (persistent)
 int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); // gemm_dma.hip
 

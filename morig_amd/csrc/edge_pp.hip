@@ -19,6 +19,7 @@
 //   producers:  B_0;  for c = 1..7: { stage chunk c; B_c }   stage chunk 0 of the NEXT tile;  E1;  scan
 // Chunk c lives in ring stage c & 1; it is overwritten only after the barrier that follows its consumption.
 #include "common.h"
+#include <atomic>
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -473,6 +474,11 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
     }
 }
 
+// CUs the caller wants left alone by the persistent kernels (set while long single-CU kernels such as FPS run on another
+// stream: a persistent workgroup that cannot be placed until they finish would hold back its whole static tile list)
+static std::atomic<int> g_reserved_cus{0};
+void set_reserved_cus(int n) { g_reserved_cus.store(n < 0 ? 0 : n); }
+
 int launch_edge_pp(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     EdgePcParams p = p0;
     static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
@@ -486,7 +492,9 @@ int launch_edge_pp(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     static unsigned long long* trace_buf = [] { void* b = nullptr; return hipMalloc(&b, 64 * 8) == hipSuccess ? (unsigned long long*)b : nullptr; }();
     p.trace = trace_buf;
 #endif
-    const int grid = nblocks < ncu ? ((nblocks + 7) / 8) * 8 : ncu;     // one persistent workgroup per CU, multiple of 8 (XCDs)
+    int avail = ncu - ((g_reserved_cus.load() + 7) / 8) * 8;
+    if (avail < 8) avail = 8;
+    const int grid = nblocks < avail ? ((nblocks + 7) / 8) * 8 : avail;  // one persistent workgroup per CU, multiple of 8 (XCDs)
 #define PP_LAUNCH(HH, QQ) hipLaunchKernelGGL((edge_pp_kernel<HH, QQ>), dim3(grid), dim3(512), 0, s, p)
     if (p.H == 256 && p.quad) PP_LAUNCH(256, true);
     else if (p.H == 256) PP_LAUNCH(256, false);

@@ -66,6 +66,8 @@ extern "C" {
 
 int morig_abi_version(void) { return MORIG_ABI_VERSION; }
 
+int morig_reserve_cus(int n) { set_reserved_cus(n); return MORIG_OK; }
+
 const char* morig_strerror(int st) {
     switch (st) {
         case MORIG_OK: return "ok";

@@ -16,6 +16,7 @@ cosine 1-NN matching (models/corrnet.py:63-65). Restructurings (exact up to fp32
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 from torch.nn import Linear as Lin, Parameter, Sequential as Seq
@@ -80,6 +81,7 @@ class CorrNet(NativeModule):
         self.output_feature = output_feature
         self.temprature = Parameter(torch.Tensor([temprature]))
         self.last_plan = None
+        self._streams = {}
 
         self.vtx_gcu_1 = GCU(in_channels=3, out_channels=32, aggr=aggr)
         self.vtx_gcu_2 = GCU(in_channels=32, out_channels=64, aggr=aggr)
@@ -100,6 +102,12 @@ class CorrNet(NativeModule):
         self.pts_mlp = Seq(MLP([64, 64]), Lin(64, output_feature))
 
         self.lin_vismask = Seq(MLP([2 * output_feature + 1, 256, 128, 64]), Lin(64, 1))
+
+    def _side_stream(self, dev):
+        key = (dev.type, dev.index)
+        if self._streams.get(key) is None:
+            self._streams[key] = torch.cuda.Stream(device=dev)
+        return self._streams[key]
 
     # ------------------------------------------------------------------------------------------
     def _pack(self):
@@ -268,8 +276,25 @@ class CorrNet(NativeModule):
                          random_start, dev)
         self.last_plan = plan                          # DeformNet reuses the offsets (no second count / sync)
         seg = ops.make_seg(vb, B, 1)
-        out_vtx = self._vertex_branch(ops, data, seg, B)
-        out_pts, ptr_p = self._point_branch(ops, data, plan)
+        if dev.type == "cuda" and os.environ.get("MORIG_TWO_STREAMS", "1") != "0":
+            # The two branches meet only at the matching (:62-65). The point branch is a chain of small launches around
+            # three FPS kernels that occupy ONE CU per cloud for milliseconds; on a second HIP stream it runs under the
+            # vertex branch's GEMM / EdgeConv launches instead of in front of them.
+            main = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                out_pts, ptr_p = self._point_branch(ops, data, plan)
+            ops.reserve_cus(B)                         # FPS holds one CU per cloud
+            try:
+                out_vtx = self._vertex_branch(ops, data, seg, B)
+            finally:
+                ops.reserve_cus(0)
+            main.wait_stream(side)
+            out_pts.record_stream(main)
+        else:
+            out_vtx = self._vertex_branch(ops, data, seg, B)
+            out_pts, ptr_p = self._point_branch(ops, data, plan)
         out_vismask = None
         if train_vismask:
             n, C = out_vtx.shape

@@ -74,6 +74,7 @@ class SegmaxArgs(C.Structure):
 _SIGNATURES = {
     "morig_abi_version": (C.c_int, []),
     "morig_strerror": (C.c_char_p, [C.c_int]),
+    "morig_reserve_cus": (C.c_int, [C.c_int]),
     "morig_last_hip_error": (C.c_int, []),
     "morig_device_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_char_p, C.c_int]),
     "morig_csr_build": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
@@ -437,6 +438,10 @@ class NativeOps:
         check(self.lib.morig_cosine_nn(v.ptr, v.ld, _p(ptr_v), p.ptr, p.ld, _p(ptr_p), n_clouds, max_rows_per_cloud, v.cols,
                                        _p(nn), _p(sim), _stream()), "morig_cosine_nn")
         return nn, sim
+
+    def reserve_cus(self, n: int):
+        """keep n CUs free of persistent EdgeConv workgroups (while FPS runs on a second stream)."""
+        check(self.lib.morig_reserve_cus(int(n)), "morig_reserve_cus")
 
     # -- DeformNet glue (csrc/deform.hip) ----------------------------------------------------------------
     def sigmoid_minmax(self, x: Mat, ptr: torch.Tensor, n_meshes: int, out: Mat):
