@@ -178,6 +178,12 @@ int morig_copy2d(const float* src, int32_t lds, float* dst, int32_t ldd, int32_t
  * (slot_cols % 32 == 0, 128-byte aligned) is written in the split-fp16 activation layout; *overflow as in morig_gemm. */
 int morig_copy2d_pad(const float* src, int32_t lds, int32_t rows, int32_t cols, float* dst, int32_t ldd,
                      int32_t slot_cols, int32_t split, int32_t* overflow, void* stream);
+/* `replicas` such copies in one launch: copy r reads the source window shifted by r * src_col_step columns and writes
+ * the destination window shifted by r * dst_row_step rows. Keyframe features (input_flow[:, 3t:3t+3] -> replica t,
+ * rignet.py:86): src_col_step = 3; position rows / position-branch columns of the motion replicas: src_col_step = 0. */
+int morig_copy2d_pad_rep(const float* src, int32_t lds, int32_t rows, int32_t cols, int32_t src_col_step, float* dst,
+                         int32_t ldd, int32_t slot_cols, int32_t replicas, int64_t dst_row_step, int32_t split,
+                         int32_t* overflow, void* stream);
 
 /* gather columns: dst[r*ldd + c] = src[r*lds + cols[c]]  (skin_input column selection,
  * models/rignet.py:158-171). cols: int32 [n_cols] on device. */

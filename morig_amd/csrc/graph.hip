@@ -151,6 +151,30 @@ __global__ void copy2d_pad_kernel(const float* __restrict__ src, int lds, int ro
     }
 }
 
+// `replicas` copies in one launch: copy r reads the source window shifted by r * src_col_step columns and writes the
+// destination window shifted by r * dst_row_step rows (keyframe features: column step 3, :86; position rows and the
+// position-branch columns of the motion replicas: column step 0)
+__global__ void copy2d_pad_rep_kernel(const float* __restrict__ src, int lds, int rows, int cols, int src_col_step,
+                                      float* __restrict__ dst, int ldd, int slot, int replicas, int64_t dst_row_step, int split, int* ovf) {
+    const int64_t n = (int64_t)rows * slot;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / slot; const int c = (int)(i - r * slot);
+        float v = c < cols ? src[r * lds + c] : 0.f;
+        for (int q = 0; q < replicas; ++q) {
+            if (q > 0 && src_col_step != 0) v = c < cols ? src[r * lds + c + q * src_col_step] : 0.f;
+            float* drow = dst + (r + q * dst_row_step) * ldd;
+            if (!split) { drow[c] = v; continue; }
+            const __fp16 h = (__fp16)v;
+            const __fp16 l = (__fp16)(v - (float)h);
+            if (!(fabsf(v) < 65000.f)) *ovf = 1;
+            __fp16* yh = reinterpret_cast<__fp16*>(drow) + (c >> 5) * 64 + (c & 31);
+            yh[0] = h;
+            yh[32] = l;
+        }
+    }
+}
+
 __global__ void gather_cols_kernel(const float* __restrict__ src, int lds, const int* __restrict__ cols, int ncols,
                                    float* __restrict__ dst, int ldd, int rows) {
     const int64_t n = (int64_t)rows * ncols;
@@ -296,6 +320,22 @@ extern "C" int morig_copy2d_pad(const float* src, int32_t lds, int32_t rows, int
     ProfScope ps(K_COPY, s, 0.0, 4.0 * rows * (cols + slot_cols));
     hipLaunchKernelGGL(copy2d_pad_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, dst, ldd,
                        slot_cols, split, overflow);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_copy2d_pad_rep(const float* src, int32_t lds, int32_t rows, int32_t cols, int32_t src_col_step, float* dst,
+                                    int32_t ldd, int32_t slot_cols, int32_t replicas, int64_t dst_row_step, int32_t split,
+                                    int32_t* overflow, void* stream) {
+    if (!src || !dst || rows < 0 || cols < 0 || slot_cols < cols || ldd < slot_cols || replicas < 1 || src_col_step < 0 || dst_row_step < 0)
+        return MORIG_E_INVALID;
+    if (lds < cols + (replicas - 1) * src_col_step) return MORIG_E_INVALID;
+    if (split && (!overflow || (slot_cols & 31) || (ldd & 31) || (reinterpret_cast<uintptr_t>(dst) & 127))) return MORIG_E_INVALID;
+    if (rows == 0 || slot_cols == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_COPY, s, 0.0, 4.0 * rows * ((double)cols + (double)slot_cols * replicas));
+    hipLaunchKernelGGL(copy2d_pad_rep_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, src_col_step,
+                       dst, ldd, slot_cols, replicas, dst_row_step, split, overflow);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

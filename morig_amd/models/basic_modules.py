@@ -238,9 +238,9 @@ class GCUMotion(NativeModule):
         # position branch: independent of the keyframe -> computed once into replica 0, copied to the others
         ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(ec, H, D, 0, n))
         ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(ec, 2 * H + D, D, 0, n))
-        for r in range(1, replicas):
-            ops.copy2d(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, r * n, n))
-            ops.copy2d(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, r * n, n))
+        if replicas > 1:                                # one launch per column window instead of one per replica
+            ops.copy2d_rep(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, n, n), replicas - 1, n)
+            ops.copy2d_rep(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, n, n), replicas - 1, n)
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split_out)
 
     def _forward(self, pos, x, tpl_edge_index, geo_edge_index):

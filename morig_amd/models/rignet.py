@@ -150,8 +150,7 @@ class GCNRig(NativeModule):
         M = n * R
         sp = ops.split_activations                    # GEMM -> GEMM activations in the split-fp16 layout
         wide = ops.empty(M, self.wide_ld, dev)
-        for r in range(R):
-            ops.copy2d_pad(Mat.of(pos4), Mat.of(wide, self.POS, 32, r * n, n), split=sp)
+        ops.copy2d_rep(Mat.of(pos4), Mat.of(wide, self.POS, 32, 0, n), R, n, split=sp)       # the same positions in every replica
         write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
         self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp)
@@ -205,9 +204,8 @@ class _MotionBackbone(NativeModule):
         csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)
         seg_T = ops.make_seg(data.batch, ng, T)
 
-        def write_flow(w: Mat, sp: bool):             # feature of replica t = input_flow[:, 3t:3t+3]  (:86)
-            for t in range(T):
-                ops.copy2d_pad(Mat.of(flow, 3 * t, 3), Mat.of(w.base, w.col0, w.cols, t * n, n), split=sp)
+        def write_flow(w: Mat, sp: bool):             # feature of replica t = input_flow[:, 3t:3t+3]  (:86), one launch
+            ops.copy2d_rep(Mat.of(flow, 0, 3), Mat.of(w.base, w.col0, w.cols, 0, n), T, n, src_col_step=3, split=sp)
 
         C = self.motionNet.chn_output
         raw = ops.empty(T * n, C, dev)

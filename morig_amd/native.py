@@ -102,6 +102,8 @@ _SIGNATURES = {
     "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_copy2d": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "morig_copy2d_pad": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
+    "morig_copy2d_pad_rep": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
+                                        C.c_int32, c_i32p, C.c_void_p]),
     "morig_gather_cols": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
     "morig_make_seg": (C.c_int, [c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_rownorm": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
@@ -551,6 +553,18 @@ class NativeOps:
             raise MorigNativeError("split-fp16 activations requested on the fp32 path (plan bug)")
         check(self.lib.morig_copy2d_pad(src.ptr, src.ld, src.rows, src.cols, dst.ptr, dst.ld, dst.cols, int(split),
                                         _p(self._flag(src.base.device)), _stream()), "morig_copy2d_pad")
+
+    def copy2d_rep(self, src: Mat, dst: Mat, replicas: int, dst_row_step: int, src_col_step: int = 0, split: bool = False):
+        """`replicas` copies in one launch: copy r = [src window shifted r * src_col_step columns | zeros] into the dst
+        window shifted r * dst_row_step rows (dst describes replica 0)."""
+        _need_gpu(src.base, dst.base)
+        assert src.rows == dst.rows and dst.cols >= src.cols and replicas >= 1
+        assert dst.row0 + dst.rows + (replicas - 1) * dst_row_step <= dst.base.shape[0]
+        assert src.col0 + src.cols + (replicas - 1) * src_col_step <= src.base.shape[1]
+        if split and not self.fast:
+            raise MorigNativeError("split-fp16 activations requested on the fp32 path (plan bug)")
+        check(self.lib.morig_copy2d_pad_rep(src.ptr, src.ld, src.rows, src.cols, src_col_step, dst.ptr, dst.ld, dst.cols, replicas,
+                                            dst_row_step, int(split), _p(self._flag(src.base.device)), _stream()), "morig_copy2d_pad_rep")
 
     def gather_cols(self, src: Mat, cols: torch.Tensor, dst: Mat):
         _need_gpu(src.base, cols, dst.base)

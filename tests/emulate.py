@@ -77,6 +77,11 @@ class EmuOps:
         d.zero_()
         d[:, : src.cols] = src.view()
 
+    def copy2d_rep(self, src: Mat, dst: Mat, replicas, dst_row_step, src_col_step=0, split=False):
+        for r in range(replicas):
+            self.copy2d_pad(Mat.of(src.base, src.col0 + r * src_col_step, src.cols, src.row0, src.rows),
+                            Mat.of(dst.base, dst.col0, dst.cols, dst.row0 + r * dst_row_step, dst.rows), split=split)
+
     def gemm(self, X: Mat, lin, relu, Y=None, rowbias=None, seg=None, pool=None, affine=True, x_split=False, y_split=False):
         if x_split:
             assert X.col0 % 32 == 0 and X.ld % 32 == 0, "split-fp16 X window must be chunk aligned"

@@ -531,3 +531,26 @@ def test_copy2d_pad_plain_and_split():
     o.copy2d_pad(Mat.of(src.to(DEV), 3, 5), Mat.of(dst2, 32, 64), split=True)
     dec = packing.unsplit_f16(dst2.cpu(), 96)
     assert maxdiff(dec[:, 32:37], src[:, 3:8]) <= 1e-6 and float(dec[:, 37:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_copy2d_rep(ops, split):
+    """one launch = R copies: keyframe features (column step 3) and plain replication (column step 0)"""
+    if split and not ops.fast:
+        pytest.skip("split-fp16 activations only exist on the split-fp16 path")
+    g = torch.Generator().manual_seed(31)
+    n, R = 500, 5
+    flow = torch.randn(n, 16, generator=g)
+    e = EmuOps()
+    for step, cols in ((3, 3), (0, 4)):
+        want = torch.full((R * n + 7, 96), float("nan"))
+        got = torch.full((R * n + 7, 96), float("nan"), device=DEV)
+        e.copy2d_rep(Mat.of(flow, 1, cols), Mat.of(want, 32, 32, 0, n), R, n, src_col_step=step, split=split)
+        ops.copy2d_rep(Mat.of(flow.to(DEV), 1, cols), Mat.of(got, 32, 32, 0, n), R, n, src_col_step=step, split=split)
+        if not split:
+            assert torch.equal(torch.nan_to_num(got.cpu(), nan=-7.0), torch.nan_to_num(want, nan=-7.0))
+        else:
+            # split layout: the 32-column chunk holds [32 hi halves | 32 lo halves]; hi + lo reproduces the values
+            raw = got.cpu()[: R * n, 32:64].contiguous().view(torch.float16).float().view(R * n, 64)
+            assert maxdiff(raw[:, :32] + raw[:, 32:], want[: R * n, 32:64]) <= 1e-6
+            assert bool(torch.isnan(got.cpu()[R * n:, :]).all()) and bool(torch.isnan(got.cpu()[:, :32]).all())
