@@ -165,19 +165,31 @@ class CorrNet(NativeModule):
         ops.rownorm(Mat.of(raw), n, 1, out_vtx, self.output_feature, 0)
         return out_vtx
 
-    def _set_abstraction(self, ops, sa: SAModule, xp: torch.Tensor, cx: int, plan: _HostPlan, level: int):
-        """xp: [N, ld] = [x(cx) | pos(3) | pad] of level ``level``; returns (x_new [M, H3], pos_new4 [M,4])."""
+    def _sample_levels(self, ops, pos0: torch.Tensor, plan: _HostPlan):
+        """The three FPS levels depend only on positions (pos_{l+1} = pos_l[fps(pos_l)], models/basic_modules.py:75,85),
+        not on the PointConv features: run them back to back, ahead of the convolutions. Each occupies one CU per cloud
+        for its whole run, so this is the part of the point branch that overlaps the vertex branch almost for free."""
+        dev = pos0.device
+        levels = [pos0]
+        for level in range(3):
+            cur = levels[-1]
+            M = sum(plan.counts[level + 1])
+            idx = ops.fps(Mat.of(cur, 0, 3), plan.ptr[level], plan.ptr[level + 1], plan.start[level], plan.B,
+                          max(plan.counts[level]), M)
+            nxt = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+            ops.gather_rows(Mat.of(cur, 0, 3), idx, Mat.of(nxt, 0, 3))
+            levels.append(nxt)
+        return levels
+
+    def _set_abstraction(self, ops, sa: SAModule, xp: torch.Tensor, cx: int, pos_new: torch.Tensor, plan: _HostPlan, level: int):
+        """xp: [N, ld] = [x(cx) | pos(3) | pad] of level ``level``; pos_new: the sampled centres [M, 4]; returns x_new [M, H3]."""
         dev = xp.device
         pk = sa.packed(dev)
         N = xp.shape[0]
-        counts, new_counts = plan.counts[level], plan.counts[level + 1]
-        ptr, out_ptr, start = plan.ptr[level], plan.ptr[level + 1], plan.start[level]
+        ptr, out_ptr = plan.ptr[level], plan.ptr[level + 1]
         n_clouds = plan.B
-        M = sum(new_counts)
+        M = pos_new.shape[0]
         posm = Mat.of(xp, cx, 3)
-        idx = ops.fps(posm, ptr, out_ptr, start, n_clouds, max(counts), M)
-        pos_new = torch.zeros((M, 4), dtype=torch.float32, device=dev)
-        ops.gather_rows(posm, idx, Mat.of(pos_new, 0, 3))
         coo = ops.ball_query(posm, ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, sa.r, sa.max_num_neighbors)
         csr = ops.csr_from_slots(coo, M, sa.max_num_neighbors, N)
         H = pk["edge"].H
@@ -189,7 +201,7 @@ class CorrNet(NativeModule):
         ops.edge_hidden(Mat.of(atgt), Mat.of(bsrc), csr, pk["edge"], Mat.of(z))
         x_new = ops.empty(M, pk["last"].N, dev)
         ops.segmax_gemm(Mat.of(z), pk["last"], True, csr, Mat.of(x_new))
-        return x_new, pos_new
+        return x_new
 
     @staticmethod
     def _with_pos(ops, x: torch.Tensor, pos4: torch.Tensor):
@@ -210,11 +222,12 @@ class CorrNet(NativeModule):
         ops.copy2d(Mat.of(data.pts.float().contiguous()), Mat.of(pos0, 0, 3))
         counts0, c1, c2, c3 = plan.counts
         ptr0, ptr1, ptr2, ptr3 = plan.ptr
-        x1, pos1 = self._set_abstraction(ops, self.pts_sa1_module, pos0, 0, plan, 0)
+        _, pos1, pos2, pos3 = self._sample_levels(ops, pos0, plan)
+        x1 = self._set_abstraction(ops, self.pts_sa1_module, pos0, 0, pos1, plan, 0)
         xp1 = self._with_pos(ops, x1, pos1)
-        x2, pos2 = self._set_abstraction(ops, self.pts_sa2_module, xp1, 64, plan, 1)
+        x2 = self._set_abstraction(ops, self.pts_sa2_module, xp1, 64, pos2, plan, 1)
         xp2 = self._with_pos(ops, x2, pos2)
-        x3, pos3 = self._set_abstraction(ops, self.pts_sa3_module, xp2, 128, plan, 2)
+        x3 = self._set_abstraction(ops, self.pts_sa3_module, xp2, 128, pos3, plan, 2)
         xp3 = self._with_pos(ops, x3, pos3)
         M3 = x3.shape[0]
         seg3 = torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev), (ptr3[1:] - ptr3[:-1]).long(),
