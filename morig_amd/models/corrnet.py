@@ -29,13 +29,6 @@ from .basic_modules import GCU, MLP, FPModule, GlobalSAModule, NativeModule, SAM
 __all__ = ["corrnet"]
 
 
-def _ptr(counts, device):
-    p = [0]
-    for c in counts:
-        p.append(p[-1] + int(c))
-    return torch.tensor(p, dtype=torch.int32, device=device)
-
-
 class _HostPlan:
     """Everything the point branch needs from the host, decided up front and shipped in ONE pinned, non-blocking
     H2D copy: per-level cloud sizes (ceil(ratio * n), models/basic_modules.py:75), their offset vectors, the vertex
