@@ -554,3 +554,52 @@ def test_copy2d_rep(ops, split):
             raw = got.cpu()[: R * n, 32:64].contiguous().view(torch.float16).float().view(R * n, 64)
             assert maxdiff(raw[:, :32] + raw[:, 32:], want[: R * n, 32:64]) <= 1e-6
             assert bool(torch.isnan(got.cpu()[R * n:, :]).all()) and bool(torch.isnan(got.cpu()[:, :32]).all())
+
+
+def test_fps_full_size_properties(ops):
+    """BASELINE.json configs[3] sizes (8192-point clouds, ratio 0.5): the oracle loop is too slow here, so check what
+    defines the result: (a) distinct indices inside the cloud, (b) every sample is a farthest point of its step -- its
+    distance to the earlier samples equals the maximum over the cloud -- and (c) the lowest index among those maxima."""
+    import math
+    counts = [8192, 8192, 5000]
+    pos4, ptr = _clouds(counts, 11)
+    newc = [math.ceil(0.5 * c) for c in counts]
+    optr = torch.tensor([0] + list(torch.tensor(newc).cumsum(0)), dtype=torch.int32)
+    got = ops.fps(Mat.of(pos4.to(DEV), 0, 3), ptr.to(DEV), optr.to(DEV), None, len(counts), max(counts), sum(newc)).cpu().long()
+    for b, (n, m) in enumerate(zip(counts, newc)):
+        p0 = int(ptr[b])
+        sel = got[int(optr[b]):int(optr[b + 1])] - p0
+        assert sel.min() >= 0 and sel.max() < n and len(set(sel.tolist())) == m and int(sel[0]) == 0
+        p = pos4[p0:p0 + n, :3].to(DEV)
+        dist = torch.full((n,), float("inf"), device=DEV)
+        for s in range(1, min(m, 600)):                            # the first 600 steps on the device, same fp32 formula
+            d = p - p[sel[s - 1]]
+            d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            dist = torch.minimum(dist, d)
+            mx = dist.max()
+            assert float(dist[sel[s]]) == float(mx)
+            assert int(torch.nonzero(dist == mx)[0]) == int(sel[s])
+
+
+def test_cosine_knn_full_size_properties(ops):
+    """4096 queries x 8192 candidates per cloud (the benchmark's pair size), k = 5: neighbours come from the query's own
+    cloud, similarities are sorted, and nothing outside the list beats its last entry (checked against a torch matmul on
+    the device for a sample of rows)."""
+    g = torch.Generator().manual_seed(12)
+    B, V, P, k = 3, 4096, 8192, 5
+    y = torch.nn.functional.normalize(torch.randn(B * V, 64, generator=g), dim=1).to(DEV)
+    x = torch.nn.functional.normalize(torch.randn(B * P, 64, generator=g), dim=1).to(DEV)
+    py = torch.arange(0, B * V + 1, V, dtype=torch.int32).to(DEV)
+    px = torch.arange(0, B * P + 1, P, dtype=torch.int32).to(DEV)
+    idx = ops.cosine_knn(Mat.of(y), py, Mat.of(x), px, B, V, k).long()
+    assert bool((idx >= 0).all())
+    cloud_q = torch.arange(B * V, device=DEV) // V
+    assert bool(((idx // P) == cloud_q[:, None]).all())
+    rows = torch.randint(0, B * V, (512,), generator=g).to(DEV)
+    sims = y[rows] @ x.t()                                                       # [512, B*P]
+    own = (torch.arange(B * P, device=DEV)[None, :] // P) == cloud_q[rows][:, None]
+    sims = sims.masked_fill(~own, -2.0)
+    got = torch.gather(sims, 1, idx[rows])
+    assert bool((got[:, :-1] >= got[:, 1:] - 1e-6).all())                        # most similar first
+    top = sims.topk(k, dim=1).values
+    assert float((got - top).abs().max()) <= 2e-6                               # the same k best similarities

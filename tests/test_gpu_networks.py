@@ -214,3 +214,36 @@ def test_corrnet_larger_clouds_against_oracle():
     got = ours.to(DEV)(batch.to(DEV), True, False)
     for g, w in zip(got[:3], want[:3]):
         assert rel_excess(g, w, TOL) <= 0
+
+
+def test_deformnet_full_size_properties():
+    """BASELINE.json configs[3] pair size (4096-vertex mesh + 8192-point cloud): size-independent properties of the DeformNet
+    stages -- mask spans [0, 1] per mesh, neighbour tables stay inside the pair, invisible vertices only consult visible
+    ones, the voted flow of a visible vertex lies in the convex hull of its candidate displacements."""
+    kw = dict(tau_nce=0.07, num_interp=5)
+    m = synth.load_recipe(models.deformnet(**kw).eval(), 7, mild=True).to(DEV)
+    batch = synth.make_batch([301, 302], n_side=64, n_pts=8192).to(DEV)
+    torch.manual_seed(1)
+    pred, vf, pf, vis, tau = m(batch)
+    torch.cuda.synchronize()
+    V, P = 4096, 8192
+    assert pred.shape == (2 * V, 3) and bool(torch.isfinite(pred).all())
+    assert float((vf.norm(dim=1) - 1).abs().max()) < 1e-5 and float((pf.norm(dim=1) - 1).abs().max()) < 1e-5
+    for b in range(2):
+        v = vis[b * V:(b + 1) * V]
+        assert float(v.min()) == 0.0 and float(v.max()) == 1.0
+    to_pts, to_vis = [t.long() for t in m.last_neighbours]
+    mesh = torch.arange(2 * V, device=DEV) // V
+    assert bool((to_pts >= 0).all()) and bool(((to_pts // P) == mesh[:, None]).all())
+    hidden = (vis < 0.5).squeeze(1)
+    assert bool((to_vis[~hidden] == -1).all()) and bool((to_vis[hidden] >= 0).all())
+    assert bool((vis[to_vis[hidden]].squeeze(-1) >= 0.5).all()) and bool(((to_vis[hidden] // V) == mesh[hidden][:, None]).all())
+    # visible vertices with positive weights: flow_init inside the per-axis range of (pts[j] - vtx[i])
+    sim = (pf[to_pts] * vf[:, None, :]).sum(-1)
+    ok = (~hidden) & (sim > 0).all(1) & (vis.squeeze(1) > 0)
+    disp = batch.pts[to_pts] - batch.vtx[:, None, :]
+    # re-derive flow_init from the tables (fp32 on the device) and compare with what GCNDeform was fed
+    w = sim * vis
+    flow = (disp * w[..., None]).sum(1) / w.sum(1, keepdim=True)
+    lo, hi = disp.min(1).values, disp.max(1).values
+    assert bool(((flow >= lo - 1e-5) & (flow <= hi + 1e-5))[ok].all())
