@@ -127,8 +127,12 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
                 Z[rl * ZLD + wn * 32 + l31] = fmaxf(acc[mt][cb][r] + b, 0.f) * sc + sh;
             }
     };
-    // quad mode scan: wave w owns quad-rows [4w, 4w+4) and every segment that STARTS there (following it into later
-    // rows); a lane holds VEC = H/64 adjacent columns, so a segment's result leaves as one 16-byte (8-byte) store per lane
+    // quad mode scan: a scanning wave owns NOWN quad-rows and every segment that STARTS there (following it into later
+    // rows); a lane holds VEC = H/64 adjacent columns, so a segment's result leaves as one 16-byte (8-byte) store per lane.
+    // Segment bookkeeping is two ballots, not a per-row state machine (which compiled to ~60 scalar-and-branch instructions
+    // per quad row, ~2 000-2 800 cycles per tile): lane q < 32 looks at quad row q, START has a bit where a row opens a
+    // segment, VALID where it holds a real vertex; the wave then walks the set bits of (START & VALID & its rows) --
+    // ~1.4 segments -- and reduces each segment's rows with up to four LDS reads in flight.
     auto scan_quad = [&](int rep, const int* sseg, bool first_cont, bool last_cont, auto nownc, int wslot) __attribute__((always_inline)) {
         constexpr int VEC = H / 64;
         constexpr int NOWN = decltype(nownc)::value;   // quad rows owned per scanning wave
@@ -136,44 +140,36 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
         const int q0 = __builtin_amdgcn_readfirstlane(wslot * NOWN);
         const float* zl = Z + VEC * lane;
         float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + VEC * lane;
-        auto flush = [&](int sg, fvec m, int qs, int qend) __attribute__((always_inline)) {
+        const int ql = lane & 31;
+        const int sq = sseg[4 * ql];                                        // id of quad row ql (its 4 rows share it)
+        const int sp = sseg[ql > 0 ? 4 * ql - 1 : 0];                       // id of the row just above
+        const unsigned START = (unsigned)__ballot(lane < 32 && (ql == 0 || sq != sp));
+        const unsigned VALID = (unsigned)__ballot(lane < 32 && sq >= 0);
+        unsigned mine = START & VALID & (((1u << NOWN) - 1u) << q0);
+        while (mine) {                                                       // wave-uniform: SALU bit walking
+            const int b = __builtin_ctz(mine);
+            mine &= mine - 1u;
+            const unsigned later = b < 31 ? (START & ~((2u << b) - 1u)) : 0u;
+            const int e = later ? __builtin_ctz(later) : 32;                 // the segment covers quad rows [b, e)
+            const int sg = __builtin_amdgcn_readlane(sq, b);
+            fvec m = *reinterpret_cast<const fvec*>(zl + b * ZQ);
+            for (int q = b + 1; q < e; q += 4) {
+                const int l = e - 1;
+                const fvec z0 = *reinterpret_cast<const fvec*>(zl + q * ZQ);
+                const fvec z1 = *reinterpret_cast<const fvec*>(zl + min(q + 1, l) * ZQ);
+                const fvec z2 = *reinterpret_cast<const fvec*>(zl + min(q + 2, l) * ZQ);
+                const fvec z3 = *reinterpret_cast<const fvec*>(zl + min(q + 3, l) * ZQ);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(fmaxf(m[v], z0[v]), fmaxf(fmaxf(z1[v], z2[v]), z3[v]));
+            }
             float* o = obase + (size_t)sg * p.ldy;
-            const bool partial = (qs == 0 && first_cont) || (qend == 32 && last_cont);
+            const bool partial = (b == 0 && first_cont) || (e == 32 && last_cont);
             if (partial) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
             } else {
                 *reinterpret_cast<fvec*>(o) = m;
             }
-        };
-        fvec zv[NOWN]; int sv[NOWN];
-#pragma unroll
-        for (int i = 0; i < NOWN; ++i) {
-            zv[i] = *reinterpret_cast<const fvec*>(zl + (q0 + i) * ZQ);
-            sv[i] = __builtin_amdgcn_readfirstlane(sseg[4 * (q0 + i)]);
-        }
-        int cur = __builtin_amdgcn_readfirstlane((q0 > 0) ? sseg[4 * q0 - 1] : -2);
-        bool open = false;
-        fvec m = zv[0]; int qs = q0;
-#pragma unroll
-        for (int i = 0; i < NOWN; ++i) {
-            if (sv[i] != cur) {
-                if (open) flush(cur, m, qs, q0 + i);
-                cur = sv[i]; open = cur >= 0; m = zv[i]; qs = q0 + i;
-            } else if (open) {
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], zv[i][v]);
-            }
-        }
-        if (open) {                                         // the last segment may run on into later waves' rows
-            int q = q0 + NOWN;
-            while (q < 32 && __builtin_amdgcn_readfirstlane(sseg[4 * q]) == cur) {
-                const fvec z = *reinterpret_cast<const fvec*>(zl + q * ZQ);
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], z[v]);
-                ++q;
-            }
-            flush(cur, m, qs, q);
         }
     };
     auto scan_pass = [&](int cb, int rep, const int* sseg, bool first_cont, bool last_cont) __attribute__((always_inline)) {
