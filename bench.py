@@ -114,6 +114,43 @@ def cpu_baseline(seconds, n_side, rank0_batch_seed):
                        f"{cores} threads, {dt:.1f} s")
 
 
+def cpu_baseline_other(workload, seconds, n_side, n_pts, seed):
+    """the CPU oracle of the secondary workloads on ONE unit of the same size (one mesh / one mesh-cloud pair): whole
+    forwards until the budget is used, at least one."""
+    from morig_amd import synth
+    from oracle import nets
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    with_pts = workload in ("corrnet", "deformnet")
+    mesh = synth.make_mesh(seed, n_side=n_side, with_skin=workload == "mask_skin")
+    clouds = [synth.make_point_cloud(mesh, int(mesh.name), n_pts)] if with_pts else None
+    batch = synth.collate([mesh], clouds)
+    if workload == "mask_skin":
+        a = synth.load_recipe(nets.masknet_motion(num_keyframes=5, chn_output=1, aggr_method="attn").eval(), 0, mild=True)
+        b = synth.load_recipe(nets.skinnet_motion(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True,
+                                                  motion_dim=32).eval(), 1, mild=True)
+        run = lambda: (a(batch, batch.pred_flow), b(batch, batch.pred_flow))
+    elif workload == "corrnet":
+        m = synth.load_recipe(nets.corrnet(input_feature=3, output_feature=64, temprature=0.07).eval(), 0, mild=True)
+        run = lambda: m(batch, True, False)
+    else:
+        m = synth.load_recipe(nets.deformnet(tau_nce=0.07, num_interp=5).eval(), 0, mild=True)
+        run = lambda: m(batch)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            run()
+            reps += 1
+            if time.perf_counter() - t0 >= 0.8 * seconds or reps >= 20:
+                break
+        dt = time.perf_counter() - t0
+    unit = "pairs/s" if with_pts else "meshes/s"
+    what = f"one {n_side * n_side}-vertex mesh" + (f" + {n_pts}-point cloud" if with_pts else "")
+    return dict(value=round(reps / dt, 4), unit=unit, cores=cores, kind="port",
+                sample=f"{reps} forward(s) of {what}, torch {torch.__version__} CPU, {cores} threads, {dt:.1f} s")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +309,8 @@ def main():
         }
         if world == 1 and args.cpu_seconds > 0 and args.workload == "jointnet":
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)
+        elif world == 1 and args.cpu_seconds > 0:
+            res["cpu_baseline"] = cpu_baseline_other(args.workload, args.cpu_seconds, args.n_side, args.n_pts, 1000)
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
