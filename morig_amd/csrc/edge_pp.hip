@@ -172,44 +172,42 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
             }
         }
     };
+    // general mode scan of one 64-column pass: wave g owns rows [16 g, 16 g + 16) and every segment that STARTS there; same
+    // ballot bookkeeping as the quad scan, over 128 rows (lane l looks at rows l and l + 64)
     auto scan_pass = [&](int cb, int rep, const int* sseg, bool first_cont, bool last_cont) __attribute__((always_inline)) {
-        constexpr int RG = 16, EXT = 32;                    // 8 row groups of 16
-        const int zc = tid & 63, zg = tid >> 6;
-        const int r0 = __builtin_amdgcn_readfirstlane(zg * RG);
+        const int zc = tid & 63;
+        const int r0 = __builtin_amdgcn_readfirstlane((tid >> 6) * 16);
         const int col = (zc >> 5) * NT * 32 + cb * 32 + (zc & 31);
         const float* zcolp = Z + zc;
         float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
-        auto flush = [&](int sg, float m, int rs, int rend) __attribute__((always_inline)) {
-            float* o = obase + (size_t)sg * p.ldy;
-            const bool partial = (rs == 0 && first_cont) || (rend == BM && last_cont);
-            if (partial) atomic_max_f32(o, m); else *o = m;
-        };
-        int cur = __builtin_amdgcn_readfirstlane((zg > 0) ? sseg[r0 - 1] : -2);
-        bool open = false, done = false;
-        float m = 0.f; int rs = 0, rnext = r0;
-#pragma unroll
-        for (int bt = 0; bt < (RG + EXT) / 16; ++bt) {
-            const int rb0 = r0 + bt * 16;
-            if (done || rb0 >= BM) break;
-            float zv[16]; int sv[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_readfirstlane(sseg[rb0 + i]); zv[i] = zcolp[(rb0 + i) * ZLD]; }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (!done) {
-                    if (sv[i] != cur) {
-                        if (open) flush(cur, m, rs, rb0 + i);
-                        if (bt * 16 + i >= RG) { open = false; done = true; }
-                        else { cur = sv[i]; open = cur >= 0; m = zv[i]; rs = rb0 + i; }
-                    } else if (open) m = fmaxf(m, zv[i]);
-                }
+        const int s_lo = sseg[lane], s_hi = sseg[lane + 64];
+        const int p_lo = sseg[lane > 0 ? lane - 1 : 0], p_hi = sseg[lane + 63];
+        const unsigned long long START_lo = __ballot(lane == 0 || s_lo != p_lo), START_hi = __ballot(s_hi != p_hi);
+        const bool upper = r0 >= 64;
+        const unsigned long long valid = upper ? __ballot(s_hi >= 0) : __ballot(s_lo >= 0);
+        unsigned long long mine = (upper ? START_hi : START_lo) & valid & (0xFFFFull << (r0 & 63));
+        while (mine) {                                                       // wave-uniform
+            const int bl = __builtin_ctzll(mine);
+            mine &= mine - 1ull;
+            const unsigned long long above = bl < 63 ? ~((2ull << bl) - 1ull) : 0ull;
+            int b, e, sg;
+            if (upper) {
+                const unsigned long long later = START_hi & above;
+                b = 64 + bl; e = later ? 64 + __builtin_ctzll(later) : BM;
+                sg = __builtin_amdgcn_readlane(s_hi, bl);
+            } else {
+                const unsigned long long later = START_lo & above;
+                b = bl; e = later ? __builtin_ctzll(later) : (START_hi ? 64 + __builtin_ctzll(START_hi) : BM);
+                sg = __builtin_amdgcn_readlane(s_lo, bl);
             }
-            rnext = rb0 + 16;
-        }
-        if (open && !done) {
-            int r = rnext;
-            while (r < BM && sseg[r] == cur) { m = fmaxf(m, zcolp[r * ZLD]); ++r; }
-            flush(cur, m, rs, r);
+            float m = zcolp[b * ZLD];
+            for (int r = b + 1; r < e; r += 4) {
+                const int l = e - 1;
+                const float z0 = zcolp[r * ZLD], z1 = zcolp[min(r + 1, l) * ZLD], z2 = zcolp[min(r + 2, l) * ZLD], z3 = zcolp[min(r + 3, l) * ZLD];
+                m = fmaxf(fmaxf(m, z0), fmaxf(fmaxf(z1, z2), z3));
+            }
+            float* o = obase + (size_t)sg * p.ldy;
+            if ((b == 0 && first_cont) || (e == BM && last_cont)) atomic_max_f32(o, m); else *o = m;
         }
     };
     // everything after E1 for tile j (both roles; the general mode re-stages Z per 64-column pass)
