@@ -174,18 +174,27 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
     };
     // general mode scan of one 64-column pass: wave g owns rows [16 g, 16 g + 16) and every segment that STARTS there; same
     // ballot bookkeeping as the quad scan, over 128 rows (lane l looks at rows l and l + 64)
-    auto scan_pass = [&](int cb, int rep, const int* sseg, bool first_cont, bool last_cont) __attribute__((always_inline)) {
-        const int zc = tid & 63;
+    struct SegMasks { unsigned long long start_lo, start_hi, own; int s_own; };     // the same for every pass of a tile
+    auto seg_masks = [&](const int* sseg) __attribute__((always_inline)) {
         const int r0 = __builtin_amdgcn_readfirstlane((tid >> 6) * 16);
+        const int s_lo = sseg[lane], s_hi = sseg[lane + 64];
+        const int p_lo = sseg[lane > 0 ? lane - 1 : 0], p_hi = sseg[lane + 63];
+        SegMasks k;
+        k.start_lo = __ballot(lane == 0 || s_lo != p_lo); k.start_hi = __ballot(s_hi != p_hi);
+        const bool upper = r0 >= 64;
+        const unsigned long long valid = upper ? __ballot(s_hi >= 0) : __ballot(s_lo >= 0);
+        k.own = (upper ? k.start_hi : k.start_lo) & valid & (0xFFFFull << (r0 & 63));
+        k.s_own = upper ? s_hi : s_lo;
+        return k;
+    };
+    auto scan_pass = [&](int cb, int rep, const SegMasks& k, bool first_cont, bool last_cont) __attribute__((always_inline)) {
+        const int zc = tid & 63;
+        const bool upper = (tid >> 6) >= 4;
         const int col = (zc >> 5) * NT * 32 + cb * 32 + (zc & 31);
         const float* zcolp = Z + zc;
         float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
-        const int s_lo = sseg[lane], s_hi = sseg[lane + 64];
-        const int p_lo = sseg[lane > 0 ? lane - 1 : 0], p_hi = sseg[lane + 63];
-        const unsigned long long START_lo = __ballot(lane == 0 || s_lo != p_lo), START_hi = __ballot(s_hi != p_hi);
-        const bool upper = r0 >= 64;
-        const unsigned long long valid = upper ? __ballot(s_hi >= 0) : __ballot(s_lo >= 0);
-        unsigned long long mine = (upper ? START_hi : START_lo) & valid & (0xFFFFull << (r0 & 63));
+        const unsigned long long START_lo = k.start_lo, START_hi = k.start_hi;
+        unsigned long long mine = k.own;
         while (mine) {                                                       // wave-uniform
             const int bl = __builtin_ctzll(mine);
             mine &= mine - 1ull;
@@ -194,12 +203,11 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
             if (upper) {
                 const unsigned long long later = START_hi & above;
                 b = 64 + bl; e = later ? 64 + __builtin_ctzll(later) : BM;
-                sg = __builtin_amdgcn_readlane(s_hi, bl);
             } else {
                 const unsigned long long later = START_lo & above;
                 b = bl; e = later ? __builtin_ctzll(later) : (START_hi ? 64 + __builtin_ctzll(START_hi) : BM);
-                sg = __builtin_amdgcn_readlane(s_lo, bl);
             }
+            sg = __builtin_amdgcn_readlane(k.s_own, bl);
             float m = zcolp[b * ZLD];
             for (int r = b + 1; r < e; r += 4) {
                 const int l = e - 1;
@@ -227,12 +235,13 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
             if constexpr (!is_producer) scan_quad(rep, sseg, fc, lc, IC<8>{}, wave);
             return;
         }
-        scan_pass(0, rep, sseg, fc, lc);
+        const SegMasks k = seg_masks(sseg);
+        scan_pass(0, rep, k, fc, lc);
         auto more = [&](auto cbc) __attribute__((always_inline)) {
             pp_barrier();                            // previous pass scanned
             if constexpr (!is_producer) write_z_pass(cbc);
             pp_barrier();
-            scan_pass(decltype(cbc)::value, rep, sseg, fc, lc);
+            scan_pass(decltype(cbc)::value, rep, k, fc, lc);
         };
         if constexpr (!QUAD && NT > 1) more(IC<1>{});
         if constexpr (!QUAD && NT > 2) more(IC<2>{});

@@ -396,9 +396,19 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
     static_assert(NTP * WN * 32 == ZC && NPASS * NTP == NT, "epilogue column blocking");
     constexpr int G = 256 / ZC;                 // row groups in the reduce phase
     constexpr int RG = BM / G;                  // 32 (ZC = 64) or 16 (ZC = 32)
-    constexpr int EXT = 32;                     // look-ahead rows for a segment running past its group
     const int zc = tid % ZC, zg = tid / ZC;
     const int r0 = (ZC == 64) ? __builtin_amdgcn_readfirstlane(zg * RG) : zg * RG;
+    // MODE_EDGEMAX: segment starts of the tile's 128 rows as two ballots, once for all column passes
+    unsigned long long seg_start_lo = 0, seg_start_hi = 0, seg_own = 0; int seg_id_own = 0;
+    if constexpr (MODE == MODE_EDGEMAX && ZC == 64) {
+        const int s_lo = sseg[lane], s_hi = sseg[lane + 64];
+        const int p_lo = sseg[lane > 0 ? lane - 1 : 0], p_hi = sseg[lane + 63];
+        seg_start_lo = __ballot(lane == 0 || s_lo != p_lo); seg_start_hi = __ballot(s_hi != p_hi);
+        const bool up = r0 >= 64;
+        const unsigned long long valid = up ? __ballot(s_hi >= 0) : __ballot(s_lo >= 0);
+        seg_own = (up ? seg_start_hi : seg_start_lo) & valid & (((1ull << RG) - 1ull) << (r0 & 63));
+        seg_id_own = up ? s_hi : s_lo;
+    }
     // one instantiation per column pass: `cb` must be a compile-time constant so that acc[][] keeps
     // static register indices (a runtime-indexed accumulator array would live in scratch memory)
     auto run_pass = [&](auto cb_const) {
@@ -449,42 +459,35 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
             }
             if (open) atomic_max_f32(p.Y + (size_t)cur * p.ldy + col, m);
         } else {
-            // a thread owns the segments that START in its row group and follows them to their end
+            // a wave (zg = wave id: ZC == 64 here) owns the segments that START in its row group and follows them to their
+            // end. Segment bookkeeping by ballots (lane l looks at rows l and l + 64), then a walk over the set bits with four
+            // LDS reads in flight per step -- not a per-row state machine (edge_pp.hip, same scheme).
+            if constexpr (ZC == 64) {                          // (BN = 32 takes the narrow path above; its pooled variant the branch above)
             float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + col;
-            auto flush = [&](int sg, float m, int rs, int rend) {
-                float* o = obase + (size_t)sg * p.ldy;
-                const bool partial = (rs == 0 && first_cont) || (rend == BM && last_cont);
-                if (partial) atomic_max_f32(o, m); else *o = m;
-            };
-            // segment ids are identical for all lanes of a wave when ZC == 64 (zg = wave id): pull them into
-            // SGPRs so the boundary tests are scalar compares + scalar branches instead of exec-mask code
-            auto uni = [&](int v) -> int { return (ZC == 64) ? __builtin_amdgcn_readfirstlane(v) : v; };
-            int cur = uni((zg > 0) ? sseg[r0 - 1] : -2);
-            bool open = false, done = false;
-            float m = 0.f; int rs = 0, rnext = r0;
-#pragma unroll
-            for (int bt = 0; bt < (RG + EXT) / 16; ++bt) {
-                const int rb0 = r0 + bt * 16;
-                if (done || rb0 >= BM) break;
-                float zv[16]; int sv[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { sv[i] = uni(sseg[rb0 + i]); zv[i] = zcolp[(rb0 + i) * ZLD]; }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    if (!done) {
-                        if (sv[i] != cur) {
-                            if (open) flush(cur, m, rs, rb0 + i);
-                            if (bt * 16 + i >= RG) { open = false; done = true; }      // next segment is not mine
-                            else { cur = sv[i]; open = cur >= 0; m = zv[i]; rs = rb0 + i; }
-                        } else if (open) m = fmaxf(m, zv[i]);
-                    }
+            const bool upper = r0 >= 64;
+            unsigned long long mine = seg_own;
+            while (mine) {                                                   // wave-uniform
+                const int bl = __builtin_ctzll(mine);
+                mine &= mine - 1ull;
+                const unsigned long long above = bl < 63 ? ~((2ull << bl) - 1ull) : 0ull;
+                int rs, re;
+                if (upper) {
+                    const unsigned long long later = seg_start_hi & above;
+                    rs = 64 + bl; re = later ? 64 + __builtin_ctzll(later) : BM;
+                } else {
+                    const unsigned long long later = seg_start_lo & above;
+                    rs = bl; re = later ? __builtin_ctzll(later) : (seg_start_hi ? 64 + __builtin_ctzll(seg_start_hi) : BM);
                 }
-                rnext = rb0 + 16;
+                const int sg = __builtin_amdgcn_readlane(seg_id_own, bl);
+                float m = zcolp[rs * ZLD];
+                for (int r = rs + 1; r < re; r += 4) {
+                    const int l = re - 1;
+                    const float z0 = zcolp[r * ZLD], z1 = zcolp[min(r + 1, l) * ZLD], z2 = zcolp[min(r + 2, l) * ZLD], z3 = zcolp[min(r + 3, l) * ZLD];
+                    m = fmaxf(fmaxf(m, z0), fmaxf(fmaxf(z1, z2), z3));
+                }
+                float* o = obase + (size_t)sg * p.ldy;
+                if ((rs == 0 && first_cont) || (re == BM && last_cont)) atomic_max_f32(o, m); else *o = m;
             }
-            if (open && !done) {                // longer than the look-ahead window, or runs to the tile end
-                int r = rnext;
-                while (r < BM && sseg[r] == cur) { m = fmaxf(m, zcolp[r * ZLD]); ++r; }
-                flush(cur, m, rs, r);
             }
         }
     };
