@@ -137,12 +137,13 @@ class CorrNet(NativeModule):
         csr_tpl = ops.csr_build(data.tpl_edge_index, n)
         csr_geo = ops.csr_build(data.geo_edge_index, n)
         csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)      # 4-aligned segments for the 128/256-wide layers
+        csr_tpl4 = ops.csr_build(data.tpl_edge_index, n, pad4=True)
         gcus = (self.vtx_gcu_1, self.vtx_gcu_2, self.vtx_gcu_3, self.vtx_gcu_4)
         widths = (32, 64, 256, 512)
         x_in = Mat.of(wide, self.VTX, 3)
         for g, off, w in zip(gcus, self.X, widths):
             out = Mat.of(wide, off, w)
-            g.run(ops, x_in, csr_tpl, csr_geo4 if w >= 256 else csr_geo, out)
+            g.run(ops, x_in, csr_tpl4 if w >= 256 else csr_tpl, csr_geo4 if w >= 256 else csr_geo, out)
             x_in = out
         pooled = ops.empty(n_graphs, 1024, dev)
         ops.gemm(Mat.of(wide, 0, 864), pk["glb"], relu=True, seg=seg, pool=pooled)

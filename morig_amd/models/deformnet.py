@@ -83,7 +83,8 @@ class DeformNet(NativeModule):
         seg = ops.make_seg(vb, B, 1)
         gd.run(ops, vtx4, lambda w, sp: ops.copy2d_pad(Mat.of(l1), w, split=sp), ops.csr_build(data.tpl_edge_index, n),
                ops.csr_build(data.geo_edge_index, n), seg, B, 1, Mat.of(pred_flow),
-               csr_geo_wide=ops.csr_build(data.geo_edge_index, n, pad4=True))
+               csr_geo_wide=ops.csr_build(data.geo_edge_index, n, pad4=True),
+               csr_tpl_wide=ops.csr_build(data.tpl_edge_index, n, pad4=True))
         return pred_flow, vtx_f, pts_f, vis, tau
 
 

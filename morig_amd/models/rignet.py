@@ -141,7 +141,7 @@ class GCNRig(NativeModule):
         )
 
     def run(self, ops, pos4: torch.Tensor, write_feature, csr_tpl, csr_geo, seg: torch.Tensor, n_graphs: int,
-            replicas: int, out: Mat, csr_geo_wide=None):
+            replicas: int, out: Mat, csr_geo_wide=None, csr_tpl_wide=None):
         """pos4: [n, 4] (pos, 0); write_feature(window Mat [R*n, feat_slot], split) fills the feature slot
         (zero padded); seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window."""
         dev = pos4.device
@@ -154,12 +154,13 @@ class GCNRig(NativeModule):
         write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
         self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp)
-        # the 128- and 256-wide layers take the geo graph with 4-aligned segments (quad-reduced epilogue of the
-        # wave-specialised kernel: measured +12..18 % there; on the tpl graph, in-degree 7 -> 8, and on the narrow
-        # layers the padding costs more than it saves)
+        # the 128- and 256-wide layers take both graphs with 4-aligned segments (quad-reduced, single-pass epilogue of the
+        # wave-specialised kernel: +12..18 % on the geo graph; on the tpl graph, in-degree 7 -> 8 rows, still -4 % since the
+        # scans became cheap: 54.05 -> 53.35 ms per step); on the narrow layers the padding costs more than it saves
         cg = csr_geo_wide or csr_geo
-        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, self.WIDTHS[0]), csr_tpl, cg, Mat.of(wide, self.X2, self.WIDTHS[1]), R, split=sp)
-        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, self.WIDTHS[1]), csr_tpl, cg, Mat.of(wide, self.X3, self.WIDTHS[2]), R, split=sp)
+        ct = csr_tpl_wide or csr_tpl
+        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, self.WIDTHS[0]), ct, cg, Mat.of(wide, self.X2, self.WIDTHS[1]), R, split=sp)
+        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, self.WIDTHS[1]), ct, cg, Mat.of(wide, self.X3, self.WIDTHS[2]), R, split=sp)
         pooled = ops.empty(R * n_graphs, 1024, dev)
         ops.gemm(Mat.of(wide, 0, self.POS), pk["glb"], relu=True, seg=seg, pool=pooled, x_split=sp)
         gb = ops.empty(R * n_graphs, 1024, dev)
@@ -202,6 +203,7 @@ class _MotionBackbone(NativeModule):
         csr_tpl = ops.csr_build(data.tpl_edge_index, n)
         csr_geo = ops.csr_build(data.geo_edge_index, n)
         csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)
+        csr_tpl4 = ops.csr_build(data.tpl_edge_index, n, pad4=True)
         seg_T = ops.make_seg(data.batch, ng, T)
 
         def write_flow(w: Mat, sp: bool):             # feature of replica t = input_flow[:, 3t:3t+3]  (:86), one launch
@@ -209,7 +211,8 @@ class _MotionBackbone(NativeModule):
 
         C = self.motionNet.chn_output
         raw = ops.empty(T * n, C, dev)
-        self.motionNet.run(ops, pos4, write_flow, csr_tpl, csr_geo, seg_T, ng, T, Mat.of(raw), csr_geo_wide=csr_geo4)
+        self.motionNet.run(ops, pos4, write_flow, csr_tpl, csr_geo, seg_T, ng, T, Mat.of(raw), csr_geo_wide=csr_geo4,
+                           csr_tpl_wide=csr_tpl4)
         motion_all = torch.empty((n, T, C), dtype=torch.float32, device=dev)
         ops.rownorm(Mat.of(raw), n, T, motion_all, T * C, C)          # F.normalize + torch.stack(dim=1)
 
@@ -223,7 +226,7 @@ class _MotionBackbone(NativeModule):
         motion_aggr = torch.empty((n, aggr_out_dim), dtype=torch.float32, device=dev)
         ops.rownorm(Mat.of(pre), n, 1, motion_aggr, aggr_out_dim, 0)
         seg_1 = seg_T[:n]
-        return dict(pos4=pos4, csr_tpl=csr_tpl, csr_geo=csr_geo, csr_geo4=csr_geo4, seg=seg_1, ng=ng, motion_all=motion_all,
+        return dict(pos4=pos4, csr_tpl=csr_tpl, csr_geo=csr_geo, csr_geo4=csr_geo4, csr_tpl4=csr_tpl4, seg=seg_1, ng=ng, motion_all=motion_all,
                     motion_aggr=motion_aggr)
 
 
@@ -249,7 +252,7 @@ class _MotionHead(_MotionBackbone):
         aggr = st["motion_aggr"]
         out = torch.empty((n, head.chn_output), dtype=torch.float32, device=aggr.device)
         head.run(ops, st["pos4"], lambda w, sp: ops.copy2d_pad(Mat.of(aggr), w, split=sp), st["csr_tpl"], st["csr_geo"],
-                 st["seg"], st["ng"], 1, Mat.of(out), csr_geo_wide=st["csr_geo4"])
+                 st["seg"], st["ng"], 1, Mat.of(out), csr_geo_wide=st["csr_geo4"], csr_tpl_wide=st["csr_tpl4"])
         return st["motion_all"], aggr, out
 
 
@@ -359,7 +362,7 @@ class SkinMotion(_MotionBackbone):
         n = data.pos.shape[0]
         aggr = st["motion_aggr"]
         out = torch.empty((n, self.skinNet.num_nearest_bone), dtype=torch.float32, device=aggr.device)
-        self.skinNet.run(ops, data, aggr, st["csr_tpl"], st["csr_geo4"], st["seg"], st["ng"], Mat.of(out))
+        self.skinNet.run(ops, data, aggr, st["csr_tpl4"], st["csr_geo4"], st["seg"], st["ng"], Mat.of(out))     # all three GCUs are 256 wide
         return st["motion_all"], aggr, out
 
 
