@@ -1,17 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- meshes/sec of the jointnet_motion eval-mode forward on synthetic 4 k-vertex meshes.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--scaling weak|strong]
 
-One step = one forward of `jointnet_motion(num_keyframes=5, chn_output=3, aggr_method='attn')` over
-a device-resident batch of 64 synthetic 4096-vertex meshes PER GPU (BASELINE.json configs[1]; weak
-scaling), including the COO->CSR graph preparation and, for N > 1, the RCCL all-gather of
-pred_shift. Rank 0 prints ONE JSON line.
+N > 1 from a bare shell re-executes itself under `python -m torch.distributed.run` (one rank per GPU, RCCL); when the
+driver already launched it that way (WORLD_SIZE set) it just joins. One step = one forward of
+`jointnet_motion(num_keyframes=5, chn_output=3, aggr_method='attn')` over a device-resident batch of 64 synthetic
+4096-vertex meshes PER GPU (BASELINE.json configs[1]; weak scaling; `--scaling strong` splits ONE 64-mesh batch),
+including the COO->CSR graph preparation and, for N > 1, the RCCL all-gather of pred_shift. Rank 0 prints ONE JSON line.
+
+Timing: W warm-up steps, then K steps bracketed by barrier + synchronize (wall clock -> `value`, max over ranks) with one
+HIP event per step boundary (median / p10 / p90); the per-kernel breakdown and the roofline come from a SECOND pass of a
+few steps with HIP events around every launch (morig_prof_*), so the timed region itself carries no per-launch events.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,26 +30,75 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense
 PEAK_HBM_GBS = 8000.0
+# MORIG_BENCH_PLUMBING=1 (set by tests/ only): gloo + CPU tensors + the torch emulation of the op layer on tiny meshes.
+# It exercises launch / sharding / all-gather / JSON assembly; its numbers are not measurements and the line says so.
+PLUMBING = os.environ.get("MORIG_BENCH_PLUMBING") == "1"
+
+KERNEL_SYMBOLS = {"edgeconv_f16x3_h256": ("edge_ws_kernel<256", "edge_pp_kernel<256"),
+                  "edgeconv_f16x3_h128": ("edge_ws_kernel<128", "edge_pp_kernel<128"),
+                  "gemm_f16x3_dma": ("gemm16_dma_kernel<256, 256, 4, 2>",), "gemm_f16x3_pool": ("gemm16_dma_kernel<256, 256, 4, 2>",),
+                  "edgeconv_h256": ("tile_kernel<256, 16, 1, 2, 0>",), "gemm_f32_bn128": ("tile_kernel<128, 32, 0, 0, 0>",)}
+
+
+def _profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
 
 
 def measured_traffic(kernel_kind):
     """HBM bytes per launch of a kernel kind from the committed rocprofv3 PMC pass (profiles/traffic_latest.json,
     produced by tools/gpu_pmc_bench.sh on the same command), corrected as MI355X_MICROARCH.md prescribes."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if not os.path.exists(path):
+    prof = _profile_json("traffic_latest.json")
+    symbols = KERNEL_SYMBOLS.get(kernel_kind)
+    if prof is None or symbols is None:
         return None
-    symbol = {"edgeconv_f16x3_h256": "edge_pp_kernel<256", "edgeconv_f16x3_h128": "edge_pp_kernel<128",
-              "gemm_f16x3_dma": "gemm16_dma_kernel<256, 256, 4, 2>",
-              "edgeconv_h256": "tile_kernel<256, 16, 1, 2, 0>", "gemm_f32_bn128": "tile_kernel<128, 32, 0, 0, 0>"}.get(kernel_kind)
-    if symbol is None:
-        return None
-    tot, n = 0.0, 0            # a kind may cover several instantiations (4-aligned / general CSR): dispatch-weighted mean
-    for name, v in json.load(open(path))["kernels"].items():
-        if symbol in name and "FETCH_SIZE_KiB_per_dispatch" in v and "WRITE_SIZE_KiB_per_dispatch" in v:
+    tot, n = 0.0, 0            # a kind may cover several instantiations: dispatch-weighted mean
+    for name, v in prof["kernels"].items():
+        if any(sy in name for sy in symbols) and "FETCH_SIZE_KiB_per_dispatch" in v and "WRITE_SIZE_KiB_per_dispatch" in v:
             d = v.get("dispatches", 1)
             tot += (2.0 * v["FETCH_SIZE_KiB_per_dispatch"] + v["WRITE_SIZE_KiB_per_dispatch"]) * 1024.0 * d
             n += d
     return round(tot / n) if n else None
+
+
+def measured_mfma_util(kernel_kind):
+    """MFMA busy fraction of a kernel kind from the committed counter pass (profiles/mfma_pmc_latest.json, produced by
+    tools/gpu_pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)); None when no pass is committed."""
+    prof = _profile_json("mfma_pmc_latest.json")
+    symbols = KERNEL_SYMBOLS.get(kernel_kind)
+    if prof is None or symbols is None:
+        return None
+    vals = [v["mfma_util"] for name, v in prof.get("kernels", {}).items() if any(sy in name for sy in symbols) and "mfma_util" in v]
+    return round(sum(vals) / len(vals), 4) if vals else None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """bare `python bench.py --gpus N`: become the launcher of N ranks (the driver's own command line, verbatim)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def _mesh(args):
@@ -109,9 +164,20 @@ def cpu_baseline(seconds, n_side, rank0_batch_seed):
             if time.perf_counter() - t0 >= 0.4 * seconds or reps >= 50:
                 break
         dt = time.perf_counter() - t0
-    return dict(value=round(n_mesh * reps / dt, 4), unit="meshes/s", cores=cores, kind="port",
+        # n = 1 thread: ONE forward of ONE mesh, only if the budget allows (~20 s on a current core)
+        one = None
+        if seconds >= 25:
+            torch.set_num_threads(1)
+            single = synth.collate([synth.make_mesh(rank0_batch_seed, n_side=n_side, with_skin=False)])
+            t1 = time.perf_counter()
+            m(single, single.pred_flow)
+            d1 = time.perf_counter() - t1
+            one = dict(value=round(1.0 / d1, 4), unit="meshes/s", sample=f"1 forward of 1 mesh, 1 thread, {d1:.1f} s")
+            torch.set_num_threads(cores)
+    return dict(value=round(n_mesh * reps / dt, 4), unit="meshes/s", cores=cores, kind="port", cpu_model=cpu_model(),
+                host_cores=os.cpu_count(), threads_1=one,
                 sample=f"{reps} forwards of a {n_mesh}-mesh batch ({n_side * n_side} vertices each), torch {torch.__version__} CPU, "
-                       f"{cores} threads, {dt:.1f} s")
+                       f"{cores} threads (best of a thread-count probe), {dt:.1f} s")
 
 
 def cpu_baseline_other(workload, seconds, n_side, n_pts, seed):
@@ -147,58 +213,32 @@ def cpu_baseline_other(workload, seconds, n_side, n_pts, seed):
         dt = time.perf_counter() - t0
     unit = "pairs/s" if with_pts else "meshes/s"
     what = f"one {n_side * n_side}-vertex mesh" + (f" + {n_pts}-point cloud" if with_pts else "")
-    return dict(value=round(reps / dt, 4), unit=unit, cores=cores, kind="port",
+    return dict(value=round(reps / dt, 4), unit=unit, cores=cores, kind="port", cpu_model=cpu_model(),
                 sample=f"{reps} forward(s) of {what}, torch {torch.__version__} CPU, {cores} threads, {dt:.1f} s")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="meshes per GPU")
-    ap.add_argument("--n-side", type=int, default=64, help="mesh grid side (64 -> 4096 vertices)")
-    ap.add_argument("--workload", default="jointnet", choices=["jointnet", "mask_skin", "corrnet", "deformnet"],
-                    help="jointnet = BASELINE.json configs[1] (the headline metric); mask_skin = configs[2]; "
-                         "corrnet = configs[3] (8192-point clouds, 32 pairs per GPU); deformnet = the producer of pred_flow "
-                         "(SURVEY 8 f-1), same pairs as corrnet")
-    ap.add_argument("--n-pts", type=int, default=8192)
-    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline leg (0 = skip)")
-    args = ap.parse_args()
+NAMES = {"jointnet": ("meshes/sec jointnet_motion forward, 4 k-vert synthetic",
+                      "jointnet_motion(num_keyframes=5, attn) eval forward", "BASELINE.json configs[1]"),
+         "mask_skin": ("meshes/sec masknet_motion + skinnet_motion forward, 4 k-vert synthetic",
+                       "masknet_motion + skinnet_motion(nearest_bone=5) eval forwards", "BASELINE.json configs[2]"),
+         "corrnet": ("pairs/sec corrnet forward, 4 k-vert mesh + 8 k-point cloud",
+                     "corrnet(train_vismask=True, random_start=False) eval forward", "BASELINE.json configs[3]"),
+         "deformnet": ("pairs/sec deformnet forward, 4 k-vert mesh + 8 k-point cloud",
+                       "deformnet(tau_nce=0.07, num_interp=5) eval forward (CorrNet + votes + GCNDeform)",
+                       "SURVEY 8(f-1), pairs of BASELINE.json configs[3]")}
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    B = args.batch
-    if args.workload in ("corrnet", "deformnet") and args.batch == 64:
-        B = 32                                         # configs[3]: 256 pairs over 8 GPUs
-    with_skin = args.workload == "mask_skin"
-    # synthetic batch on the host FIRST (forked workers), before this process touches the GPU runtime
-    host_batch = build_batch([1000 + rank * B + i for i in range(B)], args.n_side, with_skin=with_skin,
-                             n_pts=args.n_pts if args.workload in ("corrnet", "deformnet") else 0)
-
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    from morig_amd import dist as mdist, models, native, synth
-
-    data = host_batch.to(dev)
-    n_vert = data.pos.shape[0]
-    gather = (lambda t: mdist.all_gather_rows(t, equal_rows=True)) if world > 1 else (lambda t: t)
-    if args.workload == "jointnet":
+def make_step(workload, data, dev, gather):
+    """-> step() running ONE forward of `workload` over the resident batch (+ the all-gather of its outputs)."""
+    from morig_amd import models, synth
+    if workload == "jointnet":
         model = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
         synth.load_recipe(model, 0, mild=True).to(dev)
 
         def step():
             motion_all, motion_aggr, pred_shift = model(data, data.pred_flow)
             return gather(pred_shift)
-    elif args.workload == "mask_skin":
+    elif workload == "mask_skin":
         model = models.masknet_motion(num_keyframes=5, chn_output=1, aggr_method="attn").eval()
         skin = models.skinnet_motion(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True,
                                      motion_dim=32).eval()
@@ -210,7 +250,7 @@ def main():
             sk = skin(data, data.pred_flow)[2]
             gather(mask)
             return gather(sk)
-    elif args.workload == "deformnet":
+    elif workload == "deformnet":
         model = models.deformnet(tau_nce=0.07, num_interp=5).eval()
         synth.load_recipe(model, 0, mild=True).to(dev)
 
@@ -227,94 +267,243 @@ def main():
             gather(out_pts)
             gather(vis)
             return gather(out_vtx)
+    return step
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+
+def pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    i = (len(xs) - 1) * q
+    lo, hi = int(i), min(int(i) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50, help="timed steps (SURVEY 8(d): >= 50)")
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="meshes per GPU (weak) / in total (strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--n-side", type=int, default=64, help="mesh grid side (64 -> 4096 vertices)")
+    ap.add_argument("--workload", default="jointnet", choices=["jointnet", "mask_skin", "corrnet", "deformnet"],
+                    help="jointnet = BASELINE.json configs[1] (the headline metric); mask_skin = configs[2]; "
+                         "corrnet = configs[3] (8192-point clouds, 32 pairs per GPU); deformnet = the producer of pred_flow "
+                         "(SURVEY 8 f-1), same pairs as corrnet")
+    ap.add_argument("--n-pts", type=int, default=8192)
+    ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--prof-steps", type=int, default=5, help="steps of the second, per-launch-evented pass")
+    ap.add_argument("--secondary", type=int, default=-1,
+                    help="steps of the short mask_skin / corrnet / deformnet runs added to the jointnet line at N = 1 "
+                         "(-1: 3 on a default run, 0 when --steps/--warmup were given explicitly by a harness that wants speed)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (launch with --nproc-per-node {args.gpus})")
+
+    B = args.batch
+    pairs = args.workload in ("corrnet", "deformnet")
+    if pairs and args.batch == 64:
+        B = 32                                         # configs[3]: 256 pairs over 8 GPUs
+    if args.scaling == "strong":
+        if B % world:
+            raise SystemExit(f"bench.py: --scaling strong needs --batch divisible by --gpus ({B} % {world})")
+        B_local = B // world
+        seeds = [1000 + i for i in range(B) if i % world == rank]            # morig_amd.dist.shard_items: round robin
+    else:
+        B_local = B
+        seeds = [1000 + rank * B + i for i in range(B)]
+    if PLUMBING:
+        args.n_side, args.n_pts = min(args.n_side, 8), min(args.n_pts, 128)
+    with_skin = args.workload == "mask_skin"
+    # synthetic batch on the host FIRST (forked workers), before this process touches the GPU runtime
+    host_batch = build_batch(seeds, args.n_side, with_skin=with_skin, n_pts=args.n_pts if pairs else 0)
+
+    import torch.distributed as dist
+    if PLUMBING:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from emulate import EmuOps
+        from morig_amd import runtime
+        runtime._test_ops = EmuOps()
+        dev = torch.device("cpu")
+        backend = "gloo"
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        backend = "nccl"                               # RCCL on ROCm
+    rccl_ranks = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if PLUMBING:
+            dist.init_process_group(backend)
+        else:
+            dist.init_process_group(backend, device_id=dev)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)                           # a real collective over the backend: every rank must answer
+        rccl_ranks = int(one.item())
+
+    from morig_amd import dist as mdist, native
+
+    data = host_batch.to(dev)
+    n_vert = data.pos.shape[0]
+    gather = (lambda t: mdist.all_gather_rows(t, equal_rows=True)) if world > 1 else (lambda t: t)
+    step = make_step(args.workload, data, dev, gather)
+
+    def sync():
+        if not PLUMBING:
             torch.cuda.synchronize()
 
-    with torch.no_grad():
-        ops = native.get_ops()
-        ops.learn_edge_counts = True                  # accounting only: exact E' per graph (one host read each),
-        ops.csr_build(data.tpl_edge_index, n_vert)    # learned outside the steps so the FLOP counters use
-        ops.csr_build(data.geo_edge_index, n_vert)    # algorithmic edges
-        ops.learn_edge_counts = False
-        for _ in range(args.warmup):
-            step()
-        fence()
-        native.prof_reset()
-        native.prof_enable(True)                      # HIP events around every launch, on the launch stream
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
+    def fence():
+        sync()
+        if world > 1:
+            dist.barrier()
+            sync()
+
+    def timed_run(step, steps, warmup):
+        """-> (wall seconds for `steps` steps, per-step ms from HIP events, last output)"""
+        for _ in range(warmup):
             out = step()
+        ev = None if PLUMBING else [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        fence()
+        t0 = time.perf_counter()
+        if ev:
+            ev[0].record()
+        marks = [t0]
+        for i in range(steps):
+            out = step()
+            if ev:
+                ev[i + 1].record()
+            else:
+                marks.append(time.perf_counter())
         fence()
         dt = time.perf_counter() - t0
-        native.prof_enable(False)
-    prof = native.prof_collect()
+        per = ([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)] if ev
+               else [(marks[i + 1] - marks[i]) * 1e3 for i in range(steps)])
+        return dt, per, out
+
+    prof = {}
+    with torch.no_grad():
+        if not PLUMBING:
+            ops = native.get_ops()
+            ops.learn_edge_counts = True              # accounting only: exact E' per graph (one host read each),
+            ops.csr_build(data.tpl_edge_index, n_vert)    # learned outside the steps so the FLOP counters use
+            ops.csr_build(data.geo_edge_index, n_vert)    # algorithmic edges
+            ops.learn_edge_counts = False
+        dt, per_step, out = timed_run(step, args.steps, args.warmup)
+        if not PLUMBING and args.prof_steps > 0:
+            # second pass: HIP events around every launch, on the launch stream (outside the timed region)
+            native.prof_reset()
+            native.prof_enable(True)
+            for _ in range(args.prof_steps):
+                step()
+            fence()
+            native.prof_enable(False)
+            prof = native.prof_collect()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = [dt]
     if world > 1:
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        per_rank = [float(x.item()) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
     assert out.shape[0] == n_vert * world and bool(torch.isfinite(out).all())
 
+    secondary = None
+    n_secondary = args.secondary if args.secondary >= 0 else (3 if args.workload == "jointnet" else 0)
+    if rank == 0 and world == 1 and not PLUMBING and n_secondary > 0 and args.workload == "jointnet":
+        # configs[2] / configs[3] (and the deformnet row of SURVEY 8(f)) as short driver-visible runs on the same GPU
+        secondary = {}
+        del step
+        for wl in ("mask_skin", "corrnet", "deformnet"):
+            wpairs = wl in ("corrnet", "deformnet")
+            nb = 32 if wpairs else args.batch
+            hb = build_batch([1000 + i for i in range(nb)], args.n_side, with_skin=wl == "mask_skin", n_pts=args.n_pts if wpairs else 0)
+            d2 = hb.to(dev)
+            with torch.no_grad():
+                st = make_step(wl, d2, dev, lambda x: x)
+                sdt, sper, _ = timed_run(st, n_secondary, 1)
+            secondary[wl] = dict(metric=NAMES[wl][0], value=round(nb * n_secondary / sdt, 2), unit="pairs/s" if wpairs else "meshes/s",
+                                 ms_per_step=round(sdt / n_secondary * 1e3, 3), steps=n_secondary, warmup=1, batch=nb,
+                                 config=NAMES[wl][2])
+            del st, d2, hb
+            torch.cuda.empty_cache()
+
     if rank == 0:
-        total_ms = sum(v["ms"] for v in prof.values())
-        dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
-        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        # split-fp16 kernels issue 3 f16 MFMAs per algorithmic product: `achieved` stays ALGORITHMIC flops/s,
-        # `peak` is the dense f16 MFMA peak, so frac <= 1/3 by construction (frac_of_3x_split_peak rescales)
-        split = "f16x3" in dom_name
-        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        roof = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                    frac=round(achieved / peak, 4), traffic=measured_traffic(dom_name),
-                    traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/traffic_latest.json)",
-                    mfma_issued_per_product=3 if split else 1,
-                    frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
-                    launches_per_step=dom["launches"] / args.steps,
-                    avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
-                    share_of_gpu_time=round(dom["ms"] / total_ms, 4))
-        breakdown = {k: dict(ms_per_step=round(v["ms"] / args.steps, 3),
-                             tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
-                             launches_per_step=v["launches"] / args.steps)
-                     for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-        all_flops = sum(v["flops"] for v in prof.values())
-        names = {"jointnet": ("meshes/sec jointnet_motion forward, 4 k-vert synthetic",
-                              "jointnet_motion(num_keyframes=5, attn) eval forward", "BASELINE.json configs[1]"),
-                 "mask_skin": ("meshes/sec masknet_motion + skinnet_motion forward, 4 k-vert synthetic",
-                               "masknet_motion + skinnet_motion(nearest_bone=5) eval forwards", "BASELINE.json configs[2]"),
-                 "corrnet": ("pairs/sec corrnet forward, 4 k-vert mesh + 8 k-point cloud",
-                             f"corrnet(train_vismask=True, random_start=False) eval forward, {args.n_pts}-point clouds",
-                             "BASELINE.json configs[3]"),
-                 "deformnet": ("pairs/sec deformnet forward, 4 k-vert mesh + 8 k-point cloud",
-                               f"deformnet(tau_nce=0.07, num_interp=5) eval forward (CorrNet + votes + GCNDeform), "
-                               f"{args.n_pts}-point clouds", "SURVEY 8(f-1), pairs of BASELINE.json configs[3]")}[args.workload]
+        names = NAMES[args.workload]
+        roof, breakdown, hbm_kinds, all_flops = None, {}, {}, 0.0
+        psteps = max(args.prof_steps, 1)
+        if prof:
+            total_ms = sum(v["ms"] for v in prof.values())
+            dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+            # split-fp16 kernels issue 3 f16 MFMAs per algorithmic product: `achieved` stays ALGORITHMIC flops/s,
+            # `peak` is the dense f16 MFMA peak, so frac <= 1/3 by construction (frac_of_3x_split_peak rescales)
+            split = "f16x3" in dom_name
+            peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+            roof = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(achieved / peak, 4), traffic=measured_traffic(dom_name),
+                        traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/traffic_latest.json)",
+                        mfma_issued_per_product=3 if split else 1,
+                        frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
+                        mfma_util_counter=measured_mfma_util(dom_name),
+                        mfma_util_counter_source="profiles/mfma_pmc_latest.json (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES)",
+                        launches_per_step=dom["launches"] / psteps,
+                        avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+                        share_of_gpu_time=round(dom["ms"] / total_ms, 4),
+                        timing="HIP events around every launch in a separate pass of %d steps" % psteps)
+            breakdown = {k: dict(ms_per_step=round(v["ms"] / psteps, 3),
+                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+                                 launches_per_step=v["launches"] / psteps)
+                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+            # the index / copy kernels are the HBM-bound ones: bytes the launcher declares / event time, against 8 TB/s
+            for k in ("csr_build", "copy", "rownorm"):
+                v = prof.get(k)
+                if v and v["ms"] > 0 and v.get("bytes", 0) > 0:
+                    gbs = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+                    hbm_kinds[k] = dict(gb_per_s=round(gbs, 1), hbm_frac=round(gbs / PEAK_HBM_GBS, 4),
+                                        ms_per_step=round(v["ms"] / psteps, 3))
+            all_flops = sum(v["flops"] for v in prof.values()) / psteps
+        n_units = world * B_local
         res = {
             "metric": names[0],
-            "value": round(world * B * args.steps / dt, 2), "unit": "pairs/s" if args.workload in ("corrnet", "deformnet") else "meshes/s",
+            "value": round(n_units * args.steps / dt, 2), "unit": "pairs/s" if pairs else "meshes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("f32 (split-fp16: 3x f16 MFMA, f32 accumulate)" if native.get_ops().precision == "f16x3" else "f32"),
-            "data": "synthetic",
-            "config": {"workload": f"{names[1]}, batch={B} synthetic "
+            "ms_per_step_median": round(pct(per_step, 0.5), 3), "ms_per_step_p10": round(pct(per_step, 0.1), 3),
+            "ms_per_step_p90": round(pct(per_step, 0.9), 3),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+            "dtype": ("f32 (split-fp16: 3x f16 MFMA, f32 accumulate)" if (PLUMBING or native.get_ops().precision == "f16x3") else "f32"),
+            "data": "synthetic" if not PLUMBING else "synthetic (PLUMBING RUN on CPU emulation + gloo: not a measurement)",
+            "config": {"workload": f"{names[1]}, batch={B_local} synthetic "
                                    f"{args.n_side * args.n_side}-vertex meshes per GPU ({names[2]}), "
                                    "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if world > 1 else ""),
-                       "meshes_per_gpu": B, "vertices_per_mesh": args.n_side * args.n_side,
+                       "meshes_per_gpu": B_local, "global_batch": n_units, "vertices_per_mesh": args.n_side * args.n_side,
                        "parallelism": f"mesh-sharded dp{world}"},
+            "rccl_ranks": rccl_ranks, "backend": backend if world > 1 else None,
+            "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank],
             "roofline": roof,
-            "whole_forward_tflops": round(all_flops / args.steps / (dt / args.steps) / 1e12, 2),
+            "hbm_bound_kernels": hbm_kinds,
+            "whole_forward_tflops": round(all_flops / (dt / args.steps) / 1e12, 2) if prof else None,
             "kernels": breakdown,
+            "secondary": secondary,
         }
-        if world == 1 and args.cpu_seconds > 0 and args.workload == "jointnet":
+        if world == 1 and args.cpu_seconds > 0 and not PLUMBING and args.workload == "jointnet":
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)
-        elif world == 1 and args.cpu_seconds > 0:
+        elif world == 1 and args.cpu_seconds > 0 and not PLUMBING:
             res["cpu_baseline"] = cpu_baseline_other(args.workload, args.cpu_seconds, args.n_side, args.n_pts, 1000)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -481,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 // stream: a persistent workgroup that cannot be placed until they finish would hold back its whole static tile list)
 static std::atomic<int> g_reserved_cus{0};
 void set_reserved_cus(int n) { g_reserved_cus.store(n < 0 ? 0 : n); }
+int reserved_cus() { return g_reserved_cus.load(); }
 
 int launch_edge_pp(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     EdgePcParams p = p0;

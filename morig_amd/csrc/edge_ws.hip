@@ -1,0 +1,463 @@
+// Fused EdgeConv for the wide layers (H = 128, 256) on the split-fp16 path, W2-STATIONARY persistent kernel.
+//
+// edge_pp.hip streams the W2 chunk of every 128-row tile through the producer waves: 32 of the 52 KB that cross the
+// L2 -> CU path per K-chunk and 8 of the 13 VMEM wave-instructions per producer and chunk are W2, and VMEM issue beside
+// a busy matrix pipe is what bounds that kernel (chunk period 2 850 cycles for 1 536 of MFMA).
+// Here the roles are turned round: W2 never moves. All 8 waves are MFMA waves; wave (wm, wn) owns output columns
+// [32 wn, 32 wn + 32) for ALL K and keeps that slice of W2 -- hi and lo halves, H/16 k-steps x 8 registers = 128
+// VGPRs at H = 256 -- in registers for the whole launch (W2 is the B operand of v_mfma_f32_32x32x16_f16, the operand
+// tile Z = relu(A[dst] + B[src]) the A operand). What streams is only the gathered rows:
+//   D(g)  each wave fetches the rows it will convert itself -- 16 edge rows of B[src] and its 4 quads of A[dst]
+//         (4-aligned CSR) per 32-k chunk -- with global_load_lds (LDS-DMA, no VGPR round trip) into a PRIVATE 3-stage
+//         raw ring: 3 VMEM wave-instructions per wave and chunk (24 per CU against 52);
+//   V(g)  converts raw fp32 -> add, ReLU, fp16 hi/lo split -> the shared Z ring (2 stages), one chunk ahead;
+//   M(g)  every wave reads all 128 rows of the Z chunk (ds_read_b128 fragments) against its resident W2 slice.
+// One s_barrier per chunk (Z hand-over); the raw ring needs none (same-wave producer and consumer, counted vmcnt).
+// The last MFMA group of chunk g is issued AFTER barrier g+1 together with the first fragment loads of chunk g+1, so
+// the matrix pipe has work while those loads are in flight. The accumulators of a finished tile are quad-reduced
+// straight into an LDS scan region (monotone epilogue: max or min of the 4 rows of a quad, affine applied once) and the
+// segmented max + global stores of tile j run inside chunk 1 of tile j+1, beside its MFMAs.
+//
+// Only for 4-aligned CSRs (MORIG_CSR_PAD4); everything else stays on edge_pp.hip / tile_gemm.hip.
+// Reference op: models/basic_modules.py:185-202 (EdgeConvMotion.message/update), second Linear of nn_x / nn_pos.
+#include "common.h"
+#include <atomic>
+#include <stdio.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace morig {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_void_t;
+
+template <int C> using WC = std::integral_constant<int, C>;
+
+#ifdef MORIG_WS_TRACE
+#define WS_TS(k) do { if (j == 3 && blockIdx.x == 8 && lane == 0 && wave == 0) p.trace[(k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WS_TS(k) do { } while (0)
+#endif
+
+// Tile geometry. The register file is the constraint: W2 (H/16 steps x 8 VGPRs) + accumulators + two fragment sets must
+// leave room for the conversion, so H = 256 takes 64-row tiles with 64-deep chunks (accumulators 32 VGPRs, W2 128) and
+// H = 128 takes 128-row tiles with 32-deep chunks (waves 2 x 4: accumulators 32, W2 64). Either way a chunk is 16 KB of
+// gathered B rows + 4 KB of A quads per workgroup.
+template <int H> struct WsGeom { static constexpr int BM = H == 256 ? 64 : 128, KC = H == 256 ? 64 : 32; };
+
+template <int H>
+__global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
+    constexpr int BM = WsGeom<H>::BM, KC = WsGeom<H>::KC;
+    constexpr int LDB = 4 * KC + 16;                     // bytes per Z row = [KC hi | KC lo | 16 pad]
+    constexpr int NWN = H / 32;                          // waves along the output columns
+    constexpr int NWM = 8 / NWN;                         // waves along the tile rows
+    constexpr int MT = BM / 32 / NWM;                    // 32-row MFMA tiles per wave
+    static_assert(MT == 2, "one MFMA group = 2 row tiles x 3 MFMAs");
+    constexpr int NC = H / KC;                           // K-chunks per tile
+    constexpr int SPC = KC / 16;                         // 16-k MFMA steps (= groups) per chunk
+    constexpr int NS = SPC * NC;                         // steps per tile
+    constexpr int NG = SPC;
+    constexpr int NDMA = 3;                              // LDS-DMA instructions per wave and chunk
+    constexpr int RPW = BM / 8;                          // tile rows gathered and converted by one wave
+    constexpr int NQ = BM / 4;                           // quad rows per tile
+    constexpr int RAWW = 2048 + 512;                     // raw bytes per wave and stage: B rows, then A quads
+    constexpr int RAWS = 8 * RAWW;
+    constexpr int ZSTAGE = BM * LDB;
+    constexpr int ZQ = H + 4;                            // scan region: NQ quad rows x H columns (+4: 16-byte rows)
+    constexpr int VEC = H / 64;
+    constexpr int SWITCHC = NC >= 3 ? NC - 3 : (NC + NC - 3) % NC;   // chunk whose D() is the first of the NEXT tile
+    static_assert(NC == 4, "index prefetch schedule");
+
+    __shared__ __attribute__((aligned(128))) char smem[3 * RAWS + 2 * ZSTAGE + NQ * ZQ * 4 + 3 * 32 * 4 + 64 + 3 * H * 4];
+    char* raw = smem;
+    char* zring = smem + 3 * RAWS;
+    float* Z = reinterpret_cast<float*>(zring + 2 * ZSTAGE);
+    int* sq_all = reinterpret_cast<int*>(zring + 2 * ZSTAGE + NQ * ZQ * 4);   // [3][32] destination id per quad row
+    int* sflag = sq_all + 3 * 32;                                              // [3][2] first / last segment continues
+    float* sbias = reinterpret_cast<float*>(sflag + 16);                       // [3][H] bias, BN scale, BN shift
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wn = wave % NWN, wm = wave / NWN;
+
+    // ---- tile list: XCD x (= blockIdx & 7 under round-robin dispatch) owns a contiguous range ----
+    const int Etot = p.rowptr[p.n_nodes];
+    const int tpr = (Etot + BM - 1) / BM;
+    const int T = tpr * p.replicas;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+    const int t_lo = (int)((long long)T * xcd / 8), t_hi = (int)((long long)T * (xcd + 1) / 8);
+    const int n_my = (t_hi - t_lo - bi + nbx - 1) / nbx;
+    if (n_my <= 0) return;                                                     // block-uniform
+    auto tile_of = [&](int j) __attribute__((always_inline)) { return t_lo + bi + (j < n_my ? j : n_my - 1) * nbx; };
+    if (tid < H) { sbias[tid] = p.bias[tid]; sbias[H + tid] = p.scale[tid]; sbias[2 * H + tid] = p.shift[tid]; }
+
+    // ---- resident W2 slice. Z slot s2 = 2 * step + hi of a chunk holds the chunk's k = 4 s2 + {0..3} and KC/2 + 4 s2 + {0..3}
+    // (what a converting thread produces from its two 16-byte raw pieces), so the W2 fragment is built the same way.
+    // W2 memory image: 32-k chunks of [32 hi | 32 lo] halves (packing.split_f16) ----
+    f16x8 wh[NS], wl[NS];
+    {
+        const char* wrow = reinterpret_cast<const char*>(p.W + (size_t)(32 * wn + l31) * p.ldw);
+#pragma unroll
+        for (int S = 0; S < NS; ++S) {
+            const int s2 = 2 * (S % SPC) + hi;
+            const int k0 = (S / SPC) * KC + 4 * s2, k1 = k0 + KC / 2;
+            const char* c0 = wrow + (k0 >> 5) * 128 + 2 * (k0 & 31);
+            const char* c1 = wrow + (k1 >> 5) * 128 + 2 * (k1 & 31);
+            const f16x4 h0 = *reinterpret_cast<const f16x4*>(c0), h1 = *reinterpret_cast<const f16x4*>(c1);
+            const f16x4 l0 = *reinterpret_cast<const f16x4*>(c0 + 64), l1 = *reinterpret_cast<const f16x4*>(c1 + 64);
+            wh[S] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+            wl[S] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+        }
+    }
+
+    // ---- gather state: this lane's slice of D().
+    // KC = 64: B instruction i = 128-byte half i of the 256-byte row chunk of 8 rows (lane>>3), A: 2 quads x 16 pieces;
+    // KC = 32: B instruction i = rows 8 i + (lane>>3) x 8 pieces, A: 4 quads x 8 pieces. ----
+    const int drow = lane >> 3, dpiece = lane & 7;
+    const int aq = KC == 64 ? (lane >> 4) & 1 : drow & 3, apiece = KC == 64 ? lane & 15 : dpiece;    // lanes 0..31
+    unsigned ob0 = 0, ob1 = 0, oq = 0;                   // byte offsets (< 4 GB per replica)
+    int ns0 = 0, ns1 = 0, nq = 0, nfl = 0;               // next tile's indices, in flight
+    int nrow0 = 0, nrep = 0;
+    const char* abase = reinterpret_cast<const char*>(p.A);
+    const char* bbase = reinterpret_cast<const char*>(p.B);
+    auto load_indices = [&](int j) __attribute__((always_inline)) {
+        const int t = tile_of(j);
+        nrep = t / tpr; nrow0 = (t - nrep * tpr) * BM;
+        const int r = nrow0 + RPW * wave + drow;
+        ns0 = p.srcS[min(r, Etot - 1)];
+        if constexpr (KC == 32) ns1 = p.srcS[min(r + 8, Etot - 1)];
+        nq = p.dstS[min(nrow0 + 4 * ((RPW / 4) * wave + aq), Etot - 1)];
+        // wave 0, lanes 0..2: the ids just outside / at the end of the tile (segment continuation flags)
+        const int fr = lane == 0 ? nrow0 - 1 : (lane == 1 ? nrow0 + BM - 1 : nrow0 + BM);
+        nfl = p.dstS[min(max(fr, 0), Etot - 1)];
+    };
+    auto switch_tile = [&](int slot) __attribute__((always_inline)) {           // the loaded tile becomes the one fetched from
+        abase = reinterpret_cast<const char*>(p.A + (size_t)nrep * p.rep_in * p.lda);
+        bbase = reinterpret_cast<const char*>(p.B + (size_t)nrep * p.rep_in * p.ldb);
+        ob0 = ((unsigned)ns0 * (unsigned)p.ldb + 4u * dpiece) * 4u;           // rows past the end re-read the last edge:
+        if constexpr (KC == 32) ob1 = ((unsigned)ns1 * (unsigned)p.ldb + 4u * dpiece) * 4u;   // finite, ignored by the scan (id -1)
+        else ob1 = ob0 + 128u;
+        oq = ((unsigned)nq * (unsigned)p.lda + 4u * apiece) * 4u;
+        int* sq = sq_all + slot * 32;
+        if (lane < 32 && apiece == 0) {
+            const int q = (RPW / 4) * wave + aq;                                // Etot is a multiple of 4: a quad is valid as a whole
+            sq[q] = (nrow0 + 4 * q < Etot) ? nq : -1;
+        }
+        if (wave == 0) {
+            const int prev = __builtin_amdgcn_readlane(nfl, 0), last = __builtin_amdgcn_readlane(nfl, 1),
+                      after = __builtin_amdgcn_readlane(nfl, 2), first = __builtin_amdgcn_readlane(nq, 0);
+            if (lane == 0) {
+                sflag[slot * 2] = (nrow0 > 0 && prev == first) ? 1 : 0;
+                sflag[slot * 2 + 1] = (nrow0 + BM < Etot && last == after) ? 1 : 0;
+            }
+        }
+    };
+    char* raww = raw + wave * RAWW;
+    // D(): scalar base (SGPR pair) + 32-bit lane offset + immediate chunk offset; the LDS destination goes through M0. The
+    // builtin only selects the 64-bit-VGPR address form (2 v_lshl_add_u64 + moves per instruction), hence the asm.
+    const unsigned raww_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(raw + wave * RAWW));
+    auto dma = [&](auto cc, int rs) __attribute__((always_inline)) {          // chunk c of the current gather tile -> raw stage rs
+        constexpr int c = decltype(cc)::value;
+#ifdef WS_BUILTIN_DMA
+        char* dst = raww + rs * RAWS;
+        unsigned o0 = ob0, o1 = ob1, o2 = oq;
+        asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(bbase + c * (KC * 4) + o0), (lds_void_t*)(dst), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void_t*)(bbase + c * (KC * 4) + o1), (lds_void_t*)(dst + 1024), 16, 0, 0);
+        if (lane < 32) __builtin_amdgcn_global_load_lds((glb_void_t*)(abase + c * (KC * 4) + o2), (lds_void_t*)(dst + 2048), 16, 0, 0);
+#else
+        const unsigned d0 = raww_lds + rs * RAWS;
+        const unsigned vo0 = ob0, vo1 = ob1, vo2 = oq;
+        // NB the instruction's immediate offset would move BOTH the global and the LDS address: the chunk offset goes into the base
+        const char* const sb = bbase + c * (KC * 4); const char* const sa = abase + c * (KC * 4);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                     :: "s"(d0), "v"(vo0), "s"(sb), "n"(0) : "memory");
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                     :: "s"(d0 + 1024u), "v"(vo1), "s"(sb), "n"(0) : "memory");
+        // one wave-instruction whatever the exec mask: vmcnt counts 3 per chunk
+        if (lane < 32) {
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
+                         :: "s"(d0 + 2048u), "v"(vo2), "s"(sa), "n"(0) : "memory");
+        }
+#endif
+    };
+    // conversion of one raw chunk: thread = (row vrow of this wave's RPW, 16-byte raw pieces vq and vq + KC/8) -> Z slot vq.
+    // Two halves (one raw piece each) keep the transient registers down.
+    float amax = 0.f;
+    constexpr int TPR = KC / 8;                           // converting threads per row
+    const int vrow = lane / TPR, vq = lane % TPR;
+    const int vb = vrow * 128 + 16 * vq, va = 2048 + (vrow >> 2) * (KC * 4) + 16 * vq;
+    auto raw_load = [&](int rs, auto halfc, f32x4& a, f32x4& b) __attribute__((always_inline)) {
+        constexpr int hf = decltype(halfc)::value;
+        const char* src = raww + rs * RAWS;
+        b = *reinterpret_cast<const f32x4*>(src + vb + hf * (KC == 64 ? 1024 : 64));
+        a = *reinterpret_cast<const f32x4*>(src + va + hf * (KC * 2));
+    };
+    auto conv_store = [&](int zs, auto halfc, const f32x4& a, const f32x4& b) __attribute__((always_inline)) {
+        constexpr int hf = decltype(halfc)::value;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = fmaxf(a[i] + b[i], 0.f);
+        // hi = fp16(v) truncated (one v_cvt_pkrtz per pair); lo = fp16(v - hi) rounded to nearest, one v_fma_mix per element
+        // (f32 v * 1.0 - f16 hi, result rounded into one half of the destination): hi + lo == v to ~2^-22. v - hi is exact in
+        // fp32, so this is bit-identical to the cvt / sub / cvt form the compiler emits for the plain C expression (5 VALU per
+        // pair instead of 2 -- VALU issue beside the MFMA stream is what the conversion costs)
+        // (operands travel as float bit patterns: the host pass also type-checks the constraints of this asm)
+        typedef float b32x2 __attribute__((ext_vector_type(2)));
+        b32x2 hw, lw;
+#pragma unroll
+        for (int i = 0; i < 4; i += 2) {
+            const f16x2 h = __builtin_amdgcn_cvt_pkrtz(v[i], v[i + 1]);
+            const float hb = __builtin_bit_cast(float, h);
+            float lb;
+            asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v[i]), "v"(hb));
+            asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v[i + 1]), "v"(hb));
+            hw[i >> 1] = hb; lw[i >> 1] = lb;
+            amax = fmaxf(amax, fmaxf(v[i], v[i + 1]));                         // v >= 0 after the ReLU
+        }
+        char* rowp = zring + zs * ZSTAGE + (RPW * wave + vrow) * LDB + 16 * vq + 8 * hf;
+        *reinterpret_cast<b32x2*>(rowp) = hw;
+        *reinterpret_cast<b32x2*>(rowp + 2 * KC) = lw;
+    };
+    auto convert_half = [&](int rs, int zs, auto halfc) __attribute__((always_inline)) {
+        f32x4 a, b;
+        raw_load(rs, halfc, a, b);
+        conv_store(zs, halfc, a, b);
+    };
+
+    // ---- MFMA side ----
+    f32x16 acc[MT];
+    struct Frag { f16x8 ah[2], al[2]; };
+    const char* zfrag = zring + ((wm * MT) * 32 + l31) * LDB + 16 * hi;
+    auto load_frag = [&](Frag& f, int zs, int g) __attribute__((always_inline)) {   // group g of a chunk = its 16-k step g
+#ifdef WS_NO_FRAG
+        asm volatile("" : "+v"(f.ah[0]), "+v"(f.al[0]), "+v"(f.ah[1]), "+v"(f.al[1]));
+        return;
+#endif
+        const char* b = zfrag + zs * ZSTAGE + 32 * g;
+        f.ah[0] = *reinterpret_cast<const f16x8*>(b);
+        f.al[0] = *reinterpret_cast<const f16x8*>(b + 2 * KC);
+        f.ah[1] = *reinterpret_cast<const f16x8*>(b + 32 * LDB);
+        f.al[1] = *reinterpret_cast<const f16x8*>(b + 32 * LDB + 2 * KC);
+    };
+    auto mma = [&](const Frag& f, auto Sc, auto firstc) __attribute__((always_inline)) {
+        constexpr int S = decltype(Sc)::value;            // k16 step of the tile (selects the W2 registers)
+        constexpr bool first = decltype(firstc)::value != 0;
+        f32x16 c0, c1;
+        if constexpr (first) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { c0[r] = 0.f; c1[r] = 0.f; }
+        } else { c0 = acc[0]; c1 = acc[1]; }
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[0], wh[S], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[1], wh[S], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[0], wl[S], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[1], wl[S], c1, 0, 0, 0);
+        c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[0], wh[S], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[1], wh[S], c1, 0, 0, 0);
+        acc[0] = c0; acc[1] = c1;
+    };
+    // y = relu(acc + b) * sc + sh is monotone in acc: the max over a quad's four rows is f(max acc) or f(min acc)
+    auto write_z = [&]() __attribute__((always_inline)) {
+        const int col = 32 * wn + l31;
+        const float b = sbias[col], sc = sbias[H + col], sh = sbias[2 * H + col];
+        const bool rising = sc >= 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a0 = acc[mt][4 * q], a1 = acc[mt][4 * q + 1], a2 = acc[mt][4 * q + 2], a3 = acc[mt][4 * q + 3];
+                float hi4, lo4, t3;
+                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
+                asm("v_max_f32 %0, %1, %2" : "=v"(hi4) : "v"(t3), "v"(a3));
+                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
+                asm("v_min_f32 %0, %1, %2" : "=v"(lo4) : "v"(t3), "v"(a3));
+                const float x = rising ? hi4 : lo4;
+                Z[((wm * MT + mt) * 8 + 2 * q + hi) * ZQ + col] = fmaxf(x + b, 0.f) * sc + sh;
+            }
+    };
+    // segmented max over the NQ quad rows of a finished tile: a wave owns NQ/8 quad rows and every segment that STARTS
+    // there; a lane holds VEC adjacent columns; two ballots list the segment starts (same scheme as edge_pp.hip)
+    auto scan = [&](int t, int slot) __attribute__((always_inline)) {
+        typedef float fvec __attribute__((ext_vector_type(VEC)));
+        if (p.dbg & 1) return;
+        const int rep = t / tpr;
+        const int* sq = sq_all + slot * 32;
+        const bool first_cont = sflag[slot * 2] != 0, last_cont = sflag[slot * 2 + 1] != 0;
+        const int q0 = __builtin_amdgcn_readfirstlane(wave * (NQ / 8));
+        const float* zl = Z + VEC * lane;
+        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + VEC * lane;
+        const int ql = lane & (NQ - 1);
+        const int sv = sq[ql];
+        const int sp = sq[ql > 0 ? ql - 1 : 0];
+        const unsigned START = (unsigned)__ballot(lane < NQ && (ql == 0 || sv != sp));
+        const unsigned VALID = (unsigned)__ballot(lane < NQ && sv >= 0);
+        unsigned mine = START & VALID & (((1u << (NQ / 8)) - 1u) << q0);
+        while (mine) {                                                       // wave-uniform: SALU bit walking
+            const int b = __builtin_ctz(mine);
+            mine &= mine - 1u;
+            const unsigned later = b < 31 ? (START & ~((2u << b) - 1u)) : 0u;
+            const int e = later ? __builtin_ctz(later) : NQ;                 // the segment covers quad rows [b, e)
+            const int sg = __builtin_amdgcn_readlane(sv, b);
+            fvec m = *reinterpret_cast<const fvec*>(zl + b * ZQ);
+            for (int q = b + 1; q < e; q += 2) {
+                const fvec z0 = *reinterpret_cast<const fvec*>(zl + q * ZQ);
+                const fvec z1 = *reinterpret_cast<const fvec*>(zl + min(q + 1, e - 1) * ZQ);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], fmaxf(z0[v], z1[v]));
+            }
+            float* o = obase + (size_t)sg * p.ldy;
+            const bool partial = (b == 0 && first_cont) || (e == NQ && last_cont);
+            if (partial) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
+            } else {
+                *reinterpret_cast<fvec*>(o) = m;
+            }
+        }
+    };
+
+    // ---- prologue: tile 0's chunks 0..2 in flight, chunk 0 converted ----
+    load_indices(0);
+    switch_tile(0);
+    load_indices(1);                                      // the gather switches tiles at chunk 1: indices are loaded a tile ahead
+    dma(WC<0>{}, 0); dma(WC<1>{}, 1); dma(WC<2>{}, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    convert_half(0, 0, WC<0>{}); convert_half(0, 0, WC<1>{});
+    int rs = 0;                                           // raw stage of the chunk whose MFMAs run next (g % 3)
+    Frag F0, F1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                         // B_0: Z chunk 0, sbias, sq[0] visible
+
+    // One chunk interval [B_c, B_c+1) of tile j (g = NC j + c): the MFMAs -- pending last group of chunk c-1, (c == 0:
+    // accumulators -> scan region), groups 0 .. NG-2 of chunk c -- and the SIDE work: V(g+1), D(g+3), (c == 1: scan of tile
+    // j-1). Measured (tools/gpu_ws2.sh ablations): left to the compiler's order the side work simply ADDS to the MFMA time,
+    // because an in-order wave that waits for an LDS round trip or a DMA issue slot issues no MFMA either, and its SIMD
+    // partner runs the same code in phase. So the interval is cut into blocks of ONE MFMA group each (sched_barrier: nothing
+    // crosses), and every block first issues the LDS reads whose data the NEXT block consumes, then does the VALU work on
+    // data read one block earlier, then its 6 MFMAs: no wait ever follows its own issue directly.
+    auto chunk = [&](auto cc, int j) __attribute__((always_inline)) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int zs = c & 1;
+        const int rs_v = rs == 2 ? 0 : rs + 1;
+        f32x4 ra0, rb0, ra1, rb1;
+        // ---- block 0: pending group
+        load_frag(F0, zs, 0);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");           // D(g+1) landed; D(g+2) may be in flight
+#ifndef WS_NO_CONVERT
+        raw_load(rs_v, WC<0>{}, ra0, rb0);
+#endif
+        if (j > 0 || c > 0) {
+            constexpr int cp = (c + NC - 1) % NC;
+            mma(F1, WC<SPC * cp + SPC - 1>{}, WC<0>{});
+#ifndef WS_NO_WRITEZ
+            if constexpr (c == 0) { WS_TS(1); if (!(p.dbg & 1)) write_z(); WS_TS(2); }
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- block 1: group 0
+        load_frag(F1, zs, 1);
+#ifndef WS_NO_CONVERT
+        raw_load(rs_v, WC<1>{}, ra1, rb1);
+        conv_store(zs ^ 1, WC<0>{}, ra0, rb0);
+#endif
+        mma(F0, WC<SPC * c>{}, WC<(c == 0 ? 1 : 0)>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- block 2: group 1 (NG == 4) / the rest of the side work
+        if constexpr (NG == 4) load_frag(F0, zs, 2);
+#ifndef WS_NO_CONVERT
+        conv_store(zs ^ 1, WC<1>{}, ra1, rb1);
+#endif
+        if constexpr (NG == 4) {
+            mma(F1, WC<SPC * c + 1>{}, WC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- block 3: group 2
+            load_frag(F1, zs, 3);
+        }
+        if constexpr (NG == 4) mma(F0, WC<SPC * c + 2>{}, WC<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        // D() last: each LDS-DMA costs the issuing wave ~100 cycles of issue stall (measured: 3 per chunk = 14 % of the
+        // kernel when they sat in front of an MFMA group); here the wave's MFMAs are all queued and the barrier is next
+        if constexpr (c == SWITCHC) switch_tile((j + 1) % 3);
+#ifndef WS_NO_DMA
+        dma(WC<(c + 3) % NC>{}, rs);                       // raw(g) was converted during the previous interval: its stage is free
+#endif
+        if constexpr (c == 3) load_indices(j + 2);
+        rs = rs_v;
+        if constexpr (c == 1) { if (j > 0) { WS_TS(4); scan(tile_of(j - 1), (j - 1) % 3); WS_TS(5); } }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef WS_NO_BARRIER
+        __builtin_amdgcn_s_barrier();
+#endif
+    };
+#pragma unroll 1
+    for (int j = 0; j < n_my; ++j) {
+        WS_TS(0);
+        chunk(WC<0>{}, j);
+        WS_TS(3);
+        chunk(WC<1>{}, j);
+        WS_TS(6);
+        chunk(WC<2>{}, j);
+        chunk(WC<3>{}, j);
+        WS_TS(7);
+    }
+    // ---- drain: last group of the last tile, its epilogue ----
+    mma(F1, WC<NS - 1>{}, WC<0>{});
+    if (!(p.dbg & 1)) write_z();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             // no LDS-DMA may outlive the workgroup
+    __builtin_amdgcn_s_barrier();
+    scan(tile_of(n_my - 1), (n_my - 1) % 3);
+    if (!(amax < 65000.f)) *p.ovf = 1;
+}
+
+static int cu_count_of_current_device() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cache[dev].load();
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev].store(n);
+    }
+    return n;
+}
+
+int reserved_cus();
+
+int launch_edge_ws(const EdgePcParams& p0, int nblocks, hipStream_t s) {
+    EdgePcParams p = p0;
+    static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
+    p.dbg = dbg;
+    if (!p.quad) return MORIG_E_UNSUPPORTED;
+    int ncu = cu_count_of_current_device();
+    ncu = ncu > 8 ? (ncu / 8) * 8 : 8;
+#ifdef MORIG_WS_TRACE
+    static unsigned long long* trace_buf = [] { void* b = nullptr; return hipMalloc(&b, 64 * 8) == hipSuccess ? (unsigned long long*)b : nullptr; }();
+    p.trace = trace_buf;
+#endif
+    int avail = ncu - ((reserved_cus() + 7) / 8) * 8;
+    if (avail < 8) avail = 8;
+    const int grid = nblocks < avail ? ((nblocks + 7) / 8) * 8 : avail;      // one persistent workgroup per CU, multiple of 8 (XCDs)
+    if (p.H == 256) hipLaunchKernelGGL((edge_ws_kernel<256>), dim3(grid), dim3(512), 0, s, p);
+    else if (p.H == 128) hipLaunchKernelGGL((edge_ws_kernel<128>), dim3(grid), dim3(512), 0, s, p);
+    else return MORIG_E_UNSUPPORTED;
+    MORIG_LAUNCH_CHECK();
+#ifdef MORIG_WS_TRACE
+    {
+        unsigned long long h[64];
+        if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, p.trace, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "WS_TRACE H=%d:", p.H);
+            for (int q = 1; q < 8; ++q) fprintf(stderr, " %lld", (long long)(h[q] - h[q - 1]));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
+    return MORIG_OK;
+}
+
+}  // namespace morig

@@ -501,8 +501,9 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
 // Rows of `out` whose segment straddles a 128-edge tile boundary are combined with integer-atomic float max
 // by the two (or more) tiles involved: only THOSE rows need the identity pattern 0xFFFFFFFF beforehand.
 __global__ __launch_bounds__(64) void init_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
-                                                                int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out) {
-    const int e = (blockIdx.x + 1) * 128;
+                                                                int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out,
+                                                                int tile_rows) {
+    const int e = (blockIdx.x + 1) * tile_rows;
     if (e >= rowptr[n_nodes]) return;
     const int d = dstS[e];
     if (rowptr[d] >= e) return;                       // a segment starts exactly on the boundary: no sharing
@@ -511,10 +512,10 @@ __global__ __launch_bounds__(64) void init_boundary_rows_kernel(const int* __res
 }
 
 static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
-                              int rep_out, int slots, hipStream_t s) {
-    const int nb = cdiv(edge_capacity, 128) - 1;
+                              int rep_out, int slots, hipStream_t s, int tile_rows = 128) {
+    const int nb = cdiv(edge_capacity, tile_rows) - 1;
     if (nb <= 0) return MORIG_OK;
-    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(nb, slots), dim3(64), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out);
+    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(nb, slots), dim3(64), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out, tile_rows);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -714,11 +715,27 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     const int nblocks = p.tiles_per_rep * a->replicas;
     const bool f16 = a->W2_split != nullptr;
 
+    // which kernel: H = 256 / 128 on the split-fp16 path go to the specialised kernels; with a 4-aligned CSR the W2-stationary
+    // one (edge_ws.hip), whose H = 256 tiles are 64 rows. MORIG_EDGE_KERNEL=pp|pc keeps the older kernels (A/B runs).
+    static const char* ek = getenv("MORIG_EDGE_KERNEL");
+    static const bool one_shot = ek && ek[0] == 'p' && ek[1] == 'c';
+    static const bool want_pp = ek && ek[0] == 'p' && ek[1] == 'p';
+    const bool wide = f16 && (a->H == 256 || a->H == 128) && a->s1 == nullptr && !getenv("MORIG_NO_EDGE_PC");
+    // the persistent kernels store 16-byte result vectors and address gathered rows with 32-bit byte offsets
+    const bool pp_ok = (reinterpret_cast<uintptr_t>(a->out) & 15) == 0 && (a->ldo & 3) == 0 &&
+                       (double)a->n_nodes * a->lda * 4.0 < 4.0e9 && (double)a->n_nodes * a->ldb * 4.0 < 4.0e9;
+    // H = 128 has half the MFMA work per gathered byte: measured on par with / behind the producer-consumer kernel, which stays
+    // the default there (MORIG_WS128=1 selects edge_ws.hip for it too)
+    static const bool ws128 = [] { const char* e = getenv("MORIG_WS128"); return e && e[0] == '1'; }();
+    const bool use_ws = wide && !one_shot && !want_pp && pp_ok && a->quad_aligned && (a->lda & 3) == 0 && (a->ldb & 3) == 0 &&
+                        (a->H == 256 || ws128);
+    const int tile_rows = (use_ws && a->H == 256) ? 64 : 128;   // edge_ws.hip: 64-row tiles at H = 256
+
     // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
     {
         const int slots = a->replicas;
         const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
-                                           a->out_rep_stride, slots, s);
+                                           a->out_rep_stride, slots, s, tile_rows);
         if (st2 != MORIG_OK) return st2;
     }
 
@@ -726,8 +743,7 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     const double flops = 2.0 * E * a->H * (double)a->H;
     const double bytes = 4.0 * (2.0 * E * a->H) ;    // gathered operand rows (mostly L2 hits)
     // H = 256 / 128: wave-specialised kernel (1.35x / 1.25x over the symmetric one; H = 128 runs two workgroups per CU)
-    if (f16 && (a->H == 256 || a->H == 128) && a->s1 == nullptr && !getenv("MORIG_NO_EDGE_PC")) {
-        // wave-specialised producer/consumer kernel (edge_pc.hip)
+    if (wide) {
         EdgePcParams q = {};
         q.H = a->H; q.W = p.W; q.ldw = p.ldw; q.bias = p.bias; q.scale = p.scale; q.shift = p.shift;
         q.A = p.A; q.lda = p.lda; q.B = p.B; q.ldb = p.ldb;
@@ -735,10 +751,7 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
-        static const bool one_shot = [] { const char* e = getenv("MORIG_EDGE_KERNEL"); return e && e[0] == 'p' && e[1] == 'c'; }();
-        // the persistent kernel stores 16-byte result vectors and addresses gathered rows with 32-bit byte offsets
-        const bool pp_ok = (reinterpret_cast<uintptr_t>(a->out) & 15) == 0 && (a->ldo & 3) == 0 &&
-                           (double)a->n_nodes * a->lda * 4.0 < 4.0e9 && (double)a->n_nodes * a->ldb * 4.0 < 4.0e9;
+        if (use_ws) return launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
         return (one_shot || !pp_ok) ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
     }
     if (f16) {

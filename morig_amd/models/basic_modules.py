@@ -8,6 +8,9 @@ are never called on the native path.
 """
 from __future__ import annotations
 
+import itertools
+import math
+import threading
 from typing import Optional
 
 import torch
@@ -32,15 +35,31 @@ def _invalidate_packed(module, incompatible_keys):
     module._drop_packed()
 
 
+class _ForwardContext(threading.local):
+    """key of the outermost NativeModule's forward in flight on this thread: nested packed() calls reuse it instead of
+    each walking its own parameter subtree (one traversal of ~450 tensors per forward, ~1 ms of host time)."""
+    key = None
+
+
+_ctx = _ForwardContext()
+
+
 class NativeModule(torch.nn.Module):
-    """Base class: caches packed (kernel-layout) parameters and invalidates the cache whenever the
-    parameters can have changed (``load_state_dict``, ``.to()/.cuda()``, ``train()``)."""
+    """Base class: caches packed (kernel-layout) parameters. The cache is keyed on the storage address and the
+    autograd version counter of every parameter and buffer below this module, so ANY in-place edit
+    (``w.mul_(2)``, an optimizer step), ``load_state_dict`` on a plain ``Sequential`` child, or a reload of a
+    child NativeModule whose tensors a parent packs (GCUMotion packs its EdgeConvMotions' MLPs) repacks on
+    the next forward; ``load_state_dict`` / ``.to()`` / ``train()`` additionally drop it eagerly."""
 
     def __init__(self):
         super().__init__()
         self._packed = None
         self._packed_device = None
+        self._packed_key = None
         self.register_load_state_dict_post_hook(_invalidate_packed)
+
+    def _param_key(self):
+        return tuple((t.data_ptr(), t._version) for t in itertools.chain(self.parameters(), self.buffers()))
 
     def _drop_packed(self):
         for m in self.modules():
@@ -56,9 +75,11 @@ class NativeModule(torch.nn.Module):
         return super().train(mode)
 
     def packed(self, device):
-        if self._packed is None or self._packed_device != device:
+        key = _ctx.key if _ctx.key is not None else self._param_key()
+        if self._packed is None or self._packed_device != device or self._packed_key != key:
             self._packed = packing.to_device(self._pack(), device)
             self._packed_device = device
+            self._packed_key = key
         return self._packed
 
     def _pack(self):
@@ -76,7 +97,17 @@ class NativeModule(torch.nn.Module):
         def attempt():
             torch.set_rng_state(rng)
             return self._forward(*args, **kwargs)
-        return ops.guarded(dev, attempt)
+        outer = _ctx.key
+        if outer is None:
+            _ctx.key = self._param_key()               # (storage, version) of every tensor below the outermost module
+        try:
+            if dev.type == "cuda":
+                # launches go to torch's current stream OF THE MODEL'S DEVICE, whatever the caller's current device is
+                with torch.cuda.device(dev):
+                    return ops.guarded(dev, attempt)
+            return ops.guarded(dev, attempt)
+        finally:
+            _ctx.key = outer
 
     def _forward(self, *args, **kwargs):
         raise NotImplementedError
@@ -269,8 +300,38 @@ class PointConv(torch.nn.Module):
         self.global_nn = global_nn
 
 
+def _cloud_offsets(batch: torch.Tensor, n_clouds: Optional[int] = None):
+    """sorted PyG ``batch`` vector -> (per-cloud counts as a host list, int32 offsets on the device). One host sync,
+    as torch_cluster's own ``batch`` handling has (it needs the cloud sizes to size its outputs)."""
+    counts = torch.bincount(batch, minlength=n_clouds or 0).tolist()
+    off = [0]
+    for c in counts:
+        off.append(off[-1] + int(c))
+    return counts, torch.tensor(off, dtype=torch.int32, device=batch.device)
+
+
+def _with_pos(ops, x: Optional[torch.Tensor], pos4: torch.Tensor):
+    """[x | pos | 0] with a 16-byte aligned row stride (x may be None); -> (buffer, width of x)."""
+    if x is None:
+        return pos4, 0
+    n, c = x.shape
+    ld = (c + 3 + 3) // 4 * 4
+    buf = torch.zeros((n, ld), dtype=torch.float32, device=x.device)
+    ops.copy2d(Mat.of(x), Mat.of(buf, 0, c))
+    ops.copy2d(Mat.of(pos4, 0, 3), Mat.of(buf, c, 3))
+    return buf, c
+
+
+def _pos4(ops, pos: torch.Tensor) -> torch.Tensor:
+    p4 = torch.zeros((pos.shape[0], 4), dtype=torch.float32, device=pos.device)
+    ops.copy2d(Mat.of(pos.float().contiguous()), Mat.of(p4, 0, 3))
+    return p4
+
+
 class SAModule(NativeModule):
-    """models/basic_modules.py:66-86: fps -> radius ball (<= max_num_neighbors) -> PointConv(max)."""
+    """models/basic_modules.py:66-86: fps -> radius ball (<= max_num_neighbors) -> PointConv(max).
+    Semantics of the branch the reference takes on a GPU (deterministic ``radius``: first hits in index order,
+    strict <); ``radius_cpu`` (:9-29) draws a random subset with torch.multinomial and ignores ``batch``."""
 
     def __init__(self, ratio, r, nn, max_num_neighbors):
         super().__init__()
@@ -283,6 +344,46 @@ class SAModule(NativeModule):
         cx = self.conv.local_nn[0][0].weight.shape[1] - 3
         return packing.pack_pointconv(self.conv.local_nn, cx)
 
+    def run(self, ops, xp: torch.Tensor, cx: int, pos_new: torch.Tensor, ptr: torch.Tensor, out_ptr: torch.Tensor, n_clouds: int):
+        """xp: [N, ld] = [x(cx) | pos(3) | pad]; pos_new: the sampled centres [M, 4]; ptr / out_ptr: int32 cloud offsets
+        of the sources / centres; returns x_new [M, H3].
+        PointConv's first Linear on [x_j ‖ pos_j - pos_i] splits per point: B_j = W1 [x_j ‖ pos_j] + b1, A_i = -W1p pos_i."""
+        dev = xp.device
+        pk = self.packed(dev)
+        N, M = xp.shape[0], pos_new.shape[0]
+        coo = ops.ball_query(Mat.of(xp, cx, 3), ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, self.r, self.max_num_neighbors)
+        csr = ops.csr_from_slots(coo, M, self.max_num_neighbors, N)
+        H = pk["edge"].H
+        bsrc = ops.empty(N, H, dev)
+        ops.gemm(Mat.of(xp, 0, cx + 3), pk["src"], relu=False, Y=Mat.of(bsrc))
+        atgt = ops.empty(M, H, dev)
+        ops.gemm(Mat.of(pos_new, 0, 3), pk["tgt"], relu=False, Y=Mat.of(atgt))
+        z = ops.empty(csr.capacity, H, dev)
+        ops.edge_hidden(Mat.of(atgt), Mat.of(bsrc), csr, pk["edge"], Mat.of(z))
+        x_new = ops.empty(M, pk["last"].N, dev)
+        ops.segmax_gemm(Mat.of(z), pk["last"], True, csr, Mat.of(x_new))
+        return x_new
+
+    def _forward(self, x, pos, batch, random_start=True):
+        """-> (x_new [M, H3], pos[idx] [M, 3], batch[idx] [M])   (models/basic_modules.py:74-86)"""
+        ops = get_ops()
+        dev = pos.device
+        counts, ptr = _cloud_offsets(batch)
+        B = len(counts)
+        out_counts = [int(math.ceil(self.ratio * c)) for c in counts]
+        _, out_ptr = _cloud_offsets(torch.repeat_interleave(torch.arange(B, device=dev), torch.tensor(out_counts, device=dev)), B)
+        start = None
+        if random_start:                                  # same draw order as torch_cluster.fps: one randint per cloud
+            start = torch.tensor([int(torch.randint(c, (1,))) for c in counts], dtype=torch.int32, device=dev)
+        p4 = _pos4(ops, pos)
+        M = sum(out_counts)
+        idx = ops.fps(Mat.of(p4, 0, 3), ptr, out_ptr, start, B, max(counts), M)
+        pos_new = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+        ops.gather_rows(Mat.of(p4, 0, 3), idx, Mat.of(pos_new, 0, 3))
+        xp, cx = _with_pos(ops, None if x is None else x.float().contiguous(), p4)
+        x_new = self.run(ops, xp, cx, pos_new, ptr, out_ptr, B)
+        return x_new, pos_new[:, :3].contiguous(), batch[idx.long()]
+
 
 class GlobalSAModule(NativeModule):
     """models/basic_modules.py:115-125: nn([x ‖ pos]) -> global_max_pool."""
@@ -293,6 +394,29 @@ class GlobalSAModule(NativeModule):
 
     def _pack(self):
         return [packing.pack_mlp_layer(l) for l in self.nn]
+
+    def run(self, ops, xp: torch.Tensor, width: int, seg: torch.Tensor, n_clouds: int) -> torch.Tensor:
+        """xp: [M, ld] = [x | pos | pad], ``width`` = columns of [x | pos]; seg: int32 cloud id per row (sorted);
+        -> pooled [n_clouds, C_out]: the last layer's per-cloud column max is the epilogue of its GEMM."""
+        dev = xp.device
+        layers = self.packed(dev)
+        h = Mat.of(xp, 0, width)
+        for lay in layers[:-1]:
+            o = ops.empty(xp.shape[0], lay.N, dev)
+            ops.gemm(h, lay, relu=True, Y=Mat.of(o))
+            h = Mat.of(o)
+        pooled = ops.empty(n_clouds, layers[-1].N, dev)
+        ops.gemm(h, layers[-1], relu=True, seg=seg, pool=pooled)
+        return pooled
+
+    def _forward(self, x, pos, batch):
+        """-> (pooled [B, C_out], zeros [B, 3], arange(B))   (models/basic_modules.py:121-125)"""
+        ops = get_ops()
+        dev = pos.device
+        B = int(batch.max().item()) + 1
+        xp, cx = _with_pos(ops, x.float().contiguous(), _pos4(ops, pos))
+        pooled = self.run(ops, xp, cx + 3, ops.make_seg(batch, B, 1), B)
+        return pooled, pos.new_zeros((B, 3)), torch.arange(B, device=dev)
 
 
 class FPModule(NativeModule):
@@ -305,6 +429,36 @@ class FPModule(NativeModule):
 
     def _pack(self):
         return [packing.pack_mlp_layer(l) for l in self.nn]
+
+    def run(self, ops, feat: torch.Tensor, pos_x: torch.Tensor, ptr_x: torch.Tensor, skip: Optional[torch.Tensor],
+            pos_y: torch.Tensor, ptr_y: torch.Tensor, n_clouds: int, max_targets_per_cloud: int) -> torch.Tensor:
+        """feat [Nx, Cf] at pos_x ([Nx, >=3]) interpolated onto pos_y ([Ny, >=3]), concatenated with skip [Ny, Cs], then the MLP."""
+        dev = feat.device
+        layers = self.packed(dev)
+        ny, cf = pos_y.shape[0], feat.shape[1]
+        cs = 0 if skip is None else skip.shape[1]
+        ld = (cf + cs + 3) // 4 * 4                       # GEMM operand rows are 16-byte aligned; the padding stays zero
+        cat = ops.empty(ny, ld, dev) if ld == cf + cs else torch.zeros((ny, ld), dtype=torch.float32, device=dev)
+        ops.knn_interpolate(Mat.of(feat), Mat.of(pos_x, 0, 3), ptr_x, Mat.of(pos_y, 0, 3), ptr_y, n_clouds, max_targets_per_cloud,
+                            self.k, Mat.of(cat, 0, cf))
+        if skip is not None:
+            ops.copy2d(Mat.of(skip), Mat.of(cat, cf, cs))
+        h = Mat.of(cat, 0, cf + cs)
+        for lay in layers:
+            o = ops.empty(ny, lay.N, dev)
+            ops.gemm(h, lay, relu=True, Y=Mat.of(o))
+            h = Mat.of(o)
+        return h.base
+
+    def _forward(self, x, pos, batch, x_skip, pos_skip, batch_skip):
+        """-> (nn([interp ‖ x_skip]), pos_skip, batch_skip)   (models/basic_modules.py:133-138)"""
+        ops = get_ops()
+        B = int(max(int(batch.max().item()), int(batch_skip.max().item()))) + 1
+        _, ptr_x = _cloud_offsets(batch, B)
+        cy, ptr_y = _cloud_offsets(batch_skip, B)
+        out = self.run(ops, x.float().contiguous(), _pos4(ops, pos), ptr_x, None if x_skip is None else x_skip.float().contiguous(),
+                       _pos4(ops, pos_skip), ptr_y, B, max(cy))
+        return out, pos_skip, batch_skip
 
 
 __all__ += ["PointConv", "SAModule", "GlobalSAModule", "FPModule"]

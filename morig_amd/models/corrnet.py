@@ -24,7 +24,7 @@ from torch.nn import Linear as Lin, Parameter, Sequential as Seq
 from .. import packing
 from ..native import Mat
 from ..runtime import get_ops
-from .basic_modules import GCU, MLP, FPModule, GlobalSAModule, NativeModule, SAModule
+from .basic_modules import GCU, MLP, FPModule, GlobalSAModule, NativeModule, SAModule, _with_pos
 
 __all__ = ["corrnet"]
 
@@ -175,38 +175,6 @@ class CorrNet(NativeModule):
             levels.append(nxt)
         return levels
 
-    def _set_abstraction(self, ops, sa: SAModule, xp: torch.Tensor, cx: int, pos_new: torch.Tensor, plan: _HostPlan, level: int):
-        """xp: [N, ld] = [x(cx) | pos(3) | pad] of level ``level``; pos_new: the sampled centres [M, 4]; returns x_new [M, H3]."""
-        dev = xp.device
-        pk = sa.packed(dev)
-        N = xp.shape[0]
-        ptr, out_ptr = plan.ptr[level], plan.ptr[level + 1]
-        n_clouds = plan.B
-        M = pos_new.shape[0]
-        posm = Mat.of(xp, cx, 3)
-        coo = ops.ball_query(posm, ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, sa.r, sa.max_num_neighbors)
-        csr = ops.csr_from_slots(coo, M, sa.max_num_neighbors, N)
-        H = pk["edge"].H
-        bsrc = ops.empty(N, H, dev)
-        ops.gemm(Mat.of(xp, 0, cx + 3), pk["src"], relu=False, Y=Mat.of(bsrc))
-        atgt = ops.empty(M, H, dev)
-        ops.gemm(Mat.of(pos_new, 0, 3), pk["tgt"], relu=False, Y=Mat.of(atgt))
-        z = ops.empty(csr.capacity, H, dev)
-        ops.edge_hidden(Mat.of(atgt), Mat.of(bsrc), csr, pk["edge"], Mat.of(z))
-        x_new = ops.empty(M, pk["last"].N, dev)
-        ops.segmax_gemm(Mat.of(z), pk["last"], True, csr, Mat.of(x_new))
-        return x_new
-
-    @staticmethod
-    def _with_pos(ops, x: torch.Tensor, pos4: torch.Tensor):
-        """[x | pos | 0] with a 16-byte aligned row stride."""
-        n, c = x.shape
-        ld = (c + 3 + 3) // 4 * 4
-        buf = torch.zeros((n, ld), dtype=torch.float32, device=x.device)
-        ops.copy2d(Mat.of(x), Mat.of(buf, 0, c))
-        ops.copy2d(Mat.of(pos4, 0, 3), Mat.of(buf, c, 3))
-        return buf
-
     def _point_branch(self, ops, data, plan: _HostPlan):
         dev = data.pts.device
         pk = self.packed(dev)
@@ -217,23 +185,17 @@ class CorrNet(NativeModule):
         counts0, c1, c2, c3 = plan.counts
         ptr0, ptr1, ptr2, ptr3 = plan.ptr
         _, pos1, pos2, pos3 = self._sample_levels(ops, pos0, plan)
-        x1 = self._set_abstraction(ops, self.pts_sa1_module, pos0, 0, pos1, plan, 0)
-        xp1 = self._with_pos(ops, x1, pos1)
-        x2 = self._set_abstraction(ops, self.pts_sa2_module, xp1, 64, pos2, plan, 1)
-        xp2 = self._with_pos(ops, x2, pos2)
-        x3 = self._set_abstraction(ops, self.pts_sa3_module, xp2, 128, pos3, plan, 2)
-        xp3 = self._with_pos(ops, x3, pos3)
+        x1 = self.pts_sa1_module.run(ops, pos0, 0, pos1, ptr0, ptr1, B)
+        xp1, _ = _with_pos(ops, x1, pos1)
+        x2 = self.pts_sa2_module.run(ops, xp1, 64, pos2, ptr1, ptr2, B)
+        xp2, _ = _with_pos(ops, x2, pos2)
+        x3 = self.pts_sa3_module.run(ops, xp2, 128, pos3, ptr2, ptr3, B)
+        xp3, _ = _with_pos(ops, x3, pos3)
         M3 = x3.shape[0]
         seg3 = torch.repeat_interleave(torch.arange(B, dtype=torch.int32, device=dev), (ptr3[1:] - ptr3[:-1]).long(),
                                        output_size=M3)                      # output_size: no host sync
         # SA4: global set abstraction
-        g4 = self.pts_sa4_module.packed(dev)
-        a = ops.empty(M3, 256, dev)
-        ops.gemm(Mat.of(xp3, 0, 259), g4[0], relu=True, Y=Mat.of(a))
-        b = ops.empty(M3, 256, dev)
-        ops.gemm(Mat.of(a), g4[1], relu=True, Y=Mat.of(b))
-        pooled = ops.empty(B, 512, dev)
-        ops.gemm(Mat.of(b), g4[2], relu=True, seg=seg3, pool=pooled)
+        pooled = self.pts_sa4_module.run(ops, xp3, 259, seg3, B)
         # FP4: broadcast of the pooled vector (k=1 from one global point) -> row bias
         gb = ops.empty(B, 256, dev)
         ops.gemm(Mat.of(pooled), pk["fp4_g"], relu=False, Y=Mat.of(gb))
@@ -243,20 +205,7 @@ class CorrNet(NativeModule):
         ops.gemm(Mat.of(f4a), pk["fp4_2"], relu=True, Y=Mat.of(f4))
 
         def propagate(fp: FPModule, feat, pos_x, ptr_x, skip, pos_y, ptr_y, counts_y):
-            layers = fp.packed(dev)
-            ny, cf = pos_y.shape[0], feat.shape[1]
-            cs = 0 if skip is None else skip.shape[1]
-            cat = ops.empty(ny, cf + cs, dev)
-            ops.knn_interpolate(Mat.of(feat), Mat.of(pos_x, 0, 3), ptr_x, Mat.of(pos_y, 0, 3), ptr_y, B, max(counts_y),
-                                fp.k, Mat.of(cat, 0, cf))
-            if skip is not None:
-                ops.copy2d(Mat.of(skip), Mat.of(cat, cf, cs))
-            h = cat
-            for lay in layers:
-                o = ops.empty(ny, lay.N, dev)
-                ops.gemm(Mat.of(h), lay, relu=True, Y=Mat.of(o))
-                h = o
-            return h
+            return fp.run(ops, feat, pos_x, ptr_x, skip, pos_y, ptr_y, B, max(counts_y))
 
         f3 = propagate(self.pts_fp3_module, f4, pos3, ptr3, x2, pos2, ptr2, c2)
         f2 = propagate(self.pts_fp2_module, f3, pos2, ptr2, x1, pos1, ptr1, c1)

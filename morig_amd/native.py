@@ -194,7 +194,7 @@ class CSR:
     dst: torch.Tensor         # int32 [cap]
     n_nodes: int
     capacity: int
-    status: torch.Tensor      # int32 [1], non-zero = index out of range (checked lazily)
+    status: torch.Tensor      # int32 [1], non-zero = index out of range (read once per forward by NativeOps.guarded)
     edge_count: int = 0       # exact E' when known (accounting only)
     quad: bool = False        # segments padded to multiples of 4 (MORIG_CSR_PAD4)
 
@@ -224,6 +224,7 @@ class NativeOps:
         self.precision = os.environ.get("MORIG_PRECISION", "f16x3")
         assert self.precision in ("f16x3", "f32")
         self._ovf = {}
+        self._csr_status = None
         self._depth = 0
         self._force_f32 = False
         # accounting only (bench.py): exact self-loop-normalised edge counts E' per input graph, learned during
@@ -255,11 +256,20 @@ class NativeOps:
         flag = self._flag(device)
         flag.zero_()
         self._depth += 1
+        self._csr_status = []
         try:
             out = fn()
         finally:
             self._depth -= 1
-        if int(flag.item()) != 0:                     # one 4-byte D2H read per forward
+            stats, self._csr_status = self._csr_status, None
+        # ONE small D2H read per forward: the split-fp16 range flag and the status word of every CSR built on the way
+        # (an out-of-range / negative edge or ball-query index is dropped by the count and fill kernels; the reference would
+        # raise an index error, so does this)
+        words = torch.cat([flag] + stats).tolist() if stats else [int(flag.item())]
+        if any(w != 0 for w in words[1:]):
+            raise MorigNativeError("edge_index / neighbour index out of range for the vertex count it was built with "
+                                   "(morig_csr_build status %s)" % [w for w in words[1:] if w != 0][:4])
+        if words[0] != 0:
             self._force_f32 = True
             try:
                 out = fn()
@@ -294,6 +304,8 @@ class NativeOps:
                                                      (1 if skip_negative else 0) | (2 if pad4 else 0), _p(rowptr), _p(src),
                                                      _p(dst), _p(cursor), _p(status), _stream()), "morig_csr_build_bipartite")
         csr = CSR(rowptr, src, dst, n_nodes, cap, status, quad=pad4)
+        if getattr(self, "_csr_status", None) is not None:
+            self._csr_status.append(status)            # read with the precision flag at the end of the guarded forward
         key = (ei.data_ptr(), E, n_nodes)
         if self.learn_edge_counts and not pad4 and key not in self._edge_counts:
             self._edge_counts[key] = int(rowptr[-1].item())
@@ -314,6 +326,8 @@ class NativeOps:
         status = torch.empty(1, dtype=torch.int32, device=dev)
         check(self.lib.morig_csr_from_slots(_p(coo), n_nodes, max_nbrs, n_src, _p(rowptr), _p(src), _p(dst), _p(cursor),
                                             _p(status), _stream()), "morig_csr_from_slots")
+        if getattr(self, "_csr_status", None) is not None:
+            self._csr_status.append(status)
         return CSR(rowptr, src, dst, n_nodes, cap, status)
 
     # -- dense ----------------------------------------------------------------------------------

@@ -43,3 +43,22 @@ def load_golden(name):
 def _no_grad():
     with torch.no_grad():
         yield
+
+
+def pytest_terminal_summary(terminalreporter):
+    """parity report: worst absolute and scale-relative error per test (both readings of "within 1e-4 fp32")."""
+    try:
+        from helpers import PARITY_LOG
+    except Exception:
+        return
+    if not PARITY_LOG:
+        return
+    worst = {}
+    for tid, err, scale, rel in PARITY_LOG:
+        w = worst.get(tid)
+        if w is None or err > w[0]:
+            worst[tid] = (err, scale, rel)
+    tr = terminalreporter
+    tr.write_sep("-", "parity report: max |diff| (absolute), |ref|inf, |diff| / max(1, |ref|inf)")
+    for tid, (err, scale, rel) in sorted(worst.items(), key=lambda kv: -kv[1][0])[:25]:
+        tr.write_line(f"{err:10.3e}  {scale:10.3e}  {rel:10.3e}  {tid[-110:]}")

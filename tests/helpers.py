@@ -32,9 +32,76 @@ def excess(a, b, atol, rtol):
     return ((a - b).abs() - (atol + rtol * b.abs())).max().item()
 
 
-def rel_excess(a, b, tol):
+PARITY_LOG = []            # (test id, abs err, |ref|inf, err / max(1, |ref|inf)) of every parity check; printed by conftest at the end
+
+
+def rel_excess(a, b, tol, strict=None):
     """|a-b|_inf relative to max(1, |b|_inf), minus tol: the parity criterion used for network outputs
-    ("within 1e-4 fp32" of BASELINE.json, normalised by the output scale when that exceeds 1)."""
+    ("within 1e-4 fp32" of BASELINE.json, normalised by the output scale when that exceeds 1).
+    The STRICT reading -- absolute |a-b|_inf <= tol whatever the scale -- is asserted as well wherever it is known to hold:
+    by default for every reference whose |ref|_inf <= 4 (all committed jointnet / masknet / skinnet / corrnet goldens); ``strict=False``
+    switches it off for a check (large-magnitude logits), ``strict=True`` forces it. Both numbers go to the parity report."""
     a = a.detach().cpu().double()
     b = b.detach().cpu().double()
-    return (a - b).abs().max().item() / max(1.0, b.abs().max().item()) - tol
+    err, scale = (a - b).abs().max().item(), b.abs().max().item()
+    PARITY_LOG.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], err, scale, err / max(1.0, scale)))
+    if strict is None:
+        strict = scale <= 4.0
+    if strict and err > tol:
+        return err - tol
+    return err / max(1.0, scale) - tol
+
+
+# ---- standalone PointNet++ blocks (SAModule / GlobalSAModule / FPModule): one case builder for the CPU and GPU suites ----
+def point_module_case(kind, ratio=0.5, r=0.12, seed=0, device="cpu"):
+    """-> (module under test, oracle module with the same parameters, forward args tuple) for the standalone
+    forwards of models/basic_modules.py:66-86,115-138 on two ragged clouds."""
+    from morig_amd import synth
+    from morig_amd.models import basic_modules as bm
+    from oracle import nets
+    g = torch.Generator().manual_seed(seed)
+    n0, n1 = 300, 211
+    pos = torch.rand(n0 + n1, 3, generator=g) * 0.5
+    batch = torch.cat([torch.zeros(n0, dtype=torch.long), torch.ones(n1, dtype=torch.long)])
+    if kind == "sa":
+        cx = 16
+        mod = bm.SAModule(ratio, r, bm.MLP([cx + 3, 32, 32, 64]), max_num_neighbors=64)
+        ref = nets.SetAbstraction(ratio, r, nets.mlp_stack([cx + 3, 32, 32, 64]), 64)
+        args = (torch.randn(n0 + n1, cx, generator=g), pos, batch, False)
+    elif kind == "sa_nox":
+        mod = bm.SAModule(ratio, r, bm.MLP([3, 32, 32, 64]), max_num_neighbors=64)
+        ref = nets.SetAbstraction(ratio, r, nets.mlp_stack([3, 32, 32, 64]), 64)
+        args = (None, pos, batch, False)
+    elif kind == "gsa":
+        cx = 29
+        mod = bm.GlobalSAModule(bm.MLP([cx + 3, 64, 64, 128]))
+        ref = nets.GlobalSetAbstraction(nets.mlp_stack([cx + 3, 64, 64, 128]))
+        args = (torch.randn(n0 + n1, cx, generator=g), pos, batch)
+    else:                                                   # "fp1" / "fp3": k = 1 / 3, coarse level = every third point
+        k = int(kind[2:])
+        cf, cs = 24, 12
+        mod = bm.FPModule(k, bm.MLP([cf + cs, 64, 32]))
+        ref = nets.FeaturePropagation(k, nets.mlp_stack([cf + cs, 64, 32]))
+        sel = torch.arange(0, n0 + n1, 3)
+        args = (torch.randn(sel.numel(), cf, generator=g), pos[sel], batch[sel], torch.randn(n0 + n1, cs, generator=g), pos, batch)
+    synth.load_recipe(mod.eval(), seed + 3)                 # randomised BN statistics, negative gamma included
+    ref.eval().load_state_dict(mod.state_dict())
+    mod = mod.to(device)
+    args = tuple(a.to(device) if torch.is_tensor(a) else a for a in args)
+    return mod, ref, args
+
+
+POINT_MODULE_CASES = [("sa", 0.5, 0.12), ("sa", 0.25, 0.25), ("sa", 0.25, 0.5), ("sa_nox", 0.5, 0.12), ("gsa", 0, 0), ("fp1", 0, 0),
+                      ("fp3", 0, 0)]
+
+
+def check_point_module(kind, ratio, r, device):
+    mod, ref, args = point_module_case(kind, ratio, r, device=device)
+    cpu_args = tuple(a.cpu() if torch.is_tensor(a) else a for a in args)
+    with torch.no_grad():
+        got = mod(*args)
+        want = ref(*cpu_args)
+    assert len(got) == len(want) == 3
+    assert rel_excess(got[0], want[0], 2e-5) <= 0, (kind, maxdiff(got[0], want[0]))
+    assert got[1].shape == want[1].shape and maxdiff(got[1], want[1]) == 0          # positions: gathered / passed through
+    assert torch.equal(got[2].cpu().long(), want[2].long())                          # batch ids: index work, bit exact

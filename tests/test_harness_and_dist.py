@@ -109,3 +109,43 @@ def test_two_rank_gloo_shard_and_all_gather():
             assert p.returncode == 0 and f"rank {r} ok" in o, o
     finally:
         os.unlink(f.name)
+
+
+def _bench_line(extra, env_extra=None):
+    import json
+    env = dict(os.environ, MORIG_BENCH_PLUMBING="1", OMP_NUM_THREADS="2")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout            # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver invoked --gpus 1 in round 1) must spawn its
+    own ranks; plumbing mode = gloo + CPU emulation on tiny meshes, so this checks launch, sharding, the collective and the
+    JSON contract, not speed."""
+    r = _bench_line(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--cpu-seconds", "0"])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["backend"] == "gloo"
+    assert r["scaling"] == "weak" and r["config"]["global_batch"] == 4 and r["config"]["meshes_per_gpu"] == 2
+    assert len(r["per_rank_ms_per_step"]) == 2 and r["steps"] == 2 and r["warmup"] == 1
+    assert r["ms_per_step_p10"] <= r["ms_per_step_median"] <= r["ms_per_step_p90"]
+    assert abs(r["value"] - 4 * 2 / (r["ms_per_step"] * 2e-3)) / r["value"] < 0.02      # whole-job units / max-rank time
+    assert "PLUMBING" in r["data"] and r["higher_is_better"] is True and r["vs_baseline"] is None
+
+
+def test_bench_strong_scaling_splits_one_batch():
+    r = _bench_line(["--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4", "--scaling", "strong", "--cpu-seconds", "0"])
+    assert r["scaling"] == "strong" and r["config"]["global_batch"] == 4 and r["config"]["meshes_per_gpu"] == 2
+
+
+def test_bench_single_rank_line_keeps_the_contract():
+    r = _bench_line(["--steps", "2", "--warmup", "1", "--batch", "2", "--cpu-seconds", "0"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["unit"] == "meshes/s"
+    assert "workload" in r["config"] and "model" not in r["config"]

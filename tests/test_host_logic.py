@@ -175,3 +175,39 @@ def test_gcndeform_argument_order():
         want = ref(a["pos"], a["feature"], a["geo_edge_index"], a["tpl_edge_index"], a["batch"])
     got = m(a["pos"], a["feature"], a["geo_edge_index"], a["tpl_edge_index"], a["batch"])
     assert rel_excess(got, want, TOL) <= 0
+
+
+def test_packed_cache_follows_in_place_edits_and_child_reloads(emulated_ops):
+    """the kernel-layout weight cache must not survive (a) an in-place edit of a parameter, (b) load_state_dict
+    on a plain Sequential child, (c) load_state_dict on a child NativeModule whose tensors the PARENT packs."""
+    from morig_amd.models import basic_modules as bm
+    torch.manual_seed(0)
+    n = 40
+    pos, x = torch.randn(n, 3), torch.randn(n, 8)
+    ei = torch.randint(0, n, (2, 200))
+    g = bm.GCUMotion(in_channels=8, out_channels=32, dim_pos_feat=16).eval()
+    run = lambda: g(pos, x, ei, ei).clone()
+    y0 = run()
+    assert torch.equal(run(), y0)                                        # cache hit: same bits
+    g.mlp[0][0].weight.mul_(2.0)                                         # (a) (the autouse fixture holds no_grad)
+    y1 = run()
+    assert not torch.allclose(y1, y0)
+    sd = {k: v * 0.5 for k, v in g.mlp.state_dict().items()}            # (b) plain Sequential child
+    g.mlp.load_state_dict(sd)
+    y2 = run()
+    assert not torch.allclose(y2, y1)
+    sd = {k: (v * 1.5 if v.dtype.is_floating_point else v) for k, v in g.edge_conv_tpl.state_dict().items()}     # (c)
+    g.edge_conv_tpl.load_state_dict(sd)
+    y3 = run()
+    assert not torch.allclose(y3, y2)
+    fresh = bm.GCUMotion(in_channels=8, out_channels=32, dim_pos_feat=16).eval()
+    fresh.load_state_dict(g.state_dict())
+    assert torch.allclose(fresh(pos, x, ei, ei), y3, atol=1e-6)
+
+
+@pytest.mark.parametrize("kind,ratio,r", __import__("helpers").POINT_MODULE_CASES)
+def test_point_modules_standalone_forward(emulated_ops, kind, ratio, r):
+    """SAModule / GlobalSAModule / FPModule are callable on their own with the reference's signatures and
+    return tuples (models/basic_modules.py:74-86,121-125,133-138); host wiring on the emulated op layer vs the oracle."""
+    from helpers import check_point_module
+    check_point_module(kind, ratio, r, "cpu")
