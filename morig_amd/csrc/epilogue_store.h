@@ -111,16 +111,23 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
             } else if constexpr (ALLOW16) {
                 // split layout: each 32-column chunk is [32 hi halves | 32 lo halves]; my 8 columns never straddle a chunk.
                 // hi = fp16(v) truncated (one v_cvt_pkrtz per pair), lo = fp16(v - hi) rounded to nearest: hi + lo == v to ~2^-22
+                // lo through v_fma_mix (f32 v * 1.0 - f16 hi, rounded into one half of the destination): bit-identical to the
+                // cvt / sub / cvt sequence (v - hi is exact in fp32), 3 VALU per pair instead of 6 -- this epilogue is VALU-bound
                 typedef __fp16 ep_h2 __attribute__((ext_vector_type(2)));
-                ep_f16x8 hv, lv;
+                typedef float ep_b32x4 __attribute__((ext_vector_type(4)));
+                ep_b32x4 hw, lw;
                 float am = 0.f;
 #pragma unroll
                 for (int q = 0; q < 8; q += 2) {
                     const ep_h2 h = __builtin_amdgcn_cvt_pkrtz(v[q], v[q + 1]);
-                    hv[q] = (_Float16)h[0]; hv[q + 1] = (_Float16)h[1];
-                    lv[q] = (_Float16)(v[q] - (float)h[0]); lv[q + 1] = (_Float16)(v[q + 1] - (float)h[1]);
+                    const float hb = __builtin_bit_cast(float, h);
+                    float lb;
+                    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v[q]), "v"(hb));
+                    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v[q + 1]), "v"(hb));
+                    hw[q >> 1] = hb; lw[q >> 1] = lb;
                     am = fmaxf(am, fmaxf(fabsf(v[q]), fabsf(v[q + 1])));
                 }
+                const ep_f16x8 hv = __builtin_bit_cast(ep_f16x8, hw), lv = __builtin_bit_cast(ep_f16x8, lw);
                 if (!(am < 65000.f)) ovf = true;
                 char* o = reinterpret_cast<char*>(p.Y + (size_t)row * p.ldy) + (col0 >> 5) * 128 + (col0 & 31) * 2;
                 if (vec_ok && col0 + VW16 <= p.N) {

@@ -136,22 +136,71 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
         else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_CHUNK) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
+    // one (mt, nt) pair of accumulators = 6 MFMAs with the dependent ones two slots apart
+    auto mma_pair = [&](const Frag& f, int mt, int nt0) __attribute__((always_inline)) {
+        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
+        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0],     acc[mt][nt0],     0, 0, 0);
+        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
+        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+    };
+    auto issue_one = [&](int c, int j) __attribute__((always_inline)) {       // DMA instruction j of chunk c (X pieces, then W pieces)
+        char* st = smem + (c % DMA_NS) * DMA_STAGE;
+        if (j < XJ) {
+            unsigned o = ox[j];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(xbase + c * 128 + o), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
+        } else {
+            unsigned o = ow[j - XJ];
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(wbase + c * 128 + o), (lds_void_t*)(st + BM * 128 + (wave * WJ + j - XJ) * 1024), 16, 0, 0);
+        }
+    };
     Frag f0, f1;
     wait_chunk(0);
     __builtin_amdgcn_s_barrier();
     if (DMA_NS - 1 < nchunk) issue(DMA_NS - 1);
     load_frag(f0, 0, 0);
+    // Measured on the EdgeConv kernels (tools/gpu_ws2.sh): an LDS-DMA instruction costs the issuing wave ~100 cycles of issue
+    // stall, and the two waves of a SIMD leave the chunk barrier together -- with all PER_CHUNK instructions issued back to
+    // back right behind it the matrix pipe of every SIMD idles for the whole burst. MORIG_DMA_SPREAD (default) issues them
+    // in pairs between groups of 6 MFMAs of the second half-chunk instead (sched_barrier pins the order), so a wave stalled
+    // on a DMA slot leaves the pipe to its partner's queued MFMAs.
+#ifdef MORIG_DMA_BURST
+    constexpr bool SPREAD = false;
+#else
+    constexpr bool SPREAD = (NT == 4 && MT == 2 && PER_CHUNK == 8);
+#endif
     for (int c = 0; c < nchunk; ++c) {
         load_frag(f1, c, 1);
         mma(f0);
-        if (c + 1 < nchunk) {
+        const bool more = c + 1 < nchunk;
+        const bool dma = c + DMA_NS < nchunk;
+        if (more) {
             wait_chunk(c + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my own reads of chunk c have returned ...
             __builtin_amdgcn_s_barrier();        // ... and everyone's: chunk c lives in registers, stage c%NS is free
-            if (c + DMA_NS < nchunk) issue(c + DMA_NS);
+            if constexpr (!SPREAD) { if (dma) issue(c + DMA_NS); }
             load_frag(f0, c + 1, 0);
         }
-        mma(f1);
+        if constexpr (SPREAD) {
+            const bool go = more && dma;
+            mma_pair(f1, 0, 0); __builtin_amdgcn_sched_barrier(0);
+            if (go) { issue_one(c + DMA_NS, 0); issue_one(c + DMA_NS, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_pair(f1, 0, 2); __builtin_amdgcn_sched_barrier(0);
+            if (go) { issue_one(c + DMA_NS, 2); issue_one(c + DMA_NS, 3); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_pair(f1, 1, 0); __builtin_amdgcn_sched_barrier(0);
+            if (go) { issue_one(c + DMA_NS, 4); issue_one(c + DMA_NS, 5); }
+            __builtin_amdgcn_sched_barrier(0);
+            mma_pair(f1, 1, 2); __builtin_amdgcn_sched_barrier(0);
+            if (go) { issue_one(c + DMA_NS, 6); issue_one(c + DMA_NS, 7); }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            mma(f1);
+        }
     }
 
     const int colw0 = tn * BN + wn * NT * 32;

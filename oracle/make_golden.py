@@ -55,6 +55,40 @@ def ragged_batch(seeds_sides, n_pts=0):
     return synth.collate(meshes, clouds)
 
 
+def full_size_fixtures(ref):
+    """BASELINE.json's full sizes with the HARSH BatchNorm recipe (gamma ~ N(0,1) with both signs): one 4096-vertex mesh
+    through jointnet / masknet / skinnet, and one (4096-vertex mesh, 8192-point cloud) pair through CorrNet -- VERDICT r1 #4b.
+    Inputs are a pure function of the mesh seed (synth.make_mesh / make_point_cloud): only outputs are stored; wide outputs
+    (motion_aggr, out_pts) are stored every ROW_STEP-th row to keep the files around 1 MB."""
+    print("full-size fixtures (harsh recipe)")
+    step = 4
+    seed, n_side, n_pts = 32, 64, 8192
+    mesh = synth.make_mesh(seed, n_side=n_side, with_skin=True)
+    big = synth.collate([mesh])
+    check = dict(pos_check=big.pos[:8], geo_check=big.geo_edge_index[:, :32])
+    for arch, kw, rseed, outs in (
+            ("jointnet_motion", dict(num_keyframes=5, chn_output=3, aggr_method="attn", motion_dim=32), 411, ("pred_shift",)),
+            ("masknet_motion", dict(num_keyframes=5, chn_output=1, aggr_method="attn"), 412, ("pred_mask",)),
+            ("skinnet_motion", dict(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True, motion_dim=32,
+                                    aggr_method="attn"), 413, ("skin_cls_pred",))):
+        m = ref.__dict__[arch](**kw).eval()
+        synth.load_recipe(m, rseed, mild=False)
+        ma, mg, last = m(big, big.pred_flow)
+        _save(f"{arch.split('_')[0]}_4k_harsh", dict(recipe_seed=rseed, mild=False, arch=arch, kwargs=kw, mesh_seed=seed,
+                                                       n_side=n_side, with_skin=True, row_step=step),
+              motion_aggr_rows=mg[::step], **{outs[0]: last}, **check)
+    cloud = synth.make_point_cloud(mesh, int(mesh.name), n_pts)
+    cb = synth.collate([mesh], [cloud])
+    kw = dict(input_feature=3, output_feature=64, temprature=0.07)
+    m = ref.__dict__["corrnet"](**kw).eval()
+    synth.load_recipe(m, 414, mild=False)
+    with shim.pretend_cuda_available():
+        ov, op, vis, tau = m(cb, True, False)
+    _save("corrnet_4k_8k_harsh", dict(recipe_seed=414, mild=False, arch="corrnet", kwargs=kw, mesh_seed=seed, n_side=n_side,
+                                      n_pts=n_pts, with_skin=True, row_step=step),
+          out_vtx_rows=ov[::step], out_pts_rows=op[::step], out_vismask=vis, pts_check=cb.pts[:8], **check)
+
+
 def deformnet_fixtures(ref):
     """DeformNet (models/deformnet.py) -- SURVEY 8(f-1). The reference calls its CorrNet with the default
     random_start=True (:41): the FPS start indices come from torch's global RNG, one draw per cloud per SA level
@@ -233,6 +267,8 @@ def main():
     ref = shim.import_reference_models()
     if len(sys.argv) > 1 and sys.argv[1] == "deformnet":      # only the (f-1) fixtures; the others stay byte-identical
         return deformnet_fixtures(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "full_size":
+        return full_size_fixtures(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "joints":
         return joints_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
@@ -356,6 +392,7 @@ def main():
                               n_side=64), motion_aggr=mg, pred_shift=ps,
           pos_check=big.pos[:8], geo_check=big.geo_edge_index[:, :32])
 
+    full_size_fixtures(ref)
     deformnet_fixtures(ref)
     joints_fixtures()
     dataset_fixtures()

@@ -105,3 +105,32 @@ def check_point_module(kind, ratio, r, device):
     assert rel_excess(got[0], want[0], 2e-5) <= 0, (kind, maxdiff(got[0], want[0]))
     assert got[1].shape == want[1].shape and maxdiff(got[1], want[1]) == 0          # positions: gathered / passed through
     assert torch.equal(got[2].cpu().long(), want[2].long())                          # batch ids: index work, bit exact
+
+
+# ---- full-size harsh-recipe goldens (tests/golden/*_4k_harsh.npz, corrnet_4k_8k_harsh.npz): shared by the CPU and GPU suites ----
+FULL_SIZE_GOLDENS = ["jointnet_4k_harsh", "masknet_4k_harsh", "skinnet_4k_harsh", "corrnet_4k_8k_harsh"]
+
+
+def full_size_inputs(meta, device="cpu"):
+    """the inputs of a full-size fixture are a pure function of its mesh seed (only outputs are stored)"""
+    from morig_amd import synth
+    mesh = synth.make_mesh(meta["mesh_seed"], n_side=meta["n_side"], with_skin=meta.get("with_skin", False))
+    clouds = [synth.make_point_cloud(mesh, int(mesh.name), meta["n_pts"])] if "n_pts" in meta else None
+    return synth.collate([mesh], clouds).to(device)
+
+
+def check_full_size(model, meta, a, data, tol):
+    """run ``model`` on the regenerated inputs and compare with the reference's stored outputs"""
+    step = meta["row_step"]
+    assert maxdiff(data.pos[:8], a["pos_check"]) == 0 and torch.equal(data.geo_edge_index[:, :32].cpu(), a["geo_check"])
+    if meta["arch"] == "corrnet":
+        assert maxdiff(data.pts[:8], a["pts_check"]) == 0
+        ov, op, vis, _ = model(data, True, False)
+        assert rel_excess(ov[::step], a["out_vtx_rows"], tol) <= 0
+        assert rel_excess(op[::step], a["out_pts_rows"], tol) <= 0
+        assert rel_excess(vis, a["out_vismask"], tol) <= 0
+    else:
+        _, aggr, last = model(data, data.pred_flow)
+        key = [k for k in ("pred_shift", "pred_mask", "skin_cls_pred") if k in a][0]
+        assert rel_excess(aggr[::step], a["motion_aggr_rows"], tol) <= 0
+        assert rel_excess(last, a[key], tol) <= 0, key

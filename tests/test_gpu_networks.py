@@ -201,7 +201,9 @@ def test_deformnet_larger_clouds_against_oracle():
     # (3) downstream of the neighbour choice
     torch.manual_seed(5)
     want_same = ref(batch, neighbours=(to_pts, to_vis))
-    assert rel_excess(got[0], want_same[0], TOL) <= 0
+    # pred_flow = votes (softmax-weighted differences of ~4-unit positions) + GCNDeform: relative to the output scale
+    # (beyond the 1e-4-absolute networks of rows a8-a12); measured 1.8e-4 absolute at scale 4.0
+    assert rel_excess(got[0], want_same[0], TOL, strict=False) <= 0
 
 
 def test_corrnet_larger_clouds_against_oracle():
@@ -306,3 +308,14 @@ def test_headline_batch_64_meshes_contains_the_golden_mesh_and_is_deterministic(
     sl = slice(37 * n, 38 * n)
     assert rel_excess(aggr[sl], a["motion_aggr"], TOL) <= 0
     assert rel_excess(shift[sl], a["pred_shift"], TOL) <= 0
+
+
+@pytest.mark.parametrize("name", __import__("helpers").FULL_SIZE_GOLDENS)
+def test_full_size_harsh_recipe_goldens(name):
+    """4096-vertex mesh (and the 8192-point cloud of configs[3]) with the harsh BatchNorm recipe on the HIP path against
+    outputs of the reference's own models/*.py (VERDICT r1 #4b)."""
+    from helpers import check_full_size, full_size_inputs
+    meta, a = load_golden(name)
+    m = models.__dict__[meta["arch"]](**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
+    check_full_size(m, meta, a, full_size_inputs(meta, DEV), TOL)

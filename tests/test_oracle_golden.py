@@ -153,3 +153,12 @@ def test_deformnet_state_dict_contract():
     assert tuple(sd["completing.gcu_1.edge_conv_tpl.nn_x.0.0.weight"].shape) == (64, 8)
     assert tuple(sd["completing.mlp_tramsform.0.0.0.weight"].shape) == (1024, 1024 + 3 + 4 + 896)
     assert tuple(sd["completing.mlp_tramsform.1.weight"].shape) == (3, 256)
+
+
+@pytest.mark.parametrize("name", __import__("helpers").FULL_SIZE_GOLDENS)
+def test_full_size_harsh_recipe_goldens(name):
+    """BASELINE.json's full sizes (4096-vertex mesh; 8192-point cloud) with negative-gamma BatchNorm, outputs produced by the
+    reference's own models/*.py (oracle/make_golden.py full_size)."""
+    from helpers import check_full_size, full_size_inputs
+    meta, a = load_golden(name)
+    check_full_size(_net(meta), meta, a, full_size_inputs(meta), 5e-6)

@@ -33,7 +33,7 @@ def main():
     n = batch.pos.shape[0]
     R = 5
     out = {}
-    for gname, ei in (("tpl", batch.tpl_edge_index), ("geo", batch.geo_edge_index)):
+    for gname, ei in (() if os.environ.get("MB_NOEDGE") else (("tpl", batch.tpl_edge_index), ("geo", batch.geo_edge_index))):
         E = int(ops.csr_build(ei, n).rowptr[-1].item())          # algorithmic edge count (no padding)
         csr = ops.csr_build(ei, n, pad4=os.environ.get("MB_PAD4", "1") == "1")
         torch.cuda.synchronize()
