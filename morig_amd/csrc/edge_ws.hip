@@ -256,8 +256,10 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         } else { c0 = acc[0]; c1 = acc[1]; }
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[0], wh[S], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[1], wh[S], c1, 0, 0, 0);
+#ifndef MORIG_2MFMA_EDGE      // measurement build: W2 rounded to fp16
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[0], wl[S], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[1], wl[S], c1, 0, 0, 0);
+#endif
         c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[0], wh[S], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[1], wh[S], c1, 0, 0, 0);
         acc[0] = c0; acc[1] = c1;

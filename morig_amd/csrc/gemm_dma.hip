@@ -124,7 +124,9 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+#ifndef MORIG_2MFMA
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+#endif
                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
             }
     };
@@ -140,8 +142,10 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     auto mma_pair = [&](const Frag& f, int mt, int nt0) __attribute__((always_inline)) {
         acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
         acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+#ifndef MORIG_2MFMA           // measurement build: W rounded to fp16, i.e. the x_hi * w_lo product dropped
         acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0],     acc[mt][nt0],     0, 0, 0);
         acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+#endif
         acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
         acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
     };
