@@ -234,6 +234,13 @@ int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, const int32_t* 
 int morig_ball_query(const float* x, int32_t ldx, const int32_t* ptr_x, const float* y, int32_t ldy,
                      const int32_t* ptr_y, int32_t n_clouds, int32_t n_centres, float radius,
                      int32_t max_nbrs, int64_t* coo, void* stream);
+/* radius_cpu (basic_modules.py:9-29), the ball query of the reference's no-CUDA branch: for every y ALL x with
+ * |x-y| <= r (inclusive; no batch vector); a row with more than max_nbrs (<= 64) hits keeps a uniformly random
+ * subset of exactly max_nbrs (the reference: torch.multinomial on the 0/1 row; here Algorithm-R reservoir sampling
+ * with a counter-based hash of (seed, row, hit number): same distribution over subsets, a different random stream).
+ * coo: the slot table of morig_ball_query; counts[ny]: hits per row before the cap. */
+int morig_radius_sample(const float* x, int32_t ldx, int32_t nx, const float* y, int32_t ldy, int32_t ny, float radius,
+                        int32_t max_nbrs, uint32_t seed, int64_t* coo, int32_t* counts, void* stream);
 /* torch_geometric.nn.knn_interpolate (basic_modules.py:134), k <= 3: weights 1/clamp(d^2, 1e-16).
  * idx_ws/wgt_ws: scratch [n_targets][3]. */
 int morig_knn_interpolate(const float* feat, int32_t ldf, int32_t C, const float* pos_x, int32_t ldx,

@@ -211,6 +211,69 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------
+// radius_cpu (models/basic_modules.py:9-29): for each y all x with dist <= r (INCLUSIVE, no batch vector); a row with more
+// than max_nbrs hits keeps a uniformly random subset of exactly max_nbrs (the reference draws it with torch.multinomial on
+// the 0/1 validity row: every subset equally likely). One wave per y row, 64 candidates per step, Algorithm R reservoir:
+// slot j lives in lane j's register (max_nbrs <= 64), hit number t >= max replaces slot u = floor(U * (t + 1)) when
+// u < max, U from a counter-based hash of (seed, row, t). Rows with <= max_nbrs hits keep all hits in index order.
+// Output: the slot table of ball_query (unused slots -1) + the uncapped hit count per row.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned mix32(unsigned a) {
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+__global__ __launch_bounds__(256) void radius_sample_kernel(const float* __restrict__ x, int ldx, int nx,
+                                                            const float* __restrict__ y, int ldy, int ny, float r2, int max_nbrs,
+                                                            unsigned seed, int64_t* __restrict__ coo, int* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= ny) return;
+    const float cx = y[(size_t)k * ldy], cy = y[(size_t)k * ldy + 1], cz = y[(size_t)k * ldy + 2];
+    int slot = -1;                                        // reservoir entry `lane`
+    int seen = 0;                                         // hits so far (wave-uniform)
+    for (int base = 0; base < nx; base += 64) {
+        const int j = base + lane;
+        bool hit = false;
+        if (j < nx) {
+            const float* q = x + (size_t)j * ldx;
+            hit = sqdist3(cx, cy, cz, q[0], q[1], q[2]) <= r2;
+        }
+        unsigned long long mask = __ballot(hit);
+        const int nh = __popcll(mask);
+        if (nh == 0) continue;
+        if (seen + nh <= max_nbrs) {                      // still filling: hit number t goes to slot t
+            for (unsigned long long m = mask; m; m &= m - 1ull) {    // slot t receives hit number t (wave-uniform walk)
+                const int src_lane = __builtin_ctzll(m);
+                const int t = seen + __popcll(mask & ((1ull << src_lane) - 1ull));
+                const int idx = base + src_lane;
+                if (lane == t) slot = idx;
+            }
+            seen += nh;
+        } else {
+            for (unsigned long long m = mask; m; m &= m - 1ull) {      // wave-uniform walk over the hits of this step
+                const int src_lane = __builtin_ctzll(m);
+                const int idx = base + src_lane;
+                const int t = seen;
+                if (t < max_nbrs) { if (lane == t) slot = idx; }
+                else {
+                    const unsigned h = mix32(seed ^ mix32((unsigned)k * 0x9E3779B9u + (unsigned)t));
+                    const unsigned u = (unsigned)(((unsigned long long)h * (unsigned long long)(t + 1)) >> 32);   // uniform in [0, t]
+                    if ((int)u < max_nbrs && lane == (int)u) slot = idx;
+                }
+                ++seen;
+            }
+        }
+    }
+    const int64_t E = (int64_t)ny * max_nbrs;
+    if (lane < max_nbrs) {
+        const bool used = lane < seen;
+        coo[(int64_t)k * max_nbrs + lane] = used ? slot : -1;
+        coo[E + (int64_t)k * max_nbrs + lane] = used ? k : -1;
+    }
+    if (lane == 0) counts[k] = seen;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // k-NN (k <= 3) of every target among the sources of its cloud + inverse-squared-distance weights.
 // One thread per target; sources staged through LDS in tiles of 1024 points. Order: (d^2, index) ascending.
 // ---------------------------------------------------------------------------------------------------
@@ -334,6 +397,19 @@ extern "C" int morig_ball_query(const float* x, int32_t ldx, const int32_t* ptr_
     ProfScope ps(K_BALL, s, 0.0, 16.0 * n_centres * max_nbrs);
     hipLaunchKernelGGL(ball_query_kernel, dim3(cdiv(n_centres, 4)), dim3(256), 0, s, x, ldx, ptr_x, y, ldy, ptr_y, n_clouds,
                        n_centres, r2, max_nbrs, coo);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_radius_sample(const float* x, int32_t ldx, int32_t nx, const float* y, int32_t ldy, int32_t ny, float radius,
+                                   int32_t max_nbrs, uint32_t seed, int64_t* coo, int32_t* counts, void* stream) {
+    if (!x || !y || !coo || !counts || nx <= 0 || ny < 0 || ldx < 3 || ldy < 3) return MORIG_E_INVALID;
+    if (max_nbrs <= 0 || max_nbrs > 64) return MORIG_E_UNSUPPORTED;
+    if (ny == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const float r2 = (float)((double)radius * (double)radius);
+    ProfScope ps(K_BALL, s, 0.0, 12.0 * ny * (double)nx / 64.0);
+    hipLaunchKernelGGL(radius_sample_kernel, dim3(cdiv(ny, 4)), dim3(256), 0, s, x, ldx, nx, y, ldy, ny, r2, max_nbrs, seed, coo, counts);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

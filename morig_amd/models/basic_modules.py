@@ -300,6 +300,27 @@ class PointConv(torch.nn.Module):
         self.global_nn = global_nn
 
 
+def radius_cpu(x, y, r, max_num_neighbors):
+    """models/basic_modules.py:9-29 -- the ball query of the reference's no-CUDA branch, same signature and result layout:
+    ``[x_idx ; y_idx]`` (2 x E, int64) of all pairs with dist(y, x) <= r (inclusive, ``batch`` ignored); rows of y with at
+    most ``max_num_neighbors`` hits first, row-major with x indices ascending, then the over-full rows with exactly
+    ``max_num_neighbors`` hits each. The reference draws those with torch.multinomial on the 0/1 validity row (uniform over
+    subsets); here the HIP kernel keeps a uniform reservoir sample seeded from torch's RNG -- the same distribution, not the
+    same stream (SURVEY.md section 7 hard part 4). Runs on the device the points live on."""
+    ops = get_ops()
+    xm = _pos4(ops, x)
+    ym = _pos4(ops, y)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+    coo, counts = ops.radius_sample(Mat.of(xm, 0, 3), Mat.of(ym, 0, 3), r, max_num_neighbors, seed)
+    ny = ym.shape[0]
+    slots = coo[0].view(ny, max_num_neighbors)
+    rows = torch.arange(ny, device=slots.device).view(-1, 1).expand_as(slots)
+    reduced = (counts > max_num_neighbors).view(-1, 1)
+    keep_res = (slots >= 0) & ~reduced
+    keep_red = reduced.expand_as(slots)
+    return torch.cat([torch.stack([slots[keep_res], rows[keep_res]]), torch.stack([slots[keep_red], rows[keep_red]])], dim=1)
+
+
 def _cloud_offsets(batch: torch.Tensor, n_clouds: Optional[int] = None):
     """sorted PyG ``batch`` vector -> (per-cloud counts as a host list, int32 offsets on the device). One host sync,
     as torch_cluster's own ``batch`` handling has (it needs the cloud sizes to size its outputs)."""
@@ -461,4 +482,4 @@ class FPModule(NativeModule):
         return out, pos_skip, batch_skip
 
 
-__all__ += ["PointConv", "SAModule", "GlobalSAModule", "FPModule"]
+__all__ += ["PointConv", "SAModule", "GlobalSAModule", "FPModule", "radius_cpu"]

@@ -85,6 +85,8 @@ _SIGNATURES = {
     "morig_segmax_gemm": (C.c_int, [C.POINTER(SegmaxArgs), C.c_void_p]),
     "morig_fps": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_ball_query": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, c_i64p, C.c_void_p]),
+    "morig_radius_sample": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
+                                      c_i64p, c_i32p, C.c_void_p]),
     "morig_knn_interpolate": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_cosine_nn": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
@@ -433,6 +435,16 @@ class NativeOps:
         check(self.lib.morig_ball_query(x.ptr, x.ld, _p(ptr_x), y.ptr, y.ld, _p(ptr_y), n_clouds, y.rows, float(radius),
                                         max_nbrs, _p(coo), _stream()), "morig_ball_query")
         return coo
+
+    def radius_sample(self, x: Mat, y: Mat, radius: float, max_nbrs: int, seed: int):
+        """radius_cpu's neighbour table: (slot table int64 [2, ny * max_nbrs] (-1 = unused), hits per row int32 [ny])."""
+        _need_gpu(x.base, y.base)
+        dev = x.base.device
+        coo = torch.empty((2, y.rows * max_nbrs), dtype=torch.int64, device=dev)
+        counts = torch.empty(y.rows, dtype=torch.int32, device=dev)
+        check(self.lib.morig_radius_sample(x.ptr, x.ld, x.rows, y.ptr, y.ld, y.rows, float(radius), max_nbrs, int(seed) & 0xFFFFFFFF,
+                                           _p(coo), _p(counts), _stream()), "morig_radius_sample")
+        return coo, counts
 
     def knn_interpolate(self, feat: Mat, pos_x: Mat, ptr_x: torch.Tensor, pos_y: Mat, ptr_y: torch.Tensor, n_clouds: int,
                         max_targets_per_cloud: int, k: int, out: Mat):

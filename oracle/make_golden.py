@@ -89,6 +89,26 @@ def full_size_fixtures(ref):
           out_vtx_rows=ov[::step], out_pts_rows=op[::step], out_vismask=vis, pts_check=cb.pts[:8], **check)
 
 
+def radius_cpu_fixture(ref):
+    """models/basic_modules.py:9-29 run as is. Case `exact`: no row exceeds max_num_neighbors, the whole edge tensor is
+    deterministic. Case `over`: some rows overflow; their columns are a torch.multinomial draw, so only the deterministic
+    part (rows within the cap) and the per-row hit counts are stored."""
+    print("radius_cpu fixture")
+    bm = sys.modules["models.basic_modules"]
+    g = torch.Generator().manual_seed(77)
+    x = torch.rand(400, 3, generator=g) * 0.6
+    y = x[torch.randperm(400, generator=g)[:90]].clone()
+    e_exact = bm.radius_cpu(x, y, 0.12, 64)
+    torch.manual_seed(5)
+    e_over = bm.radius_cpu(x, y, 0.2, 8)
+    d = torch.cdist(y.unsqueeze(0), x.unsqueeze(0)).squeeze(0)
+    cnt = (d <= 0.2).sum(1)
+    n_res = int(cnt[cnt <= 8].sum())
+    assert int((d <= 0.12).sum(1).max()) <= 64 and int((cnt > 8).sum()) > 10
+    _save("radius_cpu_kat", dict(r_exact=0.12, max_exact=64, r_over=0.2, max_over=8), x=x, y=y, edges_exact=e_exact,
+          edges_over_reserved=e_over[:, :n_res], counts_over=cnt)
+
+
 def deformnet_fixtures(ref):
     """DeformNet (models/deformnet.py) -- SURVEY 8(f-1). The reference calls its CorrNet with the default
     random_start=True (:41): the FPS start indices come from torch's global RNG, one draw per cloud per SA level
@@ -269,6 +289,8 @@ def main():
         return deformnet_fixtures(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "full_size":
         return full_size_fixtures(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "radius_cpu":
+        return radius_cpu_fixture(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "joints":
         return joints_fixtures()
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
@@ -393,6 +415,7 @@ def main():
           pos_check=big.pos[:8], geo_check=big.geo_edge_index[:, :32])
 
     full_size_fixtures(ref)
+    radius_cpu_fixture(ref)
     deformnet_fixtures(ref)
     joints_fixtures()
     dataset_fixtures()

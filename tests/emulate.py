@@ -387,3 +387,24 @@ EmuOps.knn_bandwidth = _emu_knn_bandwidth
 EmuOps.meanshift = _emu_meanshift
 EmuOps.nms_counts = _emu_nms_counts
 EmuOps.nms_greedy = _emu_nms_greedy
+
+
+def _emu_radius_sample(self, x: Mat, y: Mat, radius, max_nbrs, seed):
+    """morig_radius_sample: inclusive ball, uniform random subset of max_nbrs for over-full rows (emulation: torch.randperm)."""
+    xv, yv = x.view()[:, :3], y.view()[:, :3]
+    r2 = float(torch.tensor(radius, dtype=torch.float64) ** 2)
+    d2 = ((yv[:, None, :] - xv[None, :, :]) ** 2).sum(-1)
+    valid = d2 <= torch.tensor(r2, dtype=torch.float32)
+    ny = yv.shape[0]
+    coo = torch.full((2, ny * max_nbrs), -1, dtype=torch.int64)
+    g = torch.Generator().manual_seed(int(seed))
+    for i in range(ny):
+        hits = torch.nonzero(valid[i]).flatten()
+        if hits.numel() > max_nbrs:
+            hits = hits[torch.randperm(hits.numel(), generator=g)[:max_nbrs]]
+        coo[0, i * max_nbrs:i * max_nbrs + hits.numel()] = hits
+        coo[1, i * max_nbrs:i * max_nbrs + hits.numel()] = i
+    return coo, valid.sum(1).to(torch.int32)
+
+
+EmuOps.radius_sample = _emu_radius_sample

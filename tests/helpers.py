@@ -134,3 +134,33 @@ def check_full_size(model, meta, a, data, tol):
         key = [k for k in ("pred_shift", "pred_mask", "skin_cls_pred") if k in a][0]
         assert rel_excess(aggr[::step], a["motion_aggr_rows"], tol) <= 0
         assert rel_excess(last, a[key], tol) <= 0, key
+
+
+def check_radius_cpu(device):
+    """radius_cpu (models/basic_modules.py:9-29) against a fixture produced by the reference's own function: the deterministic
+    case bit for bit (index work), the over-full case through the properties torch.multinomial guarantees."""
+    from conftest import load_golden
+    from morig_amd.models.basic_modules import radius_cpu
+    meta, a = load_golden("radius_cpu_kat")
+    x, y = a["x"].to(device), a["y"].to(device)
+    e = radius_cpu(x, y, meta["r_exact"], meta["max_exact"])
+    assert e.dtype == torch.int64 and torch.equal(e.cpu(), a["edges_exact"])
+    mx = meta["max_over"]
+    torch.manual_seed(1)
+    e1 = radius_cpu(x, y, meta["r_over"], mx).cpu()
+    n_res = a["edges_over_reserved"].shape[1]
+    assert torch.equal(e1[:, :n_res], a["edges_over_reserved"])                       # rows within the cap: all hits, in order
+    cnt = a["counts_over"]
+    over_rows = torch.nonzero(cnt > mx).flatten()
+    tail = e1[:, n_res:]
+    assert tail.shape[1] == over_rows.numel() * mx
+    assert torch.equal(tail[1], torch.repeat_interleave(over_rows, mx))               # exactly max per over-full row, rows ascending
+    d = torch.cdist(a["y"].double(), a["x"].double())
+    assert bool((d[tail[1], tail[0]] <= meta["r_over"] + 1e-6).all())                 # every kept neighbour is inside the ball
+    per_row = tail[0].view(-1, mx)
+    assert all(len(set(r.tolist())) == mx for r in per_row)                           # without replacement
+    torch.manual_seed(2)
+    e2 = radius_cpu(x, y, meta["r_over"], mx).cpu()
+    assert not torch.equal(e1, e2)                                                     # a new draw per call, as torch.multinomial
+    torch.manual_seed(1)
+    assert torch.equal(radius_cpu(x, y, meta["r_over"], mx).cpu(), e1)                # reproducible under torch.manual_seed

@@ -603,3 +603,23 @@ def test_cosine_knn_full_size_properties(ops):
     assert bool((got[:, :-1] >= got[:, 1:] - 1e-6).all())                        # most similar first
     top = sims.topk(k, dim=1).values
     assert float((got - top).abs().max()) <= 2e-6                               # the same k best similarities
+
+
+def test_radius_cpu_against_reference_fixture(ops):
+    """the inclusive, batch-less ball query of the reference's no-CUDA branch with a uniform random subset
+    for over-full rows (morig_radius_sample) -- exact where the reference is deterministic, distributional properties where it
+    draws; plus the uniformity of the reservoir itself."""
+    from helpers import check_radius_cpu
+    check_radius_cpu(DEV)
+    # uniformity: one centre, 40 hits, cap 8, many seeds -> every hit kept with probability 8/40 (binomial 3-sigma band)
+    x = torch.zeros(40, 4, device=DEV); x[:, 0] = torch.linspace(0, 0.01, 40, device=DEV)
+    y = torch.zeros(1, 4, device=DEV)
+    hits = torch.zeros(40)
+    trials = 4000
+    for s in range(trials):
+        coo, cnt = ops.radius_sample(Mat.of(x, 0, 3), Mat.of(y, 0, 3), 0.5, 8, 1000 + s)
+        hits[coo[0, :8].cpu()] += 1
+        assert int(cnt.item()) == 40
+    p = 8 / 40
+    sigma = (trials * p * (1 - p)) ** 0.5
+    assert float((hits - trials * p).abs().max()) < 4.5 * sigma, hits

@@ -211,3 +211,8 @@ def test_point_modules_standalone_forward(emulated_ops, kind, ratio, r):
     return tuples (models/basic_modules.py:74-86,121-125,133-138); host wiring on the emulated op layer vs the oracle."""
     from helpers import check_point_module
     check_point_module(kind, ratio, r, "cpu")
+
+
+def test_radius_cpu_host_wiring(emulated_ops):
+    from helpers import check_radius_cpu
+    check_radius_cpu("cpu")
