@@ -309,6 +309,29 @@ const char* morig_prof_name(int kind);                  /* NULL past the last ki
 /* synchronises the recorded events; per kind: launches, total ms, algorithmic flops, algorithmic bytes */
 int         morig_prof_collect(int kind, int64_t* launches, double* total_ms, double* flops, double* bytes);
 
+/* ---- train-mode forward support (forward half; training/train_rig.py:136-195) -------------------------------
+ * In model.train() every BatchNorm1d normalises with the statistics of the current batch -- over vertices in the dense
+ * MLPs, over EDGES inside the per-edge MLPs (models/basic_modules.py:31-36, 153-155, 192-195) -- so the layers run unfused:
+ * contraction (morig_gemm / morig_edge_hidden) -> statistics -> affine. */
+/* per-column mean and BIASED variance of x[rows][cols] (fp64 accumulation, fixed summation order). rows_dev != NULL: the row
+ * count is read on the device (E' = rowptr[n]) and `rows` is only the capacity. workspace: >= ceil(rows/512)*2*cols doubles.
+ * count (optional): receives the row count as a float. */
+int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, double* workspace,
+                    int64_t workspace_doubles, float* mean, float* var, float* count, void* stream);
+/* x[r][c] <- scale[c] * x[r][c] + shift[c], in place (BatchNorm once its statistics are known) */
+int morig_col_affine(float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, const float* scale,
+                     const float* shift, void* stream);
+/* Z[e] = relu(A[dst_e] + B[src_e]) for the E' = rowptr[n_nodes] edges of a CSR: the first edge ReLU
+ * (models/basic_modules.py:193-195 after the per-vertex split of Linear1), materialised for its batch statistics */
+int morig_edge_gather_relu(const float* A, int32_t lda, const float* B, int32_t ldb, const int32_t* rowptr, int32_t n_nodes,
+                           const int32_t* src_sorted, const int32_t* dst_sorted, int32_t edge_capacity, int32_t H,
+                           float* Z, int32_t ldz, void* stream);
+/* out[v][c] = max over rows e in [rowptr[v], rowptr[v+1]) of scale[c] * Z[e][c] + shift[c] (scale == shift == NULL: plain max;
+ * empty segment: 0 as torch_scatter): max aggregation behind the last BatchNorm of an edge MLP, and scatter_max over a mesh's
+ * vertices (models/rignet.py:63) */
+int morig_segmax_affine(const float* Z, int32_t ldz, const int32_t* rowptr, int32_t n_segments, int32_t H, const float* scale,
+                        const float* shift, float* out, int32_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -659,6 +659,7 @@ extern "C" int morig_edge_hidden(const morig_edgeconv_args* a, void* stream) {
     const bool f16 = a->W2_split != nullptr;
     ProfScope ps(f16 ? K_POINTCONV16 : K_POINTCONV, s, flops, 4.0 * 3.0 * E * a->H);
     switch (a->H) {
+        case 16:  return launch_tile<32, 16, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);     // fp32 MFMA (no split image below 32)
         case 32:  return f16 ? launch_tile<32, 32, LOAD_EDGE, MODE_STORE, PREC_F16X3>(p, p.tiles_per_rep, s)
                              : launch_tile<32, 32, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);
         case 64:  return f16 ? launch_tile<64, 32, LOAD_EDGE, MODE_STORE, PREC_F16X3>(p, p.tiles_per_rep, s)

@@ -89,9 +89,18 @@ class NativeModule(torch.nn.Module):
         """eval-mode forward on the HIP path. The whole forward runs inside the op layer's precision
         guard: split-fp16 MFMA first; if a kernel saw an operand outside the fp16 range the forward is
         repeated with fp32 MFMA (morig_amd.native.NativeOps.guarded)."""
-        self._require_eval()
         ops = get_ops()
         dev = next(self.parameters()).device
+        if self.training:
+            # train-mode FORWARD (batch-statistics BatchNorm, running buffers updated): implemented for the rignet family in
+            # morig_amd/train_forward.py; no autograd graph is built (SURVEY.md 8 f-4: the backward is not built yet)
+            if type(self)._forward_train is NativeModule._forward_train:
+                self._require_eval()
+            with torch.no_grad():
+                if dev.type == "cuda":
+                    with torch.cuda.device(dev):
+                        return ops.guarded(dev, lambda: self._forward_train(*args, **kwargs), rerun=False)
+                return ops.guarded(dev, lambda: self._forward_train(*args, **kwargs), rerun=False)
         rng = torch.get_rng_state()                    # random FPS starts: a repeated attempt draws the same ones
 
         def attempt():
@@ -112,11 +121,17 @@ class NativeModule(torch.nn.Module):
     def _forward(self, *args, **kwargs):
         raise NotImplementedError
 
+    def _forward_train(self, *args, **kwargs):
+        raise NotImplementedError
+
     def _require_eval(self):
         if self.training:
             raise NotImplementedError(
-                f"{type(self).__name__}: only the eval-mode forward runs on the MI355X-native path "
-                "(train-mode BatchNorm statistics over edges are out of scope, SURVEY.md 8(f-4)); call model.eval()")
+                f"{type(self).__name__}: no train-mode forward on the MI355X-native path for this module. The train-mode FORWARD "
+                "(batch-statistics BatchNorm over vertices / edges, running-buffer updates) exists for jointnet_motion, "
+                "masknet_motion and skinnet_motion (morig_amd/train_forward.py); the BACKWARD pass (arg-max scatter of the edge "
+                "max, dW / dX contractions, BatchNorm gradients) is not built yet -- SURVEY.md 8(f-4), DESIGN.md section 9. "
+                "Call model.eval() for inference.")
 
 
 def _as_matrix(x: torch.Tensor) -> torch.Tensor:

@@ -256,6 +256,12 @@ class _MotionHead(_MotionBackbone):
         return st["motion_all"], aggr, out
 
 
+    def _forward_train(self, data, input_flow):
+        """model.train(): batch-statistics forward, one motionNet pass per keyframe (morig_amd/train_forward.py)"""
+        from .. import train_forward
+        return train_forward.motion_head_train(get_ops(), self, data, input_flow)
+
+
 class JointNetMotion(_MotionHead):
     """models/rignet.py:70-100 -> (motion_all, motion_aggr, pred_shift)."""
     _head = "jointnet"
@@ -364,6 +370,11 @@ class SkinMotion(_MotionBackbone):
         out = torch.empty((n, self.skinNet.num_nearest_bone), dtype=torch.float32, device=aggr.device)
         self.skinNet.run(ops, data, aggr, st["csr_tpl4"], st["csr_geo4"], st["seg"], st["ng"], Mat.of(out))     # all three GCUs are 256 wide
         return st["motion_all"], aggr, out
+
+    def _forward_train(self, data, input_flow):
+        """model.train(): batch-statistics forward (morig_amd/train_forward.py)"""
+        from .. import train_forward
+        return train_forward.skin_motion_train(get_ops(), self, data, input_flow)
 
 
 def jointnet_motion(**kwargs):

@@ -87,6 +87,11 @@ _SIGNATURES = {
     "morig_ball_query": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, c_i64p, C.c_void_p]),
     "morig_radius_sample": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
                                       c_i64p, c_i32p, C.c_void_p]),
+    "morig_col_stats": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_void_p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
+    "morig_col_affine": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    "morig_edge_gather_relu": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
+                                         c_f32p, C.c_int32, C.c_void_p]),
+    "morig_segmax_affine": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_knn_interpolate": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_cosine_nn": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
@@ -250,10 +255,21 @@ class NativeOps:
             self._ovf[key] = torch.zeros(1, dtype=torch.int32, device=device)
         return self._ovf[key]
 
-    def guarded(self, device, fn):
+    def guarded(self, device, fn, rerun: bool = True):
         """Run ``fn()`` (a whole forward) on the fast path; if any kernel reported an operand outside the
-        fp16 range, run it again on the fp32 path. Nested calls run inside the outer guard."""
-        if self._depth > 0 or not self.fast:
+        fp16 range, run it again on the fp32 path. Nested calls run inside the outer guard.
+        rerun=False (train-mode forward: it has side effects on the BatchNorm running buffers, so it must run ONCE):
+        the whole forward runs on the exact fp32 MFMA path."""
+        if self._depth > 0:
+            return fn()
+        if not rerun:
+            old = self._force_f32
+            self._force_f32 = True
+            try:
+                return self._run_once(device, fn)
+            finally:
+                self._force_f32 = old
+        if not self.fast:
             return fn()
         flag = self._flag(device)
         flag.zero_()
@@ -277,6 +293,19 @@ class NativeOps:
                 out = fn()
             finally:
                 self._force_f32 = False
+        return out
+
+    def _run_once(self, device, fn):
+        """one pass with the CSR status words checked (no precision flag: the fp32 path cannot overflow fp16)"""
+        self._depth += 1
+        self._csr_status = []
+        try:
+            out = fn()
+        finally:
+            self._depth -= 1
+            stats, self._csr_status = self._csr_status, None
+        if stats and any(w != 0 for w in torch.cat(stats).tolist()):
+            raise MorigNativeError("edge_index / neighbour index out of range for the vertex count it was built with")
         return out
 
     # -- allocation (PyTorch owns all device memory) -------------------------------------------
@@ -435,6 +464,38 @@ class NativeOps:
         check(self.lib.morig_ball_query(x.ptr, x.ld, _p(ptr_x), y.ptr, y.ld, _p(ptr_y), n_clouds, y.rows, float(radius),
                                         max_nbrs, _p(coo), _stream()), "morig_ball_query")
         return coo
+
+    # -- train-mode forward support (csrc/train_ops.hip) ---------------------------------
+    def col_stats(self, X: Mat, rows_dev: Optional[torch.Tensor] = None):
+        """-> (mean [cols], biased var [cols], count [1]) of the rows of X (rows_dev: int32 [1] on the device = live row count)."""
+        _need_gpu(X.base)
+        dev = X.base.device
+        slabs = (max(X.rows, 1) + 511) // 512
+        ws = torch.empty(slabs * 2 * X.cols, dtype=torch.float64, device=dev)
+        mean = torch.empty(X.cols, dtype=torch.float32, device=dev)
+        var = torch.empty(X.cols, dtype=torch.float32, device=dev)
+        cnt = torch.empty(1, dtype=torch.float32, device=dev)
+        check(self.lib.morig_col_stats(X.ptr, X.ld, X.rows, _p(rows_dev), X.cols, C.c_void_p(ws.data_ptr()), ws.numel(), _p(mean),
+                                       _p(var), _p(cnt), _stream()), "morig_col_stats")
+        return mean, var, cnt
+
+    def col_affine(self, X: Mat, scale: torch.Tensor, shift: torch.Tensor, rows_dev: Optional[torch.Tensor] = None):
+        _need_gpu(X.base, scale, shift)
+        assert scale.numel() >= X.cols and shift.numel() >= X.cols and scale.dtype == shift.dtype == torch.float32
+        check(self.lib.morig_col_affine(X.ptr, X.ld, X.rows, _p(rows_dev), X.cols, _p(scale), _p(shift), _stream()), "morig_col_affine")
+
+    def edge_gather_relu(self, A: Mat, B: Mat, csr: CSR, Z: Mat):
+        _need_gpu(A.base, B.base, Z.base)
+        assert Z.rows == csr.capacity and A.cols == B.cols == Z.cols
+        check(self.lib.morig_edge_gather_relu(A.ptr, A.ld, B.ptr, B.ld, _p(csr.rowptr), csr.n_nodes, _p(csr.src), _p(csr.dst),
+                                              csr.capacity, Z.cols, Z.ptr, Z.ld, _stream()), "morig_edge_gather_relu")
+
+    def segmax_affine(self, Z: Mat, rowptr: torch.Tensor, n_segments: int, out: Mat, scale: Optional[torch.Tensor] = None,
+                      shift: Optional[torch.Tensor] = None):
+        _need_gpu(Z.base, rowptr, out.base)
+        assert rowptr.dtype == torch.int32 and out.rows == n_segments and out.cols == Z.cols
+        check(self.lib.morig_segmax_affine(Z.ptr, Z.ld, _p(rowptr), n_segments, Z.cols, _p(scale), _p(shift), out.ptr, out.ld,
+                                           _stream()), "morig_segmax_affine")
 
     def radius_sample(self, x: Mat, y: Mat, radius: float, max_nbrs: int, seed: int):
         """radius_cpu's neighbour table: (slot table int64 [2, ny * max_nbrs] (-1 = unused), hits per row int32 [ny])."""

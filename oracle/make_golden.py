@@ -89,6 +89,40 @@ def full_size_fixtures(ref):
           out_vtx_rows=ov[::step], out_pts_rows=op[::step], out_vismask=vis, pts_check=cb.pts[:8], **check)
 
 
+def train_mode_fixture(ref):
+    """SURVEY 8 f-4 (forward half): the reference's own jointnet_motion / masknet_motion in model.train() -- batch-statistics
+    BatchNorm over vertices and over edges, running buffers moved once per motionNet pass (models/rignet.py:82-100).
+    Batch-statistics BatchNorm divides by sqrt(var + eps) of channels that a ReLU may have left nearly constant, so fp32
+    results of this forward are only reproducible to ~1e-4..1e-2 (measured: torch fp32 against torch fp64 on the same batch).
+    The fixture therefore stores BOTH the reference run in float32 (what the reference user sees) and in float64 (the
+    arbitration value): a port passes when it is as close to the fp64 run as the reference's own fp32 run is."""
+    print("train-mode fixtures")
+    import copy
+    batch = synth.collate([synth.make_mesh(81, n_side=16, with_skin=True), synth.make_mesh(82, n_side=12, with_skin=True)])
+    for arch, kw, rseed in (("jointnet_motion", dict(num_keyframes=5, chn_output=3, aggr_method="attn"), 601),
+                            ("masknet_motion", dict(num_keyframes=5, chn_output=1, aggr_method="attn"), 602),
+                            ("skinnet_motion", dict(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True,
+                                                    motion_dim=32, aggr_method="attn"), 603)):
+        outs = {}
+        for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            m = ref.__dict__[arch](**kw)
+            synth.load_recipe(m, rseed, mild=True)
+            m = m.to(dt).train()
+            b = copy.deepcopy(batch)
+            b.pos, b.pred_flow, b.skin_input = b.pos.to(dt), b.pred_flow.to(dt), b.skin_input.to(dt)
+            ma, mg, last = m(b, b.pred_flow)
+            if arch == "jointnet_motion":                  # the per-keyframe embeddings once (0.5 MB in fp64)
+                outs[f"motion_all_{tag}"] = ma
+            outs[f"motion_aggr_{tag}"], outs[f"head_{tag}"] = mg, last
+            sd = m.state_dict()
+            bn_keys = [k for k in sd if k.endswith("running_mean") or k.endswith("running_var")]
+            outs[f"bn_{tag}"] = torch.cat([sd[k].flatten().double() for k in bn_keys])
+            nbt = [int(sd[k]) for k in sd if k.endswith("num_batches_tracked")]
+        _save(f"{arch.split('_')[0]}_train", dict(recipe_seed=rseed, mild=True, arch=arch, kwargs=kw, bn_keys=bn_keys,
+                                                    num_batches_tracked=nbt),
+              **outs, **_batch_arrays(batch, with_skin=(arch == "skinnet_motion")))
+
+
 def radius_cpu_fixture(ref):
     """models/basic_modules.py:9-29 run as is. Case `exact`: no row exceeds max_num_neighbors, the whole edge tensor is
     deterministic. Case `over`: some rows overflow; their columns are a torch.multinomial draw, so only the deterministic
@@ -289,6 +323,8 @@ def main():
         return deformnet_fixtures(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "full_size":
         return full_size_fixtures(ref)
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        return train_mode_fixture(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "radius_cpu":
         return radius_cpu_fixture(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "joints":
@@ -416,6 +452,7 @@ def main():
 
     full_size_fixtures(ref)
     radius_cpu_fixture(ref)
+    train_mode_fixture(ref)
     deformnet_fixtures(ref)
     joints_fixtures()
     dataset_fixtures()

@@ -17,7 +17,7 @@ class EmuOps:
     name = "emulated"
     precision = "f32"
 
-    def guarded(self, device, fn):
+    def guarded(self, device, fn, rerun=True):
         return fn()
 
     @property
@@ -408,3 +408,46 @@ def _emu_radius_sample(self, x: Mat, y: Mat, radius, max_nbrs, seed):
 
 
 EmuOps.radius_sample = _emu_radius_sample
+
+
+# ------------------------------------------------------------------------------------------------
+# train-mode forward support (csrc/train_ops.hip)
+# ------------------------------------------------------------------------------------------------
+def _emu_col_stats(self, X: Mat, rows_dev=None):
+    rows = int(rows_dev.item()) if rows_dev is not None else X.rows
+    x = X.view()[:rows].double()
+    assert not torch.isnan(x).any()
+    mean = x.mean(0)
+    var = (x * x).mean(0) - mean * mean
+    return mean.float(), var.clamp(min=0).float(), torch.tensor([float(rows)])
+
+
+def _emu_col_affine(self, X: Mat, scale, shift, rows_dev=None):
+    rows = int(rows_dev.item()) if rows_dev is not None else X.rows
+    v = X.view()
+    v[:rows] = v[:rows] * scale[: X.cols] + shift[: X.cols]
+
+
+def _emu_edge_gather_relu(self, A: Mat, B: Mat, csr: CSR, Z: Mat):
+    E = int(csr.rowptr[-1])
+    src, dst = csr.src[:E].long(), csr.dst[:E].long()
+    Z.view()[:E] = torch.relu(A.view()[dst] + B.view()[src])
+
+
+def _emu_segmax_affine(self, Z: Mat, rowptr, n_segments, out: Mat, scale=None, shift=None):
+    p = rowptr.long().tolist()
+    z = Z.view()
+    if scale is not None:
+        z = z * scale[: Z.cols] + shift[: Z.cols]
+    res = torch.zeros((n_segments, Z.cols))
+    for v in range(n_segments):
+        if p[v + 1] > p[v]:
+            assert not torch.isnan(z[p[v]:p[v + 1]]).any()
+            res[v] = z[p[v]:p[v + 1]].max(0)[0]
+    out.view().copy_(res)
+
+
+EmuOps.col_stats = _emu_col_stats
+EmuOps.col_affine = _emu_col_affine
+EmuOps.edge_gather_relu = _emu_edge_gather_relu
+EmuOps.segmax_affine = _emu_segmax_affine

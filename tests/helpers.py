@@ -164,3 +164,40 @@ def check_radius_cpu(device):
     assert not torch.equal(e1, e2)                                                     # a new draw per call, as torch.multinomial
     torch.manual_seed(1)
     assert torch.equal(radius_cpu(x, y, meta["r_over"], mx).cpu(), e1)                # reproducible under torch.manual_seed
+
+
+# ---- train-mode forward (forward half): fixtures hold the reference's own run in float32 AND float64 ----
+def check_train_mode(name, device):
+    """batch-statistics forward against the reference's model.train() run. Criterion: as close to the reference's float64 run as
+    the reference's own float32 run is, or within 1e-4 of the output scale, whichever is larger (batch-statistics BatchNorm
+    amplifies fp32 rounding through 1/sqrt(var + eps) of nearly constant channels: see oracle/make_golden.py::train_mode_fixture)."""
+    from conftest import load_golden
+    from morig_amd import models, synth
+    meta, a = load_golden(name)
+    m = models.__dict__[meta["arch"]](**meta["kwargs"])
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(device).train()
+    d = data_from(a, device)
+    got = m(d, d.pred_flow)
+    assert m.training and all(not g.requires_grad for g in got)
+    tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    for g, key in zip(got, ("motion_all", "motion_aggr", "head")):
+        if key + "_f64" not in a:
+            continue
+        r64, r32 = a[key + "_f64"].double(), a[key + "_f32"].double()
+        assert tuple(g.shape) == tuple(r64.shape), key
+        err = (g.detach().cpu().double() - r64).abs().max().item()
+        own = (r32 - r64).abs().max().item()
+        scale = r64.abs().max().item()
+        PARITY_LOG.append((tid + ":" + key, err, scale, err / max(1.0, scale)))
+        assert err <= max(1e-4 * max(1.0, scale), own), (key, err, own, scale)
+    sd = m.state_dict()
+    ours = torch.cat([sd[k].detach().cpu().flatten().double() for k in meta["bn_keys"]])
+    b64, b32 = a["bn_f64"].double(), a["bn_f32"].double()
+    err, own, scale = (ours - b64).abs().max().item(), (b32 - b64).abs().max().item(), b64.abs().max().item()
+    PARITY_LOG.append((tid + ":running_stats", err, scale, err / max(1.0, scale)))
+    assert err <= max(1e-4 * max(1.0, scale), own), ("running buffers", err, own)
+    assert [int(sd[k]) for k in sd if k.endswith("num_batches_tracked")] == meta["num_batches_tracked"]
+    # the updated buffers feed the next eval forward: the packed-weight cache must follow the in-place update
+    m.eval()
+    e1 = m(d, d.pred_flow)[2]
+    assert bool(torch.isfinite(e1).all())

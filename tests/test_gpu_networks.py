@@ -319,3 +319,11 @@ def test_full_size_harsh_recipe_goldens(name):
     m = models.__dict__[meta["arch"]](**meta["kwargs"]).eval()
     synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
     check_full_size(m, meta, a, full_size_inputs(meta, DEV), TOL)
+
+
+@pytest.mark.parametrize("name", ["jointnet_train", "masknet_train", "skinnet_train"])
+def test_train_mode_forward(name):
+    """SURVEY 8 f-4, forward half, on the HIP path: GEMMs and per-edge hidden layers on the MFMA kernels, batch statistics /
+    affine / gather / segmented max in csrc/train_ops.hip; against the reference's own model.train() run (fp32 and fp64)."""
+    from helpers import check_train_mode
+    check_train_mode(name, DEV)

@@ -45,12 +45,12 @@ def test_factories_ignore_extra_kwargs():
                           motion_dim=32, aggr_method="attn")
 
 
-def test_train_mode_is_refused():
-    m = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn")
-    _, a = load_golden("jointnet_ragged")
-    d = data_from(a)
+def test_train_mode_of_a_standalone_block_is_refused():
+    """blocks without a train-mode path (only the rignet networks have one) refuse instead of silently using running stats"""
+    m = bm.GCU(3, 32).train()
+    _, a = load_golden("gcu_3_32")
     with pytest.raises(NotImplementedError):
-        m.train()(d, d.pred_flow)
+        m(a["x"], a["tpl_edge_index"], a["geo_edge_index"])
 
 
 def test_edgeconvmotion_layer():
@@ -216,3 +216,17 @@ def test_point_modules_standalone_forward(emulated_ops, kind, ratio, r):
 def test_radius_cpu_host_wiring(emulated_ops):
     from helpers import check_radius_cpu
     check_radius_cpu("cpu")
+
+
+@pytest.mark.parametrize("name", ["jointnet_train", "masknet_train", "skinnet_train"])
+def test_train_mode_forward_host_wiring(emulated_ops, name):
+    """SURVEY 8 f-4 forward half: model.train() forward (batch-statistics BatchNorm over vertices and edges, running buffers
+    updated) on the emulated op layer against the reference's own train-mode run."""
+    from helpers import check_train_mode
+    check_train_mode(name, "cpu")
+
+
+def test_train_mode_modules_without_a_train_path_say_so(emulated_ops):
+    m = models.corrnet(input_feature=3, output_feature=64, temprature=0.07).train()
+    with pytest.raises(NotImplementedError, match="BACKWARD|train-mode"):
+        m(None, True)
