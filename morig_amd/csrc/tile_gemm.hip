@@ -511,6 +511,25 @@ __global__ __launch_bounds__(64) void init_boundary_rows_kernel(const int* __res
     for (int c = threadIdx.x; c < H; c += 64) o[c] = 0xFFFFFFFFu;
 }
 
+// out_split: a straddling segment was combined in the fp32 side rows; the tile boundary that is the FIRST one the segment
+// crosses converts its row into the split-fp16 activation layout of `out` (one block per boundary, as the init kernel)
+__global__ __launch_bounds__(64) void split_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS, int n_nodes,
+                                                                 int H, const float* __restrict__ side, int ld_side, float* __restrict__ out,
+                                                                 int ldo, int rep_out, int tile_rows, int* __restrict__ ovf) {
+    const int e = (blockIdx.x + 1) * tile_rows;
+    if (e >= rowptr[n_nodes]) return;
+    const int d = dstS[e];
+    const int s0 = rowptr[d];
+    if (s0 >= e || s0 < e - tile_rows) return;          // no straddle / an earlier boundary owns this segment
+    const size_t row = (size_t)blockIdx.y * rep_out + d;
+    const float* src = side + row * ld_side;
+    for (int c = 2 * threadIdx.x; c < H; c += 128) {
+        const float v[2] = {src[c], src[c + 1]};
+        const float am = store_split_vec<2>(out + row * ldo, c, v);
+        if (!(am < 65000.f)) *ovf = 1;
+    }
+}
+
 static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
                               int rep_out, int slots, hipStream_t s, int tile_rows = 128) {
     const int nb = cdiv(edge_capacity, tile_rows) - 1;
@@ -531,6 +550,22 @@ static int launch_tile(const TileParams& p0, int nblocks, hipStream_t s) {
 }
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// scatter_max semantics for segments that received no row (a graph id without vertices): torch_scatter fills 0; the
+// integer-atomic max leaves its identity pattern 0xFFFFFFFF (a NaN) there, which would then flag every split of the row
+__global__ void pool_identity_to_zero_kernel(float* __restrict__ pool, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned* u = reinterpret_cast<unsigned*>(pool);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) if (u[i] == 0xFFFFFFFFu) u[i] = 0u;
+}
+static int pool_finalize(float* pool, int n_seg, int ld_pool, hipStream_t s) {
+    const int64_t n = (int64_t)n_seg * ld_pool;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(pool_identity_to_zero_kernel, dim3((int)blocks), dim3(256), 0, s, pool, n);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
 
 }  // namespace morig
 
@@ -582,14 +617,17 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
             q.bias = a->bias; q.scale = a->scale; q.shift = a->shift; q.relu = a->relu; q.seg = a->seg;
             q.pool = a->pool; q.ld_pool = a->ld_pool; q.ovf = a->overflow;
             ProfScope ps(K_GEMM16_POOL, s, flops, bytes);
-            return launch_gemm16_dma(q, tiles_m, s);
+            const int st = launch_gemm16_dma(q, tiles_m, s);
+            return st != MORIG_OK ? st : pool_finalize(a->pool, a->n_seg, a->ld_pool, s);
         }
         p.Y = a->pool; p.ldy = a->ld_pool;
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_POOL : K_GEMM_POOL, s, flops, bytes);
-        if (f16 && kc64 && getenv("MORIG_KC64")) return launch_tile<128, 64, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
-        return f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
-                   : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
+        int st;
+        if (f16 && kc64 && getenv("MORIG_KC64")) st = launch_tile<128, 64, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
+        else st = f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
+                      : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
+        return st != MORIG_OK ? st : pool_finalize(a->pool, a->n_seg, a->ld_pool, s);
     }
     p.Y = a->Y; p.ldy = a->ldy;
     if (f16 && a->x_split && a->N > 64 && !getenv("MORIG_NO_DMA")) {
@@ -628,6 +666,7 @@ static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
     if (!a || !a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
     if ((a->s1 == nullptr) != (a->t1 == nullptr) || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
     if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
+    if (a->out_split && !a->W2_split) return MORIG_E_INVALID;
     if ((a->lda & 3) || (a->ldb & 3) || (a->ldw & 3) || !aligned16(a->A) || !aligned16(a->B) || !aligned16(a->W2) ||
         !aligned16(a->s1) || !aligned16(a->t1)) return MORIG_E_INVALID;
     if (a->ldo < a->H || a->lda < a->H || a->ldb < a->H || a->ldw < a->H) return MORIG_E_INVALID;
@@ -732,11 +771,19 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
                         (a->H == 256 || ws128);
     const int tile_rows = (use_ws && a->H == 256) ? 64 : 128;   // edge_ws.hip: 64-row tiles at H = 256
 
+    const bool out_split = a->out_split != 0;
+    if (out_split) {
+        // only the quad scans of edge_ws.hip / edge_pp.hip know the split store
+        if (!wide || one_shot || !pp_ok || !a->quad_aligned) return MORIG_E_UNSUPPORTED;
+        if (!a->side || a->ld_side < a->H || (a->ldo & 31) || (reinterpret_cast<uintptr_t>(a->out) & 127)) return MORIG_E_INVALID;
+    }
     // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
     {
         const int slots = a->replicas;
-        const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
-                                           a->out_rep_stride, slots, s, tile_rows);
+        const int st2 = out_split ? init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->side, a->ld_side,
+                                                       a->out_rep_stride, slots, s, tile_rows)
+                                  : init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
+                                                       a->out_rep_stride, slots, s, tile_rows);
         if (st2 != MORIG_OK) return st2;
     }
 
@@ -751,9 +798,19 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.rowptr = p.rowptr; q.srcS = p.srcS; q.dstS = p.dstS; q.n_nodes = p.n_nodes;
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
+        q.y16 = out_split ? 1 : 0; q.side = a->side; q.ld_side = a->ld_side;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
-        if (use_ws) return launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
-        return (one_shot || !pp_ok) ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
+        int st3;
+        if (use_ws) st3 = launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
+        else st3 = (one_shot || !pp_ok) ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
+        if (st3 != MORIG_OK || !out_split) return st3;
+        const int nb = cdiv(a->edge_capacity, tile_rows) - 1;
+        if (nb > 0) {
+            hipLaunchKernelGGL(split_boundary_rows_kernel, dim3(nb, a->replicas), dim3(64), 0, s, a->rowptr, a->dst_sorted, a->n_nodes, a->H,
+                               a->side, a->ld_side, a->out, a->ldo, a->out_rep_stride, tile_rows, a->overflow);
+            MORIG_LAUNCH_CHECK();
+        }
+        return MORIG_OK;
     }
     if (f16) {
         switch (a->H) {

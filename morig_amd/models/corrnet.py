@@ -96,6 +96,11 @@ class CorrNet(NativeModule):
 
         self.lin_vismask = Seq(MLP([2 * output_feature + 1, 256, 128, 64]), Lin(64, 1))
 
+    def __getstate__(self):
+        st = super().__getstate__()
+        st["_streams"], st["last_plan"] = {}, None        # HIP stream handles and the last forward's host plan are not state
+        return st
+
     def _side_stream(self, dev):
         key = (dev.type, dev.index)
         if self._streams.get(key) is None:

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 from dataclasses import dataclass
 from typing import Optional
 
@@ -55,6 +56,7 @@ class EdgeConvArgs(C.Structure):
         ("out", c_f32p), ("ldo", C.c_int32),
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
         ("quad_aligned", C.c_int32),
+        ("out_split", C.c_int32), ("side", c_f32p), ("ld_side", C.c_int32),
     ]
 
 
@@ -230,10 +232,9 @@ class NativeOps:
         # (default), "f32" = fp32 MFMA everywhere. MORIG_PRECISION overrides.
         self.precision = os.environ.get("MORIG_PRECISION", "f16x3")
         assert self.precision in ("f16x3", "f32")
-        self._ovf = {}
-        self._csr_status = None
-        self._depth = 0
-        self._force_f32 = False
+        # guard state is PER THREAD (two threads / streams may run forwards concurrently on the one NativeOps): nesting depth,
+        # forced-fp32 switch, the CSR status words of the forward in flight and the overflow flag word of each device
+        self._tls = threading.local()
         # accounting only (bench.py): exact self-loop-normalised edge counts E' per input graph, learned during
         # warm-up with one host read each, so the live FLOP counters use ALGORITHMIC edges (no capacity, no padding)
         self.learn_edge_counts = False
@@ -249,11 +250,42 @@ class NativeOps:
         """plans keep GEMM->GEMM activations in the split-fp16 layout while the fast path is active"""
         return self.fast and os.environ.get("MORIG_SPLIT_ACT", "1") != "0"
 
+    def _state(self):
+        t = self._tls
+        if not hasattr(t, "depth"):
+            t.depth, t.force_f32, t.csr_status, t.ovf = 0, False, None, {}
+        return t
+
+    @property
+    def _depth(self):
+        return self._state().depth
+
+    @_depth.setter
+    def _depth(self, v):
+        self._state().depth = v
+
+    @property
+    def _force_f32(self):
+        return self._state().force_f32
+
+    @_force_f32.setter
+    def _force_f32(self, v):
+        self._state().force_f32 = v
+
+    @property
+    def _csr_status(self):
+        return self._state().csr_status
+
+    @_csr_status.setter
+    def _csr_status(self, v):
+        self._state().csr_status = v
+
     def _flag(self, device) -> torch.Tensor:
+        ovf = self._state().ovf
         key = (device.type, device.index)
-        if key not in self._ovf:
-            self._ovf[key] = torch.zeros(1, dtype=torch.int32, device=device)
-        return self._ovf[key]
+        if key not in ovf:
+            ovf[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        return ovf[key]
 
     def guarded(self, device, fn, rerun: bool = True):
         """Run ``fn()`` (a whole forward) on the fast path; if any kernel reported an operand outside the
@@ -398,10 +430,21 @@ class NativeOps:
         check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")
 
     # -- fused edge conv ----------------------------------------------------------------------------
+    def edgeconv_can_split(self, csr: CSR, ec) -> bool:
+        """may the fused EdgeConv write its output in the split-fp16 activation layout? (wide quad kernels on the fast path)"""
+        return bool(self.fast and self.split_activations and csr.quad and ec.H in (128, 256) and ec.s1 is None and ec.W2split is not None
+                    and os.environ.get("MORIG_EDGE_SPLIT_OUT", "1") != "0" and os.environ.get("MORIG_EDGE_KERNEL", "") != "pc")
+
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
-                 in_rep_stride: int = 0, out_rep_stride: int = 0):
+                 in_rep_stride: int = 0, out_rep_stride: int = 0, out_split: bool = False):
+        """out_split: ``out`` is a window (32-column aligned) of a split-fp16 activation buffer; tile-straddling segments go
+        through an fp32 side buffer allocated here and a fix-up pass (include/morig_hip.h, morig_edgeconv_args.out_split)."""
         _need_gpu(A.base, B.base, out.base)
         a = self._edge_args(A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride)
+        if out_split:
+            assert self.edgeconv_can_split(csr, ec) and out.col0 % 32 == 0 and out.ld % 32 == 0
+            side = torch.empty((out.base.shape[0], ec.H), dtype=torch.float32, device=out.base.device)
+            a.out_split, a.side, a.ld_side = 1, side.data_ptr() + 4 * out.row0 * ec.H, ec.H
         check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
 
     def _edge_args(self, A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride):

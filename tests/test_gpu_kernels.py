@@ -623,3 +623,76 @@ def test_radius_cpu_against_reference_fixture(ops):
     p = 8 / 40
     sigma = (trials * p * (1 - p)) ** 0.5
     assert float((hits - trials * p).abs().max()) < 4.5 * sigma, hits
+
+
+def test_pooled_gemm_empty_segment_is_zero(ops):
+    """a graph id without vertices must pool to 0 (torch_scatter's fill), not to the atomic-max identity (NaN)."""
+    g = torch.Generator().manual_seed(3)
+    M, K, N, nseg = 500, 64, 128, 4
+    x = torch.randn(M, K, generator=g)
+    lin = packing.pack_linear(torch.randn(N, K, generator=g) / 8, torch.randn(N, generator=g))
+    seg = torch.cat([torch.zeros(200), torch.full((300,), 2.0)]).to(torch.int32)          # ids 1 and 3 are empty
+    pool = torch.full((nseg, N), 7.0, device=DEV)
+    ops.gemm(Mat.of(x.to(DEV), 0, K), packing.to_device(lin, DEV), True, seg=seg.to(DEV), pool=pool)
+    torch.cuda.synchronize()
+    assert not torch.isnan(pool).any()
+    assert float(pool[1].abs().max()) == 0.0 and float(pool[3].abs().max()) == 0.0 and float(pool[0].abs().max()) > 0
+
+
+def test_concurrent_forwards_from_two_threads_keep_their_own_guard_state():
+    """guard state (overflow flag, forced-fp32 switch, nesting depth) is per thread: two threads running forwards on
+    their own streams get the same bits as the sequential runs."""
+    import threading
+    from morig_amd import models, synth
+    mesh = synth.collate([synth.make_mesh(8, n_side=12)]).to(DEV)
+    m = synth.load_recipe(models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval(), 4, mild=True).to(DEV)
+    want = m(mesh, mesh.pred_flow)[2].clone()
+    outs, errs = {}, []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st), torch.no_grad():
+                for _ in range(3):
+                    o = m(mesh, mesh.pred_flow)[2]
+                st.synchronize()
+            outs[i] = o
+        except Exception as e:              # noqa: BLE001
+            errs.append(e)
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not errs, errs
+    assert all(torch.equal(outs[i], want) for i in range(2))
+
+
+@pytest.mark.parametrize("H", [128, 256])
+@pytest.mark.parametrize("n,e,hub,reps", [(300, 2500, 5, 1), (1500, 9000, None, 3), (20000, 300000, 777, 2)])
+def test_edgeconv_split_layout_output(ops, H, n, e, hub, reps):
+    """morig_edgeconv_args.out_split: complete segments are written by the scan in the split-fp16 activation layout, segments that
+    straddle a tile go through the fp32 side rows and the fix-up pass; the window sits at a chunk-aligned column of a wider
+    buffer whose other columns must stay untouched."""
+    if ops.precision != "f16x3":
+        pytest.skip("split activations exist on the split-fp16 path only")
+    g = torch.Generator().manual_seed(H + n)
+    ei = _rand_graph(n, e, 9, hub)
+    if n >= 20000:
+        ei = torch.cat([ei, torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 1234)])], dim=1)   # a 700-edge hub
+    ab = torch.randn(n * reps, 2 * H, generator=g)
+    ec = _edge_pack(H, 23, folded=True)
+    emu = EmuOps()
+    out_ref = torch.zeros(n * reps, H)
+    emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), emu.csr_build(ei, n), ec, Mat.of(out_ref), replicas=reps, in_rep_stride=n,
+                 out_rep_stride=n)
+    csr = ops.csr_build(ei.to(DEV), n, pad4=True)
+    ecd = packing.to_device(ec, DEV)
+    assert ops.edgeconv_can_split(csr, ecd)
+    abg = ab.to(DEV)
+    ld = 2 * H + 64
+    buf = torch.full((n * reps, ld), 3.0, device=DEV)                   # window [H, 2H) of a wider split buffer
+    ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), csr, ecd, Mat.of(buf, H, H), replicas=reps, in_rep_stride=n, out_rep_stride=n,
+                 out_split=True)
+    torch.cuda.synchronize()
+    got = packing.unsplit_f16(buf.cpu(), ld)[:, H:2 * H]
+    assert not torch.isnan(got).any()
+    assert maxdiff(got, out_ref) <= 2e-5 * max(1.0, out_ref.abs().max().item())
+    assert bool((buf[:, :H] == 3.0).all()) and bool((buf[:, 2 * H:] == 3.0).all())

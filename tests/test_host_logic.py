@@ -230,3 +230,20 @@ def test_train_mode_modules_without_a_train_path_say_so(emulated_ops):
     m = models.corrnet(input_feature=3, output_feature=64, temprature=0.07).train()
     with pytest.raises(NotImplementedError, match="BACKWARD|train-mode"):
         m(None, True)
+
+
+def test_modules_pickle_and_deepcopy_without_device_caches(emulated_ops):
+    """whole-model torch.save / deepcopy after a forward must not drag the kernel-layout cache, HIP streams or the
+    last host plan along."""
+    import copy, io
+    meta, a = load_golden("corrnet_ragged")
+    m = synth.load_recipe(models.corrnet(**meta["kwargs"]).eval(), meta["recipe_seed"])
+    d = data_from(a)
+    want = m(d, False, False)[0]
+    m2 = copy.deepcopy(m)
+    assert m2._packed is None and m2.last_plan is None and m2._streams == {}
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert torch.equal(m3(d, False, False)[0], want) and torch.equal(m2(d, False, False)[0], want)
