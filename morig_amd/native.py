@@ -431,9 +431,12 @@ class NativeOps:
 
     # -- fused edge conv ----------------------------------------------------------------------------
     def edgeconv_can_split(self, csr: CSR, ec) -> bool:
-        """may the fused EdgeConv write its output in the split-fp16 activation layout? (wide quad kernels on the fast path)"""
+        """may the fused EdgeConv write its output in the split-fp16 activation layout? (wide quad kernels on the fast path).
+        OPT-IN (MORIG_EDGE_SPLIT_OUT=1): measured in one call at 64 x 4096 vertices, the GCU vertex MLPs gain 1.0 ms per step on
+        the LDS-DMA GEMM and the EdgeConv scans lose 1.0 ms to the two 8-byte stores per lane, the side rows and the fix-up pass
+        (52.07 vs 52.15 ms per step): not worth a second layout by default."""
         return bool(self.fast and self.split_activations and csr.quad and ec.H in (128, 256) and ec.s1 is None and ec.W2split is not None
-                    and os.environ.get("MORIG_EDGE_SPLIT_OUT", "1") != "0" and os.environ.get("MORIG_EDGE_KERNEL", "") != "pc")
+                    and os.environ.get("MORIG_EDGE_SPLIT_OUT", "0") == "1" and os.environ.get("MORIG_EDGE_KERNEL", "") != "pc")
 
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
                  in_rep_stride: int = 0, out_rep_stride: int = 0, out_split: bool = False):

@@ -667,12 +667,13 @@ def test_concurrent_forwards_from_two_threads_keep_their_own_guard_state():
 
 @pytest.mark.parametrize("H", [128, 256])
 @pytest.mark.parametrize("n,e,hub,reps", [(300, 2500, 5, 1), (1500, 9000, None, 3), (20000, 300000, 777, 2)])
-def test_edgeconv_split_layout_output(ops, H, n, e, hub, reps):
-    """morig_edgeconv_args.out_split: complete segments are written by the scan in the split-fp16 activation layout, segments that
+def test_edgeconv_split_layout_output(ops, H, n, e, hub, reps, monkeypatch):
+    """morig_edgeconv_args.out_split (opt-in, MORIG_EDGE_SPLIT_OUT=1): complete segments are written by the scan in the split-fp16 activation layout, segments that
     straddle a tile go through the fp32 side rows and the fix-up pass; the window sits at a chunk-aligned column of a wider
     buffer whose other columns must stay untouched."""
     if ops.precision != "f16x3":
         pytest.skip("split activations exist on the split-fp16 path only")
+    monkeypatch.setenv("MORIG_EDGE_SPLIT_OUT", "1")
     g = torch.Generator().manual_seed(H + n)
     ei = _rand_graph(n, e, 9, hub)
     if n >= 20000:
