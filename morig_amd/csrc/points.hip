@@ -42,9 +42,6 @@ __device__ __forceinline__ int wave_min_int(int x) {
 // running min-distance in registers; per sample one block-wide arg-max (value desc, index asc).
 // ---------------------------------------------------------------------------------------------------
 constexpr int FPS_T = 1024;
-#ifndef MORIG_FPS_DEFAULT_FAT
-#define MORIG_FPS_DEFAULT_FAT 0
-#endif
 
 template <int PPT>
 __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
@@ -173,75 +170,6 @@ __global__ __launch_bounds__(FPS_T) void fps_lds_kernel(const float* __restrict_
         }
         __syncthreads();
         cur = (int)(0xffffffffu - (unsigned)(s_key[s % 3] & 0xffffffffull));
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The same scan with FEWER, FATTER threads (round 2): NW waves per cloud instead of 16, 8192 / (64 NW) points per thread in
-// registers. A sample is one dependent chain -- broadcast read of the selected point, distance update, wave arg-max, hand-over
-// across waves, barrier -- and with 16 waves the chain (16 LDS atomics, a 16-wave barrier, four waves per SIMD taking turns)
-// cost ~1 500 cycles for ~350 cycles of VALU work per SIMD. Here every wave owns its SIMD (NW = 4) or shares it with one
-// other (NW = 8), writes ONE 64-bit key (value bits, ~lowest index) into its slot, and after the barrier every wave reads the
-// NW slots itself (uniform addresses: broadcast) -- no atomics, no second hand-over. Same arithmetic, same tie rule: indices
-// are bit-identical to fps_lds_kernel / the oracle.
-// ---------------------------------------------------------------------------------------------------
-template <int PPT, int NW>                                // PPT even; NW * 64 * PPT points per cloud at most
-__global__ __launch_bounds__(NW * 64) void fps_fat_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
-                                                          const int* __restrict__ out_ptr, const int* __restrict__ start,
-                                                          int* __restrict__ idx_out) {
-    constexpr int T = NW * 64, NP = PPT * T, H = PPT / 2;
-    __shared__ float sx[NP], sy[NP], sz[NP];
-    __shared__ unsigned long long s_key[2][NW];
-    const int b = blockIdx.x;
-    const int p0 = ptr[b], n = ptr[b + 1] - p0;
-    const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
-    if (n <= 0 || m <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    fps_f2 px[H], py[H], pz[H], dist[H];
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-        const int j = tid + i * T;
-        float x = 0.f, y = 0.f, z = 0.f, d = -1.f;                     // d = -1: never selected
-        if (j < n) {
-            const float* q = pos + (size_t)(p0 + j) * ldp;
-            x = q[0]; y = q[1]; z = q[2]; d = INFINITY;
-        }
-        px[i >> 1][i & 1] = x; py[i >> 1][i & 1] = y; pz[i >> 1][i & 1] = z; dist[i >> 1][i & 1] = d;
-        sx[j] = x; sy[j] = y; sz[j] = z;
-    }
-    int cur = start ? start[b] : 0;
-    if (cur < 0 || cur >= n) cur = 0;
-    __syncthreads();
-    for (int s = 0; s < m; ++s) {
-        if (tid == 0) idx_out[o0 + s] = p0 + cur;
-        if (s + 1 == m) break;
-        const float cx = sx[cur], cy = sy[cur], cz = sz[cur];
-        const fps_f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
-        float best = -1.f;
-        {
-#pragma clang fp contract(off)
-#pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const fps_f2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
-                const fps_f2 d = (dx * dx + dy * dy) + dz * dz;
-                dist[h][0] = fminf(dist[h][0], d[0]); dist[h][1] = fminf(dist[h][1], d[1]);
-                best = fmaxf(best, fmaxf(dist[h][0], dist[h][1]));
-            }
-        }
-        const float wv = wave_max_nonneg(best);            // int-ordered max: correct as soon as one lane is >= 0
-        int loc = 0x7fffffff;
-        if (best == wv) {
-#pragma unroll
-            for (int i = PPT - 1; i >= 0; --i) if (dist[i >> 1][i & 1] == wv) loc = tid + i * T;
-        }
-        const int wl = wave_min_int(loc);
-        if (lane == 0)
-            s_key[s & 1][w] = wv >= 0.f ? (((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)(0xffffffffu - (unsigned)wl)) : 0ull;
-        __syncthreads();
-        unsigned long long k = s_key[s & 1][0];
-#pragma unroll
-        for (int q = 1; q < NW; ++q) { const unsigned long long kq = s_key[s & 1][q]; k = kq > k ? kq : k; }
-        cur = (int)(0xffffffffu - (unsigned)(k & 0xffffffffull));
     }
 }
 
@@ -441,23 +369,7 @@ extern "C" int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, cons
 #define MORIG_FPS_CASE(P) hipLaunchKernelGGL((fps_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
 #define MORIG_FPS_LDS_CASE(P) hipLaunchKernelGGL((fps_lds_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
     static const bool old_fps = getenv("MORIG_FPS_OLD") != nullptr;
-    // MORIG_FPS=fat4 | fat8: the few-waves variant (4 / 8 waves per cloud); lds: 16 waves + LDS atomic arg-max (round 1)
-    static const int fat = [] { const char* e = getenv("MORIG_FPS"); return (e && e[0] == 'f') ? (e[3] == '8' ? 8 : 4) : (e && e[0] == 'l' ? 0 : MORIG_FPS_DEFAULT_FAT); }();
-#define MORIG_FPS_FAT_CASE(P, W) hipLaunchKernelGGL((fps_fat_kernel<P, W>), dim3(n_clouds), dim3(W * 64), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
-    if (fat == 4 && max_cloud_points <= 8192 && !old_fps) {
-        const int p4 = cdiv(max_cloud_points, 256);
-        if (p4 <= 2) MORIG_FPS_FAT_CASE(2, 4);
-        else if (p4 <= 4) MORIG_FPS_FAT_CASE(4, 4);
-        else if (p4 <= 8) MORIG_FPS_FAT_CASE(8, 4);
-        else if (p4 <= 16) MORIG_FPS_FAT_CASE(16, 4);
-        else MORIG_FPS_FAT_CASE(32, 4);
-    } else if (fat == 8 && max_cloud_points <= 8192 && !old_fps) {
-        const int p8 = cdiv(max_cloud_points, 512);
-        if (p8 <= 2) MORIG_FPS_FAT_CASE(2, 8);
-        else if (p8 <= 4) MORIG_FPS_FAT_CASE(4, 8);
-        else if (p8 <= 8) MORIG_FPS_FAT_CASE(8, 8);
-        else MORIG_FPS_FAT_CASE(16, 8);
-    } else if (ppt <= 8 && !old_fps) {
+    if (ppt <= 8 && !old_fps) {
         if (ppt <= 2) MORIG_FPS_LDS_CASE(2);
         else if (ppt <= 4) MORIG_FPS_LDS_CASE(4);
         else MORIG_FPS_LDS_CASE(8);
