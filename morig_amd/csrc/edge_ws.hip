@@ -344,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
 
     // One chunk interval [B_c, B_c+1) of tile j (g = NC j + c): the MFMAs -- pending last group of chunk c-1, (c == 0:
     // accumulators -> scan region), groups 0 .. NG-2 of chunk c -- and the SIDE work: V(g+1), D(g+3), (c == 1: scan of tile
-    // j-1). Measured (tools/gpu_ws2.sh ablations): left to the compiler's order the side work simply ADDS to the MFMA time,
+    // j-1). Measured (tools/gpu_edge_ablate.sh ablations): left to the compiler's order the side work simply ADDS to the MFMA time,
     // because an in-order wave that waits for an LDS round trip or a DMA issue slot issues no MFMA either, and its SIMD
     // partner runs the same code in phase. So the interval is cut into blocks of ONE MFMA group each (sched_barrier: nothing
     // crosses), and every block first issues the LDS reads whose data the NEXT block consumes, then does the VALU work on

@@ -166,7 +166,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     __builtin_amdgcn_s_barrier();
     if (DMA_NS - 1 < nchunk) issue(DMA_NS - 1);
     load_frag(f0, 0, 0);
-    // Measured on the EdgeConv kernels (tools/gpu_ws2.sh): an LDS-DMA instruction costs the issuing wave ~100 cycles of issue
+    // Measured on the EdgeConv kernels (tools/gpu_edge_ablate.sh): an LDS-DMA instruction costs the issuing wave ~100 cycles of issue
     // stall, and the two waves of a SIMD leave the chunk barrier together -- with all PER_CHUNK instructions issued back to
     // back right behind it the matrix pipe of every SIMD idles for the whole burst. MORIG_DMA_SPREAD (default) issues them
     // in pairs between groups of 6 MFMAs of the second half-chunk instead (sched_barrier pins the order), so a wave stalled

@@ -1,5 +1,8 @@
 #!/bin/bash
-# edge_ws.hip: parity tests on the default build, then variants (morig_amd/lib/variants/lib_*.so) in one call
+# edge_ws.hip ablations / A-B in ONE gpurun call (box-to-box variance is ~3 %): parity tests on the default build, then the
+# micro-benchmark per library variant. Variants are whole libraries built with -DWS_NO_CONVERT / -DWS_NO_DMA / -DWS_NO_FRAG /
+# -DWS_NO_BARRIER / -DMORIG_WS_TRACE ... into morig_amd/lib/variants/lib_<name>.so (hipcc ... -c edge_ws.hip, relink with the
+# other objects) and selected with MORIG_HIP_LIB. Results of round 2: profiles/r02_edge_ws_ablations_*.txt
 mkdir -p gpurun_out
 TAG=${1:-c}
 MORIG_WS128=1 timeout 900 python -m pytest tests/test_gpu_kernels.py -q -m gpu -k "edgeconv" --timeout=600 2>&1 | tail -12 > gpurun_out/ws_tests_$TAG.txt
