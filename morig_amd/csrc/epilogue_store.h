@@ -17,15 +17,20 @@ typedef float ep_f32x16 __attribute__((ext_vector_type(16)));
 typedef float ep_f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 ep_f16x8 __attribute__((ext_vector_type(8)));
 
-template <int NT> struct EpilogueTile { static constexpr int CW = NT * 32, LDT = CW + 4, FLOATS = 32 * LDT; };
+// SLAB rows of a 32-row MFMA tile are transposed at a time (32, or 16 where the scratch has to fit beside a live ring stage:
+// gemm_dmap.hip); PAD floats between rows (4: conflict-free reads; 0: 2-way ds_write_b32 conflicts, which cost nothing)
+template <int NT, int SLAB = 32, int PAD = 4> struct EpilogueTile {
+    static constexpr int CW = NT * 32, LDT = CW + PAD, FLOATS = SLAB * LDT;
+};
 
 // acc: the wave's MT x NT accumulator tiles (C/D layout of v_mfma_f32_32x32x*: col = lane & 31,
 // row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); T: this wave's EpilogueTile<NT>::FLOATS floats of LDS;
 // rl_base: block-local row of the wave tile's first row (index into sseg); row0: global row of block-local row 0.
-template <int MT, int NT, bool ALLOW16, class P>
+template <int MT, int NT, bool ALLOW16, class P, int SLAB = 32, int PAD = 4>
 __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&acc)[MT][NT], float* T, const int* sseg,
                                                       int rl_base, int row0, int Mlim, int colw0, int lane) {
-    constexpr int CW = EpilogueTile<NT>::CW, LDT = EpilogueTile<NT>::LDT;
+    static_assert(SLAB == 32 || SLAB == 16, "slab = whole or half MFMA row tile");
+    constexpr int CW = EpilogueTile<NT, SLAB, PAD>::CW, LDT = EpilogueTile<NT, SLAB, PAD>::LDT;
     constexpr int VW = 4, LPR = CW / VW, RPI = 64 / LPR;            // fp32: 4 columns per lane
     constexpr int VW16 = 8, LPR16 = CW / VW16, RPI16 = 64 / LPR16;  // split: 8 columns = 16 B of hi + 16 B of lo
     constexpr int NV = ALLOW16 ? 8 : 4;
@@ -49,12 +54,15 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
     bool ovf = false;
     const float lo_bound = p.relu ? 0.f : -INFINITY;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int ms = 0; ms < MT * (32 / SLAB); ++ms) {
+        const int mt = ms / (32 / SLAB), hs = ms % (32 / SLAB);       // half-slab hs: accumulator registers with (r >> 3) == hs
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) T[((r & 3) + 8 * (r >> 2) + 4 * hi) * LDT + nt * 32 + l31] = acc[mt][nt][r];
-        const int nit = y16 ? 32 / RPI16 : 32 / RPI;
+            for (int r = 0; r < 16; ++r)
+                if (SLAB == 32 || (r >> 3) == hs)
+                    T[((r & 3) + 8 * ((r >> 2) & (SLAB / 8 - 1)) + 4 * hi) * LDT + nt * 32 + l31] = acc[mt][nt][r];
+        const int nit = y16 ? SLAB / RPI16 : SLAB / RPI;
         const int rstep = y16 ? RPI16 : RPI;
         // The copy-out loop must contain NO global load: vmcnt counts loads and stores in order, so waiting for a row-bias
         // load issued after the previous row's stores waits for those stores too (measured: ~0.7 us per row pass, the whole
@@ -62,7 +70,7 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
         // boundary: the row bias is fetched once, before the loop; only straddling slabs take the per-row path.
         bool per_row = false;
         if (p.rowbias) {
-            const int rl0 = rl_base + mt * 32 + rsel;
+            const int rl0 = rl_base + mt * 32 + hs * SLAB + rsel;
             const int sg0 = sseg[rl0], sg1 = sseg[rl0 + (nit - 1) * rstep];
             if (sg0 != sg1) per_row = true;
             else if (sg0 != rb_seg) {
@@ -76,8 +84,8 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
 #pragma unroll
         for (int q = 0; q < NV; ++q) cbr[q] = cb[q] + rbv[q];        // rbv stays 0 without a row bias
         auto pass = [&](int it, auto check_seg) __attribute__((always_inline)) {
-            const int rloc = it * rstep + rsel;                       // row inside the 32-row slab
-            const int rl = rl_base + mt * 32 + rloc;                  // row inside the block tile
+            const int rloc = it * rstep + rsel;                       // row inside the slab
+            const int rl = rl_base + mt * 32 + hs * SLAB + rloc;      // row inside the block tile
             const int row = row0 + rl;
             float v[NV];
             const ep_f32x4 t0 = *reinterpret_cast<const ep_f32x4*>(T + rloc * LDT + cg);

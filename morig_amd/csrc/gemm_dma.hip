@@ -257,6 +257,13 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
     static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
     static const int mode = [] { const char* e = getenv("MORIG_DMA_TILE"); return e ? atoi(e) : 256; }();
+    // persistent variant (gemm_dmap.hip): the next tile's first chunk lands under the epilogue. Measured in one call
+    // (profiles/r02_gemm_persistent_ab.txt): -3.5 % at K = 832 -> N = 1024 and on the pooled launches, -0.6 % at K = 1862, but +2.5..4 %
+    // on short-K or single-N-tile shapes (its 16-row epilogue slabs and the tile bookkeeping cost more than the ~2.5 us cold start
+    // they hide), so it takes the pooled launches and the deep, wide stores only. MORIG_DMA_PERSIST=0 / 1 forces never / always.
+    static const int persist = [] { const char* e = getenv("MORIG_DMA_PERSIST"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
+    const bool deep_wide = p.pool != nullptr || (p.K >= 768 && p.N >= 1024);
+    if (mode == 256 && p.N % 256 == 0 && p.K > 32 && (persist == 2 || (persist == 1 && deep_wide))) return launch_gemm16_dmap(p0, s);
     if (mode == 256 && p.N % 256 == 0) {
         p.tiles_n = p.N / 256;
         const int nb = cdiv(p.M, 256) * p.tiles_n;
