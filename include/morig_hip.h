@@ -147,12 +147,6 @@ typedef struct morig_edgeconv_args {
     float* out; int32_t ldo;           /* out[row][0..H)                                  */
     const void* W2_split; int32_t* overflow;   /* optional split-fp16 fast path (H >= 32), as in morig_gemm_args */
     int32_t quad_aligned;              /* the CSR was built with MORIG_CSR_PAD4: segments are 4-aligned */
-    /* optional: write `out` in the split-fp16 ACTIVATION layout (what morig_gemm's x_split reads), so the GCU's vertex MLP
-     * takes it through the LDS-DMA GEMM. Needs the split-fp16 fast path, H = 128 or 256, a 4-aligned CSR, `out` on a
-     * 32-column boundary with ldo % 32 == 0, and `side`: fp32 scratch rows [same row index as out][ld_side >= H] in which
-     * segments that straddle a tile are combined by atomic max before a fix-up pass splits them into `out`.
-     * MORIG_E_UNSUPPORTED if the kernel that would run cannot honour it. */
-    int32_t out_split; float* side; int32_t ld_side;
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 

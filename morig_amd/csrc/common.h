@@ -44,8 +44,6 @@ struct EdgePcParams {
     const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
     int replicas;
     float* Y; int ldy;
-    int y16;                                     // Y rows are in the split-fp16 activation layout (complete segments only)
-    float* side; int ld_side;                    // y16: fp32 rows [same row index as Y][H] that take the atomic max of tile-straddling segments
     int* ovf;
     int quad;                                    // CSR segments are 4-aligned (MORIG_CSR_PAD4)
     unsigned long long* trace;                   // -DMORIG_PP_TRACE builds only
@@ -72,35 +70,6 @@ int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); //
 int launch_gemm16_dmap(const GemmDmaParams& p, hipStream_t s);                // gemm_dmap.hip (persistent, 256 x 256 tiles)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-
-// one segment result of VEC adjacent columns (first column c0, VEC | 32) into a split-fp16 activation row: each 32-column chunk
-// is [32 hi halves | 32 lo halves]; hi = fp16(v) truncated, lo = fp16(v - hi) rounded to nearest (v_fma_mix). Returns max |v|.
-template <int VEC>
-__device__ __forceinline__ float store_split_vec(float* rowbase, int c0, const float* v) {
-    typedef __fp16 h2 __attribute__((ext_vector_type(2)));
-    static_assert(VEC == 2 || VEC == 4, "");
-    float hw[VEC / 2], lw[VEC / 2], am = 0.f;
-#pragma unroll
-    for (int i = 0; i < VEC; i += 2) {
-        const h2 h = __builtin_amdgcn_cvt_pkrtz(v[i], v[i + 1]);
-        const float hb = __builtin_bit_cast(float, h);
-        float lb;
-        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v[i]), "v"(hb));
-        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v[i + 1]), "v"(hb));
-        hw[i >> 1] = hb; lw[i >> 1] = lb;
-        am = fmaxf(am, fmaxf(fabsf(v[i]), fabsf(v[i + 1])));
-    }
-    char* o = reinterpret_cast<char*>(rowbase) + (c0 >> 5) * 128 + (c0 & 31) * 2;
-    if constexpr (VEC == 4) {
-        typedef float b2 __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<b2*>(o) = b2{hw[0], hw[1]};
-        *reinterpret_cast<b2*>(o + 64) = b2{lw[0], lw[1]};
-    } else {
-        *reinterpret_cast<float*>(o) = hw[0];
-        *reinterpret_cast<float*>(o + 64) = lw[0];
-    }
-    return am;
-}
 
 // ---- device helpers -------------------------------------------------------------------
 // float max via integer atomics; identity element = 0xFFFFFFFF (what hipMemset 0xFF leaves):

@@ -162,19 +162,13 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) m[v] = fmaxf(fmaxf(m[v], z0[v]), fmaxf(fmaxf(z1[v], z2[v]), z3[v]));
             }
+            float* o = obase + (size_t)sg * p.ldy;
             const bool partial = (b == 0 && first_cont) || (e == 32 && last_cont);
-            if (partial) {                                                    // combined by integer-atomic float max (fp32 rows)
-                float* o = p.y16 ? p.side + ((size_t)rep * p.rep_out + sg) * p.ld_side + VEC * lane : obase + (size_t)sg * p.ldy;
+            if (partial) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
-            } else if (p.y16) {                                               // complete segment, split-fp16 activation row
-                float mv[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) mv[v] = m[v];
-                const float am = store_split_vec<VEC>(p.Y + ((size_t)rep * p.rep_out + sg) * p.ldy, VEC * lane, mv);
-                if (!(am < 65000.f)) *p.ovf = 1;
             } else {
-                *reinterpret_cast<fvec*>(obase + (size_t)sg * p.ldy) = m;
+                *reinterpret_cast<fvec*>(o) = m;
             }
         }
     };

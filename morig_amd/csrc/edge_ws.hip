@@ -313,19 +313,13 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], fmaxf(z0[v], z1[v]));
             }
+            float* o = obase + (size_t)sg * p.ldy;
             const bool partial = (b == 0 && first_cont) || (e == NQ && last_cont);
-            if (partial) {                                                    // combined by integer-atomic float max (fp32 rows)
-                float* o = p.y16 ? p.side + ((size_t)rep * p.rep_out + sg) * p.ld_side + VEC * lane : obase + (size_t)sg * p.ldy;
+            if (partial) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
-            } else if (p.y16) {                                               // complete segment, split-fp16 activation row
-                float mv[VEC];
-#pragma unroll
-                for (int v = 0; v < VEC; ++v) mv[v] = m[v];
-                const float am = store_split_vec<VEC>(p.Y + ((size_t)rep * p.rep_out + sg) * p.ldy, VEC * lane, mv);
-                if (!(am < 65000.f)) *p.ovf = 1;
             } else {
-                *reinterpret_cast<fvec*>(obase + (size_t)sg * p.ldy) = m;
+                *reinterpret_cast<fvec*>(o) = m;
             }
         }
     };
@@ -371,8 +365,8 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         // ---- block 1: group 0
         load_frag(F1, zs, 1);
 #ifndef WS_NO_CONVERT
-        raw_load(rs_v, WC<1>{}, ra1, rb1);
         conv_store(zs ^ 1, WC<0>{}, ra0, rb0);
+        raw_load(rs_v, WC<1>{}, ra1, rb1);           // after the first half's arithmetic: its registers are free again
 #endif
         mma(F0, WC<SPC * c>{}, WC<(c == 0 ? 1 : 0)>{});
         __builtin_amdgcn_sched_barrier(0);

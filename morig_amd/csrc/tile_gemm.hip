@@ -511,25 +511,6 @@ __global__ __launch_bounds__(64) void init_boundary_rows_kernel(const int* __res
     for (int c = threadIdx.x; c < H; c += 64) o[c] = 0xFFFFFFFFu;
 }
 
-// out_split: a straddling segment was combined in the fp32 side rows; the tile boundary that is the FIRST one the segment
-// crosses converts its row into the split-fp16 activation layout of `out` (one block per boundary, as the init kernel)
-__global__ __launch_bounds__(64) void split_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS, int n_nodes,
-                                                                 int H, const float* __restrict__ side, int ld_side, float* __restrict__ out,
-                                                                 int ldo, int rep_out, int tile_rows, int* __restrict__ ovf) {
-    const int e = (blockIdx.x + 1) * tile_rows;
-    if (e >= rowptr[n_nodes]) return;
-    const int d = dstS[e];
-    const int s0 = rowptr[d];
-    if (s0 >= e || s0 < e - tile_rows) return;          // no straddle / an earlier boundary owns this segment
-    const size_t row = (size_t)blockIdx.y * rep_out + d;
-    const float* src = side + row * ld_side;
-    for (int c = 2 * threadIdx.x; c < H; c += 128) {
-        const float v[2] = {src[c], src[c + 1]};
-        const float am = store_split_vec<2>(out + row * ldo, c, v);
-        if (!(am < 65000.f)) *ovf = 1;
-    }
-}
-
 static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
                               int rep_out, int slots, hipStream_t s, int tile_rows = 128) {
     const int nb = cdiv(edge_capacity, tile_rows) - 1;
@@ -666,7 +647,6 @@ static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
     if (!a || !a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
     if ((a->s1 == nullptr) != (a->t1 == nullptr) || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
     if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
-    if (a->out_split && !a->W2_split) return MORIG_E_INVALID;
     if ((a->lda & 3) || (a->ldb & 3) || (a->ldw & 3) || !aligned16(a->A) || !aligned16(a->B) || !aligned16(a->W2) ||
         !aligned16(a->s1) || !aligned16(a->t1)) return MORIG_E_INVALID;
     if (a->ldo < a->H || a->lda < a->H || a->ldb < a->H || a->ldw < a->H) return MORIG_E_INVALID;
@@ -771,19 +751,11 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
                         (a->H == 256 || ws128);
     const int tile_rows = (use_ws && a->H == 256) ? 64 : 128;   // edge_ws.hip: 64-row tiles at H = 256
 
-    const bool out_split = a->out_split != 0;
-    if (out_split) {
-        // only the quad scans of edge_ws.hip / edge_pp.hip know the split store
-        if (!wide || one_shot || !pp_ok || !a->quad_aligned) return MORIG_E_UNSUPPORTED;
-        if (!a->side || a->ld_side < a->H || (a->ldo & 31) || (reinterpret_cast<uintptr_t>(a->out) & 127)) return MORIG_E_INVALID;
-    }
     // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
     {
         const int slots = a->replicas;
-        const int st2 = out_split ? init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->side, a->ld_side,
-                                                       a->out_rep_stride, slots, s, tile_rows)
-                                  : init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
-                                                       a->out_rep_stride, slots, s, tile_rows);
+        const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
+                                           a->out_rep_stride, slots, s, tile_rows);
         if (st2 != MORIG_OK) return st2;
     }
 
@@ -798,19 +770,9 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.rowptr = p.rowptr; q.srcS = p.srcS; q.dstS = p.dstS; q.n_nodes = p.n_nodes;
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
-        q.y16 = out_split ? 1 : 0; q.side = a->side; q.ld_side = a->ld_side;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
-        int st3;
-        if (use_ws) st3 = launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
-        else st3 = (one_shot || !pp_ok) ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
-        if (st3 != MORIG_OK || !out_split) return st3;
-        const int nb = cdiv(a->edge_capacity, tile_rows) - 1;
-        if (nb > 0) {
-            hipLaunchKernelGGL(split_boundary_rows_kernel, dim3(nb, a->replicas), dim3(64), 0, s, a->rowptr, a->dst_sorted, a->n_nodes, a->H,
-                               a->side, a->ld_side, a->out, a->ldo, a->out_rep_stride, tile_rows, a->overflow);
-            MORIG_LAUNCH_CHECK();
-        }
-        return MORIG_OK;
+        if (use_ws) return launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
+        return (one_shot || !pp_ok) ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
     }
     if (f16) {
         switch (a->H) {

@@ -235,10 +235,9 @@ class GCU(NativeModule):
         ab = ops.empty(n, 4 * H, dev)
         ops.gemm(x, pk["vertex"], relu=False, Y=Mat.of(ab))
         ec = ops.empty(n, 2 * H, dev)
-        sp = ops.edgeconv_can_split(csr_tpl, pk["et"]) and ops.edgeconv_can_split(csr_geo, pk["eg"])    # see GCUMotion.run
-        ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["et"], Mat.of(ec, 0, H), out_split=sp)
-        ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["eg"], Mat.of(ec, H, H), out_split=sp)
-        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, x_split=sp)
+        ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["et"], Mat.of(ec, 0, H))
+        ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["eg"], Mat.of(ec, H, H))
+        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out)
 
     def _forward(self, pos, tpl_edge_index, geo_edge_index):
         ops = get_ops()
@@ -265,12 +264,7 @@ class GCUMotion(NativeModule):
     def _pack(self):
         vx, (xt, xg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_x, self.edge_conv_geo.nn_x])
         vp, (pt, pg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_pos, self.edge_conv_geo.nn_pos])
-        H, D = xt.H, pt.H
-        # reference input order of self.mlp (:216): [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)]; the split-layout EdgeConv output
-        # keeps every window on a 32-column chunk: [x_tpl | x_geo | pos_tpl | pos_geo]
-        in_cols = list(range(H)) + [2 * H + i for i in range(D)] + [H + i for i in range(H)] + [2 * H + D + i for i in range(D)]
-        return dict(vx=vx, xt=xt, xg=xg, vp=vp, pt=pt, pg=pg, mlp=packing.pack_mlp_layer(self.mlp[0]),
-                    mlp_s=packing.pack_mlp_layer(self.mlp[0], in_cols=in_cols))
+        return dict(vx=vx, xt=xt, xg=xg, vp=vp, pt=pt, pg=pg, mlp=packing.pack_mlp_layer(self.mlp[0]))
 
     def run(self, ops, pos: Mat, x: Mat, csr_tpl, csr_geo, out: Mat, replicas: int = 1, split: bool = False,
             split_in=None, split_out=None):
@@ -289,20 +283,6 @@ class GCUMotion(NativeModule):
         ops.gemm(x, pk["vx"], relu=False, Y=Mat.of(ab), x_split=split_in)
         pab = ops.empty(n, 4 * D, dev)
         ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
-        if ops.edgeconv_can_split(csr_tpl, pk["xt"]) and ops.edgeconv_can_split(csr_geo, pk["xg"]) and (2 * D) % 32 == 0:
-            # wide layers on 4-aligned CSRs: the EdgeConv scans write the split-fp16 activation layout, so this GCU's vertex MLP
-            # runs on the LDS-DMA GEMM instead of the fp32-X tile kernel (K = 544 -> 512: 0.58 vs 1.06 ms per 328 k rows)
-            ec = ops.empty(M, ldo, dev)      # [x_tpl(H) | x_geo(H) | pos_tpl(D) | pos_geo(D)], split layout
-            ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
-                         replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
-            ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H, H),
-                         replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
-            pp = ops.empty(n, 2 * D, dev)    # position branch, fp32, once; split while it is copied into every replica
-            ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(pp, 0, D))
-            ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(pp, D, D))
-            ops.copy2d_rep(Mat.of(pp), Mat.of(ec, 2 * H, 2 * D, 0, n), replicas, n, split=True)
-            ops.gemm(Mat.of(ec), pk["mlp_s"], relu=True, Y=out, x_split=True, y_split=split_out)
-            return
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
         ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
                      replicas=replicas, in_rep_stride=n, out_rep_stride=n)

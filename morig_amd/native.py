@@ -56,7 +56,6 @@ class EdgeConvArgs(C.Structure):
         ("out", c_f32p), ("ldo", C.c_int32),
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
         ("quad_aligned", C.c_int32),
-        ("out_split", C.c_int32), ("side", c_f32p), ("ld_side", C.c_int32),
     ]
 
 
@@ -430,24 +429,10 @@ class NativeOps:
         check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")
 
     # -- fused edge conv ----------------------------------------------------------------------------
-    def edgeconv_can_split(self, csr: CSR, ec) -> bool:
-        """may the fused EdgeConv write its output in the split-fp16 activation layout? (wide quad kernels on the fast path).
-        OPT-IN (MORIG_EDGE_SPLIT_OUT=1): measured in one call at 64 x 4096 vertices, the GCU vertex MLPs gain 1.0 ms per step on
-        the LDS-DMA GEMM and the EdgeConv scans lose 1.0 ms to the two 8-byte stores per lane, the side rows and the fix-up pass
-        (52.07 vs 52.15 ms per step): not worth a second layout by default."""
-        return bool(self.fast and self.split_activations and csr.quad and ec.H in (128, 256) and ec.s1 is None and ec.W2split is not None
-                    and os.environ.get("MORIG_EDGE_SPLIT_OUT", "0") == "1" and os.environ.get("MORIG_EDGE_KERNEL", "") != "pc")
-
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
-                 in_rep_stride: int = 0, out_rep_stride: int = 0, out_split: bool = False):
-        """out_split: ``out`` is a window (32-column aligned) of a split-fp16 activation buffer; tile-straddling segments go
-        through an fp32 side buffer allocated here and a fix-up pass (include/morig_hip.h, morig_edgeconv_args.out_split)."""
+                 in_rep_stride: int = 0, out_rep_stride: int = 0):
         _need_gpu(A.base, B.base, out.base)
         a = self._edge_args(A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride)
-        if out_split:
-            assert self.edgeconv_can_split(csr, ec) and out.col0 % 32 == 0 and out.ld % 32 == 0
-            side = torch.empty((out.base.shape[0], ec.H), dtype=torch.float32, device=out.base.device)
-            a.out_split, a.side, a.ld_side = 1, side.data_ptr() + 4 * out.row0 * ec.H, ec.H
         check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
 
     def _edge_args(self, A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride):

@@ -111,13 +111,8 @@ class EmuOps:
             Y.view().copy_(acc)
 
     # -- fused edge conv ---------------------------------------------------------------------------
-    def edgeconv_can_split(self, csr: CSR, ec) -> bool:
-        return bool(self.emulate_split and csr.quad and ec.H in (128, 256) and ec.s1 is None)
-
-    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0, out_split=False):
+    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0):
         assert A.ld % 4 == 0 and A.col0 % 4 == 0 and B.ld % 4 == 0 and B.col0 % 4 == 0
-        if out_split:          # the alignment rules of morig_edgeconv_args.out_split (the emulation keeps plain fp32 values)
-            assert self.edgeconv_can_split(csr, ec) and out.col0 % 32 == 0 and out.ld % 32 == 0
         H = ec.H
         E = int(csr.rowptr[-1])
         src, dst = csr.src[:E].long(), csr.dst[:E].long()

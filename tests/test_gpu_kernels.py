@@ -663,37 +663,3 @@ def test_concurrent_forwards_from_two_threads_keep_their_own_guard_state():
     [t.start() for t in ts]; [t.join() for t in ts]
     assert not errs, errs
     assert all(torch.equal(outs[i], want) for i in range(2))
-
-
-@pytest.mark.parametrize("H", [128, 256])
-@pytest.mark.parametrize("n,e,hub,reps", [(300, 2500, 5, 1), (1500, 9000, None, 3), (20000, 300000, 777, 2)])
-def test_edgeconv_split_layout_output(ops, H, n, e, hub, reps, monkeypatch):
-    """morig_edgeconv_args.out_split (opt-in, MORIG_EDGE_SPLIT_OUT=1): complete segments are written by the scan in the split-fp16 activation layout, segments that
-    straddle a tile go through the fp32 side rows and the fix-up pass; the window sits at a chunk-aligned column of a wider
-    buffer whose other columns must stay untouched."""
-    if ops.precision != "f16x3":
-        pytest.skip("split activations exist on the split-fp16 path only")
-    monkeypatch.setenv("MORIG_EDGE_SPLIT_OUT", "1")
-    g = torch.Generator().manual_seed(H + n)
-    ei = _rand_graph(n, e, 9, hub)
-    if n >= 20000:
-        ei = torch.cat([ei, torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 1234)])], dim=1)   # a 700-edge hub
-    ab = torch.randn(n * reps, 2 * H, generator=g)
-    ec = _edge_pack(H, 23, folded=True)
-    emu = EmuOps()
-    out_ref = torch.zeros(n * reps, H)
-    emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), emu.csr_build(ei, n), ec, Mat.of(out_ref), replicas=reps, in_rep_stride=n,
-                 out_rep_stride=n)
-    csr = ops.csr_build(ei.to(DEV), n, pad4=True)
-    ecd = packing.to_device(ec, DEV)
-    assert ops.edgeconv_can_split(csr, ecd)
-    abg = ab.to(DEV)
-    ld = 2 * H + 64
-    buf = torch.full((n * reps, ld), 3.0, device=DEV)                   # window [H, 2H) of a wider split buffer
-    ops.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), csr, ecd, Mat.of(buf, H, H), replicas=reps, in_rep_stride=n, out_rep_stride=n,
-                 out_split=True)
-    torch.cuda.synchronize()
-    got = packing.unsplit_f16(buf.cpu(), ld)[:, H:2 * H]
-    assert not torch.isnan(got).any()
-    assert maxdiff(got, out_ref) <= 2e-5 * max(1.0, out_ref.abs().max().item())
-    assert bool((buf[:, :H] == 3.0).all()) and bool((buf[:, 2 * H:] == 3.0).all())
