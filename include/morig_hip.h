@@ -169,6 +169,28 @@ typedef struct morig_segmax_args {
 } morig_segmax_args;
 int morig_segmax_gemm(const morig_segmax_args* a, void* stream);
 
+/* The same PointConv in ONE launch pair, straight from the slot table of morig_ball_query (csrc/pointconv_fused.hip;
+ * split-fp16 arithmetic only; (H, H3) in {(32, 64), (64, 128)}, max_nbrs == 64): per centre c the kept slots
+ * (0 <= source < n_src, source != c) plus the self loop (c, c) -- the edge set morig_csr_from_slots builds, i.e.
+ * PointConv's remove_self_loops / add_self_loops (basic_modules.py:82-84) -- without a CSR, per-edge rows in HBM or atomics.
+ *   A [n_centres][lda] = -W1p pos_c, B [n_src][ldb] = W1 [x_j | pos_j] + b1 (as for morig_edge_hidden);
+ *   W2_split [H][ldw2], b2 [H]: Linear2 with BN1 folded in (packing.fold_hidden_affine);
+ *   W3_split [H3][ldw3], b3 [H3]: Linear3 with BN2 folded in the same way; s3 / t3: BN3 (NULL: identity); relu3.
+ * *status is set to 1 when a slot names a source >= n_src (out is unspecified then); *overflow as in morig_gemm.
+ * MORIG_E_UNSUPPORTED for other widths: the caller falls back to morig_edge_hidden + morig_segmax_gemm. */
+typedef struct morig_pointconv_args {
+    const float* A; int32_t lda;
+    const float* B; int32_t ldb;
+    const int64_t* slots; int32_t max_nbrs;
+    int32_t n_centres, n_src;
+    int32_t H, H3;
+    const void* W2_split; int32_t ldw2; const float* b2;
+    const void* W3_split; int32_t ldw3; const float* b3; const float* s3; const float* t3; int32_t relu3;
+    float* out; int32_t ldo;
+    int32_t* overflow; int32_t* status;
+} morig_pointconv_args;
+int morig_pointconv_fused(const morig_pointconv_args* a, void* stream);
+
 /* --------------------------------------------------------------------------------------------
  * Small vertex-parallel operators.
  */

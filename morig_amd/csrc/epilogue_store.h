@@ -61,7 +61,11 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 if (SLAB == 32 || (r >> 3) == hs)
+#ifndef EPI_NO_LDSW
                     T[((r & 3) + 8 * ((r >> 2) & (SLAB / 8 - 1)) + 4 * hi) * LDT + nt * 32 + l31] = acc[mt][nt][r];
+#else
+                    asm volatile("" :: "v"(acc[mt][nt][r]));
+#endif
         const int nit = y16 ? SLAB / RPI16 : SLAB / RPI;
         const int rstep = y16 ? RPI16 : RPI;
         // The copy-out loop must contain NO global load: vmcnt counts loads and stores in order, so waiting for a row-bias
@@ -88,11 +92,19 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
             const int rl = rl_base + mt * 32 + hs * SLAB + rloc;      // row inside the block tile
             const int row = row0 + rl;
             float v[NV];
+#ifdef EPI_NO_LDSR
+            const ep_f32x4 t0 = {acc[mt][0][0], acc[mt][0][1], acc[mt][0][2], acc[mt][0][3]};
+#else
             const ep_f32x4 t0 = *reinterpret_cast<const ep_f32x4*>(T + rloc * LDT + cg);
+#endif
             v[0] = t0[0]; v[1] = t0[1]; v[2] = t0[2]; v[3] = t0[3];
             if constexpr (ALLOW16) {
                 if (y16) {
+#ifdef EPI_NO_LDSR
+                    const ep_f32x4 t1 = {acc[mt][1][0], acc[mt][1][1], acc[mt][1][2], acc[mt][1][3]};
+#else
                     const ep_f32x4 t1 = *reinterpret_cast<const ep_f32x4*>(T + rloc * LDT + cg + 4);
+#endif
                     v[4] = t1[0]; v[5] = t1[1]; v[6] = t1[2]; v[7] = t1[3];
                 }
             }
@@ -138,6 +150,9 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
                 const ep_f16x8 hv = __builtin_bit_cast(ep_f16x8, hw), lv = __builtin_bit_cast(ep_f16x8, lw);
                 if (!(am < 65000.f)) ovf = true;
                 char* o = reinterpret_cast<char*>(p.Y + (size_t)row * p.ldy) + (col0 >> 5) * 128 + (col0 & 31) * 2;
+#ifdef EPI_NO_STORE
+                if (am == 12345.678f)
+#endif
                 if (vec_ok && col0 + VW16 <= p.N) {
                     *reinterpret_cast<ep_f16x8*>(o) = hv;
                     *reinterpret_cast<ep_f16x8*>(o + 64) = lv;

@@ -44,6 +44,12 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
     const int row0 = tm * BM;
 
+#ifdef MORIG_DMA_TRACE
+#define DMA_TS(k) do { if ((int)blockIdx.x == (int)(gridDim.x / 2 + 8) && lane == 0) p.trace[(k) * 8 + wave] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DMA_TS(k) do { } while (0)
+#endif
+    DMA_TS(0);
     if (p.seg != nullptr && tid < BM) sseg[tid] = (row0 + tid < p.M) ? p.seg[row0 + tid] : 0;
 
     // ---- per-lane DMA sources: wave w moves row blocks (8 rows x 128 B = 1 KiB per instruction) XJ*w .. XJ*w+XJ-1.
@@ -94,6 +100,16 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     const int nchunk = (p.K + 31) / 32;
+    // every workgroup of a launch takes the same time, so all CUs would reach their store epilogue together and the launch would
+    // alternate between a compute phase without stores and a store burst at HBM write speed. The first workgroup of each CU starts
+    // late by a fraction of a tile time instead (phase = a hash of the CU's first block index), which spreads the bursts for the
+    // rest of the launch.
+    if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_first) {
+        const int phase = ((int)blockIdx.x >> 3) % p.stagger_phases;
+        const unsigned long long t0 = wall_clock64();
+        const unsigned long long wait = (unsigned long long)(phase * p.stagger_ticks);
+        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
+    }
     // prologue: NS-1 chunks in flight (PER_CHUNK DMA instructions per chunk per wave)
 #pragma unroll
     for (int c = 0; c < DMA_NS - 1; ++c) if (c < nchunk) issue(c);
@@ -207,6 +223,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
         }
     }
 
+    DMA_TS(1);
     const int colw0 = tn * BN + wn * NT * 32;
     if (p.pool != nullptr) {
         // ---- pooled epilogue (scatter_max over meshes): `seg` is sorted, so the 64 rows of a wave tile almost always
@@ -248,8 +265,14 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     // ---- epilogue: bias / per-mesh row bias / ReLU / BN affine, fp32 or split-fp16 store (epilogue_store.h) ----
     __syncthreads();                             // every wave is done with the ring; sseg visible
     if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
+    DMA_TS(2);
     store_tile_transposed<MT, NT, true>(p, acc, reinterpret_cast<float*>(smem) + wave * EpilogueTile<NT>::FLOATS, sseg,
                                         wm * 64, row0, p.M, colw0, lane);
+    DMA_TS(3);
+#ifdef MORIG_DMA_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DMA_TS(4);
+#endif
 }
 
 int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
@@ -267,7 +290,28 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
     if (mode == 256 && p.N % 256 == 0) {
         p.tiles_n = p.N / 256;
         const int nb = cdiv(p.M, 256) * p.tiles_n;
+        static const int phases = [] { const char* e = getenv("MORIG_DMA_STAGGER"); return e ? atoi(e) : 0; }();
+        static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
+        p.stagger_phases = phases; p.stagger_ticks = 0; p.stagger_first = cus;
+        if (phases > 1 && nb >= 4 * cus) {                                   // only worth a delay when a CU runs several tiles
+            const float tile_us = 13.f + 0.08f * (float)p.K;                  // measured: 34 us at K = 256, 163 us at K = 1862
+            p.stagger_ticks = (int)(tile_us * 100.f / (float)phases);
+        }
+#ifdef MORIG_DMA_TRACE
+        static unsigned long long* trace_buf = [] { void* b = nullptr; return hipMalloc(&b, 64 * 8) == hipSuccess ? (unsigned long long*)b : nullptr; }();
+        p.trace = trace_buf;
+#endif
         hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2>), dim3(nb), dim3(512), 0, s, p);
+#ifdef MORIG_DMA_TRACE
+        {
+            unsigned long long h[64];
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, p.trace, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+                fprintf(stderr, "DMA_TRACE K=%d N=%d:", p.K, p.N);
+                for (int w = 0; w < 8; w += 3) { fprintf(stderr, " w%d", w); for (int q = 1; q < 5; ++q) fprintf(stderr, " %lld", (long long)(h[q * 8 + w] - h[(q - 1) * 8 + w])); }
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
     } else {
         p.tiles_n = cdiv(p.N, 128);
         // 2-stage ring = 64 KB: TWO workgroups per CU, one's prologue / epilogue under the other's main loop

@@ -395,15 +395,19 @@ class SAModule(NativeModule):
         pk = self.packed(dev)
         N, M = xp.shape[0], pos_new.shape[0]
         coo = ops.ball_query(Mat.of(xp, cx, 3), ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, self.r, self.max_num_neighbors)
-        csr = ops.csr_from_slots(coo, M, self.max_num_neighbors, N)
         H = pk["edge"].H
         bsrc = ops.empty(N, H, dev)
         ops.gemm(Mat.of(xp, 0, cx + 3), pk["src"], relu=False, Y=Mat.of(bsrc))
         atgt = ops.empty(M, H, dev)
         ops.gemm(Mat.of(pos_new, 0, 3), pk["tgt"], relu=False, Y=Mat.of(atgt))
+        x_new = ops.empty(M, pk["last"].N, dev)
+        if ops.pointconv_can_fuse(pk, self.max_num_neighbors):
+            # layers 2 and 3 and the max in one kernel, straight from the slot table: no CSR, no per-edge rows in HBM
+            ops.pointconv_fused(Mat.of(atgt), Mat.of(bsrc), coo, self.max_num_neighbors, pk, Mat.of(x_new))
+            return x_new
+        csr = ops.csr_from_slots(coo, M, self.max_num_neighbors, N)
         z = ops.empty(csr.capacity, H, dev)
         ops.edge_hidden(Mat.of(atgt), Mat.of(bsrc), csr, pk["edge"], Mat.of(z))
-        x_new = ops.empty(M, pk["last"].N, dev)
         ops.segmax_gemm(Mat.of(z), pk["last"], True, csr, Mat.of(x_new))
         return x_new
 

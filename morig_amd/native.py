@@ -59,6 +59,17 @@ class EdgeConvArgs(C.Structure):
     ]
 
 
+class PointConvArgs(C.Structure):
+    _fields_ = [
+        ("A", c_f32p), ("lda", C.c_int32), ("B", c_f32p), ("ldb", C.c_int32),
+        ("slots", C.c_void_p), ("max_nbrs", C.c_int32), ("n_centres", C.c_int32), ("n_src", C.c_int32),
+        ("H", C.c_int32), ("H3", C.c_int32),
+        ("W2_split", C.c_void_p), ("ldw2", C.c_int32), ("b2", c_f32p),
+        ("W3_split", C.c_void_p), ("ldw3", C.c_int32), ("b3", c_f32p), ("s3", c_f32p), ("t3", c_f32p), ("relu3", C.c_int32),
+        ("out", c_f32p), ("ldo", C.c_int32), ("overflow", C.c_void_p), ("status", C.c_void_p),
+    ]
+
+
 class SegmaxArgs(C.Structure):
     _fields_ = [
         ("N", C.c_int32), ("K", C.c_int32),
@@ -84,6 +95,7 @@ _SIGNATURES = {
     "morig_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
     "morig_edge_hidden": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_segmax_gemm": (C.c_int, [C.POINTER(SegmaxArgs), C.c_void_p]),
+    "morig_pointconv_fused": (C.c_int, [C.POINTER(PointConvArgs), C.c_void_p]),
     "morig_fps": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_ball_query": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, c_i64p, C.c_void_p]),
     "morig_radius_sample": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
@@ -478,6 +490,38 @@ class NativeOps:
         if self.fast and lin.Wsplit is not None:
             a.W_split, a.overflow = lin.Wsplit.data_ptr(), self._flag(X.base.device).data_ptr()
         check(self.lib.morig_segmax_gemm(C.byref(a), _stream()), "morig_segmax_gemm")
+
+    def pointconv_can_fuse(self, pk, max_nbrs: int) -> bool:
+        """the one-launch PointConv (csrc/pointconv_fused.hip) covers this packed local_nn? (split-fp16 arithmetic only)"""
+        l3 = pk.get("fused")
+        return bool(self.fast and l3 is not None and l3.Wsplit is not None and pk["edge"].W2split is not None and
+                    max_nbrs == 64 and pk["edge"].s1 is None and os.environ.get("MORIG_POINTCONV_FUSED", "1") != "0")
+
+    def pointconv_fused(self, A: Mat, B: Mat, coo: torch.Tensor, max_nbrs: int, pk, out: Mat):
+        """out[c] = max over the slot table's kept edges + the self loop (c, c) of the 3-layer PointConv message
+        (== csr_from_slots -> edge_hidden -> segmax_gemm); coo: the ball_query slot table [2, n_centres * max_nbrs]."""
+        _need_gpu(A.base, B.base, out.base, coo)
+        ec, l3 = pk["edge"], pk["fused"]
+        assert coo.dtype == torch.int64 and coo.is_contiguous() and coo.shape == (2, A.rows * max_nbrs)
+        assert A.cols == B.cols == ec.H and out.rows == A.rows and out.cols == l3.N and B.rows >= A.rows
+        dev = A.base.device
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        a = PointConvArgs()
+        a.A, a.lda, a.B, a.ldb = A.ptr, A.ld, B.ptr, B.ld
+        a.slots, a.max_nbrs, a.n_centres, a.n_src = coo.data_ptr(), max_nbrs, A.rows, B.rows
+        a.H, a.H3 = ec.H, l3.N
+        a.W2_split, a.ldw2, a.b2 = ec.W2split.data_ptr(), ec.W2split.stride(0), ec.b2.data_ptr()
+        a.W3_split, a.ldw3, a.b3 = l3.Wsplit.data_ptr(), l3.Wsplit.stride(0), l3.bias.data_ptr()
+        a.s3 = l3.scale.data_ptr() if l3.scale is not None else 0
+        a.t3 = l3.shift.data_ptr() if l3.shift is not None else 0
+        a.relu3 = 1
+        a.out, a.ldo = out.ptr, out.ld
+        a.overflow, a.status = self._flag(dev).data_ptr(), status.data_ptr()
+        check(self.lib.morig_pointconv_fused(C.byref(a), _stream()), "morig_pointconv_fused")
+        if getattr(self, "_csr_status", None) is not None:
+            self._csr_status.append(status)            # a slot naming a source >= n_src: raised at the end of the guarded forward
+        elif int(status.item()) != 0:
+            raise MorigNativeError("morig_pointconv_fused: the slot table names a source row outside B")
 
     # -- point clouds ---------------------------------------------------------------------------------
     def fps(self, pos: Mat, ptr: torch.Tensor, out_ptr: torch.Tensor, start: Optional[torch.Tensor], n_clouds: int,

@@ -153,6 +153,9 @@ def pack_edge_pair(mlps: Sequence[nn.Sequential]):
     return vertex, edges
 
 
+FUSED_POINTCONV_WIDTHS = ((32, 64), (64, 128))        # (H, H3) pairs morig_pointconv_fused is instantiated for
+
+
 def pack_pointconv(local_nn: nn.Sequential, cx: int):
     """PointConv local_nn = MLP([cx+3, H, H, H3]) on [x_j ‖ pos_j - pos_i] (PyG PointConv.message):
     -> source linear over [x | pos] (K = cx+3, with bias), target linear -W1p over the centre position,
@@ -172,7 +175,14 @@ def pack_pointconv(local_nn: nn.Sequential, cx: int):
     W2 = W2.contiguous()
     edge = PackedEdge(H, None, None, W2, _pad_vec(bf, Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp),
                       split_f16(W2) if H >= 32 else None)
-    return dict(src=src, tgt=tgt, edge=edge, last=pack_mlp_layer(l3))
+    # fused kernel (csrc/pointconv_fused.hip): BN2 folds into Linear3 exactly as BN1 folds into Linear2 above
+    fused = None
+    H3 = l3[0].weight.shape[0]
+    if (H, H3) in FUSED_POINTCONV_WIDTHS:
+        W3f, b3f = fold_hidden_affine(l3[0].weight.detach().float(), l3[0].bias.detach().float(), s2, t2)
+        s3, t3 = bn_affine(l3[2])
+        fused = PackedLinear(W3f.contiguous(), b3f.contiguous(), s3.contiguous(), t3.contiguous(), H3, H, split_f16(W3f.contiguous()))
+    return dict(src=src, tgt=tgt, edge=edge, last=pack_mlp_layer(l3), fused=fused)
 
 
 def to_device(obj, device):

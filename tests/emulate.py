@@ -200,6 +200,29 @@ def _emu_segmax_gemm(self, X: Mat, lin, relu, csr: CSR, out: Mat):
     out.view().copy_(res)
 
 
+def _emu_pointconv_can_fuse(self, pk, max_nbrs):
+    return bool(self.emulate_split and pk.get("fused") is not None and max_nbrs == 64 and pk["edge"].s1 is None)
+
+
+def _emu_pointconv_fused(self, A: Mat, B: Mat, coo, max_nbrs, pk, out: Mat):
+    """the definition morig_pointconv_fused implements, written from the slot table (not through the CSR emulation)"""
+    ec, l3 = pk["edge"], pk["fused"]
+    H, M = ec.H, A.rows
+    assert coo.shape == (2, M * max_nbrs) and A.cols == B.cols == H and out.cols == l3.N and out.rows == M
+    slots = coo[0].view(M, max_nbrs)
+    c = torch.arange(M)[:, None]
+    assert int(slots.max()) < B.rows
+    keep = (slots >= 0) & (slots != c)                       # remove_self_loops on the raw index pair ...
+    src = torch.cat([torch.where(keep, slots, c.expand_as(slots)), c], 1)      # ... add_self_loops: (c, c); fillers are duplicates of it
+    a, b = A.view()[:, None, :], B.view()[src]
+    assert not torch.isnan(a).any() and not torch.isnan(b).any()
+    z2 = torch.relu(torch.relu(a + b) @ ec.W2[:H, :H].t() + ec.b2[:H])
+    z3 = torch.relu(z2 @ l3.W[: l3.N, :H].t() + l3.bias[: l3.N])          # BN2 is folded into l3.W / l3.bias (packing.pack_pointconv)
+    if l3.scale is not None:
+        z3 = z3 * l3.scale[: l3.N] + l3.shift[: l3.N]
+    out.view().copy_(z3.amax(1))
+
+
 def _emu_fps(self, pos: Mat, ptr, out_ptr, start, n_clouds, max_cloud_points, n_samples):
     p = pos.view()[:, :3]
     pp, oo = ptr.long().tolist(), out_ptr.long().tolist()
@@ -307,6 +330,8 @@ def _emu_gather_rows(self, src: Mat, idx, dst: Mat):
 
 EmuOps.edge_hidden = _emu_edge_hidden
 EmuOps.segmax_gemm = _emu_segmax_gemm
+EmuOps.pointconv_can_fuse = _emu_pointconv_can_fuse
+EmuOps.pointconv_fused = _emu_pointconv_fused
 EmuOps.fps = _emu_fps
 EmuOps.ball_query = _emu_ball_query
 EmuOps.knn_interpolate = _emu_knn_interpolate

@@ -6,7 +6,7 @@ import torch
 
 from emulate import EmuOps
 from helpers import maxdiff
-from morig_amd import packing
+from morig_amd import native, packing
 from morig_amd.native import Mat
 
 pytestmark = pytest.mark.gpu
@@ -341,6 +341,96 @@ def test_pointconv_two_pass(ops, H, N3):
     ops.segmax_gemm(Mat.of(zg), packing.to_device(lin, DEV), True, cg, Mat.of(og))
     torch.cuda.synchronize()
     assert maxdiff(og, ow) <= 2e-5 * max(1.0, ow.abs().max().item())
+
+
+def _pointconv_module(cx, H, H3, seed):
+    """a PointConv local_nn = MLP([cx+3, H, H, H3]) with non-trivial BatchNorm statistics (negative gammas included)"""
+    g = torch.Generator().manual_seed(seed)
+    dims = [cx + 3, H, H, H3]
+    layers = []
+    for i in range(3):
+        lin = torch.nn.Linear(dims[i], dims[i + 1])
+        bn = torch.nn.BatchNorm1d(dims[i + 1])
+        with torch.no_grad():
+            lin.weight.copy_(torch.randn(dims[i + 1], dims[i], generator=g) / dims[i] ** 0.5)
+            lin.bias.copy_(torch.randn(dims[i + 1], generator=g) * 0.1)
+            bn.weight.copy_(torch.randn(dims[i + 1], generator=g))
+            bn.bias.copy_(torch.randn(dims[i + 1], generator=g) * 0.2)
+            bn.running_mean.copy_(torch.randn(dims[i + 1], generator=g) * 0.3)
+            bn.running_var.copy_(torch.rand(dims[i + 1], generator=g) + 0.5)
+        layers.append(torch.nn.Sequential(lin, torch.nn.ReLU(), bn))
+    return torch.nn.Sequential(*layers).eval()
+
+
+@pytest.mark.parametrize("H,H3,cx", [(32, 64, 0), (64, 128, 64)])
+@pytest.mark.parametrize("n_src,n_ctr,fill", [(700, 300, "mixed"), (9000, 4100, "full"), (40, 33, "sparse")])
+def test_pointconv_fused_matches_the_slot_table_definition_and_the_two_pass_path(ops, H, H3, cx, n_src, n_ctr, fill):
+    """morig_pointconv_fused against (a) the fp32 definition written from the slot table (tests/emulate.py) and (b) the HIP
+    two-pass path over morig_csr_from_slots: full tables (the self loop has no free slot), tables with unused slots, slots
+    naming the centre's own index (dropped by remove_self_loops), centres whose only edge is the self loop."""
+    g = torch.Generator().manual_seed(n_src + H)
+    nn_ = _pointconv_module(cx, H, H3, 3)
+    pk = packing.pack_pointconv(nn_, cx)
+    assert pk["fused"] is not None
+    slots = torch.randint(0, n_src, (n_ctr, 64), generator=g)
+    if fill != "full":
+        drop = torch.rand(n_ctr, 64, generator=g) < (0.3 if fill == "mixed" else 0.95)
+        slots[drop] = -1
+        slots[5] = -1                                           # only the self loop
+    slots[7, 3] = 7                                             # source index == centre index: removed
+    slots[11] = torch.arange(64) % 3 + 1                        # duplicates of three sources
+    coo = torch.stack([slots.reshape(-1), torch.arange(n_ctr).repeat_interleave(64)])
+    coo[1][coo[0] < 0] = -1
+    A, Bm = torch.randn(n_ctr, H, generator=g), torch.randn(n_src, H, generator=g)
+    emu = EmuOps()
+    emu.emulate_split = True
+    want = torch.zeros(n_ctr, H3)
+    emu.pointconv_fused(Mat.of(A), Mat.of(Bm), coo, 64, pk, Mat.of(want))
+    pkd = packing.to_device(pk, DEV)
+    if not ops.fast:
+        assert not ops.pointconv_can_fuse(pkd, 64)              # fp32 MFMA mode: the callers take the two-pass path
+        return
+    assert ops.pointconv_can_fuse(pkd, 64)
+    Ad, Bd, cood = A.to(DEV), Bm.to(DEV), coo.to(DEV)
+    got = torch.full((n_ctr, H3 + 4), float("nan"), device=DEV)
+    ops.pointconv_fused(Mat.of(Ad), Mat.of(Bd), cood, 64, pkd, Mat.of(got, 0, H3))
+    two = torch.zeros(n_ctr, H3, device=DEV)
+    csr = ops.csr_from_slots(cood, n_ctr, 64, n_src)
+    z = torch.zeros(csr.capacity, H, device=DEV)
+    ops.edge_hidden(Mat.of(Ad), Mat.of(Bd), csr, pkd["edge"], Mat.of(z))
+    ops.segmax_gemm(Mat.of(z), pkd["last"], True, csr, Mat.of(two))
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(got[:, H3:]).all()), "wrote outside its window"
+    scale = max(1.0, want.abs().max().item())
+    assert maxdiff(got[:, :H3], want) <= 2e-5 * scale
+    assert maxdiff(got[:, :H3], two.cpu()) <= 2e-5 * scale
+    again = torch.zeros(n_ctr, H3, device=DEV)
+    ops.pointconv_fused(Mat.of(Ad), Mat.of(Bd), cood, 64, pkd, Mat.of(again))
+    assert torch.equal(again, got[:, :H3]), "not deterministic"
+
+
+def test_pointconv_fused_flags_bad_slots_and_overflow(ops):
+    if not ops.fast:
+        pytest.skip("split-fp16 kernel")
+    nn_ = _pointconv_module(0, 32, 64, 5)
+    pkd = packing.to_device(packing.pack_pointconv(nn_, 0), DEV)
+    slots = torch.randint(0, 100, (50, 64))
+    coo = torch.stack([slots.reshape(-1), torch.arange(50).repeat_interleave(64)]).to(DEV)
+    A, Bm = torch.randn(50, 32, device=DEV), torch.randn(100, 32, device=DEV)
+    out = torch.zeros(50, 64, device=DEV)
+    bad = coo.clone()
+    bad[0, 17] = 100                                            # one past the last source row
+    with pytest.raises(native.MorigNativeError):
+        ops.pointconv_fused(Mat.of(A), Mat.of(Bm), bad, 64, pkd, Mat.of(out))
+    flag = ops._flag(A.device)
+    flag.zero_()
+    ops.pointconv_fused(Mat.of(A), Mat.of(Bm), coo, 64, pkd, Mat.of(out))
+    assert int(flag.item()) == 0
+    big = Bm.clone()
+    big[3, 5] = 7.0e4                                           # outside the fp16 range after the first ReLU
+    ops.pointconv_fused(Mat.of(A), Mat.of(big), coo, 64, pkd, Mat.of(out))
+    assert int(flag.item()) == 1
+    flag.zero_()
 
 
 @pytest.mark.parametrize("k", [1, 3])
