@@ -227,17 +227,18 @@ class GCU(NativeModule):
         vertex, (et, eg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_pos, self.edge_conv_geo.nn_pos])
         return dict(vertex=vertex, et=et, eg=eg, mlp=packing.pack_mlp_layer(self.mlp[0]))
 
-    def run(self, ops, x: Mat, csr_tpl, csr_geo, out: Mat):
-        """x: [n, C] window (16-byte aligned rows) -> out: [n, O] window."""
+    def run(self, ops, x: Mat, csr_tpl, csr_geo, out: Mat, split_in: bool = False, split_out: bool = False):
+        """x: [n, C] window (16-byte aligned rows) -> out: [n, O] window. split_in / split_out: the x / out window is in the
+        split-fp16 activation layout (GEMM -> GEMM hand-off between consecutive units and into the wide layers)."""
         pk = self.packed(x.base.device)
         n, H = x.rows, pk["et"].H
         dev = x.base.device
         ab = ops.empty(n, 4 * H, dev)
-        ops.gemm(x, pk["vertex"], relu=False, Y=Mat.of(ab))
+        ops.gemm(x, pk["vertex"], relu=False, Y=Mat.of(ab), x_split=split_in)
         ec = ops.empty(n, 2 * H, dev)
         ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["et"], Mat.of(ec, 0, H))
         ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["eg"], Mat.of(ec, H, H))
-        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out)
+        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split_out)
 
     def _forward(self, pos, tpl_edge_index, geo_edge_index):
         ops = get_ops()

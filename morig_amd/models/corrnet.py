@@ -104,20 +104,20 @@ class CorrNet(NativeModule):
     def _side_stream(self, dev):
         key = (dev.type, dev.index)
         if self._streams.get(key) is None:
-            self._streams[key] = torch.cuda.Stream(device=dev)
+            self._streams[key] = torch.cuda.Stream(device=dev)      # (a high-priority stream measured no different)
         return self._streams[key]
 
     # ------------------------------------------------------------------------------------------
     def _pack(self):
         l1 = self.vtx_mlp[0][0]
         W = l1[0].weight.detach()        # input order (:46): [x_global(1024) | vtx(3) | x_1..x_4(864)]
-        in_cols = [self.VTX + i for i in range(3)] + list(range(864))
+        in_cols = [self.VTX + i for i in range(3)] + list(range(864))      # feature buffer: [x_1..x_4 | vtx chunk]
         fp4 = self.pts_fp4_module.nn     # input order (FPModule): [interpolated global(512) | x_skip(256)]
         W4 = fp4[0][0].weight.detach()
         return dict(
             glb=packing.pack_mlp_layer(self.vtx_mlp_glb[0]),
             g=packing.pack_linear(W[:, :1024]),
-            t1=packing.pack_linear(W[:, 1024:], l1[0].bias, l1[2], in_cols=in_cols, k_total=self.VTX + 3),
+            t1=packing.pack_linear(W[:, 1024:], l1[0].bias, l1[2], in_cols=in_cols, k_total=self.VTX + 32),
             t2=packing.pack_mlp_layer(self.vtx_mlp[0][1]),
             t3=packing.pack_linear(self.vtx_mlp[1].weight, self.vtx_mlp[1].bias),
             fp4_g=packing.pack_linear(W4[:, :512]),
@@ -134,32 +134,36 @@ class CorrNet(NativeModule):
         dev = data.vtx.device
         pk = self.packed(dev)
         n = data.vtx.shape[0]
-        ld = self.VTX + 4
+        # feature buffer [x_1(32) | x_2(64) | x_3(256) | x_4(512) | vtx(3) + 29 zero columns]: every window is a whole number
+        # of 32-column chunks, so on the split-fp16 path the units hand their outputs to each other and to the three wide
+        # layers in the split activation layout and those layers run on the LDS-DMA GEMM (as in the rig networks)
+        sp = ops.split_activations
+        ld = self.VTX + 32
         wide = ops.empty(n, ld, dev)
         v4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
         ops.copy2d(Mat.of(data.vtx.float().contiguous()), Mat.of(v4, 0, 3))
-        ops.copy2d(Mat.of(v4), Mat.of(wide, self.VTX, 4))
+        ops.copy2d_pad(Mat.of(v4, 0, 3), Mat.of(wide, self.VTX, 32), split=sp)
         csr_tpl = ops.csr_build(data.tpl_edge_index, n)
         csr_geo = ops.csr_build(data.geo_edge_index, n)
         csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)      # 4-aligned segments for the 128/256-wide layers
         csr_tpl4 = ops.csr_build(data.tpl_edge_index, n, pad4=True)
         gcus = (self.vtx_gcu_1, self.vtx_gcu_2, self.vtx_gcu_3, self.vtx_gcu_4)
         widths = (32, 64, 256, 512)
-        x_in = Mat.of(wide, self.VTX, 3)
+        x_in, split_in = Mat.of(v4, 0, 3), False
         for g, off, w in zip(gcus, self.X, widths):
             out = Mat.of(wide, off, w)
-            g.run(ops, x_in, csr_tpl4 if w >= 256 else csr_tpl, csr_geo4 if w >= 256 else csr_geo, out)
-            x_in = out
+            g.run(ops, x_in, csr_tpl4 if w >= 256 else csr_tpl, csr_geo4 if w >= 256 else csr_geo, out, split_in=split_in, split_out=sp)
+            x_in, split_in = out, sp
         pooled = ops.empty(n_graphs, 1024, dev)
-        ops.gemm(Mat.of(wide, 0, 864), pk["glb"], relu=True, seg=seg, pool=pooled)
+        ops.gemm(Mat.of(wide, 0, 864), pk["glb"], relu=True, seg=seg, pool=pooled, x_split=sp)
         gb = ops.empty(n_graphs, 1024, dev)
         ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
         h1 = ops.empty(n, 1024, dev)
-        ops.gemm(Mat.of(wide, 0, self.VTX + 3), pk["t1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg)
+        ops.gemm(Mat.of(wide, 0, self.VTX + 32), pk["t1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg, x_split=sp, y_split=sp)
         h2 = ops.empty(n, 256, dev)
-        ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2))
+        ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2), x_split=sp, y_split=sp)
         raw = ops.empty(n, self.output_feature, dev)
-        ops.gemm(Mat.of(h2), pk["t3"], relu=False, Y=Mat.of(raw))
+        ops.gemm(Mat.of(h2), pk["t3"], relu=False, Y=Mat.of(raw), x_split=sp)
         out_vtx = torch.empty((n, self.output_feature), dtype=torch.float32, device=dev)
         ops.rownorm(Mat.of(raw), n, 1, out_vtx, self.output_feature, 0)
         return out_vtx
