@@ -270,6 +270,14 @@ int morig_knn_interpolate(const float* feat, int32_t ldf, int32_t C, const float
                           const int32_t* ptr_x, const float* pos_y, int32_t ldy, const int32_t* ptr_y,
                           int32_t n_clouds, int32_t n_targets, int32_t max_targets_per_cloud, int32_t k,
                           int32_t* idx_ws, float* wgt_ws, float* out, int32_t ldo, void* stream);
+/* The two halves of morig_knn_interpolate, for callers that know the geometry before the features (the CorrNet point branch
+ * runs the three searches on its geometry stream, under the convolutions): the k nearest sources of every target and their
+ * weights -- slots past k, or past the cloud's point count, carry weight 0 -- then the weighted mean of feature rows. */
+int morig_knn_search(const float* pos_x, int32_t ldx, const int32_t* ptr_x, const float* pos_y, int32_t ldy,
+                     const int32_t* ptr_y, int32_t n_clouds, int32_t n_targets, int32_t max_targets_per_cloud, int32_t k,
+                     int32_t* idx, float* wgt, void* stream);
+int morig_knn_apply(const float* feat, int32_t ldf, int32_t C, const int32_t* idx, const float* wgt, int32_t n_targets,
+                    float* out, int32_t ldo, void* stream);
 /* knn(out_pts, out_vtx, 1, cosine=True) on L2-normalised rows (corrnet.py:64): arg-max dot product
  * within the cloud; C must be 64. */
 int morig_cosine_nn(const float* v, int32_t ldv, const int32_t* ptr_v, const float* p, int32_t ldp,

@@ -6,6 +6,19 @@
 // discrete decision depends on it (distance = ((dx^2 + dy^2) + dz^2), no FMA contraction; sqrt before "<= bandwidth").
 #include "common.h"
 
+// Every kernel in this file makes index decisions (arg-max, "< r^2", k nearest, voxel cells) or reproduces a summation order, so
+// products and sums round separately, as on the CPU: no fma contraction anywhere below. (hipcc's default contracts, and the
+// __fmul_rn / __dadd_rn ... helpers do not prevent it: they are header functions with plain operators, compiled under the
+// default -- hence the macros, which put the same operators under this pragma.)
+#pragma clang fp contract(off)
+#define __fmul_rn(a, b) ((a) * (b))
+#define __fadd_rn(a, b) ((a) + (b))
+#define __fsub_rn(a, b) ((a) - (b))
+#define __dmul_rn(a, b) ((a) * (b))
+#define __dadd_rn(a, b) ((a) + (b))
+#define __dsub_rn(a, b) ((a) - (b))
+#define __ddiv_rn(a, b) ((a) / (b))
+
 namespace morig {
 
 __device__ __forceinline__ double sqdist3d(double ax, double ay, double az, double bx, double by, double bz) {

@@ -7,11 +7,29 @@
 // are bit-identical to the fp32 restatement they are tested against (ties -> lowest index).
 #include "common.h"
 
+// Every kernel in this file makes index decisions (arg-max, "< r^2", k nearest, voxel cells) or reproduces a summation order, so
+// products and sums round separately, as on the CPU: no fma contraction anywhere below. (hipcc's default contracts, and the
+// __fmul_rn / __dadd_rn ... helpers do not prevent it: they are header functions with plain operators, compiled under the
+// default -- hence the macros, which put the same operators under this pragma.)
+#pragma clang fp contract(off)
+#define __fmul_rn(a, b) ((a) * (b))
+#define __fadd_rn(a, b) ((a) + (b))
+#define __fsub_rn(a, b) ((a) - (b))
+#define __dmul_rn(a, b) ((a) * (b))
+#define __dadd_rn(a, b) ((a) + (b))
+#define __dsub_rn(a, b) ((a) - (b))
+#define __ddiv_rn(a, b) ((a) / (b))
+
 namespace morig {
 
+// (x - y)^2 summed left to right with every product and sum rounded: the value the CPU restatement (oracle/pyg_primitives.py) and
+// torch's (diff * diff).sum(-1) produce. hipcc contracts a * b + c into an fma by default, and __fmul_rn / __fadd_rn do NOT stop
+// it (header functions with plain operators, compiled under the default): plain operators under the pragma do.
+// [r02: the scalar callers were being contracted until now; the packed FPS / k-NN loops never were]
 __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
-    const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
-    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+#pragma clang fp contract(off)
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return (dx * dx + dy * dy) + dz * dz;
 }
 
 // Wave-wide max of a non-negative float / min of an int WITHOUT the LDS crossbar: 4 DPP steps give every lane its
@@ -281,7 +299,11 @@ constexpr int KNN_TILE = 1024;
 __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xs, int ldx, const int* __restrict__ ptr_x,
                                                    const float* __restrict__ yt, int ldy, const int* __restrict__ ptr_y,
                                                    int n_clouds, int k, int* __restrict__ idx, float* __restrict__ wgt) {
-    __shared__ float sx[KNN_TILE * 3];
+    // sources in LDS as three coordinate arrays: a pair of adjacent sources is one 8-byte broadcast read per coordinate and the
+    // distance of the pair is 8 packed-fp32 instructions (v_pk_add/mul_f32 round each component exactly like the scalar ops of
+    // sqdist3, contraction off) instead of 16 scalar ones -- the scan is VALU-bound. An odd tail is padded with a point at
+    // infinity (distance +inf: never below the running third-best).
+    __shared__ __attribute__((aligned(8))) float sx[KNN_TILE], sy[KNN_TILE], sz[KNN_TILE];
     // blocks are assigned per (cloud, chunk of 256 targets): blockIdx.y = cloud
     const int c = blockIdx.y;
     const int ys = ptr_y[c], ye = ptr_y[c + 1];
@@ -291,26 +313,35 @@ __global__ __launch_bounds__(256) void knn3_kernel(const float* __restrict__ xs,
     const bool live = t < ye;
     float tx = 0.f, ty = 0.f, tz = 0.f;
     if (live) { const float* q = yt + (size_t)t * ldy; tx = q[0]; ty = q[1]; tz = q[2]; }
+    const fps_f2 t2x = {tx, tx}, t2y = {ty, ty}, t2z = {tz, tz};
     float d0 = INFINITY, d1 = INFINITY, d2 = INFINITY;
     int i0 = -1, i1 = -1, i2 = -1;
+    auto offer = [&](float d, int j) {
+        if (d < d2) {                                // strict: on ties the earlier (lower) index stays ahead
+            if (d < d1) {
+                d2 = d1; i2 = i1;
+                if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; } else { d1 = d; i1 = j; }
+            } else { d2 = d; i2 = j; }
+        }
+    };
     for (int base = x0; base < x1; base += KNN_TILE) {
         const int cnt = min(KNN_TILE, x1 - base);
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-            const float* q = xs + (size_t)(base + i) * ldx;
-            sx[3 * i] = q[0]; sx[3 * i + 1] = q[1]; sx[3 * i + 2] = q[2];
+        for (int i = threadIdx.x; i < ((cnt + 1) & ~1); i += blockDim.x) {
+            float qx = INFINITY, qy = INFINITY, qz = INFINITY;
+            if (i < cnt) { const float* q = xs + (size_t)(base + i) * ldx; qx = q[0]; qy = q[1]; qz = q[2]; }
+            sx[i] = qx; sy[i] = qy; sz[i] = qz;
         }
         __syncthreads();
         if (live) {
-            for (int i = 0; i < cnt; ++i) {
-                const float d = sqdist3(sx[3 * i], sx[3 * i + 1], sx[3 * i + 2], tx, ty, tz);   // (x - y)^2
-                const int j = base + i;
-                if (d < d2) {                        // strict: on ties the earlier (lower) index stays ahead
-                    if (d < d1) {
-                        d2 = d1; i2 = i1;
-                        if (d < d0) { d1 = d0; i1 = i0; d0 = d; i0 = j; } else { d1 = d; i1 = j; }
-                    } else { d2 = d; i2 = j; }
-                }
+#pragma clang fp contract(off)
+            for (int i = 0; i < cnt; i += 2) {
+                const fps_f2 dx = *reinterpret_cast<const fps_f2*>(sx + i) - t2x;
+                const fps_f2 dy = *reinterpret_cast<const fps_f2*>(sy + i) - t2y;
+                const fps_f2 dz = *reinterpret_cast<const fps_f2*>(sz + i) - t2z;
+                const fps_f2 d = (dx * dx + dy * dy) + dz * dz;                  // sqdist3's order: (x - y)^2, source minus target
+                offer(d[0], base + i);
+                offer(d[1], base + i + 1);
             }
         }
     }
@@ -414,24 +445,42 @@ extern "C" int morig_radius_sample(const float* x, int32_t ldx, int32_t nx, cons
     return MORIG_OK;
 }
 
+extern "C" int morig_knn_search(const float* pos_x, int32_t ldx, const int32_t* ptr_x, const float* pos_y, int32_t ldy,
+                                const int32_t* ptr_y, int32_t n_clouds, int32_t n_targets, int32_t max_targets_per_cloud, int32_t k,
+                                int32_t* idx, float* wgt, void* stream) {
+    if (!pos_x || !pos_y || !ptr_x || !ptr_y || !idx || !wgt) return MORIG_E_INVALID;
+    if (k < 1 || k > 3) return MORIG_E_UNSUPPORTED;
+    if (n_clouds <= 0 || n_targets < 0 || max_targets_per_cloud <= 0 || ldx < 3 || ldy < 3) return MORIG_E_INVALID;
+    if (n_targets == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_KNN_INTERP, s, 0.0, 24.0 * n_targets);
+    hipLaunchKernelGGL(knn3_kernel, dim3(cdiv(max_targets_per_cloud, 256), n_clouds), dim3(256), 0, s, pos_x, ldx, ptr_x, pos_y, ldy,
+                       ptr_y, n_clouds, k, idx, wgt);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_knn_apply(const float* feat, int32_t ldf, int32_t C, const int32_t* idx, const float* wgt, int32_t n_targets,
+                               float* out, int32_t ldo, void* stream) {
+    if (!feat || !idx || !wgt || !out || n_targets < 0 || C <= 0 || ldo < C || ldf < C) return MORIG_E_INVALID;
+    if (n_targets == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_KNN_INTERP, s, 0.0, 4.0 * n_targets * (double)C * 4.0);
+    int64_t blocks = ((int64_t)n_targets * C + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(knn_interp_kernel, dim3((int)blocks), dim3(256), 0, s, feat, ldf, C, idx, wgt, n_targets, out, ldo);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
 extern "C" int morig_knn_interpolate(const float* feat, int32_t ldf, int32_t C, const float* pos_x, int32_t ldx,
                                      const int32_t* ptr_x, const float* pos_y, int32_t ldy, const int32_t* ptr_y,
                                      int32_t n_clouds, int32_t n_targets, int32_t max_targets_per_cloud, int32_t k,
                                      int32_t* idx_ws, float* wgt_ws, float* out, int32_t ldo, void* stream) {
-    if (!feat || !pos_x || !pos_y || !ptr_x || !ptr_y || !idx_ws || !wgt_ws || !out) return MORIG_E_INVALID;
-    if (k < 1 || k > 3) return MORIG_E_UNSUPPORTED;
-    if (n_clouds <= 0 || n_targets < 0 || C <= 0 || ldo < C || ldf < C || ldx < 3 || ldy < 3) return MORIG_E_INVALID;
-    if (n_targets == 0) return MORIG_OK;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    ProfScope ps(K_KNN_INTERP, s, 0.0, 4.0 * n_targets * (double)C * (k + 1));
-    hipLaunchKernelGGL(knn3_kernel, dim3(cdiv(max_targets_per_cloud, 256), n_clouds), dim3(256), 0, s, pos_x, ldx, ptr_x, pos_y, ldy,
-                       ptr_y, n_clouds, k, idx_ws, wgt_ws);
-    MORIG_LAUNCH_CHECK();
-    int64_t blocks = ((int64_t)n_targets * C + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(knn_interp_kernel, dim3((int)blocks), dim3(256), 0, s, feat, ldf, C, idx_ws, wgt_ws, n_targets, out, ldo);
-    MORIG_LAUNCH_CHECK();
-    return MORIG_OK;
+    if (!feat || !out || C <= 0 || ldo < C || ldf < C) return MORIG_E_INVALID;
+    const int st = morig_knn_search(pos_x, ldx, ptr_x, pos_y, ldy, ptr_y, n_clouds, n_targets, max_targets_per_cloud, k, idx_ws, wgt_ws, stream);
+    if (st != MORIG_OK) return st;
+    return morig_knn_apply(feat, ldf, C, idx_ws, wgt_ws, n_targets, out, ldo, stream);
 }
 
 extern "C" int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t rows, int32_t cols,

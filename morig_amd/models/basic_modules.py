@@ -388,14 +388,20 @@ class SAModule(NativeModule):
         cx = self.conv.local_nn[0][0].weight.shape[1] - 3
         return packing.pack_pointconv(self.conv.local_nn, cx)
 
-    def run(self, ops, xp: torch.Tensor, cx: int, pos_new: torch.Tensor, ptr: torch.Tensor, out_ptr: torch.Tensor, n_clouds: int):
+    def neighbours(self, ops, xp: torch.Tensor, cx: int, pos_new: torch.Tensor, ptr: torch.Tensor, out_ptr: torch.Tensor, n_clouds: int):
+        """the ball query of ``run`` (slot table): positions only, so a caller can issue it before the features exist"""
+        return ops.ball_query(Mat.of(xp, cx, 3), ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, self.r, self.max_num_neighbors)
+
+    def run(self, ops, xp: torch.Tensor, cx: int, pos_new: torch.Tensor, ptr: torch.Tensor, out_ptr: torch.Tensor, n_clouds: int,
+            coo: Optional[torch.Tensor] = None):
         """xp: [N, ld] = [x(cx) | pos(3) | pad]; pos_new: the sampled centres [M, 4]; ptr / out_ptr: int32 cloud offsets
         of the sources / centres; returns x_new [M, H3].
         PointConv's first Linear on [x_j ‖ pos_j - pos_i] splits per point: B_j = W1 [x_j ‖ pos_j] + b1, A_i = -W1p pos_i."""
         dev = xp.device
         pk = self.packed(dev)
         N, M = xp.shape[0], pos_new.shape[0]
-        coo = ops.ball_query(Mat.of(xp, cx, 3), ptr, Mat.of(pos_new, 0, 3), out_ptr, n_clouds, self.r, self.max_num_neighbors)
+        if coo is None:
+            coo = self.neighbours(ops, xp, cx, pos_new, ptr, out_ptr, n_clouds)
         H = pk["edge"].H
         bsrc = ops.empty(N, H, dev)
         ops.gemm(Mat.of(xp, 0, cx + 3), pk["src"], relu=False, Y=Mat.of(bsrc))
@@ -478,17 +484,24 @@ class FPModule(NativeModule):
     def _pack(self):
         return [packing.pack_mlp_layer(l) for l in self.nn]
 
+    def search(self, ops, pos_x: torch.Tensor, ptr_x: torch.Tensor, pos_y: torch.Tensor, ptr_y: torch.Tensor, n_clouds: int,
+               max_targets_per_cloud: int):
+        """the geometry half of ``run`` (nearest sources and weights): depends on positions only, so a caller can issue it early"""
+        return ops.knn_search(Mat.of(pos_x, 0, 3), ptr_x, Mat.of(pos_y, 0, 3), ptr_y, n_clouds, max_targets_per_cloud, self.k)
+
     def run(self, ops, feat: torch.Tensor, pos_x: torch.Tensor, ptr_x: torch.Tensor, skip: Optional[torch.Tensor],
-            pos_y: torch.Tensor, ptr_y: torch.Tensor, n_clouds: int, max_targets_per_cloud: int) -> torch.Tensor:
-        """feat [Nx, Cf] at pos_x ([Nx, >=3]) interpolated onto pos_y ([Ny, >=3]), concatenated with skip [Ny, Cs], then the MLP."""
+            pos_y: torch.Tensor, ptr_y: torch.Tensor, n_clouds: int, max_targets_per_cloud: int, nn=None) -> torch.Tensor:
+        """feat [Nx, Cf] at pos_x ([Nx, >=3]) interpolated onto pos_y ([Ny, >=3]), concatenated with skip [Ny, Cs], then the MLP.
+        nn: the result of ``search`` for the same geometry (None: searched here)."""
         dev = feat.device
         layers = self.packed(dev)
         ny, cf = pos_y.shape[0], feat.shape[1]
         cs = 0 if skip is None else skip.shape[1]
         ld = (cf + cs + 3) // 4 * 4                       # GEMM operand rows are 16-byte aligned; the padding stays zero
         cat = ops.empty(ny, ld, dev) if ld == cf + cs else torch.zeros((ny, ld), dtype=torch.float32, device=dev)
-        ops.knn_interpolate(Mat.of(feat), Mat.of(pos_x, 0, 3), ptr_x, Mat.of(pos_y, 0, 3), ptr_y, n_clouds, max_targets_per_cloud,
-                            self.k, Mat.of(cat, 0, cf))
+        if nn is None:
+            nn = self.search(ops, pos_x, ptr_x, pos_y, ptr_y, n_clouds, max_targets_per_cloud)
+        ops.knn_apply(Mat.of(feat), nn, Mat.of(cat, 0, cf))
         if skip is not None:
             ops.copy2d(Mat.of(skip), Mat.of(cat, cf, cs))
         h = Mat.of(cat, 0, cf + cs)

@@ -15,6 +15,7 @@ cosine 1-NN matching (models/corrnet.py:63-65). Restructurings (exact up to fp32
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 
@@ -101,8 +102,8 @@ class CorrNet(NativeModule):
         st["_streams"], st["last_plan"] = {}, None        # HIP stream handles and the last forward's host plan are not state
         return st
 
-    def _side_stream(self, dev):
-        key = (dev.type, dev.index)
+    def _side_stream(self, dev, which: int = 0):
+        key = (dev.type, dev.index, which)
         if self._streams.get(key) is None:
             self._streams[key] = torch.cuda.Stream(device=dev)      # (a high-priority stream measured no different)
         return self._streams[key]
@@ -168,23 +169,49 @@ class CorrNet(NativeModule):
         ops.rownorm(Mat.of(raw), n, 1, out_vtx, self.output_feature, 0)
         return out_vtx
 
-    def _sample_levels(self, ops, pos0: torch.Tensor, plan: _HostPlan):
-        """The three FPS levels depend only on positions (pos_{l+1} = pos_l[fps(pos_l)], models/basic_modules.py:75,85),
-        not on the PointConv features: run them back to back, ahead of the convolutions. Each occupies one CU per cloud
-        for its whole run, so this is the part of the point branch that overlaps the vertex branch almost for free."""
+    def _geometry(self, ops, pos0: torch.Tensor, plan: _HostPlan, geo_stream=None):
+        """Everything in the point branch that depends on positions only: the three FPS levels (pos_{l+1} = pos_l[fps(pos_l)],
+        models/basic_modules.py:75,85) and the nearest-source searches of the three interpolations (:134). With `geo_stream`
+        they run there, back to back, while the caller's stream works through the convolutions: FPS occupies one CU per cloud
+        for milliseconds and nothing else in the branch can start before its first level, so the rest of the geometry should
+        not queue behind the feature chain (or the feature chain behind it). -> (levels, searches, wait)."""
         dev = pos0.device
-        levels = [pos0]
-        for level in range(3):
-            cur = levels[-1]
-            M = sum(plan.counts[level + 1])
-            idx = ops.fps(Mat.of(cur, 0, 3), plan.ptr[level], plan.ptr[level + 1], plan.start[level], plan.B,
-                          max(plan.counts[level]), M)
-            nxt = torch.zeros((M, 4), dtype=torch.float32, device=dev)
-            ops.gather_rows(Mat.of(cur, 0, 3), idx, Mat.of(nxt, 0, 3))
-            levels.append(nxt)
-        return levels
+        cur = torch.cuda.current_stream(dev) if geo_stream is not None else None
+        events = {}
 
-    def _point_branch(self, ops, data, plan: _HostPlan):
+        def mark(tag, *tensors):
+            if geo_stream is not None:
+                events[tag] = torch.cuda.Event()
+                events[tag].record(geo_stream)
+                for t in tensors:
+                    t.record_stream(cur)                   # allocated on the geometry stream, consumed on the caller's
+
+        def wait(tag):
+            if geo_stream is not None:
+                cur.wait_event(events[tag])
+
+        if geo_stream is not None:
+            geo_stream.wait_stream(cur)                    # pos0 is written on the caller's stream
+            pos0.record_stream(geo_stream)
+        levels = [pos0]
+        with (torch.cuda.stream(geo_stream) if geo_stream is not None else contextlib.nullcontext()):
+            for level in range(3):
+                src = levels[-1]
+                M = sum(plan.counts[level + 1])
+                idx = ops.fps(Mat.of(src, 0, 3), plan.ptr[level], plan.ptr[level + 1], plan.start[level], plan.B,
+                              max(plan.counts[level]), M)
+                nxt = torch.zeros((M, 4), dtype=torch.float32, device=dev)
+                ops.gather_rows(Mat.of(src, 0, 3), idx, Mat.of(nxt, 0, 3))
+                levels.append(nxt)
+                mark(level + 1, nxt)
+            searches = {}
+            for lvl, fp in ((3, self.pts_fp3_module), (2, self.pts_fp2_module), (1, self.pts_fp1_module)):
+                searches[lvl] = fp.search(ops, levels[lvl], plan.ptr[lvl], levels[lvl - 1], plan.ptr[lvl - 1], plan.B,
+                                          max(plan.counts[lvl - 1]))
+            mark("knn", *[t for nn in searches.values() if isinstance(nn, tuple) for t in nn])
+        return levels, searches, wait
+
+    def _point_branch(self, ops, data, plan: _HostPlan, geo_stream=None):
         dev = data.pts.device
         pk = self.packed(dev)
         B = plan.B
@@ -193,11 +220,14 @@ class CorrNet(NativeModule):
         ops.copy2d(Mat.of(data.pts.float().contiguous()), Mat.of(pos0, 0, 3))
         counts0, c1, c2, c3 = plan.counts
         ptr0, ptr1, ptr2, ptr3 = plan.ptr
-        _, pos1, pos2, pos3 = self._sample_levels(ops, pos0, plan)
+        (_, pos1, pos2, pos3), searches, wait = self._geometry(ops, pos0, plan, geo_stream)
+        wait(1)
         x1 = self.pts_sa1_module.run(ops, pos0, 0, pos1, ptr0, ptr1, B)
         xp1, _ = _with_pos(ops, x1, pos1)
+        wait(2)
         x2 = self.pts_sa2_module.run(ops, xp1, 64, pos2, ptr1, ptr2, B)
         xp2, _ = _with_pos(ops, x2, pos2)
+        wait(3)
         x3 = self.pts_sa3_module.run(ops, xp2, 128, pos3, ptr2, ptr3, B)
         xp3, _ = _with_pos(ops, x3, pos3)
         M3 = x3.shape[0]
@@ -213,12 +243,13 @@ class CorrNet(NativeModule):
         f4 = ops.empty(M3, 256, dev)
         ops.gemm(Mat.of(f4a), pk["fp4_2"], relu=True, Y=Mat.of(f4))
 
-        def propagate(fp: FPModule, feat, pos_x, ptr_x, skip, pos_y, ptr_y, counts_y):
-            return fp.run(ops, feat, pos_x, ptr_x, skip, pos_y, ptr_y, B, max(counts_y))
+        def propagate(fp: FPModule, feat, pos_x, ptr_x, skip, pos_y, ptr_y, counts_y, nn):
+            return fp.run(ops, feat, pos_x, ptr_x, skip, pos_y, ptr_y, B, max(counts_y), nn=nn)
 
-        f3 = propagate(self.pts_fp3_module, f4, pos3, ptr3, x2, pos2, ptr2, c2)
-        f2 = propagate(self.pts_fp2_module, f3, pos2, ptr2, x1, pos1, ptr1, c1)
-        f1 = propagate(self.pts_fp1_module, f2, pos1, ptr1, None, pos0, ptr0, counts0)
+        wait("knn")
+        f3 = propagate(self.pts_fp3_module, f4, pos3, ptr3, x2, pos2, ptr2, c2, searches[3])
+        f2 = propagate(self.pts_fp2_module, f3, pos2, ptr2, x1, pos1, ptr1, c1, searches[2])
+        f1 = propagate(self.pts_fp1_module, f2, pos1, ptr1, None, pos0, ptr0, counts0, searches[1])
         p1 = ops.empty(N0, 64, dev)
         ops.gemm(Mat.of(f1), pk["pm1"], relu=True, Y=Mat.of(p1))
         raw = ops.empty(N0, self.output_feature, dev)
@@ -248,8 +279,9 @@ class CorrNet(NativeModule):
             main = torch.cuda.current_stream(dev)
             side = self._side_stream(dev)
             side.wait_stream(main)
+            geo = self._side_stream(dev, 1) if os.environ.get("MORIG_GEO_STREAM", "1") != "0" else None
             with torch.cuda.stream(side):
-                out_pts, ptr_p = self._point_branch(ops, data, plan)
+                out_pts, ptr_p = self._point_branch(ops, data, plan, geo)
             ops.reserve_cus(B)                         # FPS holds one CU per cloud
             try:
                 out_vtx = self._vertex_branch(ops, data, seg, B)

@@ -107,6 +107,9 @@ _SIGNATURES = {
     "morig_segmax_affine": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_knn_interpolate": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_knn_search": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   c_i32p, c_f32p, C.c_void_p]),
+    "morig_knn_apply": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_cosine_nn": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, C.c_void_p]),
     "morig_sigmoid_minmax": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_cosine_knn": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -593,6 +596,26 @@ class NativeOps:
         check(self.lib.morig_knn_interpolate(feat.ptr, feat.ld, feat.cols, pos_x.ptr, pos_x.ld, _p(ptr_x), pos_y.ptr, pos_y.ld,
                                              _p(ptr_y), n_clouds, nt, max_targets_per_cloud, k, _p(idx), _p(wgt), out.ptr, out.ld,
                                              _stream()), "morig_knn_interpolate")
+
+    def knn_search(self, pos_x: Mat, ptr_x: torch.Tensor, pos_y: Mat, ptr_y: torch.Tensor, n_clouds: int,
+                   max_targets_per_cloud: int, k: int):
+        """the geometry half of knn_interpolate: -> (idx [ny, 3] int32, wgt [ny, 3]) for ``knn_apply``."""
+        _need_gpu(pos_x.base, pos_y.base)
+        nt = pos_y.rows
+        dev = pos_x.base.device
+        idx = torch.empty((nt, 3), dtype=torch.int32, device=dev)
+        wgt = torch.empty((nt, 3), dtype=torch.float32, device=dev)
+        check(self.lib.morig_knn_search(pos_x.ptr, pos_x.ld, _p(ptr_x), pos_y.ptr, pos_y.ld, _p(ptr_y), n_clouds, nt,
+                                        max_targets_per_cloud, k, _p(idx), _p(wgt), _stream()), "morig_knn_search")
+        return idx, wgt
+
+    def knn_apply(self, feat: Mat, nn, out: Mat):
+        """out[t] = sum_s w_s feat[idx_s] / sum_s w_s with (idx, wgt) = nn from ``knn_search``."""
+        idx, wgt = nn
+        _need_gpu(feat.base, out.base, idx, wgt)
+        assert out.rows == idx.shape[0] and out.cols == feat.cols
+        check(self.lib.morig_knn_apply(feat.ptr, feat.ld, feat.cols, _p(idx), _p(wgt), out.rows, out.ptr, out.ld, _stream()),
+              "morig_knn_apply")
 
     def cosine_nn(self, v: Mat, ptr_v: torch.Tensor, p: Mat, ptr_p: torch.Tensor, n_clouds: int, max_rows_per_cloud: int):
         _need_gpu(v.base, p.base)

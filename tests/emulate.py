@@ -259,6 +259,14 @@ def _emu_knn_interpolate(self, feat: Mat, pos_x: Mat, ptr_x, pos_y: Mat, ptr_y, 
     out.view().copy_(res)
 
 
+def _emu_knn_search(self, pos_x: Mat, ptr_x, pos_y: Mat, ptr_y, n_clouds, max_targets_per_cloud, k):
+    return dict(px=pos_x.view()[:, :3].clone(), py=pos_y.view()[:, :3].clone(), bx=_batch_from_ptr(ptr_x), by=_batch_from_ptr(ptr_y), k=k)
+
+
+def _emu_knn_apply(self, feat: Mat, nn, out: Mat):
+    out.view().copy_(_P.knn_interpolate(feat.view(), nn["px"], nn["py"], nn["bx"], nn["by"], k=nn["k"]))
+
+
 def _emu_cosine_nn(self, v: Mat, ptr_v, p: Mat, ptr_p, n_clouds, max_rows_per_cloud):
     vv, pp = v.view(), p.view()
     pv, pq = ptr_v.long().tolist(), ptr_p.long().tolist()
@@ -335,6 +343,8 @@ EmuOps.pointconv_fused = _emu_pointconv_fused
 EmuOps.fps = _emu_fps
 EmuOps.ball_query = _emu_ball_query
 EmuOps.knn_interpolate = _emu_knn_interpolate
+EmuOps.knn_search = _emu_knn_search
+EmuOps.knn_apply = _emu_knn_apply
 EmuOps.cosine_nn = _emu_cosine_nn
 EmuOps.gather_rows = _emu_gather_rows
 EmuOps.sigmoid_minmax = _emu_sigmoid_minmax

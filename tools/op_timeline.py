@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from morig_amd import models, native, synth          # noqa: E402
 
-OPS = ["gemm", "edgeconv", "edge_hidden", "segmax_gemm", "pointconv_fused", "fps", "ball_query", "csr_from_slots", "csr_build", "knn_interpolate",
+OPS = ["knn_search", "knn_apply", "gemm", "edgeconv", "edge_hidden", "segmax_gemm", "pointconv_fused", "fps", "ball_query", "csr_from_slots", "csr_build", "knn_interpolate",
        "gather_rows", "copy2d", "copy2d_pad", "cosine_nn", "rownorm"]
 
 
