@@ -144,10 +144,15 @@ class CorrNet(NativeModule):
         v4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
         ops.copy2d(Mat.of(data.vtx.float().contiguous()), Mat.of(v4, 0, 3))
         ops.copy2d_pad(Mat.of(v4, 0, 3), Mat.of(wide, self.VTX, 32), split=sp)
-        csr_tpl = ops.csr_build(data.tpl_edge_index, n)
-        csr_geo = ops.csr_build(data.geo_edge_index, n)
-        csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)      # 4-aligned segments for the 128/256-wide layers
+        # ONE pair of CSRs, with 4-aligned segments (what the 128/256-wide EdgeConv kernels want). The two narrow units run on
+        # them too: padding repeats an edge of the segment, harmless under max, and costs them ~20 % more rows (+0.06 ms)
+        # where a second, unpadded pair of CSR builds cost 0.21 ms. (The rig networks keep both pairs: their narrow layers
+        # run over five keyframe replicas, so there the extra rows cost more than the builds.)
+        csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)
         csr_tpl4 = ops.csr_build(data.tpl_edge_index, n, pad4=True)
+        narrow_padded = os.environ.get("MORIG_CORRNET_ONE_CSR", "1") != "0"
+        csr_tpl = csr_tpl4 if narrow_padded else ops.csr_build(data.tpl_edge_index, n)
+        csr_geo = csr_geo4 if narrow_padded else ops.csr_build(data.geo_edge_index, n)
         gcus = (self.vtx_gcu_1, self.vtx_gcu_2, self.vtx_gcu_3, self.vtx_gcu_4)
         widths = (32, 64, 256, 512)
         x_in, split_in = Mat.of(v4, 0, 3), False
