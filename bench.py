@@ -36,7 +36,8 @@ PLUMBING = os.environ.get("MORIG_BENCH_PLUMBING") == "1"
 
 KERNEL_SYMBOLS = {"edgeconv_f16x3_h256": ("edge_ws_kernel<256", "edge_pp_kernel<256"),
                   "edgeconv_f16x3_h128": ("edge_ws_kernel<128", "edge_pp_kernel<128"),
-                  "gemm_f16x3_dma": ("gemm16_dma_kernel<256, 256, 4, 2>",), "gemm_f16x3_pool": ("gemm16_dma_kernel<256, 256, 4, 2>",),
+                  # the LDS-DMA GEMM kinds run on two kernels: one tile per workgroup (short K) and the persistent one (pooled, deep-wide)
+                  "gemm_f16x3_dma": ("gemm16_dma_kernel<256, 256, 4, 2>", "gemm16_dmap_kernel"), "gemm_f16x3_pool": ("gemm16_dmap_kernel",),
                   "edgeconv_h256": ("tile_kernel<256, 16, 1, 2, 0>",), "gemm_f32_bn128": ("tile_kernel<128, 32, 0, 0, 0>",)}
 
 
@@ -71,8 +72,13 @@ def measured_mfma_util(kernel_kind):
     symbols = KERNEL_SYMBOLS.get(kernel_kind)
     if prof is None or symbols is None:
         return None
-    vals = [v["mfma_util"] for name, v in prof.get("kernels", {}).items() if any(sy in name for sy in symbols) and "mfma_util" in v]
-    return round(sum(vals) / len(vals), 4) if vals else None
+    busy = cu = 0.0           # a kind may cover several kernels: weighted by the CU-busy cycles each contributed
+    for name, v in prof.get("kernels", {}).items():
+        if any(sy in name for sy in symbols) and v.get("SQ_BUSY_CU_CYCLES"):
+            d = v.get("dispatches", 1)
+            busy += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * d
+            cu += v["SQ_BUSY_CU_CYCLES"] * d
+    return round(busy / (4.0 * cu), 4) if cu else None
 
 
 def cpu_model():
