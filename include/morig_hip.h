@@ -363,6 +363,46 @@ int morig_edge_gather_relu(const float* A, int32_t lda, const float* B, int32_t 
 int morig_segmax_affine(const float* Z, int32_t ldz, const int32_t* rowptr, int32_t n_segments, int32_t H, const float* scale,
                         const float* shift, float* out, int32_t ldo, void* stream);
 
+/* --------------------------------------------------------------------------------------------
+ * Train-mode BACKWARD operators (backward half; csrc/train_bwd.hip): what torch.autograd computes for the two
+ * starred blocks in model.train() -- Seq(Linear, ReLU, BatchNorm1d) over vertices (models/basic_modules.py:31-36) and the
+ * per-edge MLP with BatchNorm statistics over edges and max aggregation (:153-155, :179-202). dX = dU W goes through morig_gemm.
+ */
+/* per column: sum_dz[c] = sum_r dz[r][c] (= dbeta) and sum_dzx[c] = sum_r dz[r][c] * (y[r][c] - mean[c]) * rstd[c] (= dgamma) of
+ * a training-mode BatchNorm1d whose INPUT was y; y == NULL: the plain column sum only (= dbias of a Linear). fp64 accumulation,
+ * fixed order. workspace: >= ceil(rows/512) * 2 * cols doubles; rows_dev as in morig_col_stats. */
+int morig_bn_backward_stats(const float* dz, int32_t ldz, const float* y, int32_t ldy, int32_t rows, const int32_t* rows_dev,
+                            int32_t cols, const float* mean, const float* rstd, double* workspace, int64_t workspace_doubles,
+                            float* sum_dz, float* sum_dzx, void* stream);
+/* du[r][c] = [y > 0] * gamma * rstd * (dz - sum_dz / n - xhat * sum_dzx / n): the BatchNorm and the ReLU in front of it
+ * (y = ReLU output = BatchNorm input, n = rows). du may alias dz. */
+int morig_bn_relu_backward(const float* dz, int32_t ldz, const float* y, int32_t ldy, int32_t rows, const int32_t* rows_dev,
+                           int32_t cols, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
+                           const float* sum_dzx, float* du, int32_t ldu, void* stream);
+/* morig_segmax_affine that also records which row won: arg[v][c] = row index (first on ties), -1 for an empty segment */
+int morig_segmax_affine_arg(const float* Z, int32_t ldz, const int32_t* rowptr, int32_t n_segments, int32_t H, const float* scale,
+                            const float* shift, float* out, int32_t ldo, int32_t* arg, int32_t ld_arg, void* stream);
+/* the two BatchNorm sums for the BatchNorm in FRONT of a max aggregation, from the per-segment gradient dout [n_segments][cols]
+ * and the arg-max table (the per-row gradient is one-hot per (segment, column) and never materialised); Z = BatchNorm input rows */
+int morig_segmax_bn_backward_stats(const float* dout, int32_t ldd, const int32_t* arg, int32_t ld_arg, const float* Z, int32_t ldz,
+                                   int32_t n_segments, int32_t cols, const float* mean, const float* rstd, double* workspace,
+                                   int64_t workspace_doubles, float* sum_dz, float* sum_dzx, void* stream);
+/* du[e][c] for every row e < rowptr[n_segments] (seg_of_row[e] = its segment): the BatchNorm (+ the ReLU in front of it when
+ * relu != 0) applied to that one-hot gradient; n = rowptr[n_segments] */
+int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, const int32_t* arg, int32_t ld_arg, const float* Z, int32_t ldz,
+                                  const int32_t* rowptr, int32_t n_segments, const int32_t* seg_of_row, int32_t row_capacity,
+                                  int32_t cols, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
+                                  const float* sum_dzx, int32_t relu, float* du, int32_t ldu, void* stream);
+/* backward of Z[e] = A[dst_e] + B[src_e]: dA[v] = sum of dG over the CSR segment of v (fixed order), dB[u] = sum of dG over the
+ * edges with source u (float atomics: summation order, hence the last bits, vary run to run). dB ([n_src_nodes][ldb]) is zeroed here. */
+int morig_edge_scatter_backward(const float* dG, int32_t ldg, const int32_t* rowptr, const int32_t* src_sorted, int32_t n_nodes,
+                                int32_t n_src_nodes, int32_t H, float* dA, int32_t lda, float* dB, int32_t ldb, void* stream);
+/* out[N][K] = A^T B over the rows (A [rows][N], B [rows][K], fp32 MFMA): the weight gradient dW = dU^T X. The row range is split
+ * over workgroups and the partial products are summed in a fixed order. workspace: morig_gemm_tn_workspace(rows, N, K) floats. */
+int64_t morig_gemm_tn_workspace(int32_t rows, int32_t N, int32_t K);
+int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t rows, const int32_t* rows_dev, int32_t N, int32_t K,
+                  float* workspace, int64_t workspace_floats, float* out, int32_t ldo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

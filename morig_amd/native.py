@@ -105,6 +105,22 @@ _SIGNATURES = {
     "morig_edge_gather_relu": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
                                          c_f32p, C.c_int32, C.c_void_p]),
     "morig_segmax_affine": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_bn_backward_stats": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, C.c_void_p,
+                                          C.c_int64, c_f32p, c_f32p, C.c_void_p]),
+    "morig_bn_relu_backward": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
+                                         c_f32p, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_segmax_affine_arg": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, c_i32p,
+                                          C.c_int32, C.c_void_p]),
+    "morig_segmax_bn_backward_stats": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
+                                                 c_f32p, C.c_void_p, C.c_int64, c_f32p, c_f32p, C.c_void_p]),
+    "morig_segmax_bn_relu_backward": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, c_i32p,
+                                                C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32,
+                                                C.c_void_p]),
+    "morig_edge_scatter_backward": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p,
+                                              C.c_int32, C.c_void_p]),
+    "morig_gemm_tn_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "morig_gemm_tn": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int64, c_f32p,
+                                C.c_int32, C.c_void_p]),
     "morig_knn_interpolate": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_knn_search": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -574,6 +590,79 @@ class NativeOps:
         assert rowptr.dtype == torch.int32 and out.rows == n_segments and out.cols == Z.cols
         check(self.lib.morig_segmax_affine(Z.ptr, Z.ld, _p(rowptr), n_segments, Z.cols, _p(scale), _p(shift), out.ptr, out.ld,
                                            _stream()), "morig_segmax_affine")
+
+    # -- train-mode backward support (csrc/train_bwd.hip; SURVEY 8 f-4, backward half) --------------------------------
+    def bn_backward_stats(self, dz: Mat, y: Optional[Mat] = None, mean: Optional[torch.Tensor] = None,
+                          rstd: Optional[torch.Tensor] = None, rows_dev: Optional[torch.Tensor] = None):
+        """-> (sum_dz [cols], sum_dz_xhat [cols] or None): dbeta / dgamma of a training-mode BatchNorm1d with input y
+        (y None: the plain column sum = dbias)."""
+        _need_gpu(dz.base)
+        dev = dz.base.device
+        slabs = (max(dz.rows, 1) + 511) // 512
+        ws = torch.empty(slabs * 2 * dz.cols, dtype=torch.float64, device=dev)
+        sdz = torch.empty(dz.cols, dtype=torch.float32, device=dev)
+        sdzx = torch.empty(dz.cols, dtype=torch.float32, device=dev) if y is not None else None
+        check(self.lib.morig_bn_backward_stats(dz.ptr, dz.ld, y.ptr if y is not None else 0, y.ld if y is not None else 0, dz.rows,
+                                               _p(rows_dev), dz.cols, _p(mean), _p(rstd), C.c_void_p(ws.data_ptr()), ws.numel(),
+                                               _p(sdz), _p(sdzx), _stream()), "morig_bn_backward_stats")
+        return sdz, sdzx
+
+    def bn_relu_backward(self, dz: Mat, y: Mat, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, rows_dev: Optional[torch.Tensor] = None):
+        _need_gpu(dz.base, y.base, du.base)
+        assert dz.rows == y.rows == du.rows and dz.cols == y.cols == du.cols
+        check(self.lib.morig_bn_relu_backward(dz.ptr, dz.ld, y.ptr, y.ld, dz.rows, _p(rows_dev), dz.cols, _p(mean), _p(rstd), _p(gamma),
+                                              _p(sum_dz), _p(sum_dzx), du.ptr, du.ld, _stream()), "morig_bn_relu_backward")
+
+    def segmax_affine_arg(self, Z: Mat, rowptr: torch.Tensor, n_segments: int, out: Mat, scale=None, shift=None) -> torch.Tensor:
+        """segmax_affine + the winning row per (segment, column): int32 [n_segments, cols], -1 for empty segments."""
+        _need_gpu(Z.base, rowptr, out.base)
+        assert rowptr.dtype == torch.int32 and out.rows == n_segments and out.cols == Z.cols
+        arg = torch.empty((n_segments, Z.cols), dtype=torch.int32, device=Z.base.device)
+        check(self.lib.morig_segmax_affine_arg(Z.ptr, Z.ld, _p(rowptr), n_segments, Z.cols, _p(scale), _p(shift), out.ptr, out.ld,
+                                               _p(arg), arg.stride(0), _stream()), "morig_segmax_affine_arg")
+        return arg
+
+    def segmax_bn_backward_stats(self, dout: Mat, arg: torch.Tensor, Z: Mat, mean, rstd):
+        _need_gpu(dout.base, arg, Z.base)
+        dev = dout.base.device
+        n_seg, cols = dout.rows, dout.cols
+        assert arg.shape == (n_seg, cols) and Z.cols == cols
+        slabs = (n_seg + 511) // 512
+        ws = torch.empty(slabs * 2 * cols, dtype=torch.float64, device=dev)
+        sdz = torch.empty(cols, dtype=torch.float32, device=dev)
+        sdzx = torch.empty(cols, dtype=torch.float32, device=dev)
+        check(self.lib.morig_segmax_bn_backward_stats(dout.ptr, dout.ld, _p(arg), arg.stride(0), Z.ptr, Z.ld, n_seg, cols, _p(mean), _p(rstd),
+                                                      C.c_void_p(ws.data_ptr()), ws.numel(), _p(sdz), _p(sdzx), _stream()),
+              "morig_segmax_bn_backward_stats")
+        return sdz, sdzx
+
+    def segmax_bn_relu_backward(self, dout: Mat, arg: torch.Tensor, Z: Mat, rowptr: torch.Tensor, seg_of_row: torch.Tensor, mean, rstd,
+                                gamma, sum_dz, sum_dzx, du: Mat, relu: bool = True):
+        _need_gpu(dout.base, arg, Z.base, du.base, rowptr, seg_of_row)
+        assert Z.rows == du.rows and Z.cols == du.cols == dout.cols and seg_of_row.dtype == torch.int32
+        check(self.lib.morig_segmax_bn_relu_backward(dout.ptr, dout.ld, _p(arg), arg.stride(0), Z.ptr, Z.ld, _p(rowptr), dout.rows,
+                                                     _p(seg_of_row), Z.rows, Z.cols, _p(mean), _p(rstd), _p(gamma), _p(sum_dz), _p(sum_dzx),
+                                                     1 if relu else 0, du.ptr, du.ld, _stream()), "morig_segmax_bn_relu_backward")
+
+    def edge_scatter_backward(self, dG: Mat, csr: CSR, n_src: int, dA: Mat, dB: Mat):
+        """backward of Z[e] = A[dst_e] + B[src_e] over the live edges of ``csr``."""
+        _need_gpu(dG.base, dA.base, dB.base)
+        assert dA.rows == csr.n_nodes and dB.rows == n_src and dA.cols == dB.cols == dG.cols
+        check(self.lib.morig_edge_scatter_backward(dG.ptr, dG.ld, _p(csr.rowptr), _p(csr.src), csr.n_nodes, n_src, dG.cols, dA.ptr, dA.ld,
+                                                   dB.ptr, dB.ld, _stream()), "morig_edge_scatter_backward")
+
+    def gemm_tn(self, A: Mat, B: Mat, out: Optional[Mat] = None, rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A^T B over the rows: [A.cols, B.cols] (the weight gradient dU^T X)."""
+        _need_gpu(A.base, B.base)
+        assert A.rows == B.rows
+        dev = A.base.device
+        if out is None:
+            out = Mat.of(torch.empty((A.cols, B.cols), dtype=torch.float32, device=dev))
+        n_ws = int(self.lib.morig_gemm_tn_workspace(A.rows, A.cols, B.cols))
+        ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
+        check(self.lib.morig_gemm_tn(A.ptr, A.ld, B.ptr, B.ld, A.rows, _p(rows_dev), A.cols, B.cols, _p(ws), ws.numel(), out.ptr, out.ld,
+                                     _stream()), "morig_gemm_tn")
+        return out.base
 
     def radius_sample(self, x: Mat, y: Mat, radius: float, max_nbrs: int, seed: int):
         """radius_cpu's neighbour table: (slot table int64 [2, ny * max_nbrs] (-1 = unused), hits per row int32 [ny])."""

@@ -1,0 +1,329 @@
+"""Train-mode forward AND backward of the rignet family on the MI355X-native op layer.
+
+The two starred blocks of the reference -- ``Seq(Linear, ReLU, BatchNorm1d)`` over vertices and the per-edge MLP of
+EdgeConvMotion with BatchNorm statistics over EDGES and max aggregation (/root/reference/models/basic_modules.py:31-36,
+179-202) -- are ``torch.autograd.Function``s here: ``forward`` runs the native train-mode operators of
+``train_forward.py`` and keeps what the backward needs (the ReLU outputs, the batch statistics, the arg-max table of the
+aggregation), ``backward`` runs the native backward operators of csrc/train_bwd.hip:
+
+    dense block    dz -> [bn_backward_stats] dgamma, dbeta -> [bn_relu_backward] du -> dX = du W   (morig_gemm on W^T)
+                                                                                     dW = du^T X (morig_gemm_tn), db = col sum
+    edge MLP       dOut[v] -> [segmax_bn_backward_stats / segmax_bn_relu_backward] du2[e] (dense over edges: BatchNorm2's mean
+                   terms reach every edge; the one-hot arg-max gradient itself is never materialised)
+                   -> dW2 = du2^T (s1 Z1 + t1), dZ1aff = du2 W2 -> BatchNorm1 + ReLU over edges -> dG[e]
+                   -> [edge_scatter_backward] dA[dst], dB[src] -> vertex GEMM backward (dX, dW1 mapped back to [W_a | W_b])
+
+Everything that is not a starred kernel -- concatenations, F.normalize, the 5-token attention, mesh pooling's index
+bookkeeping -- stays torch autograd on device tensors, exactly as the reference has it; losses stay in PyTorch
+(models/customized_losses.py). Gradient contractions run on the exact-fp32 MFMA kernels: gradients live many orders of
+magnitude below activations, outside what the split-fp16 operand format resolves.
+
+``motion_head_step(model, data, input_flow)`` is ``JointNetMotion`` / ``MaskNetMotion.forward`` in training mode
+(/root/reference/models/rignet.py:70-133; training/train_rig.py:136-195) with a graph attached: call ``.backward()`` on a
+loss of its outputs and every parameter's ``.grad`` is filled, BatchNorm running buffers move as in the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import packing
+from .native import CSR, Mat, get_ops
+from .train_forward import _bn_train, _ld4, _pad_to
+
+
+def _rows16(x: torch.Tensor) -> torch.Tensor:
+    """a contiguous fp32 copy of x whose rows are 16-byte aligned (columns zero-padded to a multiple of 4)"""
+    x = x.detach().float()
+    c = x.shape[1]
+    if c % 4:
+        x = F.pad(x, (0, _ld4(c) - c))
+    return x.contiguous()
+
+
+def _pack_f32(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
+    """a packed Linear for the exact-fp32 MFMA kernels (no split image: morig_gemm then takes the fp32 path)"""
+    pk = packing.pack_linear(weight.detach().float(), None if bias is None else bias.detach().float())
+    pk.Wsplit = None
+    return packing.to_device(pk, dev)
+
+
+def _gemm_f32(ops, X: Mat, weight: torch.Tensor, n_out: int) -> torch.Tensor:
+    """X @ weight^T on the fp32 MFMA path -> [rows, ld4(n_out)] (columns >= n_out are padding)"""
+    dev = X.base.device
+    out = torch.zeros((X.rows, _ld4(n_out)), dtype=torch.float32, device=dev)
+    ops.gemm(X, _pack_f32(weight, None, dev), relu=False, Y=Mat.of(out, 0, n_out))
+    return out
+
+
+class DenseTrain(torch.autograd.Function):
+    """one ``Seq(Linear, ReLU, BatchNorm1d)`` of MLP() with batch statistics (models/basic_modules.py:31-36)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, bn):
+        ops = get_ops()
+        dev = x.device
+        xa = _rows16(x)
+        K, N = x.shape[1], weight.shape[0]
+        pk = packing.to_device(packing.pack_linear(weight.detach(), bias.detach()), dev)
+        y = torch.zeros((xa.shape[0], _ld4(N)), dtype=torch.float32, device=dev)
+        ops.gemm(Mat.of(xa, 0, K), pk, relu=True, Y=Mat.of(y, 0, N))
+        mean, var, cnt = ops.col_stats(Mat.of(y, 0, N))
+        s, t = _bn_train(bn, mean, var, cnt)
+        z = y.clone()
+        ops.col_affine(Mat.of(z, 0, N), s, t)
+        ctx.save_for_backward(xa, weight, y, mean, torch.rsqrt(var + bn.eps), gamma)
+        ctx.dims = (K, N)
+        return z[:, :N]
+
+    @staticmethod
+    def backward(ctx, dz):
+        ops = get_ops()
+        xa, weight, y, mean, rstd, gamma = ctx.saved_tensors
+        K, N = ctx.dims
+        dev = dz.device
+        dza = _rows16(dz)
+        Y = Mat.of(y, 0, N)
+        sdz, sdzx = ops.bn_backward_stats(Mat.of(dza, 0, N), Y, mean, rstd)
+        du = torch.zeros_like(y)
+        DU = Mat.of(du, 0, N)
+        ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), sdz, sdzx, DU)
+        db, _ = ops.bn_backward_stats(DU)
+        dW = ops.gemm_tn(DU, Mat.of(xa, 0, K))
+        dX = _gemm_f32(ops, DU, weight.detach().t().contiguous(), K)[:, :K]
+        return dX, dW, db, sdzx, sdz, None
+
+
+class NativeLinear(torch.autograd.Function):
+    """a bare ``Linear`` (the last layer of mlp_transform, models/rignet.py:57): forward and both gradient GEMMs native"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ops = get_ops()
+        dev = x.device
+        xa = _rows16(x)
+        K, N = x.shape[1], weight.shape[0]
+        pk = packing.to_device(packing.pack_linear(weight.detach(), None if bias is None else bias.detach()), dev)
+        y = torch.zeros((xa.shape[0], _ld4(N)), dtype=torch.float32, device=dev)
+        ops.gemm(Mat.of(xa, 0, K), pk, relu=False, Y=Mat.of(y, 0, N))
+        ctx.save_for_backward(xa, weight)
+        ctx.dims = (K, N, bias is not None)
+        return y[:, :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        ops = get_ops()
+        xa, weight = ctx.saved_tensors
+        K, N, has_bias = ctx.dims
+        dya = _rows16(dy)
+        DY = Mat.of(dya, 0, N)
+        db = ops.bn_backward_stats(DY)[0] if has_bias else None
+        dW = ops.gemm_tn(DY, Mat.of(xa, 0, K))
+        dX = _gemm_f32(ops, DY, weight.detach().t().contiguous(), K)[:, :K]
+        return dX, dW, db
+
+
+class EdgeMLPTrain(torch.autograd.Function):
+    """per-edge ``MLP([2C, H, H])`` on [x_i ‖ x_j - x_i] with BatchNorm statistics over the edges and max over the incoming
+    edges (models/basic_modules.py:153-155 / 192-195 in training mode); ``csr``: the unpadded CSR of the loop-normalised graph."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, bn1, bn2, csr: CSR):
+        assert not csr.quad, "batch statistics over edges need every edge exactly once"
+        ops = get_ops()
+        dev = x.device
+        xa = _rows16(x)
+        n, C = x.shape
+        H = W1.shape[0]
+        W1f = W1.detach().float()
+        Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)                      # [A | B] = x Wv^T + [b1 | 0]
+        vertex = packing.to_device(packing.pack_linear(Wv, torch.cat([b1.detach().float(), torch.zeros(H, device=W1.device)], 0)), dev)
+        ab = torch.zeros((n, _ld4(2 * H)), dtype=torch.float32, device=dev)
+        ops.gemm(Mat.of(xa, 0, C), vertex, relu=False, Y=Mat.of(ab, 0, 2 * H))
+        A, B = Mat.of(ab, 0, H), Mat.of(ab, H, H)
+        e_live = csr.rowptr[csr.n_nodes:csr.n_nodes + 1]
+        z1 = torch.zeros((csr.capacity, _ld4(H)), dtype=torch.float32, device=dev)
+        ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H))
+        mean1, var1, cnt = ops.col_stats(Mat.of(z1, 0, H), rows_dev=e_live)
+        s1, t1 = _bn_train(bn1, mean1, var1, cnt)
+        Hp, Kp = max(H, 32), (H + 31) // 32 * 32
+        W2p = torch.zeros((Hp, Kp), dtype=torch.float32, device=dev)
+        W2p[:H, :H] = W2.detach().float()
+        pe = packing.PackedEdge(H, _pad_to(s1, Kp, 1.0), _pad_to(t1, Kp, 0.0), W2p.contiguous(), _pad_to(b2.detach().float(), Hp, 0.0),
+                                torch.ones(Hp, device=dev), torch.zeros(Hp, device=dev), None)
+        z2 = torch.zeros((csr.capacity, _ld4(H)), dtype=torch.float32, device=dev)
+        ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
+        mean2, var2, cnt2 = ops.col_stats(Mat.of(z2, 0, H), rows_dev=e_live)
+        s2, t2 = _bn_train(bn2, mean2, var2, cnt2)
+        out = torch.zeros((n, _ld4(H)), dtype=torch.float32, device=dev)
+        arg = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2)
+        ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, torch.rsqrt(var1 + bn1.eps), mean2, torch.rsqrt(var2 + bn2.eps), g1, g2, s1, t1, arg)
+        ctx.csr = csr
+        ctx.dims = (n, C, H)
+        return out[:, :H]
+
+    @staticmethod
+    def backward(ctx, dout):
+        ops = get_ops()
+        xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg = ctx.saved_tensors
+        csr: CSR = ctx.csr
+        n, C, H = ctx.dims
+        dev = dout.device
+        e_live = csr.rowptr[csr.n_nodes:csr.n_nodes + 1]
+        Z1, Z2 = Mat.of(z1, 0, H), Mat.of(z2, 0, H)
+        do = _rows16(dout)
+        DO = Mat.of(do, 0, H)
+        # BatchNorm2 + ReLU behind the max: one-hot gradient per (vertex, channel)
+        sdz2, sdzx2 = ops.segmax_bn_backward_stats(DO, arg, Z2, mean2, rstd2)
+        du2 = torch.zeros_like(z2)
+        DU2 = Mat.of(du2, 0, H)
+        ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), sdz2, sdzx2, DU2)
+        db2, _ = ops.bn_backward_stats(DU2, rows_dev=e_live)
+        # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
+        dW2 = ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]
+        dh = _gemm_f32(ops, DU2, W2.detach().t().contiguous(), H)                      # d(s1 Z1 + t1)  [capacity, H]
+        DH = Mat.of(dh, 0, H)
+        # BatchNorm1 + ReLU over the edges
+        sdz1, sdzx1 = ops.bn_backward_stats(DH, Z1, mean1, rstd1, rows_dev=e_live)
+        ops.bn_relu_backward(DH, Z1, mean1, rstd1, g1.detach().float().contiguous(), sdz1, sdzx1, DH, rows_dev=e_live)
+        # Z1 = relu(A[dst] + B[src])
+        dab = torch.zeros((n, _ld4(2 * H)), dtype=torch.float32, device=dev)
+        ops.edge_scatter_backward(DH, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H))
+        DAB = Mat.of(dab, 0, 2 * H)
+        db1, _ = ops.bn_backward_stats(Mat.of(dab, 0, H))
+        dWv = ops.gemm_tn(DAB, Mat.of(xa, 0, C))                                       # [2H, C]
+        dW1 = torch.cat([dWv[:H], dWv[H:] - dWv[:H]], 1)                               # back to [W_a | W_b]: W_v = [[W_a - W_b], [W_b]]
+        W1f = W1.detach().float()
+        Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)
+        dX = _gemm_f32(ops, DAB, Wv.t().contiguous(), C)[:, :C]
+        return dX, dW1, db1, sdzx1, sdz1, dW2, db2, sdzx2, sdz2, None, None, None
+
+
+class SegMaxPool(torch.autograd.Function):
+    """scatter_max over the vertices of each mesh (models/rignet.py:63): native arg-max forward, index routing backward"""
+
+    @staticmethod
+    def forward(ctx, x, mesh_ptr, n_graphs: int):
+        ops = get_ops()
+        xa = _rows16(x)
+        C = x.shape[1]
+        out = torch.zeros((n_graphs, _ld4(C)), dtype=torch.float32, device=x.device)
+        arg = ops.segmax_affine_arg(Mat.of(xa, 0, C), mesh_ptr, n_graphs, Mat.of(out, 0, C))
+        ctx.save_for_backward(arg)
+        ctx.shape = (x.shape[0], C)
+        return out[:, :C]
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        n, C = ctx.shape
+        dx = torch.zeros((n, C), dtype=torch.float32, device=dout.device)
+        live = arg >= 0
+        cols = torch.arange(C, device=dout.device).expand_as(arg)
+        dx[arg[live].long(), cols[live]] = dout.float()[live]
+        return dx, None, None
+
+
+# ---- the reference's modules, composed from the blocks above (parameters are the module's own nn.Parameters) -------------------
+def mlp_layer(x, layer):
+    return DenseTrain.apply(x, layer[0].weight, layer[0].bias, layer[2].weight, layer[2].bias, layer[2])
+
+
+def edge_mlp(x, csr: CSR, mlp):
+    l1, l2 = mlp[0], mlp[1]
+    return EdgeMLPTrain.apply(x, l1[0].weight, l1[0].bias, l1[2].weight, l1[2].bias, l2[0].weight, l2[0].bias, l2[2].weight, l2[2].bias,
+                              l1[2], l2[2], csr)
+
+
+def edgeconvmotion(ec, pos, x, csr: CSR):
+    """EdgeConvMotion (models/basic_modules.py:179-202): [nn_x branch | nn_pos branch], each max-aggregated"""
+    return torch.cat([edge_mlp(x, csr, ec.nn_x), edge_mlp(pos, csr, ec.nn_pos)], 1)
+
+
+def gcumotion(gcu, pos, x, csr_tpl: CSR, csr_geo: CSR):
+    """GCUMotion (models/basic_modules.py:205-219)"""
+    both = torch.cat([edgeconvmotion(gcu.edge_conv_tpl, pos, x, csr_tpl), edgeconvmotion(gcu.edge_conv_geo, pos, x, csr_geo)], 1)
+    return mlp_layer(both, gcu.mlp[0])
+
+
+def gcnrig(net, pos, feature, csr_tpl: CSR, csr_geo: CSR, batch, mesh_ptr, n_graphs: int):
+    """GCNRig.forward (models/rignet.py:59-67)"""
+    tr = getattr(net, net.TRANSFORM)
+    a = gcumotion(net.gcu_1, pos, feature, csr_tpl, csr_geo)
+    b = gcumotion(net.gcu_2, pos, a, csr_tpl, csr_geo)
+    c = gcumotion(net.gcu_3, pos, b, csr_tpl, csr_geo)
+    g = SegMaxPool.apply(mlp_layer(torch.cat([a, b, c], 1), net.mlp_glb[0]), mesh_ptr, n_graphs)
+    x5 = torch.cat([g[batch], pos, feature, a, b, c], 1)                              # repeat_interleave over sorted batch ids (:64)
+    h = mlp_layer(mlp_layer(x5, tr[0][0]), tr[0][1])
+    return NativeLinear.apply(h, tr[1].weight, tr[1].bias)
+
+
+def temporal_attn(attn, x):
+    """TemporalAttn.forward (models/rignet.py:36-46): a CLS token over the T keyframes, multi-head scaled dot-product attention,
+    only token 0 kept -- 6 tokens per vertex, left to torch; the feed-forward MLP runs on the native blocks."""
+    V = x.shape[0]
+    nh = attn.num_heads
+    tok = torch.cat([attn.cls_token.expand(V, -1, -1), x], 1)
+
+    def heads(t):
+        L = t.shape[1]
+        return t.reshape(V, L, nh, -1).permute(0, 2, 1, 3).reshape(V * nh, L, -1)
+
+    q, k, v = heads(attn.w_qs(tok)), heads(attn.w_ks(tok)), heads(attn.w_vs(tok))
+    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(k.size(-1)), dim=-1)
+    res = torch.bmm(att, v)
+    L = res.shape[1]
+    res = res.reshape(V, nh, L, -1).permute(0, 2, 1, 3).reshape(V, L, -1)
+    h = attn.w_o(res)[:, 0, :]
+    return mlp_layer(mlp_layer(h, attn.feedforward[0]), attn.feedforward[1])
+
+
+def graph_state(data):
+    """CSRs of the two loop-normalised graphs + mesh offsets: built once per batch, shared by every block"""
+    ops = get_ops()
+    dev = data.pos.device
+    n = data.pos.shape[0]
+    ng = getattr(data, "num_graphs", None)
+    if ng is None:
+        ng = int(data.batch.max().item()) + 1
+    counts = torch.bincount(data.batch, minlength=ng)
+    mesh_ptr = torch.zeros(ng + 1, dtype=torch.int32, device=dev)
+    mesh_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return dict(n=n, ng=int(ng), csr_tpl=ops.csr_build(data.tpl_edge_index, n), csr_geo=ops.csr_build(data.geo_edge_index, n),
+                mesh_ptr=mesh_ptr, batch=data.batch.long())
+
+
+def motion_head_step(model, data, input_flow):
+    """JointNetMotion / MaskNetMotion.forward in training mode with an autograd graph (models/rignet.py:82-100):
+    -> (motion_all [n, T, 32], motion_aggr, head output). Raises if an operand left the split-fp16 range on the way."""
+    ops = get_ops()
+    dev = data.pos.device
+    with torch.cuda.device(dev):
+        flag = ops._flag(dev)
+        flag.zero_()
+        st = graph_state(data)
+        pos = data.pos.float()
+        flow = input_flow.float()
+        frames = []
+        for t in range(model.num_keyframes):
+            m = gcnrig(model.motionNet, pos, flow[:, 3 * t:3 * t + 3], st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+            frames.append(F.normalize(m, dim=1))
+        motion_all = torch.stack(frames, 1)
+        if model.aggr_method == "attn":
+            aggr = temporal_attn(model.aggragator, motion_all)
+        elif model.aggr_method == "mean":
+            aggr = motion_all.mean(1)
+        elif model.aggr_method == "max":
+            aggr = motion_all.max(1)[0]
+        else:
+            raise NotImplementedError
+        aggr = F.normalize(aggr, dim=1)
+        head = getattr(model, model._head)
+        out = gcnrig(head, pos, aggr, st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+        if int(flag.item()) != 0:
+            from .native import MorigNativeError
+            raise MorigNativeError("an operand left the split-fp16 range in the train-mode forward: train with MORIG_PRECISION=f32")
+    return motion_all, aggr, out
