@@ -99,10 +99,14 @@ class NativeModule(torch.nn.Module):
         ops = get_ops()
         dev = next(self.parameters()).device
         if self.training:
-            # train-mode FORWARD (batch-statistics BatchNorm, running buffers updated): implemented for the rignet family in
-            # morig_amd/train_forward.py; no autograd graph is built (the backward is not built yet)
+            # train mode (batch-statistics BatchNorm, running buffers updated), rignet family only. With autograd enabled the
+            # forward is built from the autograd blocks of morig_amd/train_backward.py (native forward AND backward operators:
+            # loss.backward() fills every parameter's .grad, as training/train_rig.py:136-195 expects); under no_grad it is the
+            # graph-free forward of morig_amd/train_forward.py.
             if type(self)._forward_train is NativeModule._forward_train:
                 self._require_eval()
+            if torch.is_grad_enabled() and type(self)._forward_train_grad is not NativeModule._forward_train_grad:
+                return self._forward_train_grad(*args, **kwargs)
             with torch.no_grad():
                 if dev.type == "cuda":
                     with torch.cuda.device(dev):
@@ -131,13 +135,16 @@ class NativeModule(torch.nn.Module):
     def _forward_train(self, *args, **kwargs):
         raise NotImplementedError
 
+    def _forward_train_grad(self, *args, **kwargs):
+        raise NotImplementedError
+
     def _require_eval(self):
         if self.training:
             raise NotImplementedError(
                 f"{type(self).__name__}: no train-mode forward on the MI355X-native path for this module. The train-mode FORWARD "
                 "(batch-statistics BatchNorm over vertices / edges, running-buffer updates) exists for jointnet_motion, "
-                "masknet_motion and skinnet_motion (morig_amd/train_forward.py); the BACKWARD pass (arg-max scatter of the edge "
-                "max, dW / dX contractions, BatchNorm gradients) is not built yet -- SURVEY.md 8(f-4), DESIGN.md section 9. "
+                "masknet_motion and skinnet_motion (morig_amd/train_forward.py), and so does their BACKWARD pass "
+                "(morig_amd/train_backward.py); CorrNet / DeformNet and standalone blocks have neither yet -- SURVEY.md 8(f-4), DESIGN.md section 9. "
                 "Call model.eval() for inference.")
 
 

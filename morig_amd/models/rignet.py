@@ -261,6 +261,11 @@ class _MotionHead(_MotionBackbone):
         from .. import train_forward
         return train_forward.motion_head_train(get_ops(), self, data, input_flow)
 
+    def _forward_train_grad(self, data, input_flow):
+        """model.train() with autograd enabled: the same forward with a graph over the native backward operators"""
+        from .. import train_backward
+        return train_backward.motion_head_step(self, data, input_flow)
+
 
 class JointNetMotion(_MotionHead):
     """models/rignet.py:70-100 -> (motion_all, motion_aggr, pred_shift)."""
@@ -375,6 +380,10 @@ class SkinMotion(_MotionBackbone):
         """model.train(): batch-statistics forward (morig_amd/train_forward.py)"""
         from .. import train_forward
         return train_forward.skin_motion_train(get_ops(), self, data, input_flow)
+
+    def _forward_train_grad(self, data, input_flow):
+        from .. import train_backward
+        return train_backward.skin_motion_step(self, data, input_flow)
 
 
 def jointnet_motion(**kwargs):

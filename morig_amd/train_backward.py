@@ -24,15 +24,34 @@ loss of its outputs and every parameter's ``.grad`` is filled, BatchNorm running
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import os
 from typing import Optional
 
 import torch
 import torch.nn.functional as F
 
 from . import packing
-from .native import CSR, Mat, get_ops
+from .native import CSR, Mat
+from .runtime import get_ops
 from .train_forward import _bn_train, _ld4, _pad_to
+
+
+# Arithmetic of the FORWARD contractions in training mode. Default: the exact-fp32 MFMA kernels. The split-fp16 path carries
+# ~2 bits less than fp32 per product (2^-22 vs 2^-24); harmless in eval mode (1e-6 of output scale), but a train-mode forward
+# of these networks is ill-conditioned (batch statistics over edges feeding arg-max aggregations, six GCNRig passes deep):
+# measured on JointNetMotion, outputs and gradients deviate from a float64 run 4-10x more than torch's own float32 run does
+# (tests/test_gpu_backward.py). MORIG_TRAIN_PRECISION=f16x3 opts into the fast path (5x the MFMA rate).
+def train_fast() -> bool:
+    return os.environ.get("MORIG_TRAIN_PRECISION", "f32") == "f16x3"
+
+
+def _pack_fwd(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
+    pk = packing.pack_linear(weight.detach(), None if bias is None else bias.detach())
+    if not train_fast():
+        pk.Wsplit = None
+    return packing.to_device(pk, dev)
 
 
 def _rows16(x: torch.Tensor) -> torch.Tensor:
@@ -68,7 +87,7 @@ class DenseTrain(torch.autograd.Function):
         dev = x.device
         xa = _rows16(x)
         K, N = x.shape[1], weight.shape[0]
-        pk = packing.to_device(packing.pack_linear(weight.detach(), bias.detach()), dev)
+        pk = _pack_fwd(weight, bias, dev)
         y = torch.zeros((xa.shape[0], _ld4(N)), dtype=torch.float32, device=dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=True, Y=Mat.of(y, 0, N))
         mean, var, cnt = ops.col_stats(Mat.of(y, 0, N))
@@ -106,7 +125,7 @@ class NativeLinear(torch.autograd.Function):
         dev = x.device
         xa = _rows16(x)
         K, N = x.shape[1], weight.shape[0]
-        pk = packing.to_device(packing.pack_linear(weight.detach(), None if bias is None else bias.detach()), dev)
+        pk = _pack_fwd(weight, bias, dev)
         y = torch.zeros((xa.shape[0], _ld4(N)), dtype=torch.float32, device=dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=False, Y=Mat.of(y, 0, N))
         ctx.save_for_backward(xa, weight)
@@ -140,7 +159,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         H = W1.shape[0]
         W1f = W1.detach().float()
         Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)                      # [A | B] = x Wv^T + [b1 | 0]
-        vertex = packing.to_device(packing.pack_linear(Wv, torch.cat([b1.detach().float(), torch.zeros(H, device=W1.device)], 0)), dev)
+        vertex = _pack_fwd(Wv, torch.cat([b1.detach().float(), torch.zeros(H, device=W1.device)], 0), dev)
         ab = torch.zeros((n, _ld4(2 * H)), dtype=torch.float32, device=dev)
         ops.gemm(Mat.of(xa, 0, C), vertex, relu=False, Y=Mat.of(ab, 0, 2 * H))
         A, B = Mat.of(ab, 0, H), Mat.of(ab, H, H)
@@ -296,34 +315,68 @@ def graph_state(data):
                 mesh_ptr=mesh_ptr, batch=data.batch.long())
 
 
-def motion_head_step(model, data, input_flow):
-    """JointNetMotion / MaskNetMotion.forward in training mode with an autograd graph (models/rignet.py:82-100):
-    -> (motion_all [n, T, 32], motion_aggr, head output). Raises if an operand left the split-fp16 range on the way."""
+def _motion_backbone(model, data, input_flow, st, aggr_method):
+    """the keyframe loop + normalisation + aggregation shared by the three heads (models/rignet.py:82-98, 196-203): one
+    motionNet pass PER keyframe, each with its own batch statistics, as the reference's Python loop does"""
+    pos = data.pos.float()
+    flow = input_flow.float()
+    frames = []
+    for t in range(model.num_keyframes):
+        m = gcnrig(model.motionNet, pos, flow[:, 3 * t:3 * t + 3], st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+        frames.append(F.normalize(m, dim=1))
+    motion_all = torch.stack(frames, 1)
+    if aggr_method == "attn":
+        aggr = temporal_attn(model.aggragator, motion_all)
+    elif aggr_method == "mean":
+        aggr = motion_all.mean(1)
+    elif aggr_method == "max":
+        aggr = motion_all.max(1)[0]
+    else:
+        raise NotImplementedError
+    return motion_all, F.normalize(aggr, dim=1)
+
+
+def _guarded_step(data, body):
+    """run ``body(st)`` on the model's device with the split-fp16 range flag cleared before and checked after"""
     ops = get_ops()
     dev = data.pos.device
-    with torch.cuda.device(dev):
+    with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
         flag = ops._flag(dev)
         flag.zero_()
-        st = graph_state(data)
-        pos = data.pos.float()
-        flow = input_flow.float()
-        frames = []
-        for t in range(model.num_keyframes):
-            m = gcnrig(model.motionNet, pos, flow[:, 3 * t:3 * t + 3], st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
-            frames.append(F.normalize(m, dim=1))
-        motion_all = torch.stack(frames, 1)
-        if model.aggr_method == "attn":
-            aggr = temporal_attn(model.aggragator, motion_all)
-        elif model.aggr_method == "mean":
-            aggr = motion_all.mean(1)
-        elif model.aggr_method == "max":
-            aggr = motion_all.max(1)[0]
-        else:
-            raise NotImplementedError
-        aggr = F.normalize(aggr, dim=1)
-        head = getattr(model, model._head)
-        out = gcnrig(head, pos, aggr, st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+        out = body(graph_state(data))
         if int(flag.item()) != 0:
             from .native import MorigNativeError
             raise MorigNativeError("an operand left the split-fp16 range in the train-mode forward: train with MORIG_PRECISION=f32")
-    return motion_all, aggr, out
+    return out
+
+
+def skinnet_inner(net, data, motion, st):
+    """SkinNet_inner.forward (models/rignet.py:158-182)"""
+    cols = torch.tensor(net.sample_columns(data.skin_input.shape[1]), dtype=torch.long, device=motion.device)
+    raw = torch.cat([data.pos.float(), data.skin_input.float()[:, cols]], 1)
+    x1 = gcumotion(net.gcu1, raw, motion, st["csr_tpl"], st["csr_geo"])
+    g = SegMaxPool.apply(mlp_layer(mlp_layer(x1, net.multi_layer_tranform2[0]), net.multi_layer_tranform2[1]), st["mesh_ptr"], st["ng"])
+    x2 = gcumotion(net.gcu2, raw, x1, st["csr_tpl"], st["csr_geo"])
+    x3 = gcumotion(net.gcu3, raw, x2, st["csr_tpl"], st["csr_geo"])
+    cb = net.cls_branch
+    h = mlp_layer(mlp_layer(torch.cat([x3, g[st["batch"]]], 1), cb[0][0]), cb[0][1])
+    return NativeLinear.apply(h, cb[1].weight, cb[1].bias)
+
+
+def skin_motion_step(model, data, input_flow):
+    """SkinMotion.forward in training mode with an autograd graph (models/rignet.py:196-205) -> (motion_all, motion_aggr, skin_cls_pred)"""
+    def body(st):
+        motion_all, aggr = _motion_backbone(model, data, input_flow, st, "attn")
+        return motion_all, aggr, skinnet_inner(model.skinNet, data, aggr, st)
+    return _guarded_step(data, body)
+
+
+def motion_head_step(model, data, input_flow):
+    """JointNetMotion / MaskNetMotion.forward in training mode with an autograd graph (models/rignet.py:82-100):
+    -> (motion_all [n, T, 32], motion_aggr, head output). Raises if an operand left the split-fp16 range on the way."""
+    def body(st):
+        motion_all, aggr = _motion_backbone(model, data, input_flow, st, model.aggr_method)
+        head = getattr(model, model._head)
+        out = gcnrig(head, data.pos.float(), aggr, st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+        return motion_all, aggr, out
+    return _guarded_step(data, body)

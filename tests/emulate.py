@@ -482,6 +482,100 @@ def _emu_segmax_affine(self, Z: Mat, rowptr, n_segments, out: Mat, scale=None, s
     out.view().copy_(res)
 
 
+# ---- train-mode backward operators (csrc/train_bwd.hip): the formulas, in float64 ----------------------------------------------
+def _rows(M: Mat, rows_dev):
+    return int(rows_dev.item()) if rows_dev is not None else M.rows
+
+
+def _emu_bn_backward_stats(self, dz: Mat, y=None, mean=None, rstd=None, rows_dev=None):
+    r = _rows(dz, rows_dev)
+    g = dz.view()[:r].double()
+    assert not torch.isnan(g).any()
+    if y is None:
+        return g.sum(0).float(), None
+    xh = (y.view()[:r].double() - mean.double()) * rstd.double()
+    return g.sum(0).float(), (g * xh).sum(0).float()
+
+
+def _emu_bn_relu_backward(self, dz: Mat, y: Mat, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, rows_dev=None):
+    r = _rows(dz, rows_dev)
+    yv = y.view()[:r]
+    xh = (yv - mean) * rstd
+    g = gamma * rstd * (dz.view()[:r] - sum_dz / r - xh * (sum_dzx / r))
+    du.view()[:r] = torch.where(yv > 0, g, torch.zeros_like(g))
+
+
+def _emu_segmax_affine_arg(self, Z: Mat, rowptr, n_segments, out: Mat, scale=None, shift=None):
+    p = rowptr.long().tolist()
+    z = Z.view()
+    if scale is not None:
+        z = z * scale[: Z.cols] + shift[: Z.cols]
+    res = torch.zeros((n_segments, Z.cols))
+    arg = torch.full((n_segments, Z.cols), -1, dtype=torch.int32)
+    for v in range(n_segments):
+        if p[v + 1] > p[v]:
+            seg = z[p[v]:p[v + 1]]
+            res[v] = seg.max(0)[0]
+            arg[v] = ((seg == res[v]).int().argmax(0) + p[v]).int()      # first maximum
+    out.view().copy_(res)
+    return arg
+
+
+def _dense_dz(dout: Mat, arg, rows, cols):
+    dz = torch.zeros((rows, cols), dtype=torch.float64)
+    live = arg >= 0
+    cc = torch.arange(cols).expand_as(arg)
+    dz[arg[live].long(), cc[live]] = dout.view().double()[live]
+    return dz
+
+
+def _emu_segmax_bn_backward_stats(self, dout: Mat, arg, Z: Mat, mean, rstd):
+    dz = _dense_dz(dout, arg, Z.rows, Z.cols)
+    xh = (torch.nan_to_num(Z.view().double()) - mean.double()) * rstd.double()
+    return dz.sum(0).float(), (dz * xh).sum(0).float()
+
+
+def _emu_segmax_bn_relu_backward(self, dout: Mat, arg, Z: Mat, rowptr, seg_of_row, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, relu=True):
+    r = int(rowptr[-1])
+    dz = _dense_dz(dout, arg, Z.rows, Z.cols)[:r].float()
+    zv = Z.view()[:r]
+    xh = (zv - mean) * rstd
+    g = gamma * rstd * (dz - sum_dz / r - xh * (sum_dzx / r))
+    du.view()[:r] = torch.where(zv > 0, g, torch.zeros_like(g)) if relu else g
+
+
+def _emu_edge_scatter_backward(self, dG: Mat, csr: CSR, n_src, dA: Mat, dB: Mat):
+    E = int(csr.rowptr[-1])
+    g = dG.view()[:E]
+    a = torch.zeros((csr.n_nodes, dG.cols)).index_add_(0, csr.dst[:E].long(), g)
+    b = torch.zeros((n_src, dG.cols)).index_add_(0, csr.src[:E].long(), g)
+    dA.view().copy_(a)
+    dB.view().copy_(b)
+
+
+def _emu_gemm_tn(self, A: Mat, B: Mat, out=None, rows_dev=None):
+    r = _rows(A, rows_dev)
+    res = (A.view()[:r].double().t() @ B.view()[:r].double()).float()
+    if out is not None:
+        out.view().copy_(res)
+        return out.base
+    return res
+
+
+def _emu_flag(self, device):
+    if not hasattr(self, "_ovf"):
+        self._ovf = torch.zeros(1, dtype=torch.int32)
+    return self._ovf
+
+
+EmuOps.bn_backward_stats = _emu_bn_backward_stats
+EmuOps.bn_relu_backward = _emu_bn_relu_backward
+EmuOps.segmax_affine_arg = _emu_segmax_affine_arg
+EmuOps.segmax_bn_backward_stats = _emu_segmax_bn_backward_stats
+EmuOps.segmax_bn_relu_backward = _emu_segmax_bn_relu_backward
+EmuOps.edge_scatter_backward = _emu_edge_scatter_backward
+EmuOps.gemm_tn = _emu_gemm_tn
+EmuOps._flag = _emu_flag
 EmuOps.col_stats = _emu_col_stats
 EmuOps.col_affine = _emu_col_affine
 EmuOps.edge_gather_relu = _emu_edge_gather_relu

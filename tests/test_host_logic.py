@@ -247,3 +247,44 @@ def test_modules_pickle_and_deepcopy_without_device_caches(emulated_ops):
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)
     assert torch.equal(m3(d, False, False)[0], want) and torch.equal(m2(d, False, False)[0], want)
+
+
+def test_train_backward_host_wiring(emulated_ops):
+    """SURVEY 8 f-4 backward half: the autograd blocks of morig_amd/train_backward.py on the emulated op layer -- a GCNRig
+    training step (12 edge MLPs, pooling, dense layers) against torch.autograd on the oracle. The operators' formulas are
+    emulated in torch here; the HIP kernels themselves are held to the same references in tests/test_gpu_backward.py."""
+    import copy
+    from morig_amd import train_backward as TB
+    from oracle import nets
+    kw = dict(chn_feature=3, chn_output=32)
+    ref = nets.RigGCN(**kw).train().double()
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.weight[::3] *= -1.0
+                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+    mine = rn.GCNRig(**kw).train()
+    mine.load_state_dict(copy.deepcopy(ref.float().state_dict()))
+    ref.double()
+    b = synth.make_batch([5, 6], n_side=7, with_skin=False)
+    feat = torch.randn(b.pos.shape[0], 3, generator=g) * 0.05
+    w = torch.randn(b.pos.shape[0], 32, generator=g)
+    with torch.enable_grad():
+        o = ref(b.pos.double(), feat.double(), b.tpl_edge_index, b.geo_edge_index, b.batch)
+        (o * w.double()).sum().backward()
+        st = TB.graph_state(b)
+        om = TB.gcnrig(mine, b.pos.float(), feat, st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+        (om * w).sum().backward()
+    assert rel_excess(om, o, 5e-4, strict=False) <= 0          # fp32 train-mode forward against the float64 run (98 vertices)
+    med = []
+    for (k, p), (_, q) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and p.grad.shape == q.grad.shape, k
+        a, r = p.grad.double().flatten(), q.grad.flatten()
+        med.append(float((a - r).abs().max()) / max(float(r.abs().max()), 1e-12))
+        assert float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300)) >= 0.97, k       # fp32 conditioning: see test_gpu_backward.py
+    assert sorted(med)[len(med) // 2] <= 2e-2
+    for (k, v), (_, r) in zip(mine.state_dict().items(), ref.state_dict().items()):
+        if k.endswith("running_mean"):
+            assert maxdiff(v, r.float()) <= 1e-4, k

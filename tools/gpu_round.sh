@@ -4,7 +4,7 @@ mkdir -p gpurun_out
 TAG=${1:-r02a}
 timeout 1500 python -m pytest tests/test_gpu_kernels.py -q -m gpu --timeout=900 2>&1 | tail -40 > gpurun_out/pytest_kernels_$TAG.txt
 tail -4 gpurun_out/pytest_kernels_$TAG.txt
-timeout 1800 python -m pytest tests/test_gpu_networks.py tests/test_joints_host.py tests/test_harness_and_dist.py -q -m gpu --timeout=1200 2>&1 | tail -60 > gpurun_out/pytest_networks_$TAG.txt
+timeout 1800 python -m pytest tests/test_gpu_networks.py tests/test_gpu_backward.py tests/test_formats.py tests/test_joints_host.py tests/test_harness_and_dist.py -q -m gpu --timeout=1200 2>&1 | tail -60 > gpurun_out/pytest_networks_$TAG.txt
 tail -4 gpurun_out/pytest_networks_$TAG.txt
 OUT=gpurun_out/ws_ab_$TAG.txt
 : > $OUT
