@@ -35,7 +35,7 @@ import torch.nn.functional as F
 from . import packing
 from .native import CSR, Mat
 from .runtime import get_ops
-from .train_forward import _bn_train, _ld4, _pad_to
+from .train_forward import _bn_train, _ld4, _pad_to, batch_moments, set_batchnorm_sync, sync_backward_sums  # noqa: F401
 
 
 # Arithmetic of the FORWARD contractions in training mode. Default: the exact-fp32 MFMA kernels. The split-fp16 path carries
@@ -90,12 +90,13 @@ class DenseTrain(torch.autograd.Function):
         pk = _pack_fwd(weight, bias, dev)
         y = torch.zeros((xa.shape[0], _ld4(N)), dtype=torch.float32, device=dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=True, Y=Mat.of(y, 0, N))
-        mean, var, cnt = ops.col_stats(Mat.of(y, 0, N))
+        mean, var, cnt, share = batch_moments(ops, Mat.of(y, 0, N))
         s, t = _bn_train(bn, mean, var, cnt)
         z = y.clone()
         ops.col_affine(Mat.of(z, 0, N), s, t)
         ctx.save_for_backward(xa, weight, y, mean, torch.rsqrt(var + bn.eps), gamma)
         ctx.dims = (K, N)
+        ctx.share = share
         return z[:, :N]
 
     @staticmethod
@@ -107,9 +108,10 @@ class DenseTrain(torch.autograd.Function):
         dza = _rows16(dz)
         Y = Mat.of(y, 0, N)
         sdz, sdzx = ops.bn_backward_stats(Mat.of(dza, 0, N), Y, mean, rstd)
+        ksdz, ksdzx, _, _ = sync_backward_sums(sdz, sdzx, ctx.share)          # dgamma / dbeta stay per-rank partial sums (as dW)
         du = torch.zeros_like(y)
         DU = Mat.of(du, 0, N)
-        ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), sdz, sdzx, DU)
+        ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), ksdz, ksdzx, DU)
         db, _ = ops.bn_backward_stats(DU)
         dW = ops.gemm_tn(DU, Mat.of(xa, 0, K))
         dX = _gemm_f32(ops, DU, weight.detach().t().contiguous(), K)[:, :K]
@@ -166,7 +168,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         e_live = csr.rowptr[csr.n_nodes:csr.n_nodes + 1]
         z1 = torch.zeros((csr.capacity, _ld4(H)), dtype=torch.float32, device=dev)
         ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H))
-        mean1, var1, cnt = ops.col_stats(Mat.of(z1, 0, H), rows_dev=e_live)
+        mean1, var1, cnt, share1 = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live)
         s1, t1 = _bn_train(bn1, mean1, var1, cnt)
         Hp, Kp = max(H, 32), (H + 31) // 32 * 32
         W2p = torch.zeros((Hp, Kp), dtype=torch.float32, device=dev)
@@ -175,13 +177,14 @@ class EdgeMLPTrain(torch.autograd.Function):
                                 torch.ones(Hp, device=dev), torch.zeros(Hp, device=dev), None)
         z2 = torch.zeros((csr.capacity, _ld4(H)), dtype=torch.float32, device=dev)
         ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
-        mean2, var2, cnt2 = ops.col_stats(Mat.of(z2, 0, H), rows_dev=e_live)
+        mean2, var2, cnt2, share2 = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
         s2, t2 = _bn_train(bn2, mean2, var2, cnt2)
         out = torch.zeros((n, _ld4(H)), dtype=torch.float32, device=dev)
         arg = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2)
         ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, torch.rsqrt(var1 + bn1.eps), mean2, torch.rsqrt(var2 + bn2.eps), g1, g2, s1, t1, arg)
         ctx.csr = csr
         ctx.dims = (n, C, H)
+        ctx.shares = (share1, share2)
         return out[:, :H]
 
     @staticmethod
@@ -197,9 +200,10 @@ class EdgeMLPTrain(torch.autograd.Function):
         DO = Mat.of(do, 0, H)
         # BatchNorm2 + ReLU behind the max: one-hot gradient per (vertex, channel)
         sdz2, sdzx2 = ops.segmax_bn_backward_stats(DO, arg, Z2, mean2, rstd2)
+        k2, kx2, _, _ = sync_backward_sums(sdz2, sdzx2, ctx.shares[1])
         du2 = torch.zeros_like(z2)
         DU2 = Mat.of(du2, 0, H)
-        ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), sdz2, sdzx2, DU2)
+        ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2)
         db2, _ = ops.bn_backward_stats(DU2, rows_dev=e_live)
         # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
         dW2 = ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]
@@ -207,7 +211,8 @@ class EdgeMLPTrain(torch.autograd.Function):
         DH = Mat.of(dh, 0, H)
         # BatchNorm1 + ReLU over the edges
         sdz1, sdzx1 = ops.bn_backward_stats(DH, Z1, mean1, rstd1, rows_dev=e_live)
-        ops.bn_relu_backward(DH, Z1, mean1, rstd1, g1.detach().float().contiguous(), sdz1, sdzx1, DH, rows_dev=e_live)
+        k1, kx1, _, _ = sync_backward_sums(sdz1, sdzx1, ctx.shares[0])
+        ops.bn_relu_backward(DH, Z1, mean1, rstd1, g1.detach().float().contiguous(), k1, kx1, DH, rows_dev=e_live)
         # Z1 = relu(A[dst] + B[src])
         dab = torch.zeros((n, _ld4(2 * H)), dtype=torch.float32, device=dev)
         ops.edge_scatter_backward(DH, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H))

@@ -26,6 +26,50 @@ from . import packing
 from .native import CSR, Mat
 
 
+# ---- cross-rank batch statistics (SURVEY 8(e) caveat / f-4): a train-mode forward is only shardable over GPUs if every
+# BatchNorm sees the statistics of the GLOBAL batch. With a process group set here, the per-rank moments are combined by ONE
+# all-reduce of (sum x, sum x^2, n) per BatchNorm (float64, 2C + 1 numbers; RCCL on GPUs, gloo in the CPU tests), and the
+# backward combines its two sums (sum dz, sum dz xhat) the same way: exactly torch.nn.SyncBatchNorm's scheme.
+_SYNC = {"group": None}
+
+
+def set_batchnorm_sync(group) -> None:
+    """group: a torch.distributed process group, True for the default group, None to switch the synchronisation off"""
+    _SYNC["group"] = group
+
+
+def _all_reduce(buf: torch.Tensor) -> torch.Tensor:
+    import torch.distributed as dist
+    g = _SYNC["group"]
+    dist.all_reduce(buf, group=None if g is True else g)
+    return buf
+
+
+def batch_moments(ops, X: Mat, rows_dev=None):
+    """-> (mean, biased var, count [1], local share n_local / n) of the rows of X over the whole (cross-rank) batch"""
+    mean, var, cnt = ops.col_stats(X, rows_dev=rows_dev)
+    if _SYNC["group"] is None:
+        return mean, var, cnt, None
+    C = mean.numel()
+    n_loc = cnt.double()
+    buf = _all_reduce(torch.cat([mean.double() * n_loc, (var.double() + mean.double() ** 2) * n_loc, n_loc]))
+    n = buf[-1].clamp(min=1.0)
+    m = buf[:C] / n
+    v = (buf[C:2 * C] / n - m * m).clamp(min=0.0)
+    return m.float(), v.float(), n.float().reshape(1), (n_loc / n).float().reshape(1)
+
+
+def sync_backward_sums(sdz: torch.Tensor, sdzx: torch.Tensor, share):
+    """the backward's two BatchNorm sums over the global batch, pre-scaled by this rank's share of the rows: the kernels divide by
+    the LOCAL row count, and (global sum) * (n_local / n) / n_local = (global sum) / n. -> (sums for the kernel, global sums)"""
+    if _SYNC["group"] is None or share is None:
+        return sdz, sdzx, sdz, sdzx
+    C = sdz.numel()
+    buf = _all_reduce(torch.cat([sdz.double(), sdzx.double()]))
+    gs, gx = buf[:C].float(), buf[C:].float()
+    return (gs * share).contiguous(), (gx * share).contiguous(), gs, gx
+
+
 def _bn_train(bn: BatchNorm1d, mean: torch.Tensor, var: torch.Tensor, count: torch.Tensor):
     """batch-statistics affine (s, t) of a BatchNorm1d in training mode + its running-buffer update
     (torch.nn.functional.batch_norm semantics: biased variance normalises, unbiased variance is tracked)."""
@@ -61,7 +105,7 @@ def dense_train(ops, X: Mat, layer, out: Mat = None) -> torch.Tensor:
         buf = ops.empty(X.rows, _ld4(N), dev)
         out = Mat.of(buf, 0, N)
     ops.gemm(X, pk, relu=True, Y=out)
-    mean, var, cnt = ops.col_stats(out)
+    mean, var, cnt, _ = batch_moments(ops, out)
     s, t = _bn_train(bn, mean, var, cnt)
     ops.col_affine(out, s, t)
     return out.base
@@ -84,7 +128,7 @@ def edge_mlp_train(ops, X: Mat, csr: CSR, mlp, out: Mat) -> None:
     e_live = csr.rowptr[csr.n_nodes:csr.n_nodes + 1]                       # E' on the device
     z1 = ops.empty(csr.capacity, _ld4(H), dev)
     ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H))
-    mean1, var1, cnt = ops.col_stats(Mat.of(z1, 0, H), rows_dev=e_live)
+    mean1, var1, cnt, _ = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live)
     s1, t1 = _bn_train(l1[2], mean1, var1, cnt)
     Hp, Kp = max(H, 32), (H + 31) // 32 * 32
     W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=dev)
@@ -94,7 +138,7 @@ def edge_mlp_train(ops, X: Mat, csr: CSR, mlp, out: Mat) -> None:
                             ones, zeros, None)                              # hidden affine applied while gathering: fp32 MFMA path
     z2 = ops.empty(csr.capacity, _ld4(H), dev)
     ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
-    mean2, var2, cnt2 = ops.col_stats(Mat.of(z2, 0, H), rows_dev=e_live)
+    mean2, var2, cnt2, _ = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
     s2, t2 = _bn_train(l2[2], mean2, var2, cnt2)
     ops.segmax_affine(Mat.of(z2, 0, H), csr.rowptr, csr.n_nodes, out, s2, t2)
 
