@@ -136,7 +136,7 @@ def step(model, batch_meshes, sync):
     st = TB.graph_state(b)
     feat = b.pred_flow[:, :3].float()
     out = TB.gcnrig(model, b.pos.float(), feat, st['csr_tpl'], st['csr_geo'], st['batch'], st['mesh_ptr'], st['ng'])
-    w = torch.sin(torch.arange(out.numel(), dtype=torch.float32).reshape(out.shape) * 0.37 + b.pos[:, :1] * 5.0)   # a weight that depends on the vertex, not on the shard
+    w = torch.sin(b.pos[:, :1].float() * 50.0 + b.pos[:, 1:2].float() * 31.0 + torch.arange(out.shape[1], dtype=torch.float32))   # a function of the VERTEX, not of its row in the shard
     (out * w).sum().backward()
     return out.detach()
 
@@ -155,17 +155,16 @@ out_all = mdist.all_gather_rows(out_local)
 assert out_all.shape == out_full.shape
 e_out = float((out_all - out_full).abs().max()) / max(1.0, float(out_full.abs().max()))
 assert e_out < 2e-4, e_out
-# whole-network gradients are chaotic in fp32 (tests/test_gpu_backward.py), all the more on 36..64-vertex meshes: two runs that differ
-# only in the summation order of the statistics agree in the bulk (median over tensors, direction of nine tensors in ten), not
-# entry by entry -- the two blocks are held tightly (1e-3) further down instead
+# two fp32 runs that differ only in the summation order of the statistics: a 1e-6 perturbation of the input moves these gradients
+# by 6e-4 (median over tensors) to 7e-3 (worst) of a tensor's scale (measured), so that is the band; the blocks are held tighter below
 errs, worst, low = [], 0.0, 0
 for (k, p), (_, q) in zip(sharded.named_parameters(), full.named_parameters()):
     a, r = p.grad.double().flatten(), q.grad.double().flatten()
     cos = float(torch.dot(a, r) / (a.norm() * r.norm() + 1e-300))
     worst = max(worst, 1.0 - cos)
     errs.append(float((a - r).abs().max()) / max(float(r.abs().max()), 1e-9))
-    low = low + 1 if cos < 0.9 else low
-assert sorted(errs)[len(errs) // 2] <= 0.1 and low <= len(errs) // 10, (sorted(errs)[len(errs) // 2], low)
+    assert cos >= 0.999, (k, cos)
+assert sorted(errs)[len(errs) // 2] <= 5e-3 and max(errs) <= 5e-2, (sorted(errs)[len(errs) // 2], max(errs))
 for (k, v), (_, r) in zip(sharded.state_dict().items(), full.state_dict().items()):
     if k.endswith('running_var') or k.endswith('running_mean'):
         assert float((v - r).abs().max()) <= 1e-4 * max(1.0, float(r.abs().max())), k
