@@ -441,6 +441,31 @@ def main():
                                  config=NAMES[wl][2])
             del st, d2, hb
             torch.cuda.empty_cache()
+        # one TRAINING step of the headline network (train-mode forward with batch statistics, a stand-in L2 loss,
+        # backward through the native backward operators; no optimizer) -- correctness-first kernels, reported for orientation
+        try:
+            from morig_amd import models as _models, synth
+            nb = 8
+            d2 = build_batch([2000 + i for i in range(nb)], args.n_side, with_skin=False, n_pts=0).to(dev)
+            tm = _models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").train()
+            synth.load_recipe(tm, 0, mild=True).to(dev)
+
+            def train_step():
+                for p_ in tm.parameters():
+                    p_.grad = None
+                o = tm(d2, d2.pred_flow)
+                loss = (o[2] ** 2).mean() + (o[1] ** 2).mean()
+                loss.backward()
+                return loss
+            with torch.enable_grad():
+                sdt, _, _ = timed_run(train_step, n_secondary, 1)
+            secondary["train_step"] = dict(metric="meshes/sec jointnet_motion TRAINING step (train-mode forward + backward, no optimizer), 4 k-vert synthetic",
+                                           value=round(nb * n_secondary / sdt, 2), unit="meshes/s", ms_per_step=round(sdt / n_secondary * 1e3, 3),
+                                           steps=n_secondary, warmup=1, batch=nb, config="SURVEY 8(f-4); exact-fp32 MFMA contractions")
+            del tm, d2
+            torch.cuda.empty_cache()
+        except Exception as e:                                   # the secondary lines never take the headline line down
+            secondary["train_step"] = dict(error=repr(e)[:300])
 
     if rank == 0:
         names = NAMES[args.workload]

@@ -102,24 +102,29 @@ def fold_hidden_affine(W2: torch.Tensor, b2: torch.Tensor, s1: torch.Tensor, t1:
 
 def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: Optional[nn.BatchNorm1d] = None,
                 in_cols: Optional[Sequence[int]] = None, k_total: Optional[int] = None,
-                row_tile: Optional[int] = None) -> PackedLinear:
+                row_tile: Optional[int] = None, split: bool = True) -> PackedLinear:
     """weight [N, K_src]. ``in_cols[j]`` = position of source column j in the kernel's input row
-    (default identity); ``k_total`` = logical K of the kernel input (>= max(in_cols)+1)."""
+    (default identity); ``k_total`` = logical K of the kernel input (>= max(in_cols)+1). ``split=False``: no split-fp16 image
+    (the exact-fp32 MFMA kernels only; saves the range check's host synchronisation -- the training path packs every step)."""
     W = weight.detach().float()
     N, Ksrc = W.shape
+    identity = in_cols is None
     if in_cols is None:
         in_cols = list(range(Ksrc))
     K = max(in_cols) + 1 if k_total is None else k_total
     Npad = _roundup(N, row_tile or col_tile(N))
     Kpad = _roundup(K, 64)                      # 64: the split-fp16 dense kernel stages 64-deep K chunks
     Wp = torch.zeros((Npad, Kpad), dtype=torch.float32, device=W.device)
-    Wp[:N, torch.as_tensor(list(in_cols), device=W.device)] = W
+    if identity:
+        Wp[:N, :Ksrc] = W                          # a plain copy (the training path packs every step)
+    else:
+        Wp[:N, torch.as_tensor(list(in_cols), device=W.device)] = W
     s = t = None
     if bn is not None:
         s, t = bn_affine(bn)
     Wp = Wp.contiguous()
     return PackedLinear(Wp, _pad_vec(bias.detach() if bias is not None else torch.zeros(N, device=W.device), Npad),
-                        _pad_vec(s, Npad, 1.0), _pad_vec(t, Npad), N, K, split_f16(Wp))
+                        _pad_vec(s, Npad, 1.0), _pad_vec(t, Npad), N, K, split_f16(Wp) if split else None)
 
 
 def pack_mlp_layer(layer: nn.Sequential, **kw) -> PackedLinear:

@@ -48,10 +48,7 @@ def train_fast() -> bool:
 
 
 def _pack_fwd(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
-    pk = packing.pack_linear(weight.detach(), None if bias is None else bias.detach())
-    if not train_fast():
-        pk.Wsplit = None
-    return packing.to_device(pk, dev)
+    return packing.to_device(packing.pack_linear(weight.detach(), None if bias is None else bias.detach(), split=train_fast()), dev)
 
 
 def _rows16(x: torch.Tensor) -> torch.Tensor:
@@ -65,9 +62,7 @@ def _rows16(x: torch.Tensor) -> torch.Tensor:
 
 def _pack_f32(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
     """a packed Linear for the exact-fp32 MFMA kernels (no split image: morig_gemm then takes the fp32 path)"""
-    pk = packing.pack_linear(weight.detach().float(), None if bias is None else bias.detach().float())
-    pk.Wsplit = None
-    return packing.to_device(pk, dev)
+    return packing.to_device(packing.pack_linear(weight.detach().float(), None if bias is None else bias.detach().float(), split=False), dev)
 
 
 def _gemm_f32(ops, X: Mat, weight: torch.Tensor, n_out: int) -> torch.Tensor:
