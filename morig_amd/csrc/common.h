@@ -60,7 +60,6 @@ struct GemmDmaParams {
     int tiles_n;
     int* ovf;
     int dbg;                                     // ablation: 1 = no epilogue
-    int stagger_ticks, stagger_phases, stagger_first;
     unsigned long long* trace;                   // -DMORIG_DMA_TRACE measurement builds: s_memtime stamps of one mid-launch workgroup           // first wave of workgroups: start delay = phase * ticks of the 100 MHz clock (0 = none)
 };
 int launch_edge_pc(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pc.hip

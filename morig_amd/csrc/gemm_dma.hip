@@ -100,16 +100,6 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     const int nchunk = (p.K + 31) / 32;
-    // every workgroup of a launch takes the same time, so all CUs would reach their store epilogue together and the launch would
-    // alternate between a compute phase without stores and a store burst at HBM write speed. The first workgroup of each CU starts
-    // late by a fraction of a tile time instead (phase = a hash of the CU's first block index), which spreads the bursts for the
-    // rest of the launch.
-    if (p.stagger_ticks > 0 && (int)blockIdx.x < p.stagger_first) {
-        const int phase = ((int)blockIdx.x >> 3) % p.stagger_phases;
-        const unsigned long long t0 = wall_clock64();
-        const unsigned long long wait = (unsigned long long)(phase * p.stagger_ticks);
-        while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(32);
-    }
     // prologue: NS-1 chunks in flight (PER_CHUNK DMA instructions per chunk per wave)
 #pragma unroll
     for (int c = 0; c < DMA_NS - 1; ++c) if (c < nchunk) issue(c);
@@ -290,13 +280,6 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
     if (mode == 256 && p.N % 256 == 0) {
         p.tiles_n = p.N / 256;
         const int nb = cdiv(p.M, 256) * p.tiles_n;
-        static const int phases = [] { const char* e = getenv("MORIG_DMA_STAGGER"); return e ? atoi(e) : 0; }();
-        static const int cus = [] { int d = 0, n = 256; (void)hipGetDevice(&d); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d); return n; }();
-        p.stagger_phases = phases; p.stagger_ticks = 0; p.stagger_first = cus;
-        if (phases > 1 && nb >= 4 * cus) {                                   // only worth a delay when a CU runs several tiles
-            const float tile_us = 13.f + 0.08f * (float)p.K;                  // measured: 34 us at K = 256, 163 us at K = 1862
-            p.stagger_ticks = (int)(tile_us * 100.f / (float)phases);
-        }
 #ifdef MORIG_DMA_TRACE
         static unsigned long long* trace_buf = [] { void* b = nullptr; return hipMalloc(&b, 64 * 8) == hipSuccess ? (unsigned long long*)b : nullptr; }();
         p.trace = trace_buf;
