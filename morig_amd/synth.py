@@ -140,6 +140,7 @@ def collate(meshes: List[MeshData], clouds: Optional[List[torch.Tensor]] = None)
     out.pred_flow = torch.cat(flow, 0)
     out.batch = torch.cat(batch, 0)
     out.name = torch.tensor([int(m.name) for m in meshes])
+    out.num_graphs = len(meshes)                 # as torch_geometric's Batch carries it (saves the dim_size host read)
     if skin:
         out.skin_input = torch.cat(skin, 0)
     # CorrNet naming (datasets/dataset_pose.py: vtx / pts / vtx_batch / pts_batch)
