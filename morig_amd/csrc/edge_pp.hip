@@ -95,6 +95,14 @@ __global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
     // y = relu(acc + b) * sc + sh is monotone in acc (rising for sc >= 0, falling for sc < 0), so the max over a quad's
     // four rows is f(max acc) or f(min acc): two 3-input min/max per quad instead of the affine on every element
     auto write_z_quad = [&]() __attribute__((always_inline)) {
+        // The min/max below read the accumulators from INLINE ASSEMBLY, where the compiler does not insert the wait states the
+        // matrix pipe's write -> VALU read needs (lesson 11: pointconv_fused.hip read stale accumulators that
+        // way). This statement takes every accumulator as an in/out operand, so it is ordered behind the MFMAs and in front of
+        // the reads, and its own s_nop covers the 11 wait states of an 8-pass MFMA.
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) asm volatile("s_nop 15" : "+v"(acc[mt][nt]));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = wn * NT * 32 + nt * 32 + l31;

@@ -266,6 +266,10 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     };
     // y = relu(acc + b) * sc + sh is monotone in acc: the max over a quad's four rows is f(max acc) or f(min acc)
     auto write_z = [&]() __attribute__((always_inline)) {
+        // the min/max below read the accumulators from inline assembly: ordered behind the MFMAs and given their wait states by
+        // hand (see edge_pp.hip write_z_quad; DESIGN section 5, lesson 11)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("s_nop 15" : "+v"(acc[mt]));
         const int col = 32 * wn + l31;
         const float b = sbias[col], sc = sbias[H + col], sh = sbias[2 * H + col];
         const bool rising = sc >= 0.f;
