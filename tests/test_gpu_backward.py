@@ -273,3 +273,40 @@ def test_module_api_trains_like_the_reference_loop(precision):
         assert sum(moved) >= len(moved) // 3, (arch, sum(moved), len(moved))        # (|lr g| is below the last bit of many at this lr)
         nb = [v for k, v in mine.state_dict().items() if k.endswith("num_batches_tracked")]
         assert nb and all(int(v) > 0 for v in nb)
+
+
+def test_skinnet_training_step_gradients(monkeypatch):
+    """SkinMotion in training mode (models/rignet.py:136-205: three 256-wide GCUMotion units over [pos | skin samples] with 64-wide
+    position branches, pooling, the classification head): every parameter gradient against torch.autograd on the oracle."""
+    monkeypatch.setenv("MORIG_TRAIN_PRECISION", "f32")
+    kw = dict(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True, motion_dim=32)
+    ref64 = _randomise(nets.skinnet_motion(**kw), 13).train().double()
+    ref32 = copy.deepcopy(ref64).float()
+    mine = models.skinnet_motion(**kw).train()
+    mine.load_state_dict(copy.deepcopy(ref32.state_dict()))
+    mine.to(DEV)
+    b = synth.make_batch(range(31, 33), n_side=9, with_skin=True)
+    g = torch.Generator().manual_seed(6)
+    n = b.pos.shape[0]
+    w = [torch.randn(n, 5, 32, generator=g), torch.randn(n, 32, generator=g), torch.randn(n, 5, generator=g)]
+
+    def loss(o, dt, dev="cpu"):
+        return sum((o[i] * w[i].to(dev, dt)).sum() for i in range(3))
+
+    outs = {}
+    for name, net, dt in (("r64", ref64, torch.float64), ("r32", ref32, torch.float32)):
+        bb = copy.copy(b)
+        bb.pos, bb.skin_input = b.pos.to(dt), b.skin_input.to(dt)
+        o = net(bb, b.pred_flow.to(dt))
+        loss(o, dt).backward()
+        outs[name] = [t.detach() for t in o]
+    bd = b.to(DEV)
+    o = mine(bd, bd.pred_flow)                       # module API: train mode + grad enabled -> the autograd blocks
+    loss(o, torch.float32, DEV).backward()
+    for i, nm in enumerate(("motion_all", "motion_aggr", "skin_cls_pred")):
+        scale = max(float(outs["r64"][i].abs().max()), 1e-6)
+        err = float((o[i].detach().cpu().double() - outs["r64"][i]).abs().max()) / scale
+        slack = 4.0 * float((outs["r32"][i].double() - outs["r64"][i]).abs().max()) / scale
+        PARITY_LOG.append((f"backward:skinnet:{nm}", err * scale, scale, err))
+        assert err <= max(2e-4, slack), (nm, err, slack)
+    _grad_report("skinnet_f32", mine, ref64, ref32, 0.99)
