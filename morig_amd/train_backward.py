@@ -51,6 +51,13 @@ def _pack_fwd(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
     return packing.to_device(packing.pack_linear(weight.detach(), None if bias is None else bias.detach(), split=train_fast()), dev)
 
 
+def _buf(rows: int, cols: int, dev) -> torch.Tensor:
+    """[rows, ld4(cols)] fp32 work buffer: uninitialised when there are no padding columns (rows past a CSR's live edge count are
+    never read by the row-counted operators, and zero-filling an edges x H buffer is a full HBM pass), zero-filled otherwise"""
+    ld = _ld4(cols)
+    return torch.empty((rows, ld), dtype=torch.float32, device=dev) if ld == cols else torch.zeros((rows, ld), dtype=torch.float32, device=dev)
+
+
 def _rows16(x: torch.Tensor) -> torch.Tensor:
     """a contiguous fp32 copy of x whose rows are 16-byte aligned (columns zero-padded to a multiple of 4)"""
     x = x.detach().float()
@@ -68,7 +75,7 @@ def _pack_f32(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
 def _gemm_f32(ops, X: Mat, weight: torch.Tensor, n_out: int) -> torch.Tensor:
     """X @ weight^T on the fp32 MFMA path -> [rows, ld4(n_out)] (columns >= n_out are padding)"""
     dev = X.base.device
-    out = torch.zeros((X.rows, _ld4(n_out)), dtype=torch.float32, device=dev)
+    out = _buf(X.rows, n_out, dev)
     ops.gemm(X, _pack_f32(weight, None, dev), relu=False, Y=Mat.of(out, 0, n_out))
     return out
 
@@ -83,7 +90,7 @@ class DenseTrain(torch.autograd.Function):
         xa = _rows16(x)
         K, N = x.shape[1], weight.shape[0]
         pk = _pack_fwd(weight, bias, dev)
-        y = torch.zeros((xa.shape[0], _ld4(N)), dtype=torch.float32, device=dev)
+        y = _buf(xa.shape[0], N, dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=True, Y=Mat.of(y, 0, N))
         mean, var, cnt, share = batch_moments(ops, Mat.of(y, 0, N))
         s, t = _bn_train(bn, mean, var, cnt)
@@ -104,7 +111,7 @@ class DenseTrain(torch.autograd.Function):
         Y = Mat.of(y, 0, N)
         sdz, sdzx = ops.bn_backward_stats(Mat.of(dza, 0, N), Y, mean, rstd)
         ksdz, ksdzx, _, _ = sync_backward_sums(sdz, sdzx, ctx.share)          # dgamma / dbeta stay per-rank partial sums (as dW)
-        du = torch.zeros_like(y)
+        du = torch.empty_like(y) if y.shape[1] == N else torch.zeros_like(y)
         DU = Mat.of(du, 0, N)
         ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), ksdz, ksdzx, DU)
         db, _ = ops.bn_backward_stats(DU)
@@ -123,7 +130,7 @@ class NativeLinear(torch.autograd.Function):
         xa = _rows16(x)
         K, N = x.shape[1], weight.shape[0]
         pk = _pack_fwd(weight, bias, dev)
-        y = torch.zeros((xa.shape[0], _ld4(N)), dtype=torch.float32, device=dev)
+        y = _buf(xa.shape[0], N, dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=False, Y=Mat.of(y, 0, N))
         ctx.save_for_backward(xa, weight)
         ctx.dims = (K, N, bias is not None)
@@ -157,11 +164,11 @@ class EdgeMLPTrain(torch.autograd.Function):
         W1f = W1.detach().float()
         Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)                      # [A | B] = x Wv^T + [b1 | 0]
         vertex = _pack_fwd(Wv, torch.cat([b1.detach().float(), torch.zeros(H, device=W1.device)], 0), dev)
-        ab = torch.zeros((n, _ld4(2 * H)), dtype=torch.float32, device=dev)
+        ab = _buf(n, 2 * H, dev)
         ops.gemm(Mat.of(xa, 0, C), vertex, relu=False, Y=Mat.of(ab, 0, 2 * H))
         A, B = Mat.of(ab, 0, H), Mat.of(ab, H, H)
         e_live = csr.rowptr[csr.n_nodes:csr.n_nodes + 1]
-        z1 = torch.zeros((csr.capacity, _ld4(H)), dtype=torch.float32, device=dev)
+        z1 = _buf(csr.capacity, H, dev)
         ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H))
         mean1, var1, cnt, share1 = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live)
         s1, t1 = _bn_train(bn1, mean1, var1, cnt)
@@ -170,7 +177,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         W2p[:H, :H] = W2.detach().float()
         pe = packing.PackedEdge(H, _pad_to(s1, Kp, 1.0), _pad_to(t1, Kp, 0.0), W2p.contiguous(), _pad_to(b2.detach().float(), Hp, 0.0),
                                 torch.ones(Hp, device=dev), torch.zeros(Hp, device=dev), None)
-        z2 = torch.zeros((csr.capacity, _ld4(H)), dtype=torch.float32, device=dev)
+        z2 = _buf(csr.capacity, H, dev)
         ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
         mean2, var2, cnt2, share2 = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
         s2, t2 = _bn_train(bn2, mean2, var2, cnt2)
@@ -196,7 +203,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         # BatchNorm2 + ReLU behind the max: one-hot gradient per (vertex, channel)
         sdz2, sdzx2 = ops.segmax_bn_backward_stats(DO, arg, Z2, mean2, rstd2)
         k2, kx2, _, _ = sync_backward_sums(sdz2, sdzx2, ctx.shares[1])
-        du2 = torch.zeros_like(z2)
+        du2 = torch.zeros_like(z2)                      # rows past E' feed the dX GEMM below: keep them finite
         DU2 = Mat.of(du2, 0, H)
         ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2)
         db2, _ = ops.bn_backward_stats(DU2, rows_dev=e_live)

@@ -490,7 +490,7 @@ def _rows(M: Mat, rows_dev):
 def _emu_bn_backward_stats(self, dz: Mat, y=None, mean=None, rstd=None, rows_dev=None):
     r = _rows(dz, rows_dev)
     g = dz.view()[:r].double()
-    assert not torch.isnan(g).any()
+    assert not torch.isnan(g).any(), ("uninitialised rows read", tuple(g.shape), torch.nonzero(torch.isnan(g).any(1)).flatten()[:8].tolist())
     if y is None:
         return g.sum(0).float(), None
     xh = (y.view()[:r].double() - mean.double()) * rstd.double()
@@ -530,9 +530,14 @@ def _dense_dz(dout: Mat, arg, rows, cols):
 
 
 def _emu_segmax_bn_backward_stats(self, dout: Mat, arg, Z: Mat, mean, rstd):
-    dz = _dense_dz(dout, arg, Z.rows, Z.cols)
-    xh = (torch.nan_to_num(Z.view().double()) - mean.double()) * rstd.double()
-    return dz.sum(0).float(), (dz * xh).sum(0).float()
+    # as the kernel: only the winning rows of Z are read (rows past the live edge count may hold anything)
+    live = arg >= 0
+    cols = torch.arange(Z.cols).expand_as(arg)
+    g = torch.where(live, dout.view().double(), torch.zeros((), dtype=torch.float64))
+    zwin = Z.view().double()[arg.clamp(min=0).long(), cols]
+    assert not torch.isnan(zwin[live]).any()
+    xh = torch.where(live, (zwin - mean.double()) * rstd.double(), torch.zeros((), dtype=torch.float64))
+    return g.sum(0).float(), (g * xh).sum(0).float()
 
 
 def _emu_segmax_bn_relu_backward(self, dout: Mat, arg, Z: Mat, rowptr, seg_of_row, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, relu=True):
