@@ -100,7 +100,10 @@ class CorrNet(NativeModule):
     def __getstate__(self):
         st = super().__getstate__()
         st["_streams"], st["last_plan"] = {}, None        # HIP stream handles and the last forward's host plan are not state
+        st["last_csr"] = None                              # (nor are the CSRs it left for DeformNet: device buffers)
         return st
+
+    last_csr = None
 
     def _side_stream(self, dev, which: int = 0):
         key = (dev.type, dev.index, which)
@@ -150,6 +153,7 @@ class CorrNet(NativeModule):
         # run over five keyframe replicas, so there the extra rows cost more than the builds.)
         csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)
         csr_tpl4 = ops.csr_build(data.tpl_edge_index, n, pad4=True)
+        self.last_csr = (csr_tpl4, csr_geo4)           # DeformNet's GCNDeform runs on the same two graphs: no second build
         narrow_padded = os.environ.get("MORIG_CORRNET_ONE_CSR", "1") != "0"
         csr_tpl = csr_tpl4 if narrow_padded else ops.csr_build(data.tpl_edge_index, n)
         csr_geo = csr_geo4 if narrow_padded else ops.csr_build(data.geo_edge_index, n)
