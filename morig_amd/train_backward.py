@@ -116,7 +116,7 @@ class DenseTrain(torch.autograd.Function):
         ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), ksdz, ksdzx, DU)
         db, _ = ops.bn_backward_stats(DU)
         dW = ops.gemm_tn(DU, Mat.of(xa, 0, K))
-        dX = _gemm_f32(ops, DU, weight.detach().t().contiguous(), K)[:, :K]
+        dX = _gemm_f32(ops, DU, weight.detach().t().contiguous(), K)[:, :K] if ctx.needs_input_grad[0] else None
         return dX, dW, db, sdzx, sdz, None
 
 
@@ -145,7 +145,7 @@ class NativeLinear(torch.autograd.Function):
         DY = Mat.of(dya, 0, N)
         db = ops.bn_backward_stats(DY)[0] if has_bias else None
         dW = ops.gemm_tn(DY, Mat.of(xa, 0, K))
-        dX = _gemm_f32(ops, DY, weight.detach().t().contiguous(), K)[:, :K]
+        dX = _gemm_f32(ops, DY, weight.detach().t().contiguous(), K)[:, :K] if ctx.needs_input_grad[0] else None
         return dX, dW, db
 
 
@@ -222,9 +222,11 @@ class EdgeMLPTrain(torch.autograd.Function):
         db1, _ = ops.bn_backward_stats(Mat.of(dab, 0, H))
         dWv = ops.gemm_tn(DAB, Mat.of(xa, 0, C))                                       # [2H, C]
         dW1 = torch.cat([dWv[:H], dWv[H:] - dWv[:H]], 1)                               # back to [W_a | W_b]: W_v = [[W_a - W_b], [W_b]]
-        W1f = W1.detach().float()
-        Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)
-        dX = _gemm_f32(ops, DAB, Wv.t().contiguous(), C)[:, :C]
+        dX = None
+        if ctx.needs_input_grad[0]:                       # (positions and input features are leaves without a gradient)
+            W1f = W1.detach().float()
+            Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)
+            dX = _gemm_f32(ops, DAB, Wv.t().contiguous(), C)[:, :C]
         return dX, dW1, db1, sdzx1, sdz1, dW2, db2, sdzx2, sdz2, None, None, None
 
 
