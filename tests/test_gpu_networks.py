@@ -218,6 +218,23 @@ def test_corrnet_larger_clouds_against_oracle():
         assert rel_excess(g, w, TOL) <= 0
 
 
+def test_corrnet_three_streams_are_deterministic_and_equal_one_stream(monkeypatch):
+    """CorrNet runs its vertex branch, the point-feature chain and the point geometry (FPS levels, k-NN searches) on three HIP
+    streams tied together by events (morig_amd/models/corrnet.py): eight forwards of a full-size batch must be bit-identical
+    to each other and to the single-stream schedule -- a missing dependency or a buffer recycled too early shows up here."""
+    kw = dict(input_feature=3, output_feature=64, temprature=0.07)
+    m = synth.load_recipe(models.corrnet(**kw).eval(), 3, mild=True).to(DEV)
+    batch = synth.make_batch(range(40, 48), n_side=64, n_pts=8192).to(DEV)
+    monkeypatch.setenv("MORIG_TWO_STREAMS", "0")
+    ref = [t.clone() for t in m(batch, True, False)[:3]]
+    monkeypatch.setenv("MORIG_TWO_STREAMS", "1")
+    for _ in range(8):
+        got = m(batch, True, False)
+        torch.cuda.synchronize()
+        for g, r in zip(got[:3], ref):
+            assert torch.equal(g, r)
+
+
 def test_deformnet_full_size_properties():
     """BASELINE.json configs[3] pair size (4096-vertex mesh + 8192-point cloud): size-independent properties of the DeformNet
     stages -- mask spans [0, 1] per mesh, neighbour tables stay inside the pair, invisible vertices only consult visible
