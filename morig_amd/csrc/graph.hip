@@ -194,6 +194,16 @@ __global__ void make_seg_kernel(const int64_t* __restrict__ batch, int n, int ng
     }
 }
 
+// cursor[0 .. n) = 0 and *status = 0 in ONE launch. (These were two hipMemsetAsync calls; as memset NODES of a captured HIP graph
+// they made the second replay of the graph die with "write access to a read-only page" as soon as the allocator had handed out
+// other memory in between -- tools/graph_probe2.py, ROCm 7.0; the larger 0xFF memset of the pooled GEMM replays fine. A kernel
+// is also one launch instead of two.)
+__global__ void csr_clear_kernel(int* __restrict__ cursor, int n, int* __restrict__ status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) cursor[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;
+}
+
 static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -223,8 +233,8 @@ extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_ed
     const int nb = cdiv(n_nodes, SCAN_B);
     int* bsum = dst_sorted;                       // scratch until the fill pass (capacity >= n_nodes >= nb)
     ProfScope ps(K_CSR, s, 0.0, 16.0 * n_edges * 2 + 8.0 * n_edges + 12.0 * n_nodes);
-    MORIG_HIP_TRY(hipMemsetAsync(cursor, 0, (size_t)(n_nodes + 1) * sizeof(int), s));
-    MORIG_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), s));
+    hipLaunchKernelGGL(csr_clear_kernel, dim3(grid_for(n_nodes + 1)), dim3(256), 0, s, cursor, n_nodes + 1, status);
+    MORIG_LAUNCH_CHECK();
     if (n_edges > 0) {
         hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, edge_index, n_edges, n_src_nodes, n_nodes, skip_negative, cursor, status);
         MORIG_LAUNCH_CHECK();
@@ -287,7 +297,8 @@ extern "C" int morig_csr_from_slots(const int64_t* coo, int32_t n_nodes, int32_t
     const int nb = cdiv(n_nodes, SCAN_B);
     int* bsum = dst_sorted;                       // scratch until the fill pass (capacity >= n_nodes >= nb)
     ProfScope ps(K_CSR, s, 0.0, 16.0 * n_nodes * (double)max_nbrs + 8.0 * n_nodes * (double)max_nbrs);
-    MORIG_HIP_TRY(hipMemsetAsync(status, 0, sizeof(int), s));
+    hipLaunchKernelGGL(csr_clear_kernel, dim3(1), dim3(64), 0, s, cursor, 0, status);
+    MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_slots_count_kernel, dim3(cdiv(n_nodes, 4)), dim3(256), 0, s, coo, n_nodes, max_nbrs, n_src_nodes, cursor, status);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, 0, bsum);
