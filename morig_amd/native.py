@@ -332,7 +332,7 @@ class NativeOps:
             finally:
                 self._force_f32 = old
         if not self.fast:
-            return fn()
+            return self._run_once(device, fn)          # exact-fp32 mode: no range flag to read, but the CSR status words still are
         flag = self._flag(device)
         flag.zero_()
         self._depth += 1
