@@ -344,8 +344,14 @@ def main():
         dev = torch.device("cuda", local)
         backend = "nccl"                               # RCCL on ROCm
     rccl_ranks = 1
-    if world > 1:
+    # MORIG_BENCH_FORCE_DIST=1: take the collective path at world size 1 too (the 1-GPU box is the only hardware the
+    # RCCL calls can be exercised on from this side: tests/test_harness_and_dist.py::test_rccl_path_on_one_gpu)
+    use_dist = world > 1 or os.environ.get("MORIG_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if PLUMBING:
             dist.init_process_group(backend)
         else:
@@ -358,7 +364,7 @@ def main():
 
     data = host_batch.to(dev)
     n_vert = data.pos.shape[0]
-    gather = (lambda t: mdist.all_gather_rows(t, equal_rows=True)) if world > 1 else (lambda t: t)
+    gather = (lambda t: mdist.all_gather_rows(t, equal_rows=True, even_alone=True)) if use_dist else (lambda t: t)
     step = make_step(args.workload, data, dev, gather)
 
     def sync():
@@ -367,7 +373,7 @@ def main():
 
     def fence():
         sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             sync()
 
@@ -414,7 +420,7 @@ def main():
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     per_rank = [dt]
-    if world > 1:
+    if use_dist:
         allt = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(allt, t)
         per_rank = [float(x.item()) for x in allt]
@@ -516,10 +522,10 @@ def main():
             "data": "synthetic" if not PLUMBING else "synthetic (PLUMBING RUN on CPU emulation + gloo: not a measurement)",
             "config": {"workload": f"{names[1]}, batch={B_local} synthetic "
                                    f"{args.n_side * args.n_side}-vertex meshes per GPU ({names[2]}), "
-                                   "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if world > 1 else ""),
+                                   "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if use_dist else ""),
                        "meshes_per_gpu": B_local, "global_batch": n_units, "vertices_per_mesh": args.n_side * args.n_side,
                        "parallelism": f"mesh-sharded dp{world}"},
-            "rccl_ranks": rccl_ranks, "backend": backend if world > 1 else None,
+            "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
             "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank],
             "roofline": roof,
             "hbm_bound_kernels": hbm_kinds,
@@ -534,7 +540,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

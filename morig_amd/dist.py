@@ -25,13 +25,14 @@ def unshard_order(n_items: int, world: int) -> List[int]:
     return order
 
 
-def all_gather_rows(t: torch.Tensor, equal_rows: bool = False) -> torch.Tensor:
+def all_gather_rows(t: torch.Tensor, equal_rows: bool = False, even_alone: bool = False) -> torch.Tensor:
     """Concatenate every rank's [rows_r, C] tensor along dim 0 on every rank.
 
     equal_rows=True (synthetic batches: same vertex count per rank) is a single
     all_gather_into_tensor; otherwise a count exchange first, then a padded gather (meshes of real
-    datasets differ in size)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    datasets differ in size). ``even_alone``: issue the collectives at world size 1 too (hardware check of the RCCL
+    calls on a one-GPU box)."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not even_alone):
         return t
     world = dist.get_world_size()
     t = t.contiguous()

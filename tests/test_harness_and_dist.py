@@ -7,6 +7,7 @@ import sys
 import tempfile
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import ROOT, load_golden
@@ -276,3 +277,83 @@ def test_bench_single_rank_line_keeps_the_contract():
         assert k in r, k
     assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["unit"] == "meshes/s"
     assert "workload" in r["config"] and "model" not in r["config"]
+
+
+# ---- RCCL on hardware: the one-GPU box can only hold a world of one rank, but every collective the multi-GPU paths issue
+# ---- (process-group creation on the device, all-reduce, all-gather, barrier) goes through RCCL all the same
+@pytest.mark.gpu
+def test_rccl_path_on_one_gpu():
+    """the driver's own launch line at --nproc-per-node 1, with MORIG_BENCH_FORCE_DIST=1 so that bench.py takes its N > 1
+    branch: `init_process_group('nccl', device_id=...)`, the rank-count all-reduce, the RCCL all-gather of the outputs,
+    the barriers around the timed region and the max-over-ranks reduction all run on the GPU."""
+    import json, socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, MORIG_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MORIG_BENCH_PLUMBING"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--batch", "8", "--cpu-seconds", "0", "--secondary", "0", "--prof-steps", "0"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["backend"] == "nccl" and r["rccl_ranks"] == 1 and r["n_gpus"] == 1
+    assert "RCCL all-gather" in r["config"]["workload"] and r["value"] > 0 and len(r["per_rank_ms_per_step"]) == 1
+
+
+_RCCL_WORKER = r"""
+import copy, os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from morig_amd import dist as mdist, models, synth, train_backward as TB
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%s' % sys.argv[2], rank=0, world_size=1, device_id=dev)
+# ragged gather: count exchange + padded all_gather_into_tensor
+t = torch.arange(35, dtype=torch.float32, device=dev).reshape(7, 5)
+assert torch.equal(mdist.all_gather_rows(t, even_alone=True), t)
+assert torch.equal(mdist.all_gather_rows(t, equal_rows=True, even_alone=True), t)
+# one training step with the BatchNorm sums all-reduced over RCCL (fp64 buffers) == the same step without the hook
+torch.manual_seed(7)
+net = models.rignet.GCNRig(chn_feature=3, chn_output=8).train().to(dev)
+b = synth.collate([synth.make_mesh(s, n_side=12, with_skin=False) for s in (1, 2, 3)]).to(dev)
+
+
+def step(model, sync):
+    TB.set_batchnorm_sync(True if sync else None)
+    st = TB.graph_state(b)
+    out = TB.gcnrig(model, b.pos.float(), b.pred_flow[:, :3].float(), st['csr_tpl'], st['csr_geo'], st['batch'], st['mesh_ptr'], st['ng'])
+    w = torch.sin(b.pos[:, :1].float() * 50.0 + torch.arange(out.shape[1], dtype=torch.float32, device=dev))
+    (out * w).sum().backward()
+    return out.detach()
+
+
+a, c = copy.deepcopy(net), copy.deepcopy(net)
+with torch.enable_grad():
+    oa, oc = step(a, True), step(c, False)
+TB.set_batchnorm_sync(None)
+assert float((oa - oc).abs().max()) <= 1e-5 * max(1.0, float(oc.abs().max()))
+for (k, p), (_, q) in zip(a.named_parameters(), c.named_parameters()):
+    assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    x, y = p.grad.double().flatten(), q.grad.double().flatten()
+    assert float(torch.dot(x, y) / (x.norm() * y.norm() + 1e-300)) >= 0.9999, k
+dist.barrier()
+dist.destroy_process_group()
+print('rccl ok')
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_ragged_gather_and_batchnorm_sums_on_one_gpu():
+    import socket, tempfile
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(_RCCL_WORKER)
+    try:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, f.name, ROOT, str(port)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, timeout=600)
+        assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout[-3000:]
+    finally:
+        os.unlink(f.name)
