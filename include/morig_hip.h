@@ -345,7 +345,7 @@ int         morig_prof_collect(int kind, int64_t* launches, double* total_ms, do
  * MLPs, over EDGES inside the per-edge MLPs (models/basic_modules.py:31-36, 153-155, 192-195) -- so the layers run unfused:
  * contraction (morig_gemm / morig_edge_hidden) -> statistics -> affine. */
 /* per-column mean and BIASED variance of x[rows][cols] (fp64 accumulation, fixed summation order). rows_dev != NULL: the row
- * count is read on the device (E' = rowptr[n]) and `rows` is only the capacity. workspace: >= ceil(rows/512)*2*cols doubles.
+ * count is read on the device (E' = rowptr[n]) and `rows` is only the capacity. workspace: >= ceil(rows/256)*2*cols doubles.
  * count (optional): receives the row count as a float. */
 int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, double* workspace,
                     int64_t workspace_doubles, float* mean, float* var, float* count, void* stream);
@@ -370,7 +370,7 @@ int morig_segmax_affine(const float* Z, int32_t ldz, const int32_t* rowptr, int3
  */
 /* per column: sum_dz[c] = sum_r dz[r][c] (= dbeta) and sum_dzx[c] = sum_r dz[r][c] * (y[r][c] - mean[c]) * rstd[c] (= dgamma) of
  * a training-mode BatchNorm1d whose INPUT was y; y == NULL: the plain column sum only (= dbias of a Linear). fp64 accumulation,
- * fixed order. workspace: >= ceil(rows/512) * 2 * cols doubles; rows_dev as in morig_col_stats. */
+ * fixed order. workspace: >= ceil(rows/256) * 2 * cols doubles; rows_dev as in morig_col_stats. */
 int morig_bn_backward_stats(const float* dz, int32_t ldz, const float* y, int32_t ldy, int32_t rows, const int32_t* rows_dev,
                             int32_t cols, const float* mean, const float* rstd, double* workspace, int64_t workspace_doubles,
                             float* sum_dz, float* sum_dzx, void* stream);
@@ -388,7 +388,7 @@ int morig_segmax_bn_backward_stats(const float* dout, int32_t ldd, const int32_t
                                    int32_t n_segments, int32_t cols, const float* mean, const float* rstd, double* workspace,
                                    int64_t workspace_doubles, float* sum_dz, float* sum_dzx, void* stream);
 /* du[e][c] for every row e < rowptr[n_segments] (seg_of_row[e] = its segment): the BatchNorm (+ the ReLU in front of it when
- * relu != 0) applied to that one-hot gradient; n = rowptr[n_segments] */
+ * relu != 0) applied to that one-hot gradient; n = rowptr[n_segments]. Rows rowptr[n_segments] <= e < row_capacity are set to 0. */
 int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, const int32_t* arg, int32_t ld_arg, const float* Z, int32_t ldz,
                                   const int32_t* rowptr, int32_t n_segments, const int32_t* seg_of_row, int32_t row_capacity,
                                   int32_t cols, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,

@@ -90,4 +90,74 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
 
+// ---- two-pass column reductions in fp64 (train_ops.hip / train_bwd.hip) ----------------------------------------------------------
+// First pass: grid (64-column groups, row slabs), 256 threads = (float4 column quads of the group) x (row lanes); every slab writes
+// its [2][cols] partial sums (zeros past the live rows). Second pass: 16 columns x 16 slab lanes per block. Every order is fixed.
+// Rows per slab: 256, more once that would give more than 1024 slabs (the second pass then adds <= 64 partials per lane).
+inline int stats_slab_rows(int rows_cap) {
+    int r = ((rows_cap > 0 ? rows_cap : 1) + 1023) / 1024;
+    r = (r + 3) & ~3;
+    return r < 256 ? 256 : r;
+}
+
+// V consecutive floats of a row (V = 4: one 16-byte access; V = 1: any alignment). vec4_ok(): the host-side predicate
+template <int V> struct VecF { float v[V]; };
+#ifdef __HIPCC__
+template <int V> __device__ inline VecF<V> ldv(const float* p) {
+    VecF<V> r;
+    if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; }
+    else r.v[0] = *p;
+    return r;
+}
+template <int V> __device__ inline void stv(float* p, const VecF<V>& r) {
+    if constexpr (V == 4) *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    else *p = r.v[0];
+}
+#endif
+static inline bool vec4_ptr(const void* p, long ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; }
+
+#ifdef __HIPCC__
+// the block's row-lane sums (acc[k][j]: statistic k of column c0 + 4 q + j) -> part[slab][k][cols], row lanes added in order
+__device__ inline void stats_block_store(const double (&acc)[2][4], int quads, int RL, int q, int rl, int c0, int cols, int slab,
+                                         double* __restrict__ part) {
+    __shared__ double sh[2 * 1024];                                   // [k][column of the group][row lane]
+    const int gc = quads * 4;
+    if (rl < RL) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[(k * gc + q * 4 + j) * RL + rl] = acc[k][j];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 2 * gc) {
+        const int k = t / gc, col = t - k * gc;
+        double s = 0.0;
+        for (int i = 0; i < RL; ++i) s += sh[(k * gc + col) * RL + i];
+        if (c0 + col < cols) part[((size_t)slab * 2 + k) * cols + c0 + col] = s;
+    }
+}
+
+// second pass of one statistic pair: returns through s / q the sums of column c (valid on lane 0 of the column: threadIdx.x < 16)
+__device__ inline void stats_final_sums(const double* __restrict__ part, int slabs, int cols, int c, double& s, double& q) {
+    const int sl = threadIdx.x >> 4, l = threadIdx.x & 15;
+    s = 0.0; q = 0.0;
+    if (c < cols)
+        for (int b = sl; b < slabs; b += 16) { s += part[((size_t)b * 2 + 0) * cols + c]; q += part[((size_t)b * 2 + 1) * cols + c]; }
+    __shared__ double sh[2][16][16];
+    sh[0][sl][l] = s; sh[1][sl][l] = q;
+    __syncthreads();
+    if (sl == 0) {
+        double a[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double (&v)[16][16] = sh[k];
+            a[k] = (((v[0][l] + v[1][l]) + (v[2][l] + v[3][l])) + ((v[4][l] + v[5][l]) + (v[6][l] + v[7][l]))) +
+                   (((v[8][l] + v[9][l]) + (v[10][l] + v[11][l])) + ((v[12][l] + v[13][l]) + (v[14][l] + v[15][l])));
+        }
+        s = a[0]; q = a[1];
+    }
+}
+#endif
+
 }  // namespace morig

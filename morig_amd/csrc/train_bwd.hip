@@ -23,98 +23,139 @@
 
 namespace morig {
 
-constexpr int BS_ROWS = 512;
-
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ y, int ldy,
-                                                             int rows_host, const int* __restrict__ rows_dev, int cols,
+                                                             int rows_host, const int* __restrict__ rows_dev, int cols, int slab_rows,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
                                                              double* __restrict__ part /* [slabs][2][cols] */) {
     const int rows = rows_dev ? *rows_dev : rows_host;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * BS_ROWS;
-    double s = 0.0, q = 0.0;
-    if (c < cols) {
-        const int r1 = min(r0 + BS_ROWS, rows);
-        const float m = y ? mean[c] : 0.f, rs = y ? rstd[c] : 0.f;
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const float g = dz[(size_t)r * ldz + c];
-            s += (double)g;
-            if (y) q += (double)(g * ((y[(size_t)r * ldy + c] - m) * rs));
+    const int c0 = blockIdx.x * 64;
+    const int quads = min(16, (cols - c0 + 3) >> 2);
+    const int RL = 256 / quads;
+    const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
+    const int c = c0 + q * 4;
+    const int r0 = blockIdx.y * slab_rows, r1 = min(r0 + slab_rows, rows);
+    double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (rl < RL) {
+        float m[4], rs[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m[j] = (y && c + j < cols) ? mean[c + j] : 0.f; rs[j] = (y && c + j < cols) ? rstd[c + j] : 0.f; }
+        const bool vec = (ldz & 3) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0 && c + 4 <= cols &&
+                         (!y || ((ldy & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0));
+        if (vec) {
+#pragma unroll 4
+            for (int r = r0 + rl; r < r1; r += RL) {
+                const float4 g4 = *reinterpret_cast<const float4*>(dz + (size_t)r * ldz + c);
+                const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[0][j] += (double)g[j];
+                if (y) {
+                    const float4 y4 = *reinterpret_cast<const float4*>(y + (size_t)r * ldy + c);
+                    const float yv[4] = {y4.x, y4.y, y4.z, y4.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[1][j] += (double)(g[j] * ((yv[j] - m[j]) * rs[j]));
+                }
+            }
+        } else {
+            for (int r = r0 + rl; r < r1; r += RL)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < cols) {
+                        const float g = dz[(size_t)r * ldz + c + j];
+                        acc[0][j] += (double)g;
+                        if (y) acc[1][j] += (double)(g * ((y[(size_t)r * ldy + c + j] - m[j]) * rs[j]));
+                    }
         }
     }
-    __shared__ double sh[2][4][64];
-    sh[0][rl][threadIdx.x & 63] = s; sh[1][rl][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (rl == 0 && c < cols) {
-        const int l = threadIdx.x & 63;
-        part[((size_t)blockIdx.y * 2 + 0) * cols + c] = (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]);
-        part[((size_t)blockIdx.y * 2 + 1) * cols + c] = (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]);
-    }
+    stats_block_store(acc, quads, RL, q, rl, c0, cols, blockIdx.y, part);
 }
 
-__global__ void bn_bwd_final_kernel(const double* __restrict__ part, int slabs_cap, int rows_host, const int* __restrict__ rows_dev,
-                                    int cols, float* __restrict__ sum_dz, float* __restrict__ sum_dzx) {
-    const int rows = rows_dev ? *rows_dev : rows_host;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    const int slabs = min(slabs_cap, (rows + BS_ROWS - 1) / BS_ROWS);
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < slabs; ++b) { s += part[((size_t)b * 2 + 0) * cols + c]; q += part[((size_t)b * 2 + 1) * cols + c]; }
+// second pass: 16 columns x 16 slab lanes per block, fixed order (common.h)
+__global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int slabs, int cols,
+                                                           float* __restrict__ sum_dz, float* __restrict__ sum_dzx) {
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    double s, q;
+    stats_final_sums(part, slabs, cols, c, s, q);
+    if (threadIdx.x >= 16 || c >= cols) return;
     sum_dz[c] = (float)s;
     if (sum_dzx) sum_dzx[c] = (float)q;
 }
 
+template <int V>
 __global__ void bn_relu_bwd_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ y, int ldy, int rows_host,
                                    const int* __restrict__ rows_dev, int cols, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ sum_dz,
                                    const float* __restrict__ sum_dzx, float* __restrict__ du, int ldu) {
     const int rows = rows_dev ? *rows_dev : rows_host;
     const float inv_n = rows > 0 ? 1.f / (float)rows : 0.f;
-    const int64_t total = (int64_t)rows * cols;
+    const int qn = cols / V;
+    const int64_t total = (int64_t)rows * qn;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t r = i / cols; const int c = (int)(i - r * cols);
-        const float yv = y[r * ldy + c];
-        const float xh = (yv - mean[c]) * rstd[c];
-        const float g = gamma[c] * rstd[c] * (dz[r * ldz + c] - sum_dz[c] * inv_n - xh * (sum_dzx[c] * inv_n));
-        du[r * ldu + c] = yv > 0.f ? g : 0.f;
+        const int64_t r = i / qn; const int c = (int)(i - r * qn) * V;
+        const VecF<V> yv = ldv<V>(y + r * ldy + c), g = ldv<V>(dz + r * ldz + c);
+        VecF<V> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float xh = (yv.v[j] - mean[c + j]) * rstd[c + j];
+            const float d = gamma[c + j] * rstd[c + j] * (g.v[j] - sum_dz[c + j] * inv_n - xh * (sum_dzx[c + j] * inv_n));
+            o.v[j] = yv.v[j] > 0.f ? d : 0.f;
+        }
+        stv<V>(du + r * ldu + c, o);
     }
 }
 
-// one wave per (segment, 64-column group), as segmax_affine_kernel, plus the winning row
+// one thread per (segment, V columns), as segmax_affine_kernel, plus the winning row
+template <int V>
 __global__ __launch_bounds__(256) void segmax_arg_kernel(const float* __restrict__ Z, int ldz, const int* __restrict__ rowptr, int n_seg,
                                                          int H, const float* __restrict__ scale, const float* __restrict__ shift,
                                                          float* __restrict__ out, int ldo, int* __restrict__ arg, int ld_arg) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (v >= n_seg) return;
-    const int c = blockIdx.y * 64 + lane;
-    if (c >= H) return;
+    const int qn = H / V;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n_seg * qn) return;
+    const int v = (int)(t / qn), c = (int)(t - (int64_t)v * qn) * V;
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    if (e0 >= e1) { out[(size_t)v * ldo + c] = 0.f; arg[(size_t)v * ld_arg + c] = -1; return; }
-    const float s = scale ? scale[c] : 1.f, t = shift ? shift[c] : 0.f;
-    float m = Z[(size_t)e0 * ldz + c] * s + t;
-    int a = e0;
-    for (int e = e0 + 1; e < e1; ++e) {
-        const float z = Z[(size_t)e * ldz + c] * s + t;
-        if (z > m) { m = z; a = e; }                                 // strict: the first maximum keeps the gradient
+    VecF<V> m;
+    int a[V];
+    if (e0 >= e1) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { m.v[j] = 0.f; arg[(size_t)v * ld_arg + c + j] = -1; }
+        stv<V>(out + (size_t)v * ldo + c, m);
+        return;
     }
-    out[(size_t)v * ldo + c] = m;
-    arg[(size_t)v * ld_arg + c] = a;
+    VecF<V> s, sh;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s.v[j] = scale ? scale[c + j] : 1.f; sh.v[j] = shift ? shift[c + j] : 0.f; }
+    {
+        const VecF<V> z = ldv<V>(Z + (size_t)e0 * ldz + c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) { m.v[j] = z.v[j] * s.v[j] + sh.v[j]; a[j] = e0; }
+    }
+    for (int e = e0 + 1; e < e1; ++e) {
+        const VecF<V> z = ldv<V>(Z + (size_t)e * ldz + c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float w = z.v[j] * s.v[j] + sh.v[j];
+            if (w > m.v[j]) { m.v[j] = w; a[j] = e; }                // strict: the first maximum keeps the gradient
+        }
+    }
+    stv<V>(out + (size_t)v * ldo + c, m);
+    VecF<V> ab;
+#pragma unroll
+    for (int j = 0; j < V; ++j) ab.v[j] = __int_as_float(a[j]);
+    stv<V>(reinterpret_cast<float*>(arg) + (size_t)v * ld_arg + c, ab);
 }
 
 // sums over SEGMENTS of the one-hot row gradient: dz[arg[v][c]][c] = dout[v][c]
 __global__ __launch_bounds__(256) void segmax_bwd_partial_kernel(const float* __restrict__ dout, int ldd, const int* __restrict__ arg,
                                                                  int ld_arg, const float* __restrict__ Z, int ldz, int n_seg, int cols,
-                                                                 const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                                 double* __restrict__ part) {
+                                                                 int slab_rows, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, double* __restrict__ part) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
-    const int v0 = blockIdx.y * BS_ROWS;
+    const int v0 = blockIdx.y * slab_rows;
     double s = 0.0, q = 0.0;
     if (c < cols) {
-        const int v1 = min(v0 + BS_ROWS, n_seg);
+        const int v1 = min(v0 + slab_rows, n_seg);
         const float m = mean[c], rs = rstd[c];
         for (int v = v0 + rl; v < v1; v += 4) {
             const int a = arg[(size_t)v * ld_arg + c];
@@ -134,44 +175,62 @@ __global__ __launch_bounds__(256) void segmax_bwd_partial_kernel(const float* __
     }
 }
 
+template <int V>
 __global__ void segmax_bn_relu_bwd_kernel(const float* __restrict__ dout, int ldd, const int* __restrict__ arg, int ld_arg,
                                           const float* __restrict__ Z, int ldz, const int* __restrict__ rowptr, int n_seg,
-                                          const int* __restrict__ seg_of_row, int cols, const float* __restrict__ mean,
-                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                          const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx, int relu,
-                                          float* __restrict__ du, int ldu) {
+                                          const int* __restrict__ seg_of_row, int row_capacity, int cols,
+                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          const float* __restrict__ gamma, const float* __restrict__ sum_dz,
+                                          const float* __restrict__ sum_dzx, int relu, float* __restrict__ du, int ldu) {
     const int rows = rowptr[n_seg];
     const float inv_n = rows > 0 ? 1.f / (float)rows : 0.f;
-    const int64_t total = (int64_t)rows * cols;
+    const int qn = cols / V;
+    const int64_t total = (int64_t)row_capacity * qn;            // rows past the live count are zeroed: du feeds a GEMM over the capacity
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t e = i / cols; const int c = (int)(i - e * cols);
+        const int64_t e = i / qn; const int c = (int)(i - e * qn) * V;
+        VecF<V> o;
+        if (e >= rows) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) o.v[j] = 0.f;
+            stv<V>(du + e * ldu + c, o);
+            continue;
+        }
         const int v = seg_of_row[e];
-        const float zv = Z[e * ldz + c];
-        const float xh = (zv - mean[c]) * rstd[c];
-        const float dzv = arg[(size_t)v * ld_arg + c] == (int)e ? dout[(size_t)v * ldd + c] : 0.f;
-        const float g = gamma[c] * rstd[c] * (dzv - sum_dz[c] * inv_n - xh * (sum_dzx[c] * inv_n));
-        du[e * ldu + c] = (!relu || zv > 0.f) ? g : 0.f;
+        const VecF<V> zv = ldv<V>(Z + e * ldz + c);
+        const VecF<V> dv = ldv<V>(dout + (size_t)v * ldd + c);
+        const VecF<V> av = ldv<V>(reinterpret_cast<const float*>(arg) + (size_t)v * ld_arg + c);       // (row indices, moved as bits)
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            const float xh = (zv.v[j] - mean[c + j]) * rstd[c + j];
+            const float dzv = __float_as_int(av.v[j]) == (int)e ? dv.v[j] : 0.f;
+            const float g = gamma[c + j] * rstd[c + j] * (dzv - sum_dz[c + j] * inv_n - xh * (sum_dzx[c + j] * inv_n));
+            o.v[j] = (!relu || zv.v[j] > 0.f) ? g : 0.f;
+        }
+        stv<V>(du + e * ldu + c, o);
     }
 }
 
-// dA[v] = sum over the rows of segment v (fixed order); dB[src(e)] += dG[e] (atomics). One wave per (segment, 64 columns).
+// dA[v] = sum over the rows of segment v (fixed order); dB[src(e)] += dG[e] (atomics). One thread per (segment, V columns).
+template <int V>
 __global__ __launch_bounds__(256) void edge_scatter_bwd_kernel(const float* __restrict__ dG, int ldg, const int* __restrict__ rowptr,
                                                                const int* __restrict__ srcS, int n_nodes, int H,
                                                                float* __restrict__ dA, int lda, float* __restrict__ dB, int ldb) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (v >= n_nodes) return;
-    const int c = blockIdx.y * 64 + lane;
-    if (c >= H) return;
+    const int qn = H / V;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n_nodes * qn) return;
+    const int v = (int)(t / qn), c = (int)(t - (int64_t)v * qn) * V;
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    float s = 0.f;
+    VecF<V> s;
+#pragma unroll
+    for (int j = 0; j < V; ++j) s.v[j] = 0.f;
     for (int e = e0; e < e1; ++e) {
-        const float g = dG[(size_t)e * ldg + c];
-        s += g;
-        atomicAdd(dB + (size_t)srcS[e] * ldb + c, g);
+        const VecF<V> g = ldv<V>(dG + (size_t)e * ldg + c);
+        float* pb = dB + (size_t)srcS[e] * ldb + c;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { s.v[j] += g.v[j]; atomicAdd(pb + j, g.v[j]); }
     }
-    dA[(size_t)v * lda + c] = s;
+    stv<V>(dA + (size_t)v * lda + c, s);
 }
 
 // ---- C = A^T B over the rows -----------------------------------------------------------------------------------------------
@@ -203,35 +262,46 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     const int lr = tid >> 5, lc = (tid & 31) * 4;                  // loader: 8 rows x 32 float4 per pass, 4 passes per operand
     const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     const bool b_vec = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+    // 32-column sub-tiles that lie wholly past N / K (narrow layers: H = 16, 32; K = 3 position inputs) are skipped (wave-uniform)
+    const bool on_a[2] = {n0 + wn < N, n0 + wn + 32 < N}, on_b[2] = {k0 + wk < K, k0 + wk + 32 < K};
+    tn_f32x4 va[TN_R / 8], vb[TN_R / 8];
+    auto fetch = [&](int r0) {                                      // global -> registers (in flight under the MFMAs of the previous stage)
+#pragma unroll
+        for (int p = 0; p < TN_R / 8; ++p) {
+            const int r = r0 + p * 8 + lr;
+            va[p] = tn_f32x4{0.f, 0.f, 0.f, 0.f}; vb[p] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < r_end) {
+                const float* pa = A + (size_t)r * lda + n0 + lc;
+                const float* pb = B + (size_t)r * ldb + k0 + lc;
+                if (a_vec && n0 + lc + 4 <= N) va[p] = *reinterpret_cast<const tn_f32x4*>(pa);
+                else { for (int q = 0; q < 4; ++q) if (n0 + lc + q < N) va[p][q] = pa[q]; }
+                if (b_vec && k0 + lc + 4 <= K) vb[p] = *reinterpret_cast<const tn_f32x4*>(pb);
+                else { for (int q = 0; q < 4; ++q) if (k0 + lc + q < K) vb[p][q] = pb[q]; }
+            }
+        }
+    };
+    if (r_begin < r_end) fetch(r_begin);
     for (int r0 = r_begin; r0 < r_end; r0 += TN_R) {
         __syncthreads();
 #pragma unroll
         for (int p = 0; p < TN_R / 8; ++p) {
-            const int r = r0 + p * 8 + lr;
-            tn_f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
-            if (r < r_end) {
-                const float* pa = A + (size_t)r * lda + n0 + lc;
-                const float* pb = B + (size_t)r * ldb + k0 + lc;
-                if (a_vec && n0 + lc + 4 <= N) va = *reinterpret_cast<const tn_f32x4*>(pa);
-                else { for (int q = 0; q < 4; ++q) if (n0 + lc + q < N) va[q] = pa[q]; }
-                if (b_vec && k0 + lc + 4 <= K) vb = *reinterpret_cast<const tn_f32x4*>(pb);
-                else { for (int q = 0; q < 4; ++q) if (k0 + lc + q < K) vb[q] = pb[q]; }
-            }
-            *reinterpret_cast<tn_f32x4*>(&sA[p * 8 + lr][lc]) = va;
-            *reinterpret_cast<tn_f32x4*>(&sB[p * 8 + lr][lc]) = vb;
+            *reinterpret_cast<tn_f32x4*>(&sA[p * 8 + lr][lc]) = va[p];
+            *reinterpret_cast<tn_f32x4*>(&sB[p * 8 + lr][lc]) = vb[p];
         }
         __syncthreads();
+        if (r0 + TN_R < r_end) fetch(r0 + TN_R);
 #pragma unroll 4
         for (int kk = 0; kk < TN_R; kk += 2) {
             float fa[2], fb[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fa[a] = sA[kk + hi][wn + a * 32 + l31];
+            for (int a = 0; a < 2; ++a) fa[a] = on_a[a] ? sA[kk + hi][wn + a * 32 + l31] : 0.f;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = sB[kk + hi][wk + b * 32 + l31];
+            for (int b = 0; b < 2; ++b) fb[b] = on_b[b] ? sB[kk + hi][wk + b * 32 + l31] : 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b)
+                    if (on_a[a] && on_b[b]) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
     }
     float* o = part + (size_t)blockIdx.z * N * K;
@@ -246,20 +316,29 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             }
 }
 
-__global__ void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, int N, int K, float* __restrict__ out, int ldo) {
+// partial tiles -> C: 32 output elements x 8 chunk lanes per block; lane j adds chunks j, j + 8, ... in order, the eight lane sums
+// are combined as a fixed tree (deterministic; the chain per lane is <= 64 additions)
+__global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, int N, int K,
+                                                             float* __restrict__ out, int ldo) {
     const int64_t total = (int64_t)N * K;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        float s = 0.f;
-        for (int c = 0; c < chunks; ++c) s += part[(size_t)c * total + i];
-        const int64_t n = i / K; const int k = (int)(i - n * K);
-        out[n * ldo + k] = s;
-    }
+    const int el = threadIdx.x & 31, ln = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + el;
+    float s = 0.f;
+    if (i < total)
+        for (int c = ln; c < chunks; c += 8) s += part[(size_t)c * total + i];
+    __shared__ float sh[8][32];
+    sh[ln][el] = s;
+    __syncthreads();
+    if (ln != 0 || i >= total) return;
+    s = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
+    const int64_t n = i / K; const int k = (int)(i - n * K);
+    out[n * ldo + k] = s;
 }
 
 static int tn_chunks(int rows, int N, int K) {
     const int tiles = cdiv(N, TN_T) * cdiv(K, TN_T);
-    int chunks = cdiv(1024, tiles);                                   // ~4 workgroups per CU
+    int chunks = cdiv(1024, tiles);                                   // ~4 workgroups per CU ...
+    if (chunks > 512) chunks = 512;                                   // ... and at most 64 additions per lane of the reduction
     const int max_chunks = cdiv(rows > 0 ? rows : 1, 4 * TN_R);       // at least 128 rows per chunk
     if (chunks > max_chunks) chunks = max_chunks;
     return chunks < 1 ? 1 : chunks;
@@ -274,15 +353,15 @@ extern "C" int morig_bn_backward_stats(const float* dz, int32_t ldz, const float
                                        float* sum_dz, float* sum_dzx, void* stream) {
     if (!dz || !workspace || !sum_dz || rows < 0 || cols <= 0 || ldz < cols) return MORIG_E_INVALID;
     if (y && (!mean || !rstd || !sum_dzx || ldy < cols)) return MORIG_E_INVALID;
-    const int slabs = cdiv(rows > 0 ? rows : 1, BS_ROWS);
+    const int slab_rows = stats_slab_rows(rows);
+    const int slabs = cdiv(rows > 0 ? rows : 1, slab_rows);
     if (workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 8.0 * rows * (double)cols);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols, mean, rstd,
-                       workspace);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols, slab_rows,
+                       mean, rstd, workspace);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, workspace, slabs, rows, rows_dev, cols, sum_dz,
-                       y ? sum_dzx : nullptr);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, y ? sum_dzx : nullptr);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -294,11 +373,14 @@ extern "C" int morig_bn_relu_backward(const float* dz, int32_t ldz, const float*
     if (rows < 0 || cols <= 0 || ldz < cols || ldy < cols || ldu < cols) return MORIG_E_INVALID;
     if (rows == 0) return MORIG_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int64_t blocks = ((int64_t)rows * cols + 255) / 256;
+    const bool v4 = (cols & 3) == 0 && vec4_ptr(dz, ldz) && vec4_ptr(y, ldy) && vec4_ptr(du, ldu);
+    int64_t blocks = ((int64_t)rows * (cols / (v4 ? 4 : 1)) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     ProfScope ps(K_MISC, s, 0.0, 12.0 * rows * (double)cols);
-    hipLaunchKernelGGL(bn_relu_bwd_kernel, dim3((int)blocks), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols, mean, rstd, gamma,
-                       sum_dz, sum_dzx, du, ldu);
+    if (v4) hipLaunchKernelGGL(bn_relu_bwd_kernel<4>, dim3((int)blocks), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols, mean, rstd,
+                               gamma, sum_dz, sum_dzx, du, ldu);
+    else hipLaunchKernelGGL(bn_relu_bwd_kernel<1>, dim3((int)blocks), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols, mean, rstd,
+                            gamma, sum_dz, sum_dzx, du, ldu);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -310,8 +392,12 @@ extern "C" int morig_segmax_affine_arg(const float* Z, int32_t ldz, const int32_
     if ((scale == nullptr) != (shift == nullptr)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 0.0);
-    hipLaunchKernelGGL(segmax_arg_kernel, dim3(cdiv(n_segments, 4), cdiv(H, 64)), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale,
-                       shift, out, ldo, arg, ld_arg);
+    const bool v4 = (H & 3) == 0 && vec4_ptr(Z, ldz) && vec4_ptr(out, ldo) && vec4_ptr(arg, ld_arg);
+    const int blocks = cdiv((long)n_segments * (H / (v4 ? 4 : 1)), 256);
+    if (v4) hipLaunchKernelGGL(segmax_arg_kernel<4>, dim3(blocks), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale, shift, out, ldo,
+                               arg, ld_arg);
+    else hipLaunchKernelGGL(segmax_arg_kernel<1>, dim3(blocks), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale, shift, out, ldo,
+                            arg, ld_arg);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -321,15 +407,15 @@ extern "C" int morig_segmax_bn_backward_stats(const float* dout, int32_t ldd, co
                                               double* workspace, int64_t workspace_doubles, float* sum_dz, float* sum_dzx, void* stream) {
     if (!dout || !arg || !Z || !mean || !rstd || !workspace || !sum_dz || !sum_dzx) return MORIG_E_INVALID;
     if (n_segments <= 0 || cols <= 0 || ldd < cols || ld_arg < cols || ldz < cols) return MORIG_E_INVALID;
-    const int slabs = cdiv(n_segments, BS_ROWS);
+    const int slab_rows = stats_slab_rows(n_segments);
+    const int slabs = cdiv(n_segments, slab_rows);
     if (workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 12.0 * n_segments * (double)cols);
     hipLaunchKernelGGL(segmax_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, n_segments,
-                       cols, mean, rstd, workspace);
+                       cols, slab_rows, mean, rstd, workspace);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, workspace, slabs, n_segments, nullptr, cols, sum_dz,
-                       sum_dzx);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, sum_dzx);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -342,11 +428,14 @@ extern "C" int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, con
     if (!dout || !arg || !Z || !rowptr || !seg_of_row || !mean || !rstd || !gamma || !sum_dz || !sum_dzx || !du) return MORIG_E_INVALID;
     if (n_segments <= 0 || row_capacity <= 0 || cols <= 0 || ldd < cols || ld_arg < cols || ldz < cols || ldu < cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int64_t blocks = ((int64_t)row_capacity * cols + 255) / 256;
+    const bool v4 = (cols & 3) == 0 && vec4_ptr(Z, ldz) && vec4_ptr(du, ldu) && vec4_ptr(dout, ldd) && vec4_ptr(arg, ld_arg);
+    int64_t blocks = ((int64_t)row_capacity * (cols / (v4 ? 4 : 1)) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     ProfScope ps(K_MISC, s, 0.0, 16.0 * row_capacity * (double)cols);
-    hipLaunchKernelGGL(segmax_bn_relu_bwd_kernel, dim3((int)blocks), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, rowptr, n_segments,
-                       seg_of_row, cols, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu);
+    if (v4) hipLaunchKernelGGL(segmax_bn_relu_bwd_kernel<4>, dim3((int)blocks), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, rowptr,
+                               n_segments, seg_of_row, row_capacity, cols, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu);
+    else hipLaunchKernelGGL(segmax_bn_relu_bwd_kernel<1>, dim3((int)blocks), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, rowptr,
+                            n_segments, seg_of_row, row_capacity, cols, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -358,7 +447,9 @@ extern "C" int morig_edge_scatter_backward(const float* dG, int32_t ldg, const i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 0.0);
     MORIG_HIP_TRY(hipMemset2DAsync(dB, (size_t)ldb * sizeof(float), 0, (size_t)H * sizeof(float), (size_t)n_src_nodes, s));
-    hipLaunchKernelGGL(edge_scatter_bwd_kernel, dim3(cdiv(n_nodes, 4), cdiv(H, 64)), dim3(256), 0, s, dG, ldg, rowptr, src_sorted, n_nodes, H,
+    // one column per thread: a wave's atomics then fall into consecutive words (one float4 per thread -- four scattered atomic
+    // instructions per row -- measured 4x slower)
+    hipLaunchKernelGGL(edge_scatter_bwd_kernel<1>, dim3(cdiv((long)n_nodes * H, 256)), dim3(256), 0, s, dG, ldg, rowptr, src_sorted, n_nodes, H,
                        dA, lda, dB, ldb);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
@@ -380,9 +471,7 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(N, TN_T), cdiv(K, TN_T), chunks), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K,
                        chunk_rows, workspace);
     MORIG_LAUNCH_CHECK();
-    int64_t blocks = ((int64_t)N * K + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, workspace, chunks, N, K, out, ldo);
+    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((int)(((int64_t)N * K + 31) / 32)), dim3(256), 0, s, workspace, chunks, N, K, out, ldo);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -14,43 +14,47 @@
 
 namespace morig {
 
-constexpr int CS_ROWS = 512;          // rows per partial block of col_stats
 
-// partial sums of one (row slab, 64-column group): 256 threads = 64 columns x 4 row lanes
+// partial sums of one (row slab, 64-column group)
 __global__ __launch_bounds__(256) void col_stats_partial_kernel(const float* __restrict__ x, int ldx, int rows_host,
-                                                                const int* __restrict__ rows_dev, int cols,
+                                                                const int* __restrict__ rows_dev, int cols, int slab_rows,
                                                                 double* __restrict__ part /* [slabs][2][cols] */) {
     const int rows = rows_dev ? *rows_dev : rows_host;
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * CS_ROWS;
-    double s = 0.0, q = 0.0;
-    if (c < cols) {
-        const int r1 = min(r0 + CS_ROWS, rows);
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const double v = (double)x[(size_t)r * ldx + c];
-            s += v; q += v * v;
+    const int c0 = blockIdx.x * 64;
+    const int quads = min(16, (cols - c0 + 3) >> 2);
+    const int RL = 256 / quads;
+    const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
+    const int c = c0 + q * 4;
+    const int r0 = blockIdx.y * slab_rows, r1 = min(r0 + slab_rows, rows);
+    double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (rl < RL) {
+        if ((ldx & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && c + 4 <= cols) {
+#pragma unroll 4
+            for (int r = r0 + rl; r < r1; r += RL) {
+                const float4 v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+                const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { acc[0][j] += d[j]; acc[1][j] += d[j] * d[j]; }
+            }
+        } else {
+            for (int r = r0 + rl; r < r1; r += RL)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < cols) { const double d = (double)x[(size_t)r * ldx + c + j]; acc[0][j] += d; acc[1][j] += d * d; }
         }
     }
-    __shared__ double sh[2][4][64];
-    sh[0][rl][threadIdx.x & 63] = s; sh[1][rl][threadIdx.x & 63] = q;
-    __syncthreads();
-    if (rl == 0 && c < cols) {
-        const int l = threadIdx.x & 63;
-        part[((size_t)blockIdx.y * 2 + 0) * cols + c] = (sh[0][0][l] + sh[0][1][l]) + (sh[0][2][l] + sh[0][3][l]);
-        part[((size_t)blockIdx.y * 2 + 1) * cols + c] = (sh[1][0][l] + sh[1][1][l]) + (sh[1][2][l] + sh[1][3][l]);
-    }
+    stats_block_store(acc, quads, RL, q, rl, c0, cols, blockIdx.y, part);
 }
 
-__global__ void col_stats_final_kernel(const double* __restrict__ part, int slabs_cap, int rows_host, const int* __restrict__ rows_dev,
-                                       int cols, float* __restrict__ mean, float* __restrict__ var, float* __restrict__ count) {
+__global__ __launch_bounds__(256) void col_stats_final_kernel(const double* __restrict__ part, int slabs, int rows_host,
+                                                              const int* __restrict__ rows_dev, int cols, float* __restrict__ mean,
+                                                              float* __restrict__ var, float* __restrict__ count) {
     const int rows = rows_dev ? *rows_dev : rows_host;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c == 0 && count) *count = (float)rows;
-    if (c >= cols) return;
-    const int slabs = min(slabs_cap, (rows + CS_ROWS - 1) / CS_ROWS);
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < slabs; ++b) { s += part[((size_t)b * 2 + 0) * cols + c]; q += part[((size_t)b * 2 + 1) * cols + c]; }
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && count) *count = (float)rows;
+    double s, q;
+    stats_final_sums(part, slabs, cols, c, s, q);
+    if (threadIdx.x >= 16 || c >= cols) return;
     const double n = rows > 0 ? (double)rows : 1.0;
     const double m = s / n;
     double v = q / n - m * m;                          // fp64: the cancellation costs ~1e-16 relative, far below fp32
@@ -58,46 +62,68 @@ __global__ void col_stats_final_kernel(const double* __restrict__ part, int slab
     mean[c] = (float)m; var[c] = (float)v;
 }
 
+template <int V>
 __global__ void col_affine_kernel(float* __restrict__ x, int ldx, int rows_host, const int* __restrict__ rows_dev, int cols,
                                   const float* __restrict__ scale, const float* __restrict__ shift) {
     const int rows = rows_dev ? *rows_dev : rows_host;
-    const int64_t total = (int64_t)rows * cols;
+    const int qn = cols / V;
+    const int64_t total = (int64_t)rows * qn;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t r = i / cols; const int c = (int)(i - r * cols);
+        const int64_t r = i / qn; const int c = (int)(i - r * qn) * V;
         float* p = x + r * ldx + c;
-        *p = *p * scale[c] + shift[c];
+        VecF<V> v = ldv<V>(p);
+        const VecF<V> sc = ldv<V>(scale + c), sh = ldv<V>(shift + c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) v.v[j] = v.v[j] * sc.v[j] + sh.v[j];
+        stv<V>(p, v);
     }
 }
 
+template <int V>
 __global__ void edge_gather_relu_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                         const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ srcS,
                                         const int* __restrict__ dstS, int H, float* __restrict__ Z, int ldz) {
     const int E = rowptr[n_nodes];
-    const int64_t total = (int64_t)E * H;
+    const int qn = H / V;
+    const int64_t total = (int64_t)E * qn;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t e = i / H; const int c = (int)(i - e * H);
-        const float v = A[(size_t)dstS[e] * lda + c] + B[(size_t)srcS[e] * ldb + c];
-        Z[e * ldz + c] = v > 0.f ? v : 0.f;
+        const int64_t e = i / qn; const int c = (int)(i - e * qn) * V;
+        const VecF<V> a = ldv<V>(A + (size_t)dstS[e] * lda + c), b = ldv<V>(B + (size_t)srcS[e] * ldb + c);
+        VecF<V> z;
+#pragma unroll
+        for (int j = 0; j < V; ++j) { const float v = a.v[j] + b.v[j]; z.v[j] = v > 0.f ? v : 0.f; }
+        stv<V>(Z + e * ldz + c, z);
     }
 }
 
-// one wave per (segment, 64-column group): lanes = columns, rows walked in order
+// one thread per (segment, V columns): the threads of a segment read consecutive columns of a row, rows walked in order
+template <int V>
 __global__ __launch_bounds__(256) void segmax_affine_kernel(const float* __restrict__ Z, int ldz, const int* __restrict__ rowptr,
                                                             int n_seg, int H, const float* __restrict__ scale,
                                                             const float* __restrict__ shift, float* __restrict__ out, int ldo) {
-    const int lane = threadIdx.x & 63;
-    const int v = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (v >= n_seg) return;
-    const int c = blockIdx.y * 64 + lane;
-    if (c >= H) return;
+    const int qn = H / V;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n_seg * qn) return;
+    const int v = (int)(t / qn), c = (int)(t - (int64_t)v * qn) * V;
     const int e0 = rowptr[v], e1 = rowptr[v + 1];
-    if (e0 >= e1) { out[(size_t)v * ldo + c] = 0.f; return; }       // torch_scatter 'max' fill of an empty segment
-    const float s = scale ? scale[c] : 1.f, t = shift ? shift[c] : 0.f;
-    float m = -INFINITY;
-    for (int e = e0; e < e1; ++e) m = fmaxf(m, Z[(size_t)e * ldz + c] * s + t);
-    out[(size_t)v * ldo + c] = m;
+    VecF<V> m;
+    if (e0 >= e1) {                                                   // torch_scatter 'max' fill of an empty segment
+#pragma unroll
+        for (int j = 0; j < V; ++j) m.v[j] = 0.f;
+        stv<V>(out + (size_t)v * ldo + c, m);
+        return;
+    }
+    VecF<V> s, sh;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { s.v[j] = scale ? scale[c + j] : 1.f; sh.v[j] = shift ? shift[c + j] : 0.f; m.v[j] = -INFINITY; }
+    for (int e = e0; e < e1; ++e) {
+        const VecF<V> z = ldv<V>(Z + (size_t)e * ldz + c);
+#pragma unroll
+        for (int j = 0; j < V; ++j) m.v[j] = fmaxf(m.v[j], z.v[j] * s.v[j] + sh.v[j]);
+    }
+    stv<V>(out + (size_t)v * ldo + c, m);
 }
 
 }  // namespace morig
@@ -107,13 +133,15 @@ using namespace morig;
 extern "C" int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, double* workspace,
                                int64_t workspace_doubles, float* mean, float* var, float* count, void* stream) {
     if (!x || !workspace || !mean || !var || rows < 0 || cols <= 0 || ldx < cols) return MORIG_E_INVALID;
-    const int slabs = cdiv(rows > 0 ? rows : 1, CS_ROWS);           // `rows` is the capacity when rows_dev is given
+    const int slab_rows = stats_slab_rows(rows);                    // `rows` is the capacity when rows_dev is given
+    const int slabs = cdiv(rows > 0 ? rows : 1, slab_rows);
     if (workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 4.0 * rows * (double)cols);
-    hipLaunchKernelGGL(col_stats_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, workspace);
+    hipLaunchKernelGGL(col_stats_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, slab_rows,
+                       workspace);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_stats_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, workspace, slabs, rows, rows_dev, cols, mean, var, count);
+    hipLaunchKernelGGL(col_stats_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, rows, rows_dev, cols, mean, var, count);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -123,10 +151,12 @@ extern "C" int morig_col_affine(float* x, int32_t ldx, int32_t rows, const int32
     if (!x || !scale || !shift || rows < 0 || cols <= 0 || ldx < cols) return MORIG_E_INVALID;
     if (rows == 0) return MORIG_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int64_t blocks = ((int64_t)rows * cols + 255) / 256;
+    const bool v4 = (cols & 3) == 0 && vec4_ptr(x, ldx) && vec4_ptr(scale, 0) && vec4_ptr(shift, 0);
+    int64_t blocks = ((int64_t)rows * (cols / (v4 ? 4 : 1)) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     ProfScope ps(K_MISC, s, 0.0, 8.0 * rows * (double)cols);
-    hipLaunchKernelGGL(col_affine_kernel, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, scale, shift);
+    if (v4) hipLaunchKernelGGL(col_affine_kernel<4>, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, scale, shift);
+    else hipLaunchKernelGGL(col_affine_kernel<1>, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, scale, shift);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -137,11 +167,14 @@ extern "C" int morig_edge_gather_relu(const float* A, int32_t lda, const float* 
     if (!A || !B || !rowptr || !src_sorted || !dst_sorted || !Z || n_nodes <= 0 || edge_capacity <= 0 || H <= 0) return MORIG_E_INVALID;
     if (lda < H || ldb < H || ldz < H) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    int64_t blocks = ((int64_t)edge_capacity * H + 255) / 256;
+    const bool v4 = (H & 3) == 0 && vec4_ptr(A, lda) && vec4_ptr(B, ldb) && vec4_ptr(Z, ldz);
+    int64_t blocks = ((int64_t)edge_capacity * (H / (v4 ? 4 : 1)) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     ProfScope ps(K_MISC, s, 0.0, 12.0 * edge_capacity * (double)H);
-    hipLaunchKernelGGL(edge_gather_relu_kernel, dim3((int)blocks), dim3(256), 0, s, A, lda, B, ldb, rowptr, n_nodes, src_sorted, dst_sorted,
-                       H, Z, ldz);
+    if (v4) hipLaunchKernelGGL(edge_gather_relu_kernel<4>, dim3((int)blocks), dim3(256), 0, s, A, lda, B, ldb, rowptr, n_nodes, src_sorted,
+                               dst_sorted, H, Z, ldz);
+    else hipLaunchKernelGGL(edge_gather_relu_kernel<1>, dim3((int)blocks), dim3(256), 0, s, A, lda, B, ldb, rowptr, n_nodes, src_sorted,
+                            dst_sorted, H, Z, ldz);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -152,8 +185,10 @@ extern "C" int morig_segmax_affine(const float* Z, int32_t ldz, const int32_t* r
     if ((scale == nullptr) != (shift == nullptr)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 0.0);
-    hipLaunchKernelGGL(segmax_affine_kernel, dim3(cdiv(n_segments, 4), cdiv(H, 64)), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale,
-                       shift, out, ldo);
+    const bool v4 = (H & 3) == 0 && vec4_ptr(Z, ldz) && vec4_ptr(out, ldo);
+    const int blocks = cdiv((long)n_segments * (H / (v4 ? 4 : 1)), 256);
+    if (v4) hipLaunchKernelGGL(segmax_affine_kernel<4>, dim3(blocks), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale, shift, out, ldo);
+    else hipLaunchKernelGGL(segmax_affine_kernel<1>, dim3(blocks), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale, shift, out, ldo);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -564,7 +564,7 @@ class NativeOps:
         """-> (mean [cols], biased var [cols], count [1]) of the rows of X (rows_dev: int32 [1] on the device = live row count)."""
         _need_gpu(X.base)
         dev = X.base.device
-        slabs = (max(X.rows, 1) + 511) // 512
+        slabs = (max(X.rows, 1) + 255) // 256
         ws = torch.empty(slabs * 2 * X.cols, dtype=torch.float64, device=dev)
         mean = torch.empty(X.cols, dtype=torch.float32, device=dev)
         var = torch.empty(X.cols, dtype=torch.float32, device=dev)
@@ -598,7 +598,7 @@ class NativeOps:
         (y None: the plain column sum = dbias)."""
         _need_gpu(dz.base)
         dev = dz.base.device
-        slabs = (max(dz.rows, 1) + 511) // 512
+        slabs = (max(dz.rows, 1) + 255) // 256
         ws = torch.empty(slabs * 2 * dz.cols, dtype=torch.float64, device=dev)
         sdz = torch.empty(dz.cols, dtype=torch.float32, device=dev)
         sdzx = torch.empty(dz.cols, dtype=torch.float32, device=dev) if y is not None else None
@@ -627,7 +627,7 @@ class NativeOps:
         dev = dout.base.device
         n_seg, cols = dout.rows, dout.cols
         assert arg.shape == (n_seg, cols) and Z.cols == cols
-        slabs = (n_seg + 511) // 512
+        slabs = (n_seg + 255) // 256
         ws = torch.empty(slabs * 2 * cols, dtype=torch.float64, device=dev)
         sdz = torch.empty(cols, dtype=torch.float32, device=dev)
         sdzx = torch.empty(cols, dtype=torch.float32, device=dev)

@@ -181,7 +181,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
         mean2, var2, cnt2, share2 = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
         s2, t2 = _bn_train(bn2, mean2, var2, cnt2)
-        out = torch.zeros((n, _ld4(H)), dtype=torch.float32, device=dev)
+        out = _buf(n, H, dev)
         arg = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2)
         ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, torch.rsqrt(var1 + bn1.eps), mean2, torch.rsqrt(var2 + bn2.eps), g1, g2, s1, t1, arg)
         ctx.csr = csr
@@ -203,7 +203,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         # BatchNorm2 + ReLU behind the max: one-hot gradient per (vertex, channel)
         sdz2, sdzx2 = ops.segmax_bn_backward_stats(DO, arg, Z2, mean2, rstd2)
         k2, kx2, _, _ = sync_backward_sums(sdz2, sdzx2, ctx.shares[1])
-        du2 = torch.zeros_like(z2)                      # rows past E' feed the dX GEMM below: keep them finite
+        du2 = _buf(z2.shape[0], H, dev)                 # (the kernel zeroes the rows past E': they feed the dX GEMM below)
         DU2 = Mat.of(du2, 0, H)
         ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2)
         db2, _ = ops.bn_backward_stats(DU2, rows_dev=e_live)
@@ -216,7 +216,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         k1, kx1, _, _ = sync_backward_sums(sdz1, sdzx1, ctx.shares[0])
         ops.bn_relu_backward(DH, Z1, mean1, rstd1, g1.detach().float().contiguous(), k1, kx1, DH, rows_dev=e_live)
         # Z1 = relu(A[dst] + B[src])
-        dab = torch.zeros((n, _ld4(2 * H)), dtype=torch.float32, device=dev)
+        dab = _buf(n, 2 * H, dev)                       # dA is written whole, dB is cleared by the operator
         ops.edge_scatter_backward(DH, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H))
         DAB = Mat.of(dab, 0, 2 * H)
         db1, _ = ops.bn_backward_stats(Mat.of(dab, 0, H))
@@ -255,6 +255,26 @@ class SegMaxPool(torch.autograd.Function):
         return dx, None, None
 
 
+class RowGather(torch.autograd.Function):
+    """``g[batch]`` (the per-mesh row repeated over the mesh's vertices, models/rignet.py:64). The backward is the segment sum
+    ``onehot(batch)^T dout`` on morig_gemm_tn: products with 0 / 1 are exact and the row chunks are added in a fixed order, where
+    torch's index backward sorts and serialises (5.4 ms per call on a 32 768 x 1024 gradient, measured)."""
+
+    @staticmethod
+    def forward(ctx, g, batch, n_graphs: int):
+        ctx.save_for_backward(batch)
+        ctx.ng = n_graphs
+        return g.index_select(0, batch)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (batch,) = ctx.saved_tensors
+        ops = get_ops()
+        onehot = _rows16(F.one_hot(batch, ctx.ng))
+        do = _rows16(dout)
+        return ops.gemm_tn(Mat.of(onehot, 0, ctx.ng), Mat.of(do, 0, dout.shape[1])), None, None
+
+
 # ---- the reference's modules, composed from the blocks above (parameters are the module's own nn.Parameters) -------------------
 def mlp_layer(x, layer):
     return DenseTrain.apply(x, layer[0].weight, layer[0].bias, layer[2].weight, layer[2].bias, layer[2])
@@ -284,7 +304,7 @@ def gcnrig(net, pos, feature, csr_tpl: CSR, csr_geo: CSR, batch, mesh_ptr, n_gra
     b = gcumotion(net.gcu_2, pos, a, csr_tpl, csr_geo)
     c = gcumotion(net.gcu_3, pos, b, csr_tpl, csr_geo)
     g = SegMaxPool.apply(mlp_layer(torch.cat([a, b, c], 1), net.mlp_glb[0]), mesh_ptr, n_graphs)
-    x5 = torch.cat([g[batch], pos, feature, a, b, c], 1)                              # repeat_interleave over sorted batch ids (:64)
+    x5 = torch.cat([RowGather.apply(g, batch, n_graphs), pos, feature, a, b, c], 1)                              # repeat_interleave over sorted batch ids (:64)
     h = mlp_layer(mlp_layer(x5, tr[0][0]), tr[0][1])
     return NativeLinear.apply(h, tr[1].weight, tr[1].bias)
 
@@ -368,7 +388,7 @@ def skinnet_inner(net, data, motion, st):
     x2 = gcumotion(net.gcu2, raw, x1, st["csr_tpl"], st["csr_geo"])
     x3 = gcumotion(net.gcu3, raw, x2, st["csr_tpl"], st["csr_geo"])
     cb = net.cls_branch
-    h = mlp_layer(mlp_layer(torch.cat([x3, g[st["batch"]]], 1), cb[0][0]), cb[0][1])
+    h = mlp_layer(mlp_layer(torch.cat([x3, RowGather.apply(g, st["batch"], st["ng"])], 1), cb[0][0]), cb[0][1])
     return NativeLinear.apply(h, cb[1].weight, cb[1].bias)
 
 

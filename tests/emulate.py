@@ -547,6 +547,7 @@ def _emu_segmax_bn_relu_backward(self, dout: Mat, arg, Z: Mat, rowptr, seg_of_ro
     xh = (zv - mean) * rstd
     g = gamma * rstd * (dz - sum_dz / r - xh * (sum_dzx / r))
     du.view()[:r] = torch.where(zv > 0, g, torch.zeros_like(g)) if relu else g
+    du.view()[r:] = 0.0                                 # the operator clears the rows past the live count
 
 
 def _emu_edge_scatter_backward(self, dG: Mat, csr: CSR, n_src, dA: Mat, dB: Mat):

@@ -80,7 +80,36 @@ def test_gemm_tn(rows, N, K):
     assert torch.equal(got, again), "fixed summation order"
 
 
-@pytest.mark.parametrize("rows,K,N", [(700, 35, 64), (4096, 832, 128), (257, 3, 16)])
+@pytest.mark.parametrize("rows,cols,ld,c0", [(300000, 16, 16, 0), (70000, 250, 252, 0), (1200000, 64, 64, 0), (777, 35, 37, 0),
+                                             (262145, 130, 136, 2), (1, 5, 8, 0)])
+def test_column_statistics_kernels(rows, cols, ld, c0):
+    """the two-pass fp64 column reductions (col_stats, bn_backward_stats) at edge-buffer sizes: many slabs, the float4 and the
+    scalar loader (ld or window not 16-byte aligned), a device-side live row count, bit-identical repeats"""
+    ops = native.get_ops()
+    g = torch.Generator().manual_seed(rows + cols)
+    X = (torch.randn(rows, ld, generator=g) * 3.0 + 0.7)
+    D = torch.randn(rows, ld, generator=g)
+    Xd, Dd = X.to(DEV), D.to(DEV)
+    for live in (rows, max(1, rows // 3)):
+        rd = None if live == rows else torch.tensor([live], dtype=torch.int32, device=DEV)
+        x64 = X[:live, c0:c0 + cols].double()
+        mean, var, cnt = ops.col_stats(Mat.of(Xd, c0, cols), rows_dev=rd)
+        assert float(cnt) == live
+        assert _rel(mean, x64.mean(0)) <= 1e-6 and _rel(var, x64.var(0, unbiased=False)) <= 1e-6
+        m2, v2, _ = ops.col_stats(Mat.of(Xd, c0, cols), rows_dev=rd)
+        assert torch.equal(mean, m2) and torch.equal(var, v2)
+        rstd = torch.rsqrt(var + 1e-5)
+        d64 = D[:live, c0:c0 + cols].double()
+        xh = ((X[:live, c0:c0 + cols] - mean.cpu()) * rstd.cpu()).double()
+        sdz, sdzx = ops.bn_backward_stats(Mat.of(Dd, c0, cols), Mat.of(Xd, c0, cols), mean, rstd, rows_dev=rd)
+        scale = float(d64.abs().sum(0).max())
+        assert float((sdz.cpu().double() - d64.sum(0)).abs().max()) <= 1e-6 * scale
+        assert float((sdzx.cpu().double() - (d64 * xh).sum(0)).abs().max()) <= 1e-5 * float((d64 * xh).abs().sum(0).max())
+        only, none = ops.bn_backward_stats(Mat.of(Dd, c0, cols), rows_dev=rd)
+        assert none is None and torch.equal(only, sdz)
+
+
+@pytest.mark.parametrize("rows,K,N", [(700, 35, 64), (4096, 832, 128), (257, 3, 16), (513, 20, 30)])
 def test_dense_block_backward(rows, K, N):
     layer = _randomise(nets.mlp_stack([K, N]), K)[0].train()
     g = torch.Generator().manual_seed(rows)
