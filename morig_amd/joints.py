@@ -82,6 +82,12 @@ def extract_joints(shifted_pts, attn, vox=None, bandwidth_quantile: float = 0.04
     Returns dict(joints numpy [J, 3], side, bandwidth float, modes device [2m, 3], attn device [2m, 1])."""
     if device is None:
         device = shifted_pts.device if torch.is_tensor(shifted_pts) and shifted_pts.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    if device.type == "cuda" and torch.cuda.current_device() != device.index:
+        with torch.cuda.device(device):                                   # the native launches go to the current device's stream
+            return extract_joints(shifted_pts, attn, vox, bandwidth_quantile, threshold1, threshold2, max_iter, device)
     pts = _dev_pts(shifted_pts, device)
     a = _dev_attn(attn, device)
     a = (a - a.min()) / (a.max() - a.min())                               # float32, as numpy does on the loaded array

@@ -1,3 +1,5 @@
+"""Whole-network gradient conditioning: torch float32 vs float64 autograd on the oracle next to the HIP backward (the yardstick of
+tests/test_gpu_backward.py::_grad_report). usage: python tools/debug_bw.py (through gpurun)"""
 import copy, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1,4 +1,5 @@
 #!/bin/bash
+# tools/microbench.py under a list of MORIG_DEBUG_FLAGS settings (phase ablations) -> gpurun_out/microbench_<tag>.txt
 mkdir -p gpurun_out
 OUT=gpurun_out/microbench_${1:-x}.txt
 FLAGS=${2:-"0 1"}
