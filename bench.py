@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense
+SCLK_UNDER_LOAD_MHZ = 2036.0           # measured (tools/gpu_clocks.sh): the power controller holds ~2.04 GHz under this load; peaks are quoted at 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 # MORIG_BENCH_PLUMBING=1 (set by tests/ only): gloo + CPU tensors + the torch emulation of the op layer on tiny meshes.
 # It exercises launch / sharding / all-gather / JSON assembly; its numbers are not measurements and the line says so.
@@ -491,6 +492,9 @@ def main():
                         traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/traffic_latest.json)",
                         mfma_issued_per_product=3 if split else 1,
                         frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
+                        sclk_under_load_mhz=SCLK_UNDER_LOAD_MHZ,
+                        sclk_source="rocm-smi sampled while this workload ran: 2.04 GHz at 1.26 kW (profiles/r02m_clocks_under_load.txt); `peak` is quoted at 2.4 GHz",
+                        frac_of_3x_split_peak_at_sclk=round(3 * achieved / peak * 2400.0 / SCLK_UNDER_LOAD_MHZ, 4) if split else None,
                         mfma_util_counter=measured_mfma_util(dom_name),
                         mfma_util_counter_source="profiles/mfma_pmc_latest.json (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES)",
                         launches_per_step=dom["launches"] / psteps,
