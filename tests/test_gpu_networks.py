@@ -327,6 +327,27 @@ def test_headline_batch_64_meshes_contains_the_golden_mesh_and_is_deterministic(
     assert rel_excess(shift[sl], a["pred_shift"], TOL) <= 0
 
 
+def test_batch_past_the_32_bit_row_offsets_still_equals_the_golden():
+    """260 meshes x 4096 vertices: the [A | B] operand of the 256-wide EdgeConv layers is 4.4 GB, past what the persistent
+    kernels' 32-bit gather offsets reach -- the launcher must take the 64-bit-address kernel there (tile_gemm.hip `pp_ok`),
+    not wrap around. Every mesh is the committed 4096-vertex golden mesh: first, last and one in the middle are compared."""
+    meta, a = load_golden("jointnet_4k")
+    mesh = synth.make_mesh(meta["mesh_seed"], n_side=meta["n_side"], with_skin=False)
+    nb = 260
+    d = synth.collate([mesh] * nb).to(DEV)
+    m = models.jointnet_motion(**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
+    n = meta["n_side"] ** 2
+    _, aggr, shift = m(d, d.pred_flow)
+    assert shift.shape[0] == nb * n and bool(torch.isfinite(shift).all())
+    for k in (0, 131, nb - 1):
+        sl = slice(k * n, (k + 1) * n)
+        assert rel_excess(aggr[sl], a["motion_aggr"], TOL) <= 0, k
+        assert rel_excess(shift[sl], a["pred_shift"], TOL) <= 0, k
+    del d, aggr, shift
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("name", __import__("helpers").FULL_SIZE_GOLDENS)
 def test_full_size_harsh_recipe_goldens(name):
     """4096-vertex mesh (and the 8192-point cloud of configs[3]) with the harsh BatchNorm recipe on the HIP path against
