@@ -221,6 +221,16 @@ class CorrNet(NativeModule):
         return levels, searches, wait
 
     def _point_branch(self, ops, data, plan: _HostPlan, geo_stream=None):
+        steps = self._point_branch_steps(ops, data, plan, geo_stream)
+        try:
+            while True:
+                next(steps)
+        except StopIteration as done:
+            return done.value
+
+    def _point_branch_steps(self, ops, data, plan: _HostPlan, geo_stream=None):
+        """the point branch as a generator: yields once, after the geometry chain (sampling + searches) has been enqueued and
+        before the feature chain, so that the caller can enqueue the vertex branch in between (``_forward``)"""
         dev = data.pts.device
         pk = self.packed(dev)
         B = plan.B
@@ -230,6 +240,7 @@ class CorrNet(NativeModule):
         counts0, c1, c2, c3 = plan.counts
         ptr0, ptr1, ptr2, ptr3 = plan.ptr
         (_, pos1, pos2, pos3), searches, wait = self._geometry(ops, pos0, plan, geo_stream)
+        yield
         wait(1)
         x1 = self.pts_sa1_module.run(ops, pos0, 0, pos1, ptr0, ptr1, B)
         xp1, _ = _with_pos(ops, x1, pos1)
@@ -289,13 +300,30 @@ class CorrNet(NativeModule):
             side = self._side_stream(dev)
             side.wait_stream(main)
             geo = self._side_stream(dev, 1) if os.environ.get("MORIG_GEO_STREAM", "1") != "0" else None
+            # Enqueue order: the geometry chain (a dozen launches, the FPS latency chain starts at once), then the vertex branch
+            # (the large kernels that fill the chip), then the point branch's feature chain (~150 small launches that wait for
+            # the first sampling level anyway). Host enqueue time is serial: with the feature chain in front of it the vertex
+            # branch reached the GPU ~2 ms into an 11 ms step.
+            steps = self._point_branch_steps(ops, data, plan, geo)
+            vertex_first = os.environ.get("MORIG_CORRNET_ORDER", "vertex_first") == "vertex_first"
             with torch.cuda.stream(side):
-                out_pts, ptr_p = self._point_branch(ops, data, plan, geo)
+                next(steps)
+                if not vertex_first:
+                    try:
+                        next(steps)
+                    except StopIteration as done:
+                        out_pts, ptr_p = done.value
             ops.reserve_cus(B)                         # FPS holds one CU per cloud
             try:
                 out_vtx = self._vertex_branch(ops, data, seg, B)
             finally:
                 ops.reserve_cus(0)
+            if vertex_first:
+                with torch.cuda.stream(side):
+                    try:
+                        next(steps)
+                    except StopIteration as done:
+                        out_pts, ptr_p = done.value
             main.wait_stream(side)
             out_pts.record_stream(main)
         else:
