@@ -269,8 +269,11 @@ class RowGather(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         (batch,) = ctx.saved_tensors
+        if ctx.ng > 256:                                   # many small meshes: the one-hot operand would dwarf the gradient itself
+            return torch.zeros((ctx.ng, dout.shape[1]), dtype=torch.float32, device=dout.device).index_add_(0, batch, dout.float()), None, None
         ops = get_ops()
-        onehot = _rows16(F.one_hot(batch, ctx.ng))
+        onehot = torch.zeros((batch.shape[0], _ld4(ctx.ng)), dtype=torch.float32, device=dout.device)
+        onehot.scatter_(1, batch.view(-1, 1), 1.0)
         do = _rows16(dout)
         return ops.gemm_tn(Mat.of(onehot, 0, ctx.ng), Mat.of(do, 0, dout.shape[1])), None, None
 
