@@ -24,6 +24,8 @@ def main():
             if g > min_gap: big.append((g, key))
         if e > prev_end: prev_end, prev_name = e, n
     print(f"span {span:.0f} us, kernel busy {busy:.0f} us, idle {span - busy:.0f} us ({100 * (span - busy) / span:.1f} %), {len(rows)} launches")
+    union_idle = sum(gsum.values())
+    print(f"no kernel running at all (concurrent streams counted once): {union_idle:.0f} us of {span:.0f} us ({100 * union_idle / span:.1f} %)")
     print("-- largest total idle by transition")
     for k, v in gsum.most_common(25): print(f"{v:9.1f} us  n={gaps[k]:4d}  avg {v / gaps[k]:7.1f}  {k}")
     print("-- single gaps above", min_gap, "us:", len(big), "total", round(sum(g for g, _ in big)), "us")
