@@ -39,9 +39,11 @@ class _ForwardContext(threading.local):
     """key of the outermost NativeModule's forward in flight on this thread: nested packed() calls reuse it instead of
     each walking its own parameter subtree (one traversal of ~450 tensors per forward, ~1 ms of host time)."""
     key = None
+    root = None
 
 
 _ctx = _ForwardContext()
+_LAZY_KEY = object()
 
 
 class NativeModule(torch.nn.Module):
@@ -101,7 +103,11 @@ class NativeModule(torch.nn.Module):
         return super().train(mode)
 
     def packed(self, device):
-        key = _ctx.key if _ctx.key is not None else self._param_key()
+        key = _ctx.key
+        if key is _LAZY_KEY:                           # first use inside this forward: see forward()
+            key = _ctx.key = _ctx.root._param_key()
+        elif key is None:
+            key = self._param_key()
         if self._packed is None or self._packed_device != device or self._packed_key != key:
             self._packed = packing.to_device(self._pack(), device)
             self._packed_device = device
@@ -138,7 +144,10 @@ class NativeModule(torch.nn.Module):
             return self._forward(*args, **kwargs)
         outer = _ctx.key
         if outer is None:
-            _ctx.key = self._param_key()               # (storage, version) of every tensor below the outermost module
+            # (storage, version) of every tensor below the outermost module -- computed at the first packed() call of the forward,
+            # not here: the plans enqueue their weight-free launches first (CSR builds, sampling), so the ~0.2 ms walk runs while
+            # the GPU already works instead of in front of the first launch
+            _ctx.key, _ctx.root = _LAZY_KEY, self
         try:
             if dev.type == "cuda":
                 # launches go to torch's current stream OF THE MODEL'S DEVICE, whatever the caller's current device is
@@ -147,6 +156,8 @@ class NativeModule(torch.nn.Module):
             return ops.guarded(dev, attempt)
         finally:
             _ctx.key = outer
+            if outer is None:
+                _ctx.root = None
 
     def _forward(self, *args, **kwargs):
         raise NotImplementedError

@@ -136,7 +136,6 @@ class CorrNet(NativeModule):
     # ------------------------------------------------------------------------------------------
     def _vertex_branch(self, ops, data, seg, n_graphs):
         dev = data.vtx.device
-        pk = self.packed(dev)
         n = data.vtx.shape[0]
         # feature buffer [x_1(32) | x_2(64) | x_3(256) | x_4(512) | vtx(3) + 29 zero columns]: every window is a whole number
         # of 32-column chunks, so on the split-fp16 path the units hand their outputs to each other and to the three wide
@@ -157,6 +156,7 @@ class CorrNet(NativeModule):
         narrow_padded = os.environ.get("MORIG_CORRNET_ONE_CSR", "1") != "0"
         csr_tpl = csr_tpl4 if narrow_padded else ops.csr_build(data.tpl_edge_index, n)
         csr_geo = csr_geo4 if narrow_padded else ops.csr_build(data.geo_edge_index, n)
+        pk = self.packed(dev)                          # first weight use of the forward: behind the CSR builds (lazy cache key)
         gcus = (self.vtx_gcu_1, self.vtx_gcu_2, self.vtx_gcu_3, self.vtx_gcu_4)
         widths = (32, 64, 256, 512)
         x_in, split_in = Mat.of(v4, 0, 3), False
@@ -232,7 +232,6 @@ class CorrNet(NativeModule):
         """the point branch as a generator: yields once, after the geometry chain (sampling + searches) has been enqueued and
         before the feature chain, so that the caller can enqueue the vertex branch in between (``_forward``)"""
         dev = data.pts.device
-        pk = self.packed(dev)
         B = plan.B
         N0 = data.pts.shape[0]
         pos0 = torch.zeros((N0, 4), dtype=torch.float32, device=dev)
@@ -241,6 +240,7 @@ class CorrNet(NativeModule):
         ptr0, ptr1, ptr2, ptr3 = plan.ptr
         (_, pos1, pos2, pos3), searches, wait = self._geometry(ops, pos0, plan, geo_stream)
         yield
+        pk = self.packed(dev)                          # (after the weight-free geometry launches: NativeModule.forward, lazy cache key)
         wait(1)
         x1 = self.pts_sa1_module.run(ops, pos0, 0, pos1, ptr0, ptr1, B)
         xp1, _ = _with_pos(ops, x1, pos1)
@@ -281,7 +281,6 @@ class CorrNet(NativeModule):
     def _forward(self, data, train_vismask, random_start=True):
         ops = get_ops()
         dev = data.vtx.device
-        pk = self.packed(dev)
         B = getattr(data, "num_graphs", None)
         vb, pb = data.vtx_batch, data.pts_batch
         if B is None:
@@ -331,6 +330,7 @@ class CorrNet(NativeModule):
             out_pts, ptr_p = self._point_branch(ops, data, plan)
         out_vismask = None
         if train_vismask:
+            pk = self.packed(dev)
             n, C = out_vtx.shape
             nn, sim = ops.cosine_nn(Mat.of(out_vtx), plan.ptr_v, Mat.of(out_pts), ptr_p, B, max(vcounts))
             ld = (2 * C + 1 + 3) // 4 * 4
