@@ -1,5 +1,5 @@
 #!/bin/bash
-# CorrNet enqueue order A/B in one call (MORIG_CORRNET_ORDER=vertex_first|points_first): parity tests, then alternating bench runs
+# CorrNet enqueue order A/B in one call (MORIG_CORRNET_ORDER=vertex_first or points_first): parity tests, then alternating bench runs
 mkdir -p gpurun_out
 OUT=gpurun_out/corrnet_order_ab.txt
 : > $OUT
