@@ -131,6 +131,54 @@ def test_against_oracle_on_fresh_inputs():
         assert rel_excess(g, w, TOL) <= 0
 
 
+def test_degenerate_graphs_against_oracle():
+    """graphs the generator never produces: a vertex with no incoming edge in either graph (only the self loop the network adds),
+    duplicated edges, explicit self loops in the input (removed and re-added by the reference: models/basic_modules.py:188-189),
+    a mesh of ONE vertex with no edges at all, a 9-vertex mesh (far below one kernel tile), all in one ragged batch; jointnet and
+    masknet against the CPU oracle."""
+    from oracle import nets
+    tiny = synth.make_mesh(301, n_side=3, with_skin=False)
+    holes = synth.make_mesh(302, n_side=7, with_skin=False)
+    for name, dead in (("tpl_edge_index", (0, 11, 48)), ("geo_edge_index", (0, 5, 30))):
+        ei = getattr(holes, name)
+        keep = ~torch.isin(ei[1], torch.tensor(dead))                     # vertices 0 (both), 11 / 48 (tpl), 5 / 30 (geo): no incoming edge
+        ei = ei[:, keep]
+        loops = torch.tensor([[3, 3, 17], [3, 3, 17]])                    # explicit self loops, one of them twice
+        setattr(holes, name, torch.cat([ei, ei[:, :40], loops], 1))       # + 40 duplicated edges
+    one = synth.make_mesh(303, n_side=3, with_skin=False)
+    one.pos, one.pred_flow = one.pos[:1].clone(), one.pred_flow[:1].clone()
+    one.tpl_edge_index = torch.zeros((2, 0), dtype=torch.long)
+    one.geo_edge_index = torch.zeros((2, 0), dtype=torch.long)
+    normal = synth.make_mesh(304, n_side=10, with_skin=False)
+    batch = synth.collate([tiny, holes, one, normal])
+    d = batch.to(DEV)
+    for arch, kw in (("jointnet_motion", dict(num_keyframes=5, chn_output=3, aggr_method="attn")),
+                     ("masknet_motion", dict(num_keyframes=5, chn_output=1, aggr_method="max"))):
+        ours = synth.load_recipe(models.__dict__[arch](**kw).eval(), 404)
+        ref = synth.load_recipe(nets.__dict__[arch](**kw).eval(), 404)
+        want = ref(batch, batch.pred_flow)
+        got = ours.to(DEV)(d, d.pred_flow)
+        for g, w in zip(got, want):
+            assert g.shape == w.shape and rel_excess(g, w, TOL) <= 0, arch
+
+
+def test_corrnet_tiny_and_lopsided_clouds_against_oracle():
+    """clouds far below every tile and sampling size: 37, 700 and 9 points (the last one keeps 5 / 2 / 1 points through the three
+    sampling levels) against meshes of 9, 81 and 25 vertices; deterministic FPS start, CPU oracle."""
+    from oracle import nets
+    ms = [synth.make_mesh(311, n_side=3, with_skin=False), synth.make_mesh(312, n_side=9, with_skin=False),
+          synth.make_mesh(313, n_side=5, with_skin=False)]
+    clouds = [synth.make_point_cloud(ms[0], 1, 37), synth.make_point_cloud(ms[1], 2, 700), synth.make_point_cloud(ms[2], 3, 9)]
+    batch = synth.collate(ms, clouds)
+    kw = dict(input_feature=3, output_feature=64, temprature=0.07)
+    ref = synth.load_recipe(nets.corrnet(**kw).eval(), 5)
+    ours = synth.load_recipe(models.corrnet(**kw).eval(), 5).to(DEV)
+    want = ref(batch, True, False)
+    got = ours(batch.to(DEV), True, False)
+    for g, w in zip(got[:3], want[:3]):
+        assert g.shape == w.shape and rel_excess(g, w, TOL) <= 0
+
+
 def test_corrnet_against_reference_golden():
     """vertex branch + PointNet++ point branch + cosine matching + vis-mask, deterministic FPS start."""
     meta, a = load_golden("corrnet_ragged")
