@@ -474,6 +474,28 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:                                   # the secondary lines never take the headline line down
             secondary["train_step"] = dict(error=repr(e)[:300])
+        # the joint extraction that follows the networks (evaluate/eval_rigging.py:72-95), one mesh at a time as the
+        # reference does it: 4096 shifted points + their mirror images, bandwidth, 29 weighted mean-shift steps, NMS, flip
+        try:
+            import numpy as np
+            from morig_amd import joints as _joints
+            rng = np.random.default_rng(3)
+            centres = rng.uniform(-0.4, 0.4, (20, 3)); centres[:, 0] = -np.abs(centres[:, 0])
+            half = centres[rng.integers(0, 20, 4096)] + rng.normal(0, 0.03, (4096, 3))
+            jp = torch.from_numpy(half).to(dev)
+            ja = torch.from_numpy((rng.random((4096, 1)) ** 2).astype(np.float32)).to(dev)
+            n_found = []
+
+            def joint_step():
+                n_found.append(len(_joints.extract_joints(jp, ja, None, 0.04, -1.0, 0.02, 30)["joints"]))
+                return jp
+            reps = max(3, n_secondary)
+            sdt, _, _ = timed_run(joint_step, reps, 1)
+            secondary["joint_extraction"] = dict(metric="meshes/sec joint extraction (mirror, bandwidth, mean-shift, NMS) from 4096 shifted points",
+                                                 value=round(reps / sdt, 2), unit="meshes/s", ms_per_step=round(sdt / reps * 1e3, 3),
+                                                 steps=reps, warmup=1, batch=1, joints_found=n_found[-1], config="SURVEY 8(f-2); float64 kernels")
+        except Exception as e:
+            secondary["joint_extraction"] = dict(error=repr(e)[:300])
 
     if rank == 0:
         names = NAMES[args.workload]
