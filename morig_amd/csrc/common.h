@@ -100,6 +100,26 @@ inline int stats_slab_rows(int rows_cap) {
     return r < 256 ? 256 : r;
 }
 
+#ifdef __HIPCC__
+// Two fp32 values split for the split-fp16 contraction: hi = the two fp16(v) (truncated: ONE v_cvt_pkrtz), lo = the two
+// fp16(v - hi) rounded to nearest (one v_fma_mix each: f32 v * 1.0 - f16 hi, written into one half of the destination).
+// v - hi is exact in fp32, so this is bit-identical to the cvt / sub / cvt sequence the plain C expression compiles to, at 3 VALU
+// per pair instead of 7. Operands travel as float bit patterns (the host pass type-checks the asm constraints too).
+__device__ inline void split_pair_f16(float v0, float v1, float& hi, float& lo) {
+    typedef __fp16 split_h2 __attribute__((ext_vector_type(2)));
+    const split_h2 h = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    hi = __builtin_bit_cast(float, h);
+#ifdef MORIG_SPLIT_C_FORM                                  // measurement variant: the plain C expression (A/B of the conversion cost)
+    split_h2 l;
+    l[0] = (__fp16)(v0 - (float)h[0]); l[1] = (__fp16)(v1 - (float)h[1]);
+    lo = __builtin_bit_cast(float, l);
+#else
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(v0), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(hi));
+#endif
+}
+#endif
+
 // V consecutive floats of a row (V = 4: one 16-byte access; V = 1: any alignment). vec4_ok(): the host-side predicate
 template <int V> struct VecF { float v[V]; };
 #ifdef __HIPCC__

@@ -217,20 +217,18 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
                 *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 16 * lkq) = ra[i];
             } else {
                 // hi = fp16(x) (round-toward-zero, 2 per instruction), lo = fp16(x - hi): x - hi is exact in fp32
-                const f16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-                const f16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                // (hi may truncate: lo absorbs it exactly; lo itself is rounded to nearest-even so the split is unbiased)
-                f16x2 l01, l23;
-                l01[0] = (__fp16)(v[0] - (float)h01[0]); l01[1] = (__fp16)(v[1] - (float)h01[1]);
-                l23[0] = (__fp16)(v[2] - (float)h23[0]); l23[1] = (__fp16)(v[3] - (float)h23[1]);
+                // (hi may truncate: lo absorbs it exactly; lo itself is rounded to nearest-even so the split is unbiased; common.h)
+                typedef float b32x2 __attribute__((ext_vector_type(2)));
+                b32x2 h, l;
+                float h0, h1, l0, l1;
+                split_pair_f16(v[0], v[1], h0, l0);
+                split_pair_f16(v[2], v[3], h1, l1);
+                h[0] = h0; h[1] = h1; l[0] = l0; l[1] = l1;
                 const float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
                 if (!(amax < 65000.f)) *p.ovf = 1;                     // also catches NaN
-                f16x4 h, l;
-                h[0] = (_Float16)h01[0]; h[1] = (_Float16)h01[1]; h[2] = (_Float16)h23[0]; h[3] = (_Float16)h23[1];
-                l[0] = (_Float16)l01[0]; l[1] = (_Float16)l01[1]; l[2] = (_Float16)l23[0]; l[3] = (_Float16)l23[1];
                 char* rowp = reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 128 * (lkq >> 3) + 8 * (lkq & 7);
-                *reinterpret_cast<f16x4*>(rowp) = h;
-                *reinterpret_cast<f16x4*>(rowp + 64) = l;
+                *reinterpret_cast<b32x2*>(rowp) = h;
+                *reinterpret_cast<b32x2*>(rowp + 64) = l;
             }
         }
 #pragma unroll
