@@ -92,18 +92,18 @@ __global__ __launch_bounds__(512, (H == 128 ? 4 : 2)) void edge_pc_kernel(const 
                 f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf(ra[S][i][q] + rb[S][i][q], 0.f);     // invalid rows were fetched as 0
-                const f16x2 h01 = __builtin_amdgcn_cvt_pkrtz(v[0], v[1]);
-                const f16x2 h23 = __builtin_amdgcn_cvt_pkrtz(v[2], v[3]);
-                f16x4 h, l;
-                h[0] = (_Float16)h01[0]; h[1] = (_Float16)h01[1]; h[2] = (_Float16)h23[0]; h[3] = (_Float16)h23[1];
-                l[0] = (_Float16)(v[0] - (float)h01[0]); l[1] = (_Float16)(v[1] - (float)h01[1]);
-                l[2] = (_Float16)(v[2] - (float)h23[0]); l[3] = (_Float16)(v[3] - (float)h23[1]);
+                typedef float b32x2 __attribute__((ext_vector_type(2)));
+                b32x2 h, l;
+                float h0, h1, l0, l1;
+                split_pair_f16(v[0], v[1], h0, l0);
+                split_pair_f16(v[2], v[3], h1, l1);
+                h[0] = h0; h[1] = h1; l[0] = l0; l[1] = l1;
                 const float amax = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));               // v >= 0 after the ReLU
                 if (!(amax < 65000.f)) *p.ovf = 1;
                 char* rowp = sA + (lrow + 32 * i) * LDB + 8 * lkq;
                 if (p.dbg & 16) continue;
-                *reinterpret_cast<f16x4*>(rowp) = h;
-                *reinterpret_cast<f16x4*>(rowp + 64) = l;
+                *reinterpret_cast<b32x2*>(rowp) = h;
+                *reinterpret_cast<b32x2*>(rowp + 64) = l;
             }
             if (p.dbg & 8) return;
 #pragma unroll
