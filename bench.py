@@ -303,7 +303,7 @@ def main():
     ap.add_argument("--prof-steps", type=int, default=5, help="steps of the second, per-launch-evented pass")
     ap.add_argument("--secondary", type=int, default=-1,
                     help="steps of the short mask_skin / corrnet / deformnet runs added to the jointnet line at N = 1 "
-                         "(-1: 3 on a default run, 0 when --steps/--warmup were given explicitly by a harness that wants speed)")
+                         "(-1 = 3; 0 switches them off: profiler passes and A/B scripts do)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  MORIG_BENCH_NPROC=1 timeout 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmcb_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --batch ${2:-64} > /tmp/pmcb_$C.log 2>&1
+  MORIG_BENCH_NPROC=1 timeout 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmcb_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --secondary 0 --prof-steps 0 --batch ${2:-64} > /tmp/pmcb_$C.log 2>&1
   echo "$C pass rc=$? $(tail -c 300 /tmp/pmcb_$C.log | tr '\n' ' ')" | cut -c1-400
 done
 python - "$TAG" <<'PY'
