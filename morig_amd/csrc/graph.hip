@@ -175,6 +175,36 @@ __global__ void copy2d_pad_rep_kernel(const float* __restrict__ src, int lds, in
     }
 }
 
+// The same copies with four columns per thread (slot width a multiple of 4, 16-byte aligned destination rows): one 16-byte store
+// per replica on the fp32 path, two 8-byte stores (hi pairs, lo pairs) in the split layout instead of eight 2-byte stores. The
+// split is split_pair_f16 (common.h): hi truncated, lo = fp16(v - hi) rounded to nearest, as every GEMM epilogue writes it.
+__global__ void copy2d_pad_rep4_kernel(const float* __restrict__ src, int lds, int rows, int cols, int src_col_step,
+                                       float* __restrict__ dst, int ldd, int slot, int replicas, int64_t dst_row_step, int split, int* ovf) {
+    const int q4 = slot >> 2;
+    const int64_t n = (int64_t)rows * q4;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / q4; const int c = (int)(i - r * q4) * 4;
+        float v[4];
+        for (int q = 0; q < replicas; ++q) {
+            if (q == 0 || src_col_step != 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = c + j < cols ? src[r * lds + c + j + q * src_col_step] : 0.f;
+            }
+            float* drow = dst + (r + q * dst_row_step) * ldd;
+            if (!split) { *reinterpret_cast<float4*>(drow + c) = make_float4(v[0], v[1], v[2], v[3]); continue; }
+            float h0, h1, l0, l1;
+            split_pair_f16(v[0], v[1], h0, l0);
+            split_pair_f16(v[2], v[3], h1, l1);
+            const float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            if (!(am < 65000.f)) *ovf = 1;
+            char* yh = reinterpret_cast<char*>(drow) + 2 * ((c >> 5) * 64 + (c & 31));      // halves -> bytes; c % 4 == 0: 8-byte aligned
+            *reinterpret_cast<float2*>(yh) = make_float2(h0, h1);
+            *reinterpret_cast<float2*>(yh + 64) = make_float2(l0, l1);
+        }
+    }
+}
+
 __global__ void gather_cols_kernel(const float* __restrict__ src, int lds, const int* __restrict__ cols, int ncols,
                                    float* __restrict__ dst, int ldd, int rows) {
     const int64_t n = (int64_t)rows * ncols;
@@ -345,8 +375,12 @@ extern "C" int morig_copy2d_pad_rep(const float* src, int32_t lds, int32_t rows,
     if (rows == 0 || slot_cols == 0) return MORIG_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_COPY, s, 0.0, 4.0 * rows * ((double)cols + (double)slot_cols * replicas));
-    hipLaunchKernelGGL(copy2d_pad_rep_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, src_col_step,
-                       dst, ldd, slot_cols, replicas, dst_row_step, split, overflow);
+    if ((slot_cols & 3) == 0 && (ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (dst_row_step * ldd) % 4 == 0)
+        hipLaunchKernelGGL(copy2d_pad_rep4_kernel, dim3(grid_for((int64_t)rows * (slot_cols >> 2))), dim3(256), 0, s, src, lds, rows, cols,
+                           src_col_step, dst, ldd, slot_cols, replicas, dst_row_step, split, overflow);
+    else
+        hipLaunchKernelGGL(copy2d_pad_rep_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, src_col_step,
+                           dst, ldd, slot_cols, replicas, dst_row_step, split, overflow);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
