@@ -3,23 +3,32 @@
 
 namespace morig {
 
-// one wave per row; y = x / max(||x||, 1e-12)  (torch.nn.functional.normalize, p=2, eps=1e-12)
+// one wave per row -- two rows per wave when a row has at most 32 columns (each half-wave reduces on its own: the same partial
+// sums in the same order as a whole wave whose upper half holds zeros); y = x / max(||x||, 1e-12)
+// (torch.nn.functional.normalize, p=2, eps=1e-12)
 __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, int ldx, int rows_per_rep, int reps, int cols,
                                                       float* __restrict__ y, int ld_row, int ld_rep) {
-    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6, l64 = threadIdx.x & 63;
+    const int two = cols <= 32 ? 1 : 0;
+    const int lane = two ? (l64 & 31) : l64, half = two ? (l64 >> 5) : 0, step = two ? 32 : 64, rpw = two ? 2 : 1;
     const int64_t total = (int64_t)rows_per_rep * reps;
-    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6);
-    for (int64_t m = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); m < total; m += wstride) {
-        const float* xr = x + m * ldx;
+    const int64_t wstride = (int64_t)gridDim.x * (blockDim.x >> 6) * rpw;
+    for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * rpw; base < total; base += wstride) {   // wave-uniform
+        const int64_t m = base + half;
+        const bool live = m < total;
+        const float* xr = x + (live ? m : 0) * ldx;
         float ss = 0.f;
-        for (int c = lane; c < cols; c += 64) { const float v = xr[c]; ss += v * v; }
+        if (live)
+            for (int c = lane; c < cols; c += step) { const float v = xr[c]; ss += v * v; }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+        for (int o = 32; o > 0; o >>= 1)
+            if (!(two && o == 32)) ss += __shfl_xor(ss, o, 64);
+        if (!live) continue;
         const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
         const int r = (int)(m / rows_per_rep);
         const int64_t v = m - (int64_t)r * rows_per_rep;
         float* yr = y + v * ld_row + (int64_t)r * ld_rep;
-        for (int c = lane; c < cols; c += 64) yr[c] = xr[c] * inv;
+        for (int c = lane; c < cols; c += step) yr[c] = xr[c] * inv;
     }
 }
 
@@ -101,6 +110,7 @@ extern "C" int morig_rownorm(const float* x, int32_t ldx, int32_t rows_per_rep, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t rows = (int64_t)rows_per_rep * replicas;
     int64_t blocks = (rows + 3) / 4;
+    if (cols <= 32) blocks = (rows + 7) / 8;                         // two rows per wave
     if (blocks > 256 * 32) blocks = 256 * 32;
     ProfScope ps(K_ROWNORM, s, 3.0 * rows * cols, 8.0 * rows * cols);
     hipLaunchKernelGGL(rownorm_kernel, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows_per_rep, replicas, cols, y, ld_row, ld_rep);
