@@ -35,51 +35,65 @@ PEAK_HBM_GBS = 8000.0
 # It exercises launch / sharding / all-gather / JSON assembly; its numbers are not measurements and the line says so.
 PLUMBING = os.environ.get("MORIG_BENCH_PLUMBING") == "1"
 
-KERNEL_SYMBOLS = {"edgeconv_f16x3_h256": ("edge_ws_kernel<256", "edge_pp_kernel<256"),
-                  "edgeconv_f16x3_h128": ("edge_ws_kernel<128", "edge_pp_kernel<128"),
-                  # the LDS-DMA GEMM kinds run on two kernels: one tile per workgroup (short K) and the persistent one (pooled, deep-wide)
-                  "gemm_f16x3_dma": ("gemm16_dma_kernel<256, 256, 4, 2>", "gemm16_dmap_kernel"), "gemm_f16x3_pool": ("gemm16_dmap_kernel",),
-                  "edgeconv_h256": ("tile_kernel<256, 16, 1, 2, 0>",), "gemm_f32_bn128": ("tile_kernel<128, 32, 0, 0, 0>",)}
-
-
-def _profile_json(name):
-    path = os.path.join(ROOT, "profiles", name)
+def lib_sha256():
+    """sha256 of the libmorig_hip.so this process loads: the counter passes under profiles/ carry the hash of the library they
+    were collected on, and their numbers enter the line only when it is the same build."""
+    import hashlib
+    from morig_amd import native
     try:
-        return json.load(open(path))
+        return hashlib.sha256(open(native.library_path(), "rb").read()).hexdigest()
     except Exception:
         return None
 
 
-def measured_traffic(kernel_kind):
-    """HBM bytes per launch of a kernel kind from the committed rocprofv3 PMC pass (profiles/traffic_latest.json,
-    produced by tools/gpu_pmc_bench.sh on the same command), corrected as MI355X_MICROARCH.md prescribes."""
-    prof = _profile_json("traffic_latest.json")
-    symbols = KERNEL_SYMBOLS.get(kernel_kind)
-    if prof is None or symbols is None:
-        return None
-    tot, n = 0.0, 0            # a kind may cover several instantiations: dispatch-weighted mean
-    for name, v in prof["kernels"].items():
-        if any(sy in name for sy in symbols) and "FETCH_SIZE_KiB_per_dispatch" in v and "WRITE_SIZE_KiB_per_dispatch" in v:
+def _profile_json(name):
+    """-> (parsed counter pass or None, reason it is not usable or None)"""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        prof = json.load(open(path))
+    except Exception:
+        return None, f"profiles/{name} not found"
+    want, have = prof.get("lib_sha256"), lib_sha256()
+    if want is None:
+        return None, f"profiles/{name} carries no lib_sha256 stamp"
+    if want != have:
+        return None, f"profiles/{name} was collected on library {want[:12]}, this run loaded {str(have)[:12]}"
+    return prof, None
+
+
+def _kernels_of(prof, symbol):
+    return [(n, v) for n, v in prof.get("kernels", {}).items() if symbol in n]
+
+
+def measured_traffic(symbol):
+    """HBM bytes per launch of a kernel symbol from the committed rocprofv3 PMC pass (profiles/traffic_latest.json, produced
+    by tools/gpu_pmc_bench.sh on the same command and the same library build), corrected as MI355X_MICROARCH.md prescribes:
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB. -> (bytes or None, reason or None)"""
+    prof, why = _profile_json("traffic_latest.json")
+    if prof is None or symbol is None:
+        return None, why or "no single kernel symbol"
+    tot, n = 0.0, 0            # a symbol prefix may cover several instantiations: dispatch-weighted mean
+    for name, v in _kernels_of(prof, symbol):
+        if "FETCH_SIZE_KiB_per_dispatch" in v and "WRITE_SIZE_KiB_per_dispatch" in v:
             d = v.get("dispatches", 1)
             tot += (2.0 * v["FETCH_SIZE_KiB_per_dispatch"] + v["WRITE_SIZE_KiB_per_dispatch"]) * 1024.0 * d
             n += d
-    return round(tot / n) if n else None
+    return (round(tot / n), None) if n else (None, f"{symbol} not in profiles/traffic_latest.json")
 
 
-def measured_mfma_util(kernel_kind):
-    """MFMA busy fraction of a kernel kind from the committed counter pass (profiles/mfma_pmc_latest.json, produced by
-    tools/gpu_pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)); None when no pass is committed."""
-    prof = _profile_json("mfma_pmc_latest.json")
-    symbols = KERNEL_SYMBOLS.get(kernel_kind)
-    if prof is None or symbols is None:
-        return None
-    busy = cu = 0.0           # a kind may cover several kernels: weighted by the CU-busy cycles each contributed
-    for name, v in prof.get("kernels", {}).items():
-        if any(sy in name for sy in symbols) and v.get("SQ_BUSY_CU_CYCLES"):
+def measured_mfma_util(symbol):
+    """MFMA busy fraction of a kernel symbol from the committed counter pass (profiles/mfma_pmc_latest.json, produced by
+    tools/gpu_pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES)). -> (fraction or None, reason or None)"""
+    prof, why = _profile_json("mfma_pmc_latest.json")
+    if prof is None or symbol is None:
+        return None, why or "no single kernel symbol"
+    busy = cu = 0.0
+    for name, v in _kernels_of(prof, symbol):
+        if v.get("SQ_BUSY_CU_CYCLES"):
             d = v.get("dispatches", 1)
             busy += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * d
             cu += v["SQ_BUSY_CU_CYCLES"] * d
-    return round(busy / (4.0 * cu), 4) if cu else None
+    return (round(busy / (4.0 * cu), 4), None) if cu else (None, f"{symbol} not in profiles/mfma_pmc_latest.json")
 
 
 def cpu_model():
@@ -101,7 +115,7 @@ def free_port():
 def self_launch(n):
     """bare `python bench.py --gpus N`: become the launcher of N ranks (the driver's own command line, verbatim)."""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(free_port()), os.environ.get("MORIG_BENCH_ENTRY") or os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
@@ -334,10 +348,9 @@ def main():
 
     import torch.distributed as dist
     if PLUMBING:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from emulate import EmuOps
         from morig_amd import runtime
-        runtime._test_ops = EmuOps()
+        # tests/bench_plumbing.py (the only entry that sets MORIG_BENCH_PLUMBING) installed its CPU emulation of the op layer
+        assert runtime._test_ops is not None, "MORIG_BENCH_PLUMBING is for tests/bench_plumbing.py only"
         dev = torch.device("cpu")
         backend = "gloo"
     else:
@@ -503,29 +516,48 @@ def main():
         psteps = max(args.prof_steps, 1)
         if prof:
             total_ms = sum(v["ms"] for v in prof.values())
-            dom_name, dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+            # group the launch kinds by the ONE kernel symbol they run (morig_prof_symbol): the dominant entry is then the same
+            # object `rocprofv3 --kernel-trace --stats` ranks first, and frac follows from profiles/ + this line alone
+            by_sym = {}
+            for k, v in prof.items():
+                key = v.get("symbol") or ("kind:" + k)
+                g = by_sym.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, kinds=[], symbol=v.get("symbol")))
+                g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]; g["launches"] += v["launches"]
+                g["kinds"].append(k)
+            dom_key, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
             achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
             # split-fp16 kernels issue 3 f16 MFMAs per algorithmic product: `achieved` stays ALGORITHMIC flops/s,
             # `peak` is the dense f16 MFMA peak, so frac <= 1/3 by construction (frac_of_3x_split_peak rescales)
-            split = "f16x3" in dom_name
+            split = any("f16x3" in k for k in dom["kinds"])
             peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-            roof = dict(bound="mfma", kernel=dom_name, achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(achieved / peak, 4), traffic=measured_traffic(dom_name),
-                        traffic_unit="HBM bytes per launch (rocprofv3 FETCH_SIZE/WRITE_SIZE, profiles/traffic_latest.json)",
+            traffic, traffic_why = measured_traffic(dom["symbol"])
+            util, util_why = measured_mfma_util(dom["symbol"])
+            alg_bytes = round(dom["bytes"] / dom["launches"]) if dom["launches"] else None
+            roof = dict(bound="mfma", kernel=dom["symbol"] or dom_key, kernel_is="rocprofv3 kernel symbol (prefix)",
+                        launch_kinds=sorted(dom["kinds"]),
+                        achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                        frac=round(achieved / peak, 4),
+                        algorithmic_flops_per_launch=round(dom["flops"] / dom["launches"]) if dom["launches"] else None,
+                        algorithmic_bytes=alg_bytes,
+                        algorithmic_bytes_unit="operand + result bytes per launch as the launcher declares them (fp32 elements, each once)",
+                        traffic=traffic, traffic_unavailable=traffic_why,
+                        traffic_over_algorithmic=round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
+                        traffic_unit="HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc, profiles/traffic_latest.json)",
                         mfma_issued_per_product=3 if split else 1,
                         frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
                         sclk_under_load_mhz=SCLK_UNDER_LOAD_MHZ,
                         sclk_source="rocm-smi sampled while this workload ran: 2.04 GHz at 1.26 kW (profiles/r02m_clocks_under_load.txt); `peak` is quoted at 2.4 GHz",
                         frac_of_3x_split_peak_at_sclk=round(3 * achieved / peak * 2400.0 / SCLK_UNDER_LOAD_MHZ, 4) if split else None,
-                        mfma_util_counter=measured_mfma_util(dom_name),
+                        mfma_util_counter=util, mfma_util_counter_unavailable=util_why,
                         mfma_util_counter_source="profiles/mfma_pmc_latest.json (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES)",
+                        lib_sha256=lib_sha256(),
                         launches_per_step=dom["launches"] / psteps,
                         avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
                         share_of_gpu_time=round(dom["ms"] / total_ms, 4),
                         timing="HIP events around every launch in a separate pass of %d steps" % psteps)
             breakdown = {k: dict(ms_per_step=round(v["ms"] / psteps, 3),
                                  tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
-                                 launches_per_step=v["launches"] / psteps)
+                                 launches_per_step=v["launches"] / psteps, symbol=v.get("symbol"))
                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
             # the index / copy kernels are the HBM-bound ones: bytes the launcher declares / event time, against 8 TB/s
             for k in ("csr_build", "copy", "rownorm"):

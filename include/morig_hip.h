@@ -337,6 +337,9 @@ int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t
 int         morig_prof_enable(int on);                 /* returns previous state */
 int         morig_prof_reset(void);
 const char* morig_prof_name(int kind);                  /* NULL past the last kind */
+/* the ONE kernel symbol every launch of this kind runs, as rocprofv3 --kernel-trace prints it (a prefix: template arguments
+ * that do not matter are cut); NULL for kinds that cover several kernels (index / copy / point-cloud helpers) */
+const char* morig_prof_symbol(int kind);
 /* synchronises the recorded events; per kind: launches, total ms, algorithmic flops, algorithmic bytes */
 int         morig_prof_collect(int kind, int64_t* launches, double* total_ms, double* flops, double* bytes);
 

@@ -15,6 +15,7 @@ enum Kind : int {
     K_GEMM16_BN128, K_GEMM16_BN64, K_GEMM16_BN32, K_GEMM16_POOL,
     K_EDGE16_H32, K_EDGE16_H64, K_EDGE16_H128, K_EDGE16_H256, K_POINTCONV16, K_GEMM16_DMA,
     K_COSINE_KNN, K_FLOW_VOTE, K_JOINTS,
+    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH,
     K_COUNT
 };
 static_assert(K_COUNT <= MORIG_PROF_KINDS, "raise MORIG_PROF_KINDS");
@@ -24,8 +25,11 @@ void set_hip_error(hipError_t e);
 struct ProfScope {
     ProfScope(int kind, hipStream_t s, double flops, double bytes);
     ~ProfScope();
-    int slot; hipStream_t stream;
+    int slot; hipStream_t stream; ProfScope* outer;
 };
+// The launcher that finally picks the kernel re-labels the innermost open scope of this thread, so that every kind of the
+// hot kernels maps to ONE kernel symbol (morig_prof_symbol): bench.py's roofline is then recomputable from a rocprofv3 trace.
+void prof_retag(int kind);
 
 inline int check_hip(hipError_t e) {
     if (e == hipSuccess) return MORIG_OK;

@@ -276,7 +276,10 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
     // they hide), so it takes the pooled launches and the deep, wide stores only. MORIG_DMA_PERSIST=0 / 1 forces never / always.
     static const int persist = [] { const char* e = getenv("MORIG_DMA_PERSIST"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
     const bool deep_wide = p.pool != nullptr || (p.K >= 768 && p.N >= 1024);
-    if (mode == 256 && p.N % 256 == 0 && p.K > 32 && (persist == 2 || (persist == 1 && deep_wide))) return launch_gemm16_dmap(p0, s);
+    if (mode == 256 && p.N % 256 == 0 && p.K > 32 && (persist == 2 || (persist == 1 && deep_wide))) {
+        if (!p.pool) prof_retag(K_GEMM16_DMAP);       // the pooled kind already names this kernel
+        return launch_gemm16_dmap(p0, s);
+    }
     if (mode == 256 && p.N % 256 == 0) {
         p.tiles_n = p.N / 256;
         const int nb = cdiv(p.M, 256) * p.tiles_n;
@@ -297,6 +300,7 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
 #endif
     } else {
         p.tiles_n = cdiv(p.N, 128);
+        prof_retag(K_GEMM16_DMA128);
         // 2-stage ring = 64 KB: TWO workgroups per CU, one's prologue / epilogue under the other's main loop
         // (measured 25 % faster than a 4-stage ring at one workgroup per CU)
         hipLaunchKernelGGL((gemm16_dma_kernel<128, 128, 2, 2>), dim3(tiles_m128 * p.tiles_n), dim3(256), 0, s, p);

@@ -769,8 +769,13 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
-        if (use_ws) return launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
-        return (one_shot || !pp_ok) ? launch_edge_pc(q, nblocks, s) : launch_edge_pp(q, nblocks, s);
+        if (use_ws) {
+            if (a->H == 128) prof_retag(K_EDGE16_H128_WS);
+            return launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
+        }
+        if (one_shot || !pp_ok) { prof_retag(K_EDGE16_PC); return launch_edge_pc(q, nblocks, s); }
+        if (a->H == 256) prof_retag(K_EDGE16_H256_PP);
+        return launch_edge_pp(q, nblocks, s);
     }
     if (f16) {
         switch (a->H) {

@@ -80,11 +80,13 @@ __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restr
     if (sum_dzx) sum_dzx[c] = (float)q;
 }
 
+// dz and du may be the SAME buffer (the autograd block runs it in place): neither is __restrict__; every thread reads its
+// elements of dz before it writes them to du
 template <int V>
-__global__ void bn_relu_bwd_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ y, int ldy, int rows_host,
+__global__ void bn_relu_bwd_kernel(const float* dz, int ldz, const float* __restrict__ y, int ldy, int rows_host,
                                    const int* __restrict__ rows_dev, int cols, const float* __restrict__ mean,
                                    const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ sum_dz,
-                                   const float* __restrict__ sum_dzx, float* __restrict__ du, int ldu) {
+                                   const float* __restrict__ sum_dzx, float* du, int ldu) {
     const int rows = rows_dev ? *rows_dev : rows_host;
     const float inv_n = rows > 0 ? 1.f / (float)rows : 0.f;
     const int qn = cols / V;

@@ -51,7 +51,9 @@ class NativeModule(torch.nn.Module):
     autograd version counter of every parameter and buffer below this module, so ANY in-place edit
     (``w.mul_(2)``, an optimizer step), ``load_state_dict`` on a plain ``Sequential`` child, or a reload of a
     child NativeModule whose tensors a parent packs (GCUMotion packs its EdgeConvMotions' MLPs) repacks on
-    the next forward; ``load_state_dict`` / ``.to()`` / ``train()`` additionally drop it eagerly."""
+    the next forward; ``load_state_dict`` / ``.to()`` / ``train()`` additionally drop it eagerly.
+    NOT seen: edits made through ``.data`` (``p.data.copy_(ema)``, ``p.data.clamp_()``) -- they bypass the version counter;
+    call ``invalidate_packed()`` after such an edit."""
 
     def __init__(self):
         super().__init__()
@@ -93,6 +95,11 @@ class NativeModule(torch.nn.Module):
         for m in self.modules():
             if isinstance(m, NativeModule):
                 m._packed = None
+
+    def invalidate_packed(self):
+        """drop the kernel-layout weight cache of this module and everything below it (needed only after parameter edits the
+        autograd version counter does not see, i.e. writes through ``.data``)"""
+        self._drop_packed()
 
     def _apply(self, fn, *a, **kw):
         self._drop_packed()

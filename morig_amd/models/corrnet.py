@@ -18,6 +18,7 @@ from __future__ import annotations
 import contextlib
 import math
 import os
+import threading
 
 import torch
 from torch.nn import Linear as Lin, Parameter, Sequential as Seq
@@ -74,8 +75,8 @@ class CorrNet(NativeModule):
         self.input_feature = input_feature
         self.output_feature = output_feature
         self.temprature = Parameter(torch.Tensor([temprature]))
-        self.last_plan = None
-        self._streams = {}
+        self._last = threading.local()      # what one forward leaves for DeformNet (host plan, the two CSRs): per THREAD, so two
+        self._streams = {}                  # threads running different batches through one model never see each other's graphs
 
         self.vtx_gcu_1 = GCU(in_channels=3, out_channels=32, aggr=aggr)
         self.vtx_gcu_2 = GCU(in_channels=32, out_channels=64, aggr=aggr)
@@ -99,11 +100,29 @@ class CorrNet(NativeModule):
 
     def __getstate__(self):
         st = super().__getstate__()
-        st["_streams"], st["last_plan"] = {}, None        # HIP stream handles and the last forward's host plan are not state
-        st["last_csr"] = None                              # (nor are the CSRs it left for DeformNet: device buffers)
+        st["_streams"] = {}                                # HIP stream handles, the last forward's host plan and the CSRs it left
+        st.pop("_last", None)                              # for DeformNet (device buffers) are not state
         return st
 
-    last_csr = None
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._last = threading.local()
+
+    @property
+    def last_plan(self):
+        return getattr(self._last, "plan", None)
+
+    @last_plan.setter
+    def last_plan(self, v):
+        self._last.plan = v
+
+    @property
+    def last_csr(self):
+        return getattr(self._last, "csr", None)
+
+    @last_csr.setter
+    def last_csr(self, v):
+        self._last.csr = v
 
     def _side_stream(self, dev, which: int = 0):
         key = (dev.type, dev.index, which)

@@ -83,8 +83,9 @@ class DeformNet(NativeModule):
         seg = ops.make_seg(vb, B, 1)
         # the 4-aligned CSRs of the two graphs were built by the CorrNet forward above; the 16-wide position layers run on them
         # too (padding repeats an edge: harmless under max, ~20 % more rows on layers that cost 0.1 ms; four CSR builds saved)
-        csr_tpl4, csr_geo4 = getattr(self.corr_extractor, "last_csr", None) or (ops.csr_build(data.tpl_edge_index, n, pad4=True),
-                                                                   ops.csr_build(data.geo_edge_index, n, pad4=True))
+        csr_tpl4, csr_geo4 = self.corr_extractor.last_csr or (ops.csr_build(data.tpl_edge_index, n, pad4=True),
+                                                              ops.csr_build(data.geo_edge_index, n, pad4=True))
+        self.corr_extractor.last_csr = None               # consumed: the device buffers are not pinned between forwards
         gd.run(ops, vtx4, lambda w, sp: ops.copy2d_pad(Mat.of(l1), w, split=sp), csr_tpl4, csr_geo4, seg, B, 1, Mat.of(pred_flow),
                csr_geo_wide=csr_geo4, csr_tpl_wide=csr_tpl4)
         return pred_flow, vtx_f, pts_f, vis, tau

@@ -151,6 +151,7 @@ _SIGNATURES = {
     "morig_prof_enable": (C.c_int, [C.c_int]),
     "morig_prof_reset": (C.c_int, []),
     "morig_prof_name": (C.c_char_p, [C.c_int]),
+    "morig_prof_symbol": (C.c_char_p, [C.c_int]),
     "morig_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
@@ -179,6 +180,11 @@ def load_library(path: str = LIB_PATH):
         raise MorigNativeError("libmorig_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def library_path() -> str:
+    """the file load_library() maps (MORIG_HIP_LIB selects an A/B build)"""
+    return LIB_PATH
 
 
 def check(status: int, what: str) -> None:
@@ -910,7 +916,9 @@ def prof_collect():
         n, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
         check(lib.morig_prof_collect(k, C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "morig_prof_collect")
         if n.value:
-            out[nm.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+            sym = lib.morig_prof_symbol(k)
+            out[nm.decode()] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value,
+                                    symbol=sym.decode() if sym else None)
         k += 1
     return out
 

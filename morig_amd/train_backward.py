@@ -369,16 +369,31 @@ def _motion_backbone(model, data, input_flow, st, aggr_method):
 
 
 def _guarded_step(data, body):
-    """run ``body(st)`` on the model's device with the split-fp16 range flag cleared before and checked after"""
+    """run ``body(st)`` on the model's device. The CSR status words of the graph build are read BEFORE the body runs (an
+    out-of-range edge index raises like the reference's index error, and nothing has touched the BatchNorm buffers yet); the
+    split-fp16 range flag is cleared before and checked after (only MORIG_TRAIN_PRECISION=f16x3 can raise it -- by then the
+    running buffers of this step have moved, as they would have in a step that ends in a NaN loss)."""
     ops = get_ops()
     dev = data.pos.device
+    from .native import MorigNativeError
     with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
         flag = ops._flag(dev)
         flag.zero_()
-        out = body(graph_state(data))
+        collect = getattr(ops, "_csr_status", None) is None and hasattr(ops, "_state")
+        if collect:
+            ops._csr_status = []
+        try:
+            st = graph_state(data)
+        finally:
+            stats = None
+            if collect:
+                stats, ops._csr_status = ops._csr_status, None
+        if stats and any(w != 0 for w in torch.cat(stats).tolist()):
+            raise MorigNativeError("edge_index out of range for the vertex count it was built with (train-mode step)")
+        out = body(st)
         if int(flag.item()) != 0:
-            from .native import MorigNativeError
-            raise MorigNativeError("an operand left the split-fp16 range in the train-mode forward: train with MORIG_PRECISION=f32")
+            raise MorigNativeError("an operand left the split-fp16 range in the train-mode forward: unset MORIG_TRAIN_PRECISION "
+                                   "(the default runs the train-mode contractions on the exact-fp32 MFMA kernels)")
     return out
 
 

@@ -241,10 +241,10 @@ def test_two_rank_gloo_sharded_training_step_with_synchronised_batchnorm():
 
 def _bench_line(extra, env_extra=None):
     import json
-    env = dict(os.environ, MORIG_BENCH_PLUMBING="1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     env.update(env_extra or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, stdout=subprocess.PIPE,
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "bench_plumbing.py")] + extra, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]

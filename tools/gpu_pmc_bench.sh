@@ -7,7 +7,7 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  MORIG_BENCH_NPROC=1 timeout 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmcb_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --secondary 0 --prof-steps 0 --batch ${2:-64} > /tmp/pmcb_$C.log 2>&1
+  MORIG_BENCH_NPROC=1 timeout 420 rocprofv3 --kernel-trace --pmc $C --output-format csv -d /tmp/pmcb_$C -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --secondary 0 --prof-steps 0 --batch ${BATCH:-64} > /tmp/pmcb_$C.log 2>&1
   echo "$C pass rc=$? $(tail -c 300 /tmp/pmcb_$C.log | tr '\n' ' ')" | cut -c1-400
 done
 python - "$TAG" <<'PY'
@@ -27,7 +27,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     for k in acc:
         out[k][c + "_KiB_per_dispatch"] = acc[k] / n[k]
         out[k]["dispatches"] = n[k]
-res = {"note": "rocprofv3 --pmc, bench.py --steps 1 --warmup 1; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 "
+import hashlib
+sha = hashlib.sha256(open(os.environ.get("MORIG_HIP_LIB") or os.path.join(os.environ["GRAFT_REPO_ROOT"], "morig_amd", "lib", "libmorig_hip.so"), "rb").read()).hexdigest()
+res = {"lib_sha256": sha, "batch": int(os.environ.get("BATCH", "64")), "note": "rocprofv3 --pmc, bench.py --steps 1 --warmup 1; FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 "
                "(MI355X_MICROARCH.md HBM): hbm_bytes = (2*FETCH + WRITE) * 1024", "kernels": out}
 json.dump(res, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", f"traffic_{tag}.json"), "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("FETCH_SIZE_KiB_per_dispatch", 0))[:12]:

@@ -39,7 +39,9 @@ for k, v in out.items():
         v["mfma_util"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * v["SQ_BUSY_CU_CYCLES"])
     if v.get("SQ_LDS_IDX_ACTIVE"):
         v["lds_conflict_frac"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / v["SQ_LDS_IDX_ACTIVE"]
-res = {"note": "rocprofv3 --pmc passes over bench.py --steps 1 --warmup 1 (per-dispatch averages, all XCDs summed by rocprofv3); "
+import hashlib
+sha = hashlib.sha256(open(os.environ.get("MORIG_HIP_LIB") or os.path.join(os.environ["GRAFT_REPO_ROOT"], "morig_amd", "lib", "libmorig_hip.so"), "rb").read()).hexdigest()
+res = {"lib_sha256": sha, "batch": int(os.environ.get("BATCH", "64")), "note": "rocprofv3 --pmc passes over bench.py --steps 1 --warmup 1 (per-dispatch averages, all XCDs summed by rocprofv3); "
                "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_BUSY_CU_CYCLES)", "kernels": out}
 json.dump(res, open(os.path.join(os.environ["GRAFT_REPO_ROOT"], "gpurun_out", f"mfma_pmc_{tag}.json"), "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0))[:12]:
