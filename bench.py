@@ -122,26 +122,15 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def _mesh(args):
+def build_batch(seeds, n_side, with_skin=False, n_pts=0, dev=None):
+    """the synthetic batch of SURVEY 8(d). On the GPU its geodesic-ball graph is built on the device for all meshes at once
+    (morig_geo_ball_graph, the reference's get_geo_edges: data_proc/common_ops.py:214-226); positions, the 1-ring graph and the
+    flows are host numpy (no O(V^2) work). PLUMBING (CPU emulation, tiny meshes): the host recipe."""
     from morig_amd import synth
-    return synth.make_mesh(args[0], n_side=args[1], with_skin=args[2])
-
-
-def build_batch(seeds, n_side, with_skin=False, n_pts=0):
-    from morig_amd import synth
-    import multiprocessing as mp
-    nproc = max(1, min(len(seeds), (os.cpu_count() or 8) // 4, 32))
-    if os.environ.get("MORIG_BENCH_NPROC"):
-        nproc = int(os.environ["MORIG_BENCH_NPROC"])     # profilers dislike forked workers: set to 1 under rocprofv3 --pmc
-    if nproc > 1:
-        torch.set_num_threads(1)
-        with mp.get_context("fork").Pool(nproc) as pool:
-            meshes = pool.map(_mesh, [(s, n_side, with_skin) for s in seeds])
-        torch.set_num_threads(max(1, (os.cpu_count() or 8) // 2))
+    if dev is None or dev.type != "cuda":
+        b = synth.make_batch(seeds, n_side=n_side, n_pts=n_pts, with_skin=with_skin)
     else:
-        meshes = [_mesh((s, n_side, with_skin)) for s in seeds]
-    clouds = [synth.make_point_cloud(m, int(m.name), n_pts) for m in meshes] if n_pts else None
-    b = synth.collate(meshes, clouds)
+        b = synth.make_batch_device(seeds, dev, n_side=n_side, n_pts=n_pts, with_skin=with_skin, geo_seed=seeds[0])
     b.num_graphs = len(seeds)
     return b
 
@@ -249,16 +238,40 @@ NAMES = {"jointnet": ("meshes/sec jointnet_motion forward, 4 k-vert synthetic",
                        "SURVEY 8(f-1), pairs of BASELINE.json configs[3]")}
 
 
-def make_step(workload, data, dev, gather):
-    """-> step() running ONE forward of `workload` over the resident batch (+ the all-gather of its outputs)."""
+def make_step(workload, data, dev, gather, model_only=False):
+    """-> step() running ONE forward of `workload` over the resident batch (+ the all-gather of its outputs);
+    model_only (jointnet): -> step(data) for any batch"""
     from morig_amd import models, synth
     if workload == "jointnet":
         model = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
         synth.load_recipe(model, 0, mild=True).to(dev)
+        if model_only:
+            return lambda d: model(d, d.pred_flow)[2]
+        if os.environ.get("MORIG_BENCH_GUARD", "deferred") == "sync":
+            def step():
+                motion_all, motion_aggr, pred_shift = model(data, data.pred_flow)
+                return gather(pred_shift)
+            return step
+        # serving loop with the guard read deferred by one forward (NativeModule.forward_async): forward k + 1 is enqueued before
+        # the host reads forward k's range flag / CSR status words, so the GPU does not idle on that read. EVERY forward's guard
+        # is still read inside the timed region (the last one by drain(), in front of the closing fence).
+        pending = []
+
+        def check(p):
+            if p is not None and not p.result():
+                raise RuntimeError("bench input left the split-fp16 range: the timed forwards would have to be re-run in fp32")
 
         def step():
-            motion_all, motion_aggr, pred_shift = model(data, data.pred_flow)
+            (motion_all, motion_aggr, pred_shift), pend = model.forward_async(data, data.pred_flow)
+            pending.append(pend)
+            if len(pending) > 1:
+                check(pending.pop(0))
             return gather(pred_shift)
+
+        def drain():
+            while pending:
+                check(pending.pop(0))
+        step.drain = drain
     elif workload == "mask_skin":
         model = models.masknet_motion(num_keyframes=5, chn_output=1, aggr_method="attn").eval()
         skin = models.skinnet_motion(nearest_bone=5, use_Dg=False, use_Lf=False, num_keyframes=5, use_motion=True,
@@ -343,9 +356,6 @@ def main():
     if PLUMBING:
         args.n_side, args.n_pts = min(args.n_side, 8), min(args.n_pts, 128)
     with_skin = args.workload == "mask_skin"
-    # synthetic batch on the host FIRST (forked workers), before this process touches the GPU runtime
-    host_batch = build_batch(seeds, args.n_side, with_skin=with_skin, n_pts=args.n_pts if pairs else 0)
-
     import torch.distributed as dist
     if PLUMBING:
         from morig_amd import runtime
@@ -376,7 +386,7 @@ def main():
 
     from morig_amd import dist as mdist, native
 
-    data = host_batch.to(dev)
+    data = build_batch(seeds, args.n_side, with_skin=with_skin, n_pts=args.n_pts if pairs else 0, dev=dev).to(dev)
     n_vert = data.pos.shape[0]
     gather = (lambda t: mdist.all_gather_rows(t, equal_rows=True, even_alone=True)) if use_dist else (lambda t: t)
     step = make_step(args.workload, data, dev, gather)
@@ -395,6 +405,8 @@ def main():
         """-> (wall seconds for `steps` steps, per-step ms from HIP events, last output)"""
         for _ in range(warmup):
             out = step()
+        if hasattr(step, "drain"):
+            step.drain()
         ev = None if PLUMBING else [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         fence()
         t0 = time.perf_counter()
@@ -407,6 +419,8 @@ def main():
                 ev[i + 1].record()
             else:
                 marks.append(time.perf_counter())
+        if hasattr(step, "drain"):
+            step.drain()                                # the deferred guard read of the last forward(s) belongs to the timed region
         fence()
         dt = time.perf_counter() - t0
         per = ([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)] if ev
@@ -428,6 +442,8 @@ def main():
             native.prof_enable(True)
             for _ in range(args.prof_steps):
                 step()
+            if hasattr(step, "drain"):
+                step.drain()
             fence()
             native.prof_enable(False)
             prof = native.prof_collect()
@@ -451,8 +467,7 @@ def main():
         for wl in ("mask_skin", "corrnet", "deformnet"):
             wpairs = wl in ("corrnet", "deformnet")
             nb = 32 if wpairs else args.batch
-            hb = build_batch([1000 + i for i in range(nb)], args.n_side, with_skin=wl == "mask_skin", n_pts=args.n_pts if wpairs else 0)
-            d2 = hb.to(dev)
+            d2 = build_batch([1000 + i for i in range(nb)], args.n_side, with_skin=wl == "mask_skin", n_pts=args.n_pts if wpairs else 0, dev=dev)
             ns, nw = (4 * n_secondary, 3) if wpairs else (n_secondary, 1)        # the pair workloads are 12-18 ms steps: more of them
             with torch.no_grad():
                 st = make_step(wl, d2, dev, lambda x: x)
@@ -460,14 +475,51 @@ def main():
             secondary[wl] = dict(metric=NAMES[wl][0], value=round(nb * ns / sdt, 2), unit="pairs/s" if wpairs else "meshes/s",
                                  ms_per_step=round(sdt / ns * 1e3, 3), steps=ns, warmup=nw, batch=nb,
                                  config=NAMES[wl][2])
-            del st, d2, hb
+            del st, d2
             torch.cuda.empty_cache()
+        # north_star's one-mesh-per-GPU operating point (and what `--scaling strong --gpus 8` gives each rank: 8 meshes): the same
+        # forward at B = 1, 2, 4, 8 meshes per launch set
+        try:
+            sb = {}
+            with torch.no_grad():
+                st = make_step("jointnet", None, dev, lambda x: x, model_only=True)
+                for nb in (1, 2, 4, 8):
+                    d2 = build_batch([1000 + i for i in range(nb)], args.n_side, dev=dev)
+                    sdt, sper, _ = timed_run(lambda: st(d2), 30, 5)
+                    sb[f"B{nb}"] = dict(ms_per_forward=round(sdt / 30 * 1e3, 3), ms_median=round(pct(sper, 0.5), 3),
+                                         meshes_per_s=round(nb * 30 / sdt, 1))
+                    del d2
+            sb["per_mesh_throughput_B8_over_B64"] = round(sb["B8"]["meshes_per_s"] / (B_local * args.steps / dt), 3)
+            secondary["small_batch"] = dict(metric="jointnet_motion forward at 1 / 2 / 4 / 8 meshes per GPU (4 k-vert synthetic)", **sb)
+            del st
+            torch.cuda.empty_cache()
+        except Exception as e:
+            secondary["small_batch"] = dict(error=repr(e)[:300])
+        # a17: the batched geodesic-ball graph build that produces geo_edge_index (data_proc/common_ops.py:214-226) on the device
+        try:
+            from morig_amd import graph_build, synth
+            gbatch = synth.collate([synth.make_mesh(1000 + i, n_side=args.n_side, geo="none", with_skin=False) for i in range(args.batch)]).to(dev)
+            r_geo = 0.06 * 64.0 / args.n_side
+            fn = lambda: graph_build.get_geo_edges(gbatch.pos, gbatch.batch, r_geo, 15, seed=1, self_loops=True, num_graphs=args.batch)
+            sdt, _, ei = timed_run(fn, 10, 2)
+            nv = gbatch.pos.shape[0]
+            pairs_n = float(args.batch) * (nv / args.batch) ** 2
+            secondary["geo_graph"] = dict(metric="batched geodesic-ball graph build (ball r = 0.06, <= 15 random members, + self loops), meshes/s",
+                                          value=round(args.batch * 10 / sdt, 1), unit="meshes/s", ms_per_batch=round(sdt / 10 * 1e3, 3),
+                                          batch=args.batch, edges=int(ei.shape[1]), pair_tests_per_s=round(pairs_n * 10 / sdt / 1e12, 3),
+                                          pair_tests_unit="1e12 distance tests / s (V^2 per mesh: the kernel is bound by these, not by its "
+                                                          "%.1f MB of compulsory HBM bytes)" % ((12.0 * nv + 16.0 * ei.shape[1]) / 1e6),
+                                          includes="slot kernel + scan + one host read of the edge count + fill",
+                                          config="VERDICT r2 a17; SURVEY 8(d) synthetic recipe")
+            del gbatch, ei
+        except Exception as e:
+            secondary["geo_graph"] = dict(error=repr(e)[:300])
         # one TRAINING step of the headline network (train-mode forward with batch statistics, a stand-in L2 loss,
         # backward through the native backward operators; no optimizer) -- correctness-first kernels, reported for orientation
         try:
             from morig_amd import models as _models, synth
             nb = 8
-            d2 = build_batch([2000 + i for i in range(nb)], args.n_side, with_skin=False, n_pts=0).to(dev)
+            d2 = build_batch([2000 + i for i in range(nb)], args.n_side, with_skin=False, n_pts=0, dev=dev)
             tm = _models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").train()
             synth.load_recipe(tm, 0, mild=True).to(dev)
 
@@ -582,7 +634,10 @@ def main():
                                    f"{args.n_side * args.n_side}-vertex meshes per GPU ({names[2]}), "
                                    "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if use_dist else ""),
                        "meshes_per_gpu": B_local, "global_batch": n_units, "vertices_per_mesh": args.n_side * args.n_side,
-                       "parallelism": f"mesh-sharded dp{world}"},
+                       "parallelism": f"mesh-sharded dp{world}",
+                       "guard_read": ("sync: one host read at the end of every forward" if (args.workload != "jointnet" or os.environ.get("MORIG_BENCH_GUARD") == "sync")
+                                      else "deferred by one forward (forward_async): every forward's range flag / CSR status still read inside the timed region"),
+                       "geo_graph": "built on the device (morig_geo_ball_graph)" if not PLUMBING else "host recipe"},
             "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
             "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank],
             "roofline": roof,

@@ -331,6 +331,33 @@ int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t
                       float* dst, int32_t ldd, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * Geodesic-ball graph on the device: data_proc/common_ops.py:214-226 get_geo_edges (radius = 0.06, max_nn = 15), the producer of
+ * `geo_edge_index` (datasets/dataset_rig.py:86,122), batched over the meshes of a batch. For every vertex i: the members j != i
+ * of its mesh with dist(i, j) <= radius (inclusive) in index order; a row with more than max_nn (<= 64) members keeps a uniformly
+ * random subset of exactly max_nn (the reference: np.random.choice(members, max_nn, replace=False) on numpy's global stream;
+ * here Algorithm-R reservoir sampling on a counter hash of (seed, row, member number): the same distribution over subsets).
+ *   slots   [n_nodes][max_nn] int32, unused = -1        counts [n_nodes] = min(members, max_nn)
+ *   members [n_nodes] uncapped member counts (may be NULL)
+ *   offsets [n_nodes + 1] exclusive prefix sums of counts (offsets[n_nodes] = number of edges)
+ *   scan_ws scratch, >= ceil(n_nodes / 2048) ints
+ * morig_geo_ball_graph: Euclidean distance between positions (what SURVEY 8(d)'s synthetic recipe puts in the geodesic's place):
+ *   LDS-tiled brute force, d^2 = (dx*dx + dy*dy) + dz*dz in fp32 (no fma) against fp32(radius)^2; meshes = contiguous row
+ *   ranges mesh_ptr[n_meshes + 1].
+ * morig_geo_ball_graph_dist: the reference's own input, a precomputed n x n float64 distance matrix of ONE mesh
+ *   (calc_surface_geodesic, common_ops.py:162-211); the diagonal counts as dist + 10 (common_ops.py:218).
+ * morig_geo_ball_fill: rows [i, member] in row order into an int64 COO [2][n_out] (row 0 = i, row 1 = member: the layout of
+ *   np.loadtxt(geo_e).T, dataset_rig.py:86); self_loops != 0 appends the n_nodes pairs (i, i) that add_self_loops appends
+ *   (dataset_rig.py:122): n_out = offsets[n_nodes] (+ n_nodes). */
+int morig_geo_ball_graph(const float* pos, int32_t ldp, const int32_t* mesh_ptr, int32_t n_meshes, int32_t n_nodes,
+                         float radius, int32_t max_nn, uint32_t seed, int32_t* slots, int32_t* counts, int32_t* members,
+                         int32_t* offsets, int32_t* scan_ws, void* stream);
+int morig_geo_ball_graph_dist(const double* dist, int64_t ldd, int32_t n_nodes, double radius, int32_t max_nn, uint32_t seed,
+                              int32_t* slots, int32_t* counts, int32_t* members, int32_t* offsets, int32_t* scan_ws,
+                              void* stream);
+int morig_geo_ball_fill(const int32_t* slots, const int32_t* offsets, int32_t n_nodes, int32_t max_nn, int32_t self_loops,
+                        int64_t* coo, int64_t n_out, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline object.
  */
 #define MORIG_PROF_KINDS 48

@@ -50,7 +50,8 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /* >= SCAN_T/64 + 
 // segment length of a target: its non-loop in-edges + one self loop, optionally rounded up to a multiple of 4
 // (the padding slots repeat the self loop: max-aggregation is idempotent, and 4-aligned segments let the
 // EdgeConv epilogue reduce each lane's 4 consecutive accumulator rows in registers)
-__device__ __forceinline__ int seg_len(int cnt, int pad4) { const int d = cnt + 1; return pad4 ? ((d + 3) & ~3) : d; }
+// (pad4 == 2: the plain count -- the prefix sums of morig_geo_ball_graph's per-row member counts)
+__device__ __forceinline__ int seg_len(int cnt, int pad4) { if (pad4 == 2) return cnt; const int d = cnt + 1; return pad4 ? ((d + 3) & ~3) : d; }
 
 __global__ __launch_bounds__(SCAN_T) void scan_reduce_kernel(const int* __restrict__ cnt, int n, int pad4, int* __restrict__ bsum) {
     __shared__ int sh[SCAN_T / 64 + 1];
@@ -234,6 +235,156 @@ __global__ void csr_clear_kernel(int* __restrict__ cursor, int n, int* __restric
     if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Geodesic-ball graph on the device (data_proc/common_ops.py:214-226 get_geo_edges; SURVEY 8(d) synthetic recipe): for every
+// vertex i the members j != i of its mesh with dist(i, j) <= radius, in index order; a row with more than max_nn members keeps a
+// uniformly random subset of exactly max_nn (the reference: np.random.choice(members, max_nn, replace=False)); rows [i, member].
+//
+// Positions variant (Euclidean distance standing in for the geodesic one, as the synthetic recipe does): LDS-tiled brute force.
+// A 256-thread block owns 4 x CPW consecutive centres; the candidates of their mesh(es) pass through LDS in tiles of GEO_TILE
+// points (SoA, 12 KB), every wave tests 64 candidates per step against each of its CPW centres: ballot + popcount give the
+// member ranks, the reservoir (Algorithm R, as morig_radius_sample: slot t lives in lane t's register, member number t >= max_nn
+// replaces slot u = floor(U (t + 1)) when u < max_nn, U from a counter hash of (seed, row, t)) keeps the subset. No atomics, no
+// distance matrix in memory: 12 B read per vertex per tile pass, max_nn int32 written per row.
+// Distance-matrix variant (true geodesics: an n x n float64 matrix, the reference's own input): one wave per row streams the
+// row (HBM-bound: 8 n^2 bytes), diagonal + 10 as common_ops.py:218 does.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int GEO_TILE = 1024;
+
+__device__ __forceinline__ unsigned geo_mix32(unsigned a) {
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+
+// one 64-candidate step of a row's reservoir: `mask` = member lanes (index order = lane order), idx0 = candidate index of lane 0
+__device__ __forceinline__ void geo_reservoir_step(unsigned long long mask, int idx0, int lane, int row, int max_nn, unsigned seed,
+                                                   int& slot, int& seen) {
+    const int nh = __popcll(mask);
+    if (nh == 0) return;
+    if (seen + nh <= max_nn) {                            // still filling: member number t goes to slot t (one assignment per lane)
+        const int t = lane - seen;                        // which member of this step lands in my slot
+        if (t >= 0 && t < nh) {
+            unsigned long long m = mask;
+            for (int q = 0; q < t; ++q) m &= m - 1ull;    // drop the t lowest members (nh <= max_nn <= 64: short)
+            slot = idx0 + __builtin_ctzll(m);
+        }
+        seen += nh;
+        return;
+    }
+    for (unsigned long long m = mask; m; m &= m - 1ull) { // wave-uniform walk over the members of this step
+        const int idx = idx0 + __builtin_ctzll(m);
+        const int t = seen;
+        if (t < max_nn) { if (lane == t) slot = idx; }
+        else {
+            const unsigned h = geo_mix32(seed ^ geo_mix32((unsigned)row * 0x9E3779B9u + (unsigned)t));
+            const unsigned u = (unsigned)(((unsigned long long)h * (unsigned long long)(t + 1)) >> 32);   // uniform in [0, t]
+            if ((int)u < max_nn && lane == (int)u) slot = idx;
+        }
+        ++seen;
+    }
+}
+
+__device__ __forceinline__ int geo_mesh_of(const int* __restrict__ mesh_ptr, int n_meshes, int v) {
+    int lo = 0, hi = n_meshes;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (mesh_ptr[mid] <= v) lo = mid; else hi = mid; }
+    return lo;
+}
+
+template <int CPW>
+__global__ __launch_bounds__(256) void geo_ball_graph_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ mesh_ptr,
+                                                             int n_meshes, int n, float r2, int max_nn, unsigned seed,
+                                                             int* __restrict__ slots, int* __restrict__ counts, int* __restrict__ members) {
+    __shared__ float sx[GEO_TILE], sy[GEO_TILE], sz[GEO_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int blk0 = blockIdx.x * 4 * CPW;
+    const int blk1 = min(n, blk0 + 4 * CPW) - 1;          // last centre of the block (blk0 < n by the grid size)
+    const int xs = mesh_ptr[geo_mesh_of(mesh_ptr, n_meshes, blk0)];
+    const int xe = mesh_ptr[geo_mesh_of(mesh_ptr, n_meshes, blk1) + 1];
+    int c[CPW], cs[CPW], ce[CPW], slot[CPW], seen[CPW];
+    float cx[CPW], cy[CPW], cz[CPW];
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        c[q] = blk0 + wave * CPW + q;
+        slot[q] = -1; seen[q] = 0; cs[q] = ce[q] = 0; cx[q] = cy[q] = cz[q] = 0.f;
+        if (c[q] < n) {
+            const int mq = geo_mesh_of(mesh_ptr, n_meshes, c[q]);
+            cs[q] = mesh_ptr[mq]; ce[q] = mesh_ptr[mq + 1];
+            cx[q] = pos[(size_t)c[q] * ldp]; cy[q] = pos[(size_t)c[q] * ldp + 1]; cz[q] = pos[(size_t)c[q] * ldp + 2];
+        }
+    }
+    for (int t0 = xs; t0 < xe; t0 += GEO_TILE) {
+        __syncthreads();                                  // the previous tile is consumed
+#pragma unroll
+        for (int i = tid; i < GEO_TILE; i += 256) {
+            const int j = t0 + i;
+            if (j < xe) { const float* pj = pos + (size_t)j * ldp; sx[i] = pj[0]; sy[i] = pj[1]; sz[i] = pj[2]; }
+        }
+        __syncthreads();
+        const int nt = min(GEO_TILE, xe - t0);
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            if (c[q] >= n || t0 >= ce[q] || t0 + nt <= cs[q]) continue;     // wave-uniform: this tile holds none of the centre's mesh
+            for (int b = 0; b < nt; b += 64) {
+                const int i = b + lane, j = t0 + i;
+                bool hit = false;
+                if (i < nt && j >= cs[q] && j < ce[q] && j != c[q]) {
+                    const float dx = cx[q] - sx[i], dy = cy[q] - sy[i], dz = cz[q] - sz[i];
+                    hit = (dx * dx + dy * dy) + dz * dz <= r2;
+                }
+                geo_reservoir_step(__ballot(hit), t0 + b, lane, c[q], max_nn, seed, slot[q], seen[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPW; ++q) {
+        if (c[q] >= n) continue;
+        if (lane < max_nn) slots[(int64_t)c[q] * max_nn + lane] = lane < seen[q] ? slot[q] : -1;
+        if (lane == 0) { counts[c[q]] = min(seen[q], max_nn); if (members) members[c[q]] = seen[q]; }
+    }
+}
+
+// distance-matrix variant: one wave per row, 4 x 64 candidates in flight per step
+__global__ __launch_bounds__(256) void geo_ball_graph_dist_kernel(const double* __restrict__ dist, int64_t ldd, int n, double radius,
+                                                                  int max_nn, unsigned seed, int* __restrict__ slots,
+                                                                  int* __restrict__ counts, int* __restrict__ members) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n) return;
+    const double* drow = dist + (int64_t)row * ldd;
+    int slot = -1, seen = 0;
+    for (int b = 0; b < n; b += 256) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int j = b + u * 64 + lane; v[u] = j < n ? drow[j] : 1e300; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = b + u * 64 + lane;
+            const double d = j == row ? v[u] + 10.0 : v[u];               // surface_geodesic += 10 * eye (common_ops.py:218)
+            geo_reservoir_step(__ballot(j < n && d <= radius), b + u * 64, lane, row, max_nn, seed, slot, seen);
+        }
+    }
+    if (lane < max_nn) slots[(int64_t)row * max_nn + lane] = lane < seen ? slot : -1;
+    if (lane == 0) { counts[row] = min(seen, max_nn); if (members) members[row] = seen; }
+}
+
+// rows [i, member] in row order, members in slot order; then (optionally) the n self loops the datasets append
+// (datasets/dataset_rig.py:121-122). coo: int64 [2][n_out], n_out = offsets[n] (+ n)
+__global__ __launch_bounds__(256) void geo_ball_fill_kernel(const int* __restrict__ slots, const int* __restrict__ offsets, int n, int max_nn,
+                                                            int self_loops, int64_t* __restrict__ coo, int64_t n_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += stride) {
+        const int o = offsets[row], cnt = offsets[row + 1] - o;
+        if (lane < cnt) { coo[o + lane] = row; coo[n_out + o + lane] = slots[row * max_nn + lane]; }
+    }
+    if (self_loops) {
+        const int64_t e0 = offsets[n];
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            coo[e0 + i] = i; coo[n_out + e0 + i] = i;
+        }
+    }
+}
+
 static inline int grid_for(int64_t n, int block = 256, int cap = 256 * 16) {
     int64_t g = (n + block - 1) / block;
     if (g < 1) g = 1;
@@ -338,6 +489,59 @@ extern "C" int morig_csr_from_slots(const int64_t* coo, int32_t n_nodes, int32_t
     hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cursor, n_nodes, 0, bsum, rowptr, cursor);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_slots_fill_kernel, dim3(cdiv(n_nodes, 4)), dim3(256), 0, s, coo, n_nodes, max_nbrs, n_src_nodes, rowptr, src_sorted, dst_sorted);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+// ---- geodesic-ball graph (kernels above) -------------------------------------------------------------------------------
+static int geo_offsets(const int* counts, int n, int* offsets, int* scan_ws, hipStream_t s) {
+    const int nb = cdiv(n, SCAN_B);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, counts, n, 2, scan_ws);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, scan_ws, nb, offsets + n);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, counts, n, 2, scan_ws, offsets, offsets);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_geo_ball_graph(const float* pos, int32_t ldp, const int32_t* mesh_ptr, int32_t n_meshes, int32_t n_nodes,
+                                    float radius, int32_t max_nn, uint32_t seed, int32_t* slots, int32_t* counts, int32_t* members,
+                                    int32_t* offsets, int32_t* scan_ws, void* stream) {
+    if (!pos || !mesh_ptr || !slots || !counts || !offsets || !scan_ws) return MORIG_E_INVALID;
+    if (ldp < 3 || n_meshes <= 0 || n_nodes <= 0 || max_nn <= 0 || max_nn > 64 || !(radius >= 0.f)) return MORIG_E_INVALID;
+    if ((int64_t)n_nodes * max_nn > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    constexpr int CPW = 4;
+    // algorithmic bytes: positions once, the slot table + counts + offsets written once
+    ProfScope ps(K_GEOGRAPH, s, 0.0, 12.0 * n_nodes + 4.0 * n_nodes * (double)max_nn + 8.0 * n_nodes);
+    hipLaunchKernelGGL(geo_ball_graph_kernel<CPW>, dim3(cdiv(n_nodes, 4 * CPW)), dim3(256), 0, s, pos, ldp, mesh_ptr, n_meshes, n_nodes,
+                       radius * radius, max_nn, seed, slots, counts, members);
+    MORIG_LAUNCH_CHECK();
+    return geo_offsets(counts, n_nodes, offsets, scan_ws, s);
+}
+
+extern "C" int morig_geo_ball_graph_dist(const double* dist, int64_t ldd, int32_t n_nodes, double radius, int32_t max_nn, uint32_t seed,
+                                         int32_t* slots, int32_t* counts, int32_t* members, int32_t* offsets, int32_t* scan_ws,
+                                         void* stream) {
+    if (!dist || !slots || !counts || !offsets || !scan_ws) return MORIG_E_INVALID;
+    if (n_nodes <= 0 || ldd < n_nodes || max_nn <= 0 || max_nn > 64 || !(radius >= 0.0)) return MORIG_E_INVALID;
+    if ((int64_t)n_nodes * max_nn > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_GEOGRAPH, s, 0.0, 8.0 * n_nodes * (double)n_nodes + 4.0 * n_nodes * (double)max_nn);
+    hipLaunchKernelGGL(geo_ball_graph_dist_kernel, dim3(cdiv(n_nodes, 4)), dim3(256), 0, s, dist, ldd, n_nodes, radius, max_nn, seed,
+                       slots, counts, members);
+    MORIG_LAUNCH_CHECK();
+    return geo_offsets(counts, n_nodes, offsets, scan_ws, s);
+}
+
+extern "C" int morig_geo_ball_fill(const int32_t* slots, const int32_t* offsets, int32_t n_nodes, int32_t max_nn, int32_t self_loops,
+                                   int64_t* coo, int64_t n_out, void* stream) {
+    if (!slots || !offsets || !coo || n_nodes <= 0 || max_nn <= 0 || max_nn > 64 || n_out < 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_GEOGRAPH, s, 0.0, 4.0 * n_nodes * (double)max_nn + 16.0 * (double)n_out);
+    hipLaunchKernelGGL(geo_ball_fill_kernel, dim3(grid_for((int64_t)n_nodes * 64)), dim3(256), 0, s, slots, offsets, n_nodes, max_nn,
+                       self_loops, coo, n_out);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

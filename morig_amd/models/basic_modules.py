@@ -166,6 +166,25 @@ class NativeModule(torch.nn.Module):
             if outer is None:
                 _ctx.root = None
 
+    def forward_async(self, *args, **kwargs):
+        """The eval forward with its guard read DEFERRED: -> (outputs, pending). ``pending.result()`` (morig_amd.native.PendingGuard)
+        is the one host read ``forward()`` does before it returns; call it after the NEXT forward has been enqueued and the GPU
+        never waits for the host between forwards. result() False = an operand left the split-fp16 range: the outputs are invalid,
+        run ``forward()`` (which re-runs on the exact-fp32 kernels). Eval mode, deterministic plans only (no random FPS starts)."""
+        assert not self.training, "forward_async is the eval-mode path"
+        ops = get_ops()
+        dev = next(self.parameters()).device
+        outer = _ctx.key
+        assert outer is None, "forward_async is for the outermost module"
+        _ctx.key, _ctx.root = _LAZY_KEY, self
+        try:
+            with torch.cuda.device(dev):
+                if not ops.fast:                        # exact-fp32 mode: nothing can overflow, the status words still are checked
+                    return ops.guarded(dev, lambda: self._forward(*args, **kwargs)), None
+                return ops.guarded_async(dev, lambda: self._forward(*args, **kwargs))
+        finally:
+            _ctx.key, _ctx.root = outer, None
+
     def _forward(self, *args, **kwargs):
         raise NotImplementedError
 

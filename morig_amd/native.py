@@ -100,6 +100,11 @@ _SIGNATURES = {
     "morig_ball_query": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, c_i64p, C.c_void_p]),
     "morig_radius_sample": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
                                       c_i64p, c_i32p, C.c_void_p]),
+    "morig_geo_ball_graph": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
+                                       c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
+    "morig_geo_ball_graph_dist": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint32,
+                                            c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
+    "morig_geo_ball_fill": (C.c_int, [c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i64p, C.c_int64, C.c_void_p]),
     "morig_col_stats": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_void_p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "morig_col_affine": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
     "morig_edge_gather_relu": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
@@ -255,6 +260,26 @@ def _need_gpu(*ts):
                                    "move the model and data to 'cuda'")
 
 
+class PendingGuard:
+    """What a forward enqueued with ``NativeOps.guarded_async`` leaves behind: ONE small device tensor [range flag, CSR status
+    words ...] snapshotted on the stream behind the forward's last launch. ``result()`` is the host read the synchronous guard
+    does at the end of every forward -- a serving loop calls it AFTER it has enqueued the next forward, so the GPU never idles
+    on it. -> True: results valid; False: an operand left the split-fp16 range (re-run on the fp32 path); raises on a bad index."""
+
+    def __init__(self, snapshot: torch.Tensor):
+        self.snapshot = snapshot
+        self._done = None
+
+    def result(self) -> bool:
+        if self._done is None:
+            words = self.snapshot.tolist()
+            if any(w != 0 for w in words[1:]):
+                raise MorigNativeError("edge_index / neighbour index out of range for the vertex count it was built with "
+                                       "(morig_csr_build status %s)" % [w for w in words[1:] if w != 0][:4])
+            self._done = words[0] == 0
+        return self._done
+
+
 class NativeOps:
     """Thin, validating wrappers: tensors in, C ABI calls out, everything on the current stream."""
 
@@ -362,6 +387,23 @@ class NativeOps:
             finally:
                 self._force_f32 = False
         return out
+
+    def guarded_async(self, device, fn):
+        """``fn()`` (a whole eval forward) on the fast path WITHOUT the host read at its end -> (outputs, PendingGuard).
+        The flag and the CSR status words of this forward are copied into a fresh tensor on the stream, so the next forward may
+        be enqueued (it clears the shared flag word) before ``PendingGuard.result()`` is called. Also what a HIP-graph capture
+        of a forward runs through (no host read inside a capture; every replay refreshes the snapshot)."""
+        assert self._depth == 0, "guarded_async is for the outermost forward"
+        flag = self._flag(device)
+        flag.zero_()
+        self._depth += 1
+        self._csr_status = []
+        try:
+            out = fn()
+        finally:
+            self._depth -= 1
+            stats, self._csr_status = self._csr_status, None
+        return out, PendingGuard(torch.cat([flag] + stats))
 
     def _run_once(self, device, fn):
         """one pass with the CSR status words checked (no precision flag: the fp32 path cannot overflow fp16)"""
@@ -679,6 +721,39 @@ class NativeOps:
         check(self.lib.morig_radius_sample(x.ptr, x.ld, x.rows, y.ptr, y.ld, y.rows, float(radius), max_nbrs, int(seed) & 0xFFFFFFFF,
                                            _p(coo), _p(counts), _stream()), "morig_radius_sample")
         return coo, counts
+
+    def geo_ball_graph(self, pos: Optional[Mat], mesh_ptr: Optional[torch.Tensor], radius: float, max_nn: int, seed: int,
+                       self_loops: bool = False, dist: Optional[torch.Tensor] = None):
+        """get_geo_edges (data_proc/common_ops.py:214-226) on the device -> (edge_index int64 [2, E] rows [i, member],
+        members int32 [n] uncapped ball sizes). Positions variant: pos [n, >=3] + mesh_ptr int32 [B + 1]; distance variant:
+        dist float64 [n, n] of one mesh. ONE host read (the edge count sizes the result)."""
+        if dist is not None:
+            _need_gpu(dist)
+            assert dist.dtype == torch.float64 and dist.dim() == 2 and dist.shape[0] == dist.shape[1] and dist.stride(1) == 1
+            n, dev = dist.shape[0], dist.device
+        else:
+            _need_gpu(pos.base, mesh_ptr)
+            assert mesh_ptr.dtype == torch.int32
+            n, dev = pos.rows, pos.base.device
+        slots = torch.empty((n, max_nn), dtype=torch.int32, device=dev)
+        counts = torch.empty(n, dtype=torch.int32, device=dev)
+        members = torch.empty(n, dtype=torch.int32, device=dev)
+        offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        ws = torch.empty(max(1, (n + 2047) // 2048), dtype=torch.int32, device=dev)
+        sd = int(seed) & 0xFFFFFFFF
+        if dist is not None:
+            check(self.lib.morig_geo_ball_graph_dist(_p(dist), dist.stride(0), n, float(radius), max_nn, sd, _p(slots), _p(counts),
+                                                     _p(members), _p(offsets), _p(ws), _stream()), "morig_geo_ball_graph_dist")
+        else:
+            check(self.lib.morig_geo_ball_graph(pos.ptr, pos.ld, _p(mesh_ptr), mesh_ptr.numel() - 1, n, float(radius), max_nn, sd,
+                                                _p(slots), _p(counts), _p(members), _p(offsets), _p(ws), _stream()),
+                  "morig_geo_ball_graph")
+        n_out = int(offsets[n].item()) + (n if self_loops else 0)
+        coo = torch.empty((2, n_out), dtype=torch.int64, device=dev)
+        if n_out:
+            check(self.lib.morig_geo_ball_fill(_p(slots), _p(offsets), n, max_nn, 1 if self_loops else 0, _p(coo), n_out, _stream()),
+                  "morig_geo_ball_fill")
+        return coo, members
 
     def knn_interpolate(self, feat: Mat, pos_x: Mat, ptr_x: torch.Tensor, pos_y: Mat, ptr_y: torch.Tensor, n_clouds: int,
                         max_targets_per_cloud: int, k: int, out: Mat):

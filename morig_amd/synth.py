@@ -24,7 +24,7 @@ import numpy as np
 import torch
 
 __all__ = [
-    "MeshData", "make_mesh", "make_point_cloud", "collate", "make_batch",
+    "MeshData", "make_mesh", "make_point_cloud", "collate", "make_batch", "make_batch_device",
     "recipe_state_dict", "load_recipe", "KEYFRAMES",
 ]
 
@@ -57,8 +57,10 @@ def _torus(n_side: int, R: float, r: float) -> np.ndarray:
 
 
 def make_mesh(seed: int, n_side: int = 64, geo_radius: Optional[float] = None,
-              geo_max_nn: int = 15, with_skin: bool = True) -> MeshData:
-    """One synthetic character-like mesh: an ``n_side x n_side`` triangulated torus grid."""
+              geo_max_nn: int = 15, with_skin: bool = True, geo: str = "host") -> MeshData:
+    """One synthetic character-like mesh: an ``n_side x n_side`` triangulated torus grid.
+    geo="host": the ball graph by a V x V distance matrix on the CPU (tests, oracle, CPU baseline); geo="none": only the self
+    loops -- ``make_batch_device`` then builds the ball graph of the whole batch on the GPU (morig_amd/graph_build.py)."""
     rng = np.random.default_rng([0x4D6F5269, seed])
     R = 0.35 * (1.0 + 0.1 * rng.uniform(-1, 1))
     r = 0.12 * (1.0 + 0.1 * rng.uniform(-1, 1))
@@ -76,18 +78,22 @@ def make_mesh(seed: int, n_side: int = 64, geo_radius: Optional[float] = None,
     # geodesic-ball edges, Euclidean distance standing in for geodesic distance
     if geo_radius is None:
         geo_radius = 0.06 * 64.0 / n_side
-    pt = torch.from_numpy(pos)
-    d2 = torch.cdist(pt, pt, compute_mode="donot_use_mm_for_euclid_dist") ** 2
-    d2.fill_diagonal_(1e9)
-    # random subset of <= geo_max_nn ball members per row (np.random.choice in the reference):
-    # the members with the smallest random keys
-    keys = torch.from_numpy(rng.random((V, V), dtype=np.float32))
-    keys[d2 > geo_radius * geo_radius] = 2.0
-    k = min(geo_max_nn, V - 1)
-    val, pick = torch.topk(keys, k, dim=1, largest=False, sorted=True)
-    valid = val < 2.0
-    rows = torch.arange(V)[:, None].expand(-1, k)
-    geo = torch.stack([rows[valid], pick[valid]], dim=0).numpy().astype(np.int64)
+    if geo == "host":
+        pt = torch.from_numpy(pos)
+        d2 = torch.cdist(pt, pt, compute_mode="donot_use_mm_for_euclid_dist") ** 2
+        d2.fill_diagonal_(1e9)
+        # random subset of <= geo_max_nn ball members per row (np.random.choice in the reference):
+        # the members with the smallest random keys
+        keys = torch.from_numpy(rng.random((V, V), dtype=np.float32))
+        keys[d2 > geo_radius * geo_radius] = 2.0
+        k = min(geo_max_nn, V - 1)
+        val, pick = torch.topk(keys, k, dim=1, largest=False, sorted=True)
+        valid = val < 2.0
+        rows = torch.arange(V)[:, None].expand(-1, k)
+        geo = torch.stack([rows[valid], pick[valid]], dim=0).numpy().astype(np.int64)
+    else:
+        assert geo == "none"
+        geo = np.zeros((2, 0), dtype=np.int64)
 
     loops = np.stack([np.arange(V), np.arange(V)], axis=0)
     tpl = np.concatenate([tpl, loops], axis=1)     # datasets/dataset_rig.py:121
@@ -157,6 +163,22 @@ def make_batch(seeds: Iterable[int], n_side: int = 64, n_pts: int = 0, **kw) -> 
     meshes = [make_mesh(s, n_side=n_side, **kw) for s in seeds]
     clouds = [make_point_cloud(m, int(m.name), n_pts) for m in meshes] if n_pts else None
     return collate(meshes, clouds)
+
+
+def make_batch_device(seeds: Iterable[int], device, n_side: int = 64, n_pts: int = 0, geo_radius: Optional[float] = None,
+                      geo_max_nn: int = 15, geo_seed: int = 0, **kw) -> MeshData:
+    """The same synthetic batch with its ``geo_edge_index`` built ON THE DEVICE for all meshes at once
+    (``graph_build.get_geo_edges`` = morig_geo_ball_graph: the reference's get_geo_edges, data_proc/common_ops.py:214-226, then
+    the datasets' self loops): positions, the 1-ring graph and the flows come from the host recipe, the V x V ball search --
+    the only O(V^2) part -- never runs on the CPU. Needs the HIP library and a GPU (no fallback)."""
+    from . import graph_build
+    meshes = [make_mesh(s, n_side=n_side, geo="none", **kw) for s in seeds]
+    clouds = [make_point_cloud(m, int(m.name), n_pts) for m in meshes] if n_pts else None
+    b = collate(meshes, clouds).to(device)
+    r = 0.06 * 64.0 / n_side if geo_radius is None else geo_radius
+    b.geo_edge_index = graph_build.get_geo_edges(b.pos, b.batch, r, geo_max_nn, seed=geo_seed, self_loops=True,
+                                                 num_graphs=b.num_graphs)
+    return b
 
 
 # --------------------------------------------------------------------------------------

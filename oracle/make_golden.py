@@ -223,6 +223,57 @@ def joints_fixtures():
               modes_unweighted=plain, joints_nms=joints_nms, joints=joints, side=side)
 
 
+def geo_edges_fixture():
+    """data_proc/common_ops.py:214-226 run as is on a precomputed distance matrix: `calc_surface_geodesic` (open3d remeshing +
+    Dijkstra, :162-211) is replaced by a function that hands back the matrix, the mesh object is a stand-in with `.vertices`.
+    Case `exact`: no row exceeds max_nn, the whole edge array is deterministic. Case `over`: rows overflow; their members are a
+    np.random.choice draw, so the reference's output is stored together with the per-row member counts (properties are checked
+    for those rows, the rows within the cap bit-exactly). The matrix of `euclid` holds float32 squared distances of seeded
+    positions (radius = float32(r)^2): the membership the device kernel's positions variant must reproduce."""
+    print("geo-edges fixture")
+    import types
+    from oracle import graph_build
+    sys.path.insert(0, shim.REFERENCE_ROOT)
+    for name in ("open3d", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    co = __import__("data_proc.common_ops", fromlist=["get_geo_edges"])
+    rng = np.random.default_rng(2024)
+    n = 220
+    pos = (rng.random((n, 3)) * np.array([0.5, 0.3, 0.4])).astype(np.float32)
+    dist = np.sqrt(((pos[:, None, :].astype(np.float64) - pos[None]) ** 2).sum(-1))
+    dist = dist * (1.0 + 0.2 * rng.random((n, n)))                  # not symmetric, not Euclidean: a generic "geodesic" matrix
+    np.fill_diagonal(dist, 0.0)
+    obj = types.SimpleNamespace(vertices=pos.astype(np.float64))
+    orig = co.calc_surface_geodesic
+
+    def run(matrix, radius, max_nn, seed):
+        co.calc_surface_geodesic = lambda mesh: matrix.copy()
+        try:
+            np.random.seed(seed)
+            return co.get_geo_edges(obj, radius=radius, max_nn=max_nn)
+        finally:
+            co.calc_surface_geodesic = orig
+    e_exact = run(dist, 0.05, 64, 1)
+    e_over = run(dist, 0.09, 6, 2)
+    cnt_exact = ((dist + 10 * np.eye(n)) <= 0.05).sum(1)
+    cnt_over = ((dist + 10 * np.eye(n)) <= 0.09).sum(1)
+    assert cnt_exact.max() <= 64 and (cnt_over > 6).sum() > 20 and (cnt_over <= 6).sum() > 20 and (cnt_exact == 0).sum() > 0
+    d2 = graph_build.euclid_sq_f32(pos).astype(np.float64)
+    r2 = float(np.float32(0.07) * np.float32(0.07))
+    e_euclid = run(d2, r2, 64, 3)
+    e_euclid_over = run(d2, r2, 5, 4)
+    cnt_euclid = ((d2 + 10 * np.eye(n)) <= r2).sum(1)
+    assert cnt_euclid.max() <= 64 and (cnt_euclid > 5).sum() > 20
+    # the oracle restatement reproduces the reference's draws when it is handed the same numpy stream
+    for m_, r_, k_, sd_, want in ((dist, 0.05, 64, 1, e_exact), (dist, 0.09, 6, 2, e_over), (d2, r2, 5, 4, e_euclid_over)):
+        np.random.seed(sd_)
+        assert np.array_equal(graph_build.get_geo_edges_from_distance(m_, r_, k_), want)
+    _save("geo_edges_kat", dict(r_exact=0.05, max_exact=64, r_over=0.09, max_over=6, r_euclid=0.07, max_euclid=64, max_euclid_over=5,
+                                seeds=[1, 2, 3, 4]),
+          pos=pos, dist=dist, edges_exact=e_exact, edges_over=e_over, counts_exact=cnt_exact, counts_over=cnt_over,
+          edges_euclid=e_euclid, edges_euclid_over=e_euclid_over, counts_euclid=cnt_euclid)
+
+
 def write_rig_sample(folder, name, seed, n_side=6, n_joints=7, n_bones=24):
     """A synthetic model in the reference's raw file formats (datasets/dataset_rig.py:82-115); returns the file map
     {relative path: bytes} so a test can lay the same files down again anywhere."""
@@ -329,6 +380,8 @@ def main():
         return radius_cpu_fixture(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "joints":
         return joints_fixtures()
+    if len(sys.argv) > 1 and sys.argv[1] == "geo_edges":
+        return geo_edges_fixture()
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
         return dataset_fixtures()
     bm = sys.modules["models.basic_modules"]
