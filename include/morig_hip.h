@@ -326,6 +326,21 @@ int morig_meanshift(const double* pts, const float* weights, int32_t n, const do
 int morig_nms_counts(const double* pts, int32_t n, const double* bandwidth, int32_t* counts, void* stream);
 int morig_nms_greedy(const double* pts, const float* attn, int32_t n, const double* bandwidth, const int32_t* order,
                      double thrd_density, float thrd_attn, uint8_t* alive, void* stream);
+/* The same four stages over the point sets of SEVERAL meshes at once (the reference loops over models, eval_rigging.py:62-98):
+ * sets concatenated, mesh b = rows [ptr[b], ptr[b + 1]) (int32 [n_meshes + 1] on the device), n_all rows in total, max_n = the
+ * largest set (sizes the launch grids). Per mesh the arithmetic and its order are those of the one-set entry points.
+ *   bandwidth [n_meshes]; k of mesh b = max(int(n_b * quantile), 1) (sklearn estimate_bandwidth);
+ *   state [n_meshes][max_iter]; order_local: the visiting order of every mesh as indices LOCAL to the mesh, concatenated. */
+int morig_knn_bandwidth_batched(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int32_t max_n,
+                                double quantile, double* kth_ws, double* bandwidth, void* stream);
+int morig_meanshift_batched(const double* pts, const float* weights, const int32_t* ptr, int32_t n_meshes, int32_t n_all,
+                            int32_t max_n, const double* bandwidth, int32_t max_iter, double* buf_a, double* buf_b,
+                            double* state, int32_t* result_in_a, void* stream);
+int morig_nms_counts_batched(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int32_t max_n,
+                             const double* bandwidth, int32_t* counts, void* stream);
+int morig_nms_greedy_batched(const double* pts, const float* attn, const int32_t* ptr, int32_t n_meshes, int32_t n_all,
+                             const double* bandwidth, const int32_t* order_local, double thrd_density, float thrd_attn,
+                             uint8_t* alive, void* stream);
 /* dst[r] = src[idx[r]] (pos[idx], out_pts[nn]); idx < 0 -> zeros */
 int morig_gather_rows(const float* src, int32_t lds, const int32_t* idx, int32_t rows, int32_t cols,
                       float* dst, int32_t ldd, void* stream);

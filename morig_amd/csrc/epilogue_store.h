@@ -169,4 +169,109 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
     if (ovf) *p.ovf = 1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Register epilogue for TRANSPOSED accumulators (gemm_dma.hip / gemm_dmap.hip store launches). The kernels issue their MFMAs
+// with the operands swapped -- A = W fragment, B = X fragment -- so the result tile is D^T: a lane owns ONE OUTPUT ROW
+// (m = lane & 31) and, per 32 x 32 tile, the 16 columns n = (r & 3) + 8 (r >> 2) + 4 (lane >> 5): four groups of 4 ADJACENT
+// columns. One v_permlane32_swap per register pair exchanges groups between the two half-waves, after which a lane holds 8
+// consecutive columns twice (16 P + 8 (lane >> 5) ..+7, P = 0, 1): its results leave as 16-byte stores straight from the
+// accumulators -- no LDS transposition, no barrier in front of the epilogue, no scratch to reserve in the operand ring.
+// The bias (and the per-mesh row bias when the tile lies in one mesh) is the accumulators' INITIAL value, so what is left per
+// element is ReLU / BN affine when the layer has them (constants: broadcast ds_read_b128 from a 3 x BN float panel) and the
+// fp16 (hi, lo) split for split-layout outputs.
+//   acc[mt][nt][r] (before the exchange) = Y[row0 + rl_base + 32 mt + (lane & 31)][colw0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)]
+//   ps / pt: LDS panels (scale, shift) indexed by the block-local column, or nullptr; cl0 = block-local column of colw0
+//   rb_slow: the tile spans several meshes, the row bias was NOT folded into the accumulators: added here per row (rare)
+template <int MT, int NT, class P>
+__device__ __forceinline__ void store_tile_regs(const P& p, ep_f32x16 (&acc)[MT][NT], const float* ps, const float* pt,
+                                                int rl_base, int row0, int Mlim, int colw0, int cl0, int lane, bool rb_slow) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const bool y16 = p.y16 != 0;
+    const bool relu = p.relu != 0, aff = ps != nullptr;
+    bool ovf = false;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int row = row0 + rl_base + mt * 32 + l31;
+        const bool ok = row < Mlim;
+        float* yrow = p.Y + (size_t)(ok ? row : 0) * p.ldy;
+        const float* rbrow = nullptr;
+        if (rb_slow && ok) rbrow = p.rowbias + (size_t)p.seg[row] * p.ld_rowbias;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {                   // registers 8 P2 + q  <->  8 P2 + 4 + q of the other half-wave
+                const int a = (q >> 2) * 8 + (q & 3), b = a + 4;
+                // (scalar copies first: __builtin_bit_cast applied to an ext-vector ELEMENT expression casts the whole vector and
+                // takes element 0 with this compiler -- every swap then exchanged register 0 with itself)
+                const float fa = acc[mt][nt][a], fb = acc[mt][nt][b];
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);
+                const unsigned ua = sw[0], ub = sw[1];
+                acc[mt][nt][a] = __uint_as_float(ua);
+                acc[mt][nt][b] = __uint_as_float(ub);
+            }
+#pragma unroll
+            for (int P2 = 0; P2 < 2; ++P2) {
+                const int c8 = nt * 32 + 16 * P2 + 8 * hi;   // my 8 columns inside the wave tile
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = acc[mt][nt][8 * P2 + q];
+                if (rbrow) {
+                    const ep_f32x4 r0 = *reinterpret_cast<const ep_f32x4*>(rbrow + colw0 + c8);
+                    const ep_f32x4 r1 = *reinterpret_cast<const ep_f32x4*>(rbrow + colw0 + c8 + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] += r0[q]; v[4 + q] += r1[q]; }
+                }
+                if (relu) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+                }
+                if (aff) {
+                    const ep_f32x4 s0 = *reinterpret_cast<const ep_f32x4*>(ps + cl0 + c8), s1 = *reinterpret_cast<const ep_f32x4*>(ps + cl0 + c8 + 4);
+                    const ep_f32x4 t0 = *reinterpret_cast<const ep_f32x4*>(pt + cl0 + c8), t1 = *reinterpret_cast<const ep_f32x4*>(pt + cl0 + c8 + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { v[q] = v[q] * s0[q] + t0[q]; v[4 + q] = v[4 + q] * s1[q] + t1[q]; }
+                }
+                if (!ok) continue;
+                const int col = colw0 + c8;
+                if (!y16) {
+                    ep_f32x4 w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
+#ifdef MORIG_EPI_NT
+                    __builtin_nontemporal_store(w0, reinterpret_cast<ep_f32x4*>(yrow + col));
+                    __builtin_nontemporal_store(w1, reinterpret_cast<ep_f32x4*>(yrow + col + 4));
+#else
+                    *reinterpret_cast<ep_f32x4*>(yrow + col) = w0;
+                    *reinterpret_cast<ep_f32x4*>(yrow + col + 4) = w1;
+#endif
+                } else {
+                    // split layout: each 32-column chunk is [32 hi halves | 32 lo halves]; my 8 columns never straddle a chunk
+                    typedef __fp16 ep_h2 __attribute__((ext_vector_type(2)));
+                    typedef float ep_b32x4 __attribute__((ext_vector_type(4)));
+                    ep_b32x4 hw, lw;
+                    float am = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; q += 2) {
+                        const ep_h2 h = __builtin_amdgcn_cvt_pkrtz(v[q], v[q + 1]);
+                        const float hb = __builtin_bit_cast(float, h);
+                        float lb;
+                        asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(lb) : "v"(v[q]), "v"(hb));
+                        asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lb) : "v"(v[q + 1]), "v"(hb));
+                        hw[q >> 1] = hb; lw[q >> 1] = lb;
+                        am = fmaxf(am, fmaxf(fabsf(v[q]), fabsf(v[q + 1])));
+                    }
+                    if (!(am < 65000.f)) ovf = true;
+                    char* o = reinterpret_cast<char*>(yrow) + (col >> 5) * 128 + (col & 31) * 2;
+#ifdef MORIG_EPI_NT
+                    __builtin_nontemporal_store(hw, reinterpret_cast<ep_b32x4*>(o));
+                    __builtin_nontemporal_store(lw, reinterpret_cast<ep_b32x4*>(o + 64));
+#else
+                    *reinterpret_cast<ep_f16x8*>(o) = __builtin_bit_cast(ep_f16x8, hw);
+                    *reinterpret_cast<ep_f16x8*>(o + 64) = __builtin_bit_cast(ep_f16x8, lw);
+#endif
+                }
+            }
+        }
+    }
+    if (ovf) *p.ovf = 1;
+}
+
 }  // namespace morig

@@ -23,7 +23,10 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // Tile shapes. The split layout doubles the operand bytes per MFMA (hi and lo fragments), so LDS bandwidth --
 // fragment reads plus the DMA writes -- is what binds a 128x128 / 64x64-per-wave tile (measured plateau
 // ~260 TFLOP/s for every staging scheme). BIG = 256x256 block, 8 waves of 64x128: 3x fewer LDS bytes per MFMA.
-template <int BM, int BN, int NT, int DMA_NS>
+// TR (store launches of the 256 x 256 tile): the MFMAs run with the operands swapped (A = W fragment, B = X fragment), the result
+// tile is D^T and leaves through the register epilogue (epilogue_store.h: store_tile_regs) -- no LDS transposition; the bias and,
+// when the tile lies in one mesh, the row bias are the accumulators' initial value (panel in LDS, filled under the prologue DMA).
+template <int BM, int BN, int NT, int DMA_NS, bool TR = false>
 __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_kernel(const GemmDmaParams p) {
     constexpr int MT = 2;
     constexpr int WNW = BN / (32 * NT);          // waves along N
@@ -33,9 +36,11 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     constexpr int PER_CHUNK = XJ + WJ;
     constexpr int TBYTES = NW * EpilogueTile<NT>::FLOATS * 4;     // per-wave transposition tiles of the store epilogue
     constexpr int RING = DMA_NS * DMA_STAGE;
-    constexpr int SM0 = RING > TBYTES ? RING : TBYTES;
-    __shared__ __attribute__((aligned(128))) char smem[SM0 + BM * 4];
+    constexpr int SM0 = (TR || RING > TBYTES) ? RING : TBYTES;
+    constexpr int PANEL = TR ? 3 * BN * 4 : 0;                    // TR: [bias (+ row bias) | scale | shift] of the tile's BN columns
+    __shared__ __attribute__((aligned(128))) char smem[SM0 + BM * 4 + PANEL];
     int* sseg = reinterpret_cast<int*>(smem + SM0);
+    float* pan = reinterpret_cast<float*>(smem + SM0 + BM * 4);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -50,7 +55,22 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
 #define DMA_TS(k) do { } while (0)
 #endif
     DMA_TS(0);
-    if (p.seg != nullptr && tid < BM) sseg[tid] = (row0 + tid < p.M) ? p.seg[row0 + tid] : 0;
+    if (!TR && p.seg != nullptr && tid < BM) sseg[tid] = (row0 + tid < p.M) ? p.seg[row0 + tid] : 0;
+    // TR: this thread's column constants (loads issued AHEAD of the prologue DMA: vmcnt retires in order, so they are back first)
+    float pv_b = 0.f, pv_s = 1.f, pv_t = 0.f;
+    bool rb_slow = false;
+    if constexpr (TR) {
+        if (tid < BN) {
+            const int col = tn * BN + tid;
+            if (p.bias) pv_b = p.bias[col];
+            if (p.scale) { pv_s = p.scale[col]; pv_t = p.shift[col]; }
+        }
+        if (p.rowbias != nullptr) {
+            const int s0 = p.seg[row0], s1 = p.seg[min(row0 + BM, p.M) - 1];      // block-uniform: `seg` is sorted
+            rb_slow = s0 != s1;
+            if (!rb_slow && tid < BN) pv_b += p.rowbias[(size_t)s0 * p.ld_rowbias + tn * BN + tid];
+        }
+    }
 
     // ---- per-lane DMA sources: wave w moves row blocks (8 rows x 128 B = 1 KiB per instruction) XJ*w .. XJ*w+XJ-1.
     // Addresses are (block-uniform base in SGPRs) + (32-bit per-lane byte offset): half the address VGPRs of pointers ----
@@ -103,6 +123,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     // prologue: NS-1 chunks in flight (PER_CHUNK DMA instructions per chunk per wave)
 #pragma unroll
     for (int c = 0; c < DMA_NS - 1; ++c) if (c < nchunk) issue(c);
+    if constexpr (TR) { if (tid < BN) { pan[tid] = pv_b; pan[BN + tid] = pv_s; pan[2 * BN + tid] = pv_t; } }
 
     const int x7 = (l31 >> 1) & 7;               // 128-B rows: slot position in the 256-B bank window = 8*(r&1) + slot,
                                                  // so XOR-ing with (r>>1)&7 makes any 16 consecutive rows conflict-free
@@ -124,16 +145,21 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
             f.bl[nt] = *reinterpret_cast<const f16x8*>(st + boff + nt * 32 * 128 + sl);
         }
     };
+    // one split product term: x (a fragment of X) times w (a fragment of W); TR swaps the operand roles (D^T = W X^T)
+    auto mm = [&](const f16x8& x, const f16x8& w, f32x16& c) __attribute__((always_inline)) {
+        if constexpr (TR) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+        else              c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
+    };
     auto mma = [&](const Frag& f) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                mm(f.al[mt], f.bh[nt], acc[mt][nt]);
 #ifndef MORIG_2MFMA
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
+                mm(f.ah[mt], f.bl[nt], acc[mt][nt]);
 #endif
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                mm(f.ah[mt], f.bh[nt], acc[mt][nt]);
             }
     };
     auto wait_chunk = [&](int c) {               // chunk c landed for this wave: only younger chunks' DMAs outstanding
@@ -146,14 +172,14 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     };
     // one (mt, nt) pair of accumulators = 6 MFMAs with the dependent ones two slots apart
     auto mma_pair = [&](const Frag& f, int mt, int nt0) __attribute__((always_inline)) {
-        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
-        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+        mm(f.al[mt], f.bh[nt0],     acc[mt][nt0]);
+        mm(f.al[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1]);
 #ifndef MORIG_2MFMA           // measurement build: W rounded to fp16, i.e. the x_hi * w_lo product dropped
-        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0],     acc[mt][nt0],     0, 0, 0);
-        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+        mm(f.ah[mt], f.bl[nt0],     acc[mt][nt0]);
+        mm(f.ah[mt], f.bl[nt0 + 1], acc[mt][nt0 + 1]);
 #endif
-        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
-        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+        mm(f.ah[mt], f.bh[nt0],     acc[mt][nt0]);
+        mm(f.ah[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1]);
     };
     auto issue_one = [&](int c, int j) __attribute__((always_inline)) {       // DMA instruction j of chunk c (X pieces, then W pieces)
         char* st = smem + (c % DMA_NS) * DMA_STAGE;
@@ -169,8 +195,23 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     };
     Frag f0, f1;
     wait_chunk(0);
-    __builtin_amdgcn_s_barrier();
+    if constexpr (TR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // my panel writes have landed ...
+    __builtin_amdgcn_s_barrier();                                            // ... and everyone's
     if (DMA_NS - 1 < nchunk) issue(DMA_NS - 1);
+    if constexpr (TR) {
+        // accumulators start at bias (+ row bias): register r of tile nt is column 32 nt + (r & 3) + 8 (r >> 2) + 4 hi
+        typedef float pf32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const pf32x4 b4 = *reinterpret_cast<const pf32x4*>(pan + wn * NT * 32 + nt * 32 + 8 * g4 + 4 * hi);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[mt][nt][4 * g4 + q] = b4[q];
+            }
+    }
     load_frag(f0, 0, 0);
     // Measured on the EdgeConv kernels (tools/gpu_edge_ablate.sh): an LDS-DMA instruction costs the issuing wave ~100 cycles of issue
     // stall, and the two waves of a SIMD leave the chunk barrier together -- with all PER_CHUNK instructions issued back to
@@ -215,7 +256,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
 
     DMA_TS(1);
     const int colw0 = tn * BN + wn * NT * 32;
-    if (p.pool != nullptr) {
+    if (!TR && p.pool != nullptr) {
         // ---- pooled epilogue (scatter_max over meshes): `seg` is sorted, so the 64 rows of a wave tile almost always
         // belong to ONE mesh: reduce them in registers (32 values per lane, then the two half-waves) and issue one
         // integer-atomic float max per column; a wave tile that straddles meshes falls back to per-element atomics ----
@@ -253,6 +294,13 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
         return;
     }
     // ---- epilogue: bias / per-mesh row bias / ReLU / BN affine, fp32 or split-fp16 store (epilogue_store.h) ----
+    if constexpr (TR) {
+        if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
+        DMA_TS(2);
+        store_tile_regs<MT, NT>(p, acc, p.scale ? pan + BN : nullptr, pan + 2 * BN, wm * 64, row0, p.M, colw0, wn * NT * 32, lane, rb_slow);
+        DMA_TS(3);
+        return;
+    }
     __syncthreads();                             // every wave is done with the ring; sseg visible
     if (p.dbg & 1) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
     DMA_TS(2);
@@ -287,7 +335,13 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
         static unsigned long long* trace_buf = [] { void* b = nullptr; return hipMalloc(&b, 64 * 8) == hipSuccess ? (unsigned long long*)b : nullptr; }();
         p.trace = trace_buf;
 #endif
-        hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2>), dim3(nb), dim3(512), 0, s, p);
+        // stores: the transposed-accumulator kernel with the register epilogue (16-byte aligned output rows); MORIG_GEMM_TR=0 and
+        // pooled launches keep the LDS-transposition epilogue
+        static const bool want_tr = [] { const char* e = getenv("MORIG_GEMM_TR"); return !(e && e[0] == '0'); }();
+        const bool tr = want_tr && !p.pool && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0 &&
+                        (!p.rowbias || ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0 && (p.ld_rowbias & 3) == 0));
+        if (tr) hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, true>), dim3(nb), dim3(512), 0, s, p);
+        else    hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, false>), dim3(nb), dim3(512), 0, s, p);
 #ifdef MORIG_DMA_TRACE
         {
             unsigned long long h[64];
@@ -303,7 +357,7 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
         prof_retag(K_GEMM16_DMA128);
         // 2-stage ring = 64 KB: TWO workgroups per CU, one's prologue / epilogue under the other's main loop
         // (measured 25 % faster than a 4-stage ring at one workgroup per CU)
-        hipLaunchKernelGGL((gemm16_dma_kernel<128, 128, 2, 2>), dim3(tiles_m128 * p.tiles_n), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm16_dma_kernel<128, 128, 2, 2, false>), dim3(tiles_m128 * p.tiles_n), dim3(256), 0, s, p);
     }
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;

@@ -31,6 +31,14 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // 26 spilled VGPRs in a kernel that needs 250 for accumulators and fragments.
 struct GemmDmaHot { int M, K, ldx, ldw, tiles_n; const float* X; const float* W; const int* seg; };
 typedef __attribute__((address_space(4))) const GemmDmaParams* kernarg_params_t;
+// POOL = true : pooled launches (column max per mesh): accumulators in the usual layout (a lane owns a column: the max over the
+//               rows of a wave tile is 32 register maxima + one half-wave exchange).
+// POOL = false: store launches: the MFMAs run with the operands swapped (A = W fragment, B = X fragment), the result tile is D^T
+//               (a lane owns an output ROW and groups of 4 adjacent columns) and leaves through the register epilogue
+//               (epilogue_store.h: store_tile_regs): no LDS scratch, no barrier in front of the epilogue; bias (+ the row bias of
+//               a one-mesh tile) = initial accumulator value, taken from a double-buffered LDS panel that is loaded for tile
+//               j + 1 BEFORE tile j's stores are issued (vmcnt retires in order).
+template <bool POOL>
 __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
 #if defined(__HIP_DEVICE_COMPILE__)              // (the host pass only needs the symbol: the body reads the kernarg segment directly)
     kernarg_params_t q = (kernarg_params_t)__builtin_amdgcn_kernarg_segment_ptr();   // the one by-value argument
@@ -41,10 +49,9 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
     constexpr int NW = (BM / 64) * WNW;          // 8 waves
     constexpr int STAGE = (BM + BN) * 128;       // 64 KB: X tile + W tile of one 32-column chunk
     constexpr int XJ = BM / 8 / NW, WJ = BN / 8 / NW;     // 4 + 4 one-KiB DMA instructions per wave and chunk
-    typedef EpilogueTile<NT, 16, 0> ET;          // 16 x 128 floats = 8 KB per wave: the 8 waves fill exactly one stage
-    static_assert(NW * ET::FLOATS * 4 <= STAGE, "epilogue scratch must fit in ONE ring stage");
-    __shared__ __attribute__((aligned(128))) char smem[2 * STAGE + BM * 4];
-    int* sseg = reinterpret_cast<int*>(smem + 2 * STAGE);
+    constexpr int PANEL = 3 * BN;                // floats: [bias (+ row bias) | scale | shift] of a tile's columns
+    __shared__ __attribute__((aligned(128))) char smem[2 * STAGE + (POOL ? 0 : 2 * PANEL * 4)];
+    float* pan = reinterpret_cast<float*>(smem + 2 * STAGE);          // POOL = false: two panels (tile parity)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -101,23 +108,54 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
         }
     };
     f32x16 acc[MT][NT];
+    // one split product term: x (a fragment of X) times w (a fragment of W); the store variant swaps the operand roles (D^T = W X^T)
+    auto mm = [&](const f16x8& x, const f16x8& w, f32x16& c) __attribute__((always_inline)) {
+        if constexpr (POOL) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
+        else                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
+    };
     auto mma = [&](const Frag& f) __attribute__((always_inline)) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt], acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt], acc[mt][nt], 0, 0, 0);
+                mm(f.al[mt], f.bh[nt], acc[mt][nt]);
+                mm(f.ah[mt], f.bl[nt], acc[mt][nt]);
+                mm(f.ah[mt], f.bh[nt], acc[mt][nt]);
             }
     };
     auto mma_pair = [&](const Frag& f, int mt, int nt0) __attribute__((always_inline)) {
-        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
-        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
-        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0],     acc[mt][nt0],     0, 0, 0);
-        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bl[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
-        acc[mt][nt0]     = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0],     acc[mt][nt0],     0, 0, 0);
-        acc[mt][nt0 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1], 0, 0, 0);
+        mm(f.al[mt], f.bh[nt0],     acc[mt][nt0]);
+        mm(f.al[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1]);
+        mm(f.ah[mt], f.bl[nt0],     acc[mt][nt0]);
+        mm(f.ah[mt], f.bl[nt0 + 1], acc[mt][nt0 + 1]);
+        mm(f.ah[mt], f.bh[nt0],     acc[mt][nt0]);
+        mm(f.ah[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1]);
+    };
+    // ---- store variant: the column constants of one tile. Threads 0..255 fetch bias (+ the row bias when all rows of the tile lie
+    // in one mesh), threads 256..511 scale and shift; `slow` (block-uniform) = the tile spans several meshes, the row bias is added
+    // per row in the epilogue instead. Parameters come from the kernarg segment (scalar loads). ----
+    float pv0 = 0.f, pv1 = 0.f;
+    auto panel_fetch = [&](int plin, bool& slow) __attribute__((always_inline)) {
+        asm volatile("" : "+s"(q));
+        const float* bias = q->bias; const float* scale = q->scale; const float* shift = q->shift;
+        const float* rowbias = q->rowbias; const int* seg = q->seg;
+        const int col = (plin % p.tiles_n) * BN + (tid & (BN - 1));
+        slow = false;
+        pv0 = 0.f; pv1 = 0.f;
+        if (tid < BN) {
+            if (bias) pv0 = bias[col];
+        } else if (scale) { pv0 = scale[col]; pv1 = shift[col]; }
+        if (rowbias != nullptr) {
+            const int prow0 = (plin / p.tiles_n) * BM;
+            const int s0 = seg[prow0], s1 = seg[min(prow0 + BM, p.M) - 1];       // `seg` is sorted: one mesh iff the ends agree
+            slow = s0 != s1;
+            if (!slow && tid < BN) pv1 = rowbias[(size_t)s0 * q->ld_rowbias + col];
+        }
+    };
+    auto panel_write = [&](int par) __attribute__((always_inline)) {
+        float* pn = pan + par * PANEL;
+        if (tid < BN) pn[tid] = pv0 + pv1;
+        else { pn[BN + (tid - BN)] = pv0; pn[2 * BN + (tid - BN)] = pv1; }
     };
 
     // one K-chunk of the stream. `more`: a chunk of this tile follows (hand-over barrier in the middle); `go`: this chunk's DMA slot
@@ -164,8 +202,11 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
         for (int j = 0; j < XJ; ++j) dma_x(xbase, x_offset(j, row0), 0, 0, j);
 #pragma unroll
         for (int j = 0; j < WJ; ++j) dma_w(wbase, 0, 0, j);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    bool slow_cur = false, slow_next = false;    // POOL = false: does the current / next tile span several meshes (row bias per row)?
+    if constexpr (!POOL) { panel_fetch(lin, slow_cur); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (!POOL) { panel_write(0); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 #pragma unroll 1
     for (int jt = 0; jt < n_my; ++jt) {
@@ -175,18 +216,33 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
 #pragma unroll
         for (int j = 0; j < XJ; ++j) ox[j] = x_offset(j, row0);
 
-        __builtin_amdgcn_s_barrier();            // chunk 0 landed for everyone; previous epilogue's scratch and sseg are free
-        if (p.seg != nullptr && tid < BM) sseg[tid] = (row0 + tid < p.M) ? p.seg[row0 + tid] : 0;
+        __builtin_amdgcn_s_barrier();            // chunk 0 landed for everyone; this tile's panel is visible
 #pragma unroll
         for (int j = 0; j < XJ; ++j) dma_x(xbase, ox[j], 1, (g + 1) & 1, j);          // chunk 1: the usual prologue slot
 #pragma unroll
         for (int j = 0; j < WJ; ++j) dma_w(wbase, 1, (g + 1) & 1, j);
+        if constexpr (POOL) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+        } else {
+            // accumulators start at bias (+ row bias): register r of tile nt is column 32 nt + (r & 3) + 8 (r >> 2) + 4 hi
+            typedef float pf32x4 __attribute__((ext_vector_type(4)));
+            const float* pn = pan + (jt & 1) * PANEL + wn * NT * 32 + 4 * hi;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const pf32x4 b4 = *reinterpret_cast<const pf32x4*>(pn + nt * 32 + 8 * g4);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int qq = 0; qq < 4; ++qq) acc[mt][nt][4 * g4 + qq] = b4[qq];
+                }
+        }
         load_frag(f0, g & 1, 0);
 
 #pragma unroll 1
@@ -198,6 +254,9 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
             const int nrow0 = (nlin / p.tiles_n) * BM;
             const char* nxbase = reinterpret_cast<const char*>(p.X + (size_t)nrow0 * p.ldx);
             const char* nwbase = reinterpret_cast<const char*>(p.W + (size_t)((nlin % p.tiles_n) * BN) * p.ldw);
+            // the next tile's column constants: requested two chunks ahead of the epilogue's stores (vmcnt retires in order, so
+            // a load issued behind the stores could only be waited for together with them)
+            if constexpr (!POOL) panel_fetch(nlin, slow_next);
             chunk_iter((g + nchunk - 2) & 1, Yes{}, Yes{}, nxbase, nwbase, 0, true, nrow0);
             chunk_iter((g + nchunk - 1) & 1, No{}, No{}, nxbase, nwbase, 0, false, 0);
             lin = nlin;
@@ -205,17 +264,12 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
 
         // ---- tile done: chunk 0 of the next tile must have landed BEFORE the epilogue issues stores (vmcnt is in order) ----
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();            // every wave is done with the last chunk: its stage is the epilogue's scratch
-        asm volatile("" : "+s"(q));
-        GemmDmaParams pe;                        // field by field: scalar loads from the kernarg segment (a memcpy becomes VMEM loads)
-        pe.M = q->M; pe.N = q->N; pe.K = q->K; pe.X = q->X; pe.ldx = q->ldx; pe.W = q->W; pe.ldw = q->ldw;
-        pe.bias = q->bias; pe.scale = q->scale; pe.shift = q->shift; pe.relu = q->relu;
-        pe.rowbias = q->rowbias; pe.ld_rowbias = q->ld_rowbias; pe.seg = q->seg;
-        pe.Y = q->Y; pe.ldy = q->ldy; pe.y16 = q->y16; pe.pool = q->pool; pe.ld_pool = q->ld_pool;
-        pe.tiles_n = q->tiles_n; pe.ovf = q->ovf; pe.dbg = q->dbg;          // the epilogue's parameters, read here (scalar cache), not held through the main loop
-        const int sl = (g + nchunk - 1) & 1;
         const int colw0 = tn * BN + wn * NT * 32;
-        if (pe.pool != nullptr) {
+        if constexpr (POOL) {
+            asm volatile("" : "+s"(q));
+            GemmDmaParams pe;                    // field by field: scalar loads from the kernarg segment (a memcpy becomes VMEM loads)
+            pe.M = q->M; pe.N = q->N; pe.bias = q->bias; pe.scale = q->scale; pe.shift = q->shift; pe.relu = q->relu; pe.seg = q->seg;
+            pe.pool = q->pool; pe.ld_pool = q->ld_pool;
             // pooled epilogue (scatter_max over meshes), as gemm_dma.hip
             const int rfirst = row0 + wm * 64;
             if (rfirst < pe.M) {
@@ -249,9 +303,19 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
                     }
                 }
             }
-        } else if (!(pe.dbg & 1)) {
-            store_tile_transposed<MT, NT, true, GemmDmaParams, 16, 0>(pe, acc, reinterpret_cast<float*>(smem + sl * STAGE) + wave * ET::FLOATS, sseg,
-                                                                      wm * 64, row0, pe.M, colw0, lane);
+        } else {
+            panel_write((jt + 1) & 1);           // the next tile's panel (its loads returned with the vmcnt(0) above); published by the
+                                                 // barrier at the top of the next tile. This tile's panel: parity jt & 1
+            asm volatile("" : "+s"(q));
+            GemmDmaParams pe;
+            pe.M = q->M; pe.N = q->N; pe.scale = q->scale; pe.relu = q->relu;
+            pe.rowbias = q->rowbias; pe.ld_rowbias = q->ld_rowbias; pe.seg = q->seg;
+            pe.Y = q->Y; pe.ldy = q->ldy; pe.y16 = q->y16; pe.ovf = q->ovf; pe.dbg = q->dbg;
+            const float* pn = pan + (jt & 1) * PANEL;
+            if (!(pe.dbg & 1))
+                store_tile_regs<MT, NT>(pe, acc, pe.scale ? pn + BN : nullptr, pn + 2 * BN, wm * 64, row0, pe.M, colw0, wn * NT * 32, lane,
+                                        slow_cur);
+            slow_cur = slow_next;
         }
         g += nchunk;                             // the next tile's chunk 0 sits in stage (g + nchunk) & 1
     }
@@ -282,7 +346,8 @@ int launch_gemm16_dmap(const GemmDmaParams& p0, hipStream_t s) {
     int avail = ncu - ((reserved_cus() + 7) / 8) * 8;
     if (avail < 8) avail = 8;
     const int grid = T < avail ? ((T + 7) / 8) * 8 : avail;
-    hipLaunchKernelGGL(gemm16_dmap_kernel, dim3(grid), dim3(512), 0, s, p);
+    if (p.pool) hipLaunchKernelGGL(gemm16_dmap_kernel<true>, dim3(grid), dim3(512), 0, s, p);
+    else        hipLaunchKernelGGL(gemm16_dmap_kernel<false>, dim3(grid), dim3(512), 0, s, p);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -47,10 +47,26 @@ __global__ void inside_check_kernel(const double* __restrict__ pts, int n, const
 // ---- distance to the k-th nearest neighbour (the point itself included), one workgroup per point: radix select over
 // the bit pattern of the squared distances (non-negative doubles order like their bits), 8 bits per pass, distances
 // recomputed in every pass instead of stored ----
-__global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ pts, int n, int k, double* __restrict__ kth) {
+// Batched form of every kernel below: point sets of several meshes concatenated, mesh b = rows [ptr[b], ptr[b + 1]); blockIdx.y = b
+// (ptr == nullptr: ONE set of n points). Per mesh the arithmetic and its order are those of the one-set launch.
+__device__ __forceinline__ void mesh_range(const int* __restrict__ ptr, int n, int& s, int& e) {
+    if (ptr) { s = ptr[blockIdx.y]; e = ptr[blockIdx.y + 1]; } else { s = 0; e = n; }
+}
+
+// k of mesh b: the given k, or (quantile >= 0) sklearn's int(n_b * quantile) floored at 1 (estimate_bandwidth's n_neighbors)
+__global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ pts_all, const int* __restrict__ ptr, int n_all, int k_given,
+                                                     double quantile, double* __restrict__ kth_all) {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_k;
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    if ((int)blockIdx.x >= n) return;
+    const double* pts = pts_all + (size_t)s0 * 3;
+    double* kth = kth_all + s0;
+    int k = k_given;
+    if (quantile >= 0.0) { k = (int)((double)n * quantile); if (k < 1) k = 1; }
     const int row = blockIdx.x, tid = threadIdx.x;
     const double px = pts[(size_t)row * 3], py = pts[(size_t)row * 3 + 1], pz = pts[(size_t)row * 3 + 2];
     if (tid == 0) { s_prefix = 0ull; s_k = k; }
@@ -76,14 +92,20 @@ __global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ 
 }
 
 // fixed-order sum (one workgroup): the bandwidth is deterministic from run to run
-__global__ __launch_bounds__(256) void sum_f64_kernel(const double* __restrict__ x, int n, double scale, double* __restrict__ out) {
+// (per mesh: mean of its kth distances -> out[b])
+__global__ __launch_bounds__(256) void mean_f64_kernel(const double* __restrict__ x_all, const int* __restrict__ ptr, int n_all,
+                                                       double* __restrict__ out) {
     __shared__ double part[256];
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    const double* x = x_all + s0;
     double s = 0.0;
     for (int i = threadIdx.x; i < n; i += 256) s += x[i];
     part[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o]; __syncthreads(); }
-    if (threadIdx.x == 0) out[0] = part[0] * scale;
+    if (threadIdx.x == 0) out[blockIdx.y] = n > 0 ? part[0] * (1.0 / (double)n) : 0.0;
 }
 
 // ---- one mean-shift step (cluster_utils.py:24-35), sources i streamed through LDS: moved_j = p_j + 0.3 (sum_i k_ij w_i p_i / (sum_i k_ij w_i + 1e-10) - p_j), k_ij = max(h^2 - d_ij^2, 0).
@@ -93,11 +115,21 @@ __global__ __launch_bounds__(256) void sum_f64_kernel(const double* __restrict__
 // a dependent fp64 chain of ~n x 20 operations, 0.4 ms per step at n = 8192). Slice s takes sources 32 s .. 32 s + 31 of
 // every 256-source tile; the 8 partial sums of a target are added in slice order (deterministic).
 constexpr int MS_TILE = 256, MS_TGT = 32, MS_SL = MS_TILE / MS_TGT;
-__global__ __launch_bounds__(MS_TILE) void meanshift_step_kernel(const double* __restrict__ src, const float* __restrict__ w, int n,
-                                                                 const double* __restrict__ bandwidth, int t,
-                                                                 double* __restrict__ state, double* __restrict__ dst) {
+__global__ __launch_bounds__(MS_TILE) void meanshift_step_kernel(const double* __restrict__ src_all, const float* __restrict__ w_all,
+                                                                 const int* __restrict__ ptr, int n_all,
+                                                                 const double* __restrict__ bandwidth_all, int t, int max_iter,
+                                                                 double* __restrict__ state_all, double* __restrict__ dst_all) {
     __shared__ double sx[MS_TILE], sy[MS_TILE], sz[MS_TILE], sw[MS_TILE];
     __shared__ double part[MS_SL][4][MS_TGT];
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    if ((int)blockIdx.x * MS_TGT >= n) return;
+    const double* src = src_all + (size_t)s0 * 3;
+    double* dst = dst_all + (size_t)s0 * 3;
+    const float* w = w_all ? w_all + s0 : nullptr;
+    const double* bandwidth = bandwidth_all + blockIdx.y;
+    double* state = state_all + (size_t)blockIdx.y * max_iter;
     const int tg = threadIdx.x & (MS_TGT - 1), sl = threadIdx.x / MS_TGT;
     const int j = blockIdx.x * MS_TGT + tg;
     const bool live = j < n;
@@ -143,10 +175,22 @@ __global__ __launch_bounds__(MS_TILE) void meanshift_step_kernel(const double* _
     }
 }
 
+__global__ void meanshift_state_init_kernel(double* __restrict__ state, int max_iter, int n_meshes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < max_iter * n_meshes) state[i] = (i % max_iter) == 0 ? 1e20 : 0.0;
+}
+
 // ---- NMS (cluster_utils.py:48-51): neighbour counts within the bandwidth (the point itself included) ----
-__global__ __launch_bounds__(256) void nms_counts_kernel(const double* __restrict__ pts, int n, const double* __restrict__ bandwidth,
-                                                         int* __restrict__ counts) {
+__global__ __launch_bounds__(256) void nms_counts_kernel(const double* __restrict__ pts_all, const int* __restrict__ ptr, int n_all,
+                                                         const double* __restrict__ bandwidth_all, int* __restrict__ counts_all) {
     __shared__ double sx[256], sy[256], sz[256];
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    if ((int)blockIdx.x * 256 >= n) return;
+    const double* pts = pts_all + (size_t)s0 * 3;
+    int* counts = counts_all + s0;
+    const double* bandwidth = bandwidth_all + blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     const bool live = j < n;
     const double px = live ? pts[(size_t)j * 3] : 0.0, py = live ? pts[(size_t)j * 3 + 1] : 0.0, pz = live ? pts[(size_t)j * 3 + 2] : 0.0;
@@ -167,14 +211,23 @@ __global__ __launch_bounds__(256) void nms_counts_kernel(const double* __restric
 // alive suppresses everything within the bandwidth (itself included) and is restored only if its neighbourhood is
 // well attended (float32 compare, as numpy compares a float32 with a Python float) or dense ----
 constexpr int NMS_T = 1024;
-__global__ __launch_bounds__(NMS_T) void nms_greedy_kernel(const double* __restrict__ pts, const float* __restrict__ attn, int n,
-                                                           const double* __restrict__ bandwidth, const int* __restrict__ order,
-                                                           double thrd_density, float thrd_attn, unsigned char* __restrict__ alive) {
+// (batched: one workgroup per mesh; `order` holds indices LOCAL to the mesh)
+__global__ __launch_bounds__(NMS_T) void nms_greedy_kernel(const double* __restrict__ pts_all, const float* __restrict__ attn_all,
+                                                           const int* __restrict__ ptr, int n_all,
+                                                           const double* __restrict__ bandwidth_all, const int* __restrict__ order_all,
+                                                           double thrd_density, float thrd_attn, unsigned char* __restrict__ alive_all) {
     __shared__ int s_cnt[NMS_T / 64];
     __shared__ float s_att[NMS_T / 64];
     __shared__ int s_alive_i;
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    const double* pts = pts_all + (size_t)s0 * 3;
+    const float* attn = attn_all + s0;
+    const int* order = order_all + s0;
+    unsigned char* alive = alive_all + s0;
     const int tid = threadIdx.x;
-    const double h = bandwidth[0];
+    const double h = bandwidth_all[blockIdx.y];
     for (int r = tid; r < n; r += NMS_T) alive[r] = 1;
     __syncthreads();
     for (int s = 0; s < n; ++s) {
@@ -224,10 +277,28 @@ extern "C" int morig_knn_bandwidth(const double* pts, int32_t n, int32_t k, doub
     if (!pts || !kth_ws || !bandwidth || n <= 0 || k < 1 || k > n) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    hipLaunchKernelGGL(kth_nn_kernel, dim3(n), dim3(256), 0, s, pts, n, k, kth_ws);
+    hipLaunchKernelGGL(kth_nn_kernel, dim3(n, 1), dim3(256), 0, s, pts, nullptr, n, k, -1.0, kth_ws);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, s, kth_ws, n, 1.0 / (double)n, bandwidth);
+    hipLaunchKernelGGL(mean_f64_kernel, dim3(1, 1), dim3(256), 0, s, kth_ws, nullptr, n, bandwidth);
     MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+static int meanshift_run(const double* pts, const float* weights, const int* ptr, int n_all, int n_meshes, int max_n,
+                         const double* bandwidth, int max_iter, double* buf_a, double* buf_b, double* state, int32_t* result_in_a,
+                         hipStream_t s) {
+    // per mesh: state[0] = 1e20 (the reference's diff = 1e10, squared), state[1 .. max_iter-1] = 0
+    hipLaunchKernelGGL(meanshift_state_init_kernel, dim3(cdiv((long)max_iter * n_meshes, 256)), dim3(256), 0, s, state, max_iter, n_meshes);
+    MORIG_LAUNCH_CHECK();
+    MORIG_HIP_TRY(hipMemcpyAsync(buf_a, pts, sizeof(double) * 3 * (size_t)n_all, hipMemcpyDeviceToDevice, s));
+    double* cur = buf_a; double* nxt = buf_b;
+    for (int t = 1; t < max_iter; ++t) {                  // num_iter runs 1 .. max_iter - 1 (cluster_utils.py:23)
+        hipLaunchKernelGGL(meanshift_step_kernel, dim3(cdiv(max_n, MS_TGT), n_meshes), dim3(MS_TILE), 0, s, cur, weights, ptr, n_all,
+                           bandwidth, t, max_iter, state, nxt);
+        MORIG_LAUNCH_CHECK();
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *result_in_a = (cur == buf_a) ? 1 : 0;
     return MORIG_OK;
 }
 
@@ -236,26 +307,14 @@ extern "C" int morig_meanshift(const double* pts, const float* weights, int32_t 
     if (!pts || !bandwidth || !buf_a || !buf_b || !state || !result_in_a || n <= 0 || max_iter < 1) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    // state[0] = 1e20 (the reference's diff = 1e10, squared), state[1 .. max_iter-1] = 0
-    MORIG_HIP_TRY(hipMemsetAsync(state, 0, sizeof(double) * (size_t)max_iter, s));
-    const double first = 1e20;
-    MORIG_HIP_TRY(hipMemcpyAsync(state, &first, sizeof(double), hipMemcpyHostToDevice, s));
-    MORIG_HIP_TRY(hipMemcpyAsync(buf_a, pts, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, s));
-    double* cur = buf_a; double* nxt = buf_b;
-    for (int t = 1; t < max_iter; ++t) {                  // num_iter runs 1 .. max_iter - 1 (cluster_utils.py:23)
-        hipLaunchKernelGGL(meanshift_step_kernel, dim3(cdiv(n, MS_TGT)), dim3(MS_TILE), 0, s, cur, weights, n, bandwidth, t, state, nxt);
-        MORIG_LAUNCH_CHECK();
-        double* tmp = cur; cur = nxt; nxt = tmp;
-    }
-    *result_in_a = (cur == buf_a) ? 1 : 0;
-    return MORIG_OK;
+    return meanshift_run(pts, weights, nullptr, n, 1, n, bandwidth, max_iter, buf_a, buf_b, state, result_in_a, s);
 }
 
 extern "C" int morig_nms_counts(const double* pts, int32_t n, const double* bandwidth, int32_t* counts, void* stream) {
     if (!pts || !bandwidth || !counts || n <= 0) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    hipLaunchKernelGGL(nms_counts_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, pts, n, bandwidth, counts);
+    hipLaunchKernelGGL(nms_counts_kernel, dim3(cdiv(n, 256), 1), dim3(256), 0, s, pts, nullptr, n, bandwidth, counts);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -265,7 +324,52 @@ extern "C" int morig_nms_greedy(const double* pts, const float* attn, int32_t n,
     if (!pts || !attn || !bandwidth || !order || !alive || n <= 0) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(1), dim3(NMS_T), 0, s, pts, attn, n, bandwidth, order, thrd_density, thrd_attn, alive);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(1, 1), dim3(NMS_T), 0, s, pts, attn, nullptr, n, bandwidth, order, thrd_density, thrd_attn, alive);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+// ---- batched over meshes (evaluate/eval_rigging.py:80-95 is a loop over models; here every stage takes all point sets at once) ----
+extern "C" int morig_knn_bandwidth_batched(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int32_t max_n,
+                                           double quantile, double* kth_ws, double* bandwidth, void* stream) {
+    if (!pts || !ptr || !kth_ws || !bandwidth || n_meshes <= 0 || n_all <= 0 || max_n <= 0 || !(quantile >= 0.0)) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(kth_nn_kernel, dim3(max_n, n_meshes), dim3(256), 0, s, pts, ptr, n_all, 0, quantile, kth_ws);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(mean_f64_kernel, dim3(1, n_meshes), dim3(256), 0, s, kth_ws, ptr, n_all, bandwidth);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_meanshift_batched(const double* pts, const float* weights, const int32_t* ptr, int32_t n_meshes, int32_t n_all,
+                                       int32_t max_n, const double* bandwidth, int32_t max_iter, double* buf_a, double* buf_b,
+                                       double* state, int32_t* result_in_a, void* stream) {
+    if (!pts || !ptr || !bandwidth || !buf_a || !buf_b || !state || !result_in_a || n_meshes <= 0 || n_all <= 0 || max_n <= 0 || max_iter < 1)
+        return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    return meanshift_run(pts, weights, ptr, n_all, n_meshes, max_n, bandwidth, max_iter, buf_a, buf_b, state, result_in_a, s);
+}
+
+extern "C" int morig_nms_counts_batched(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int32_t max_n,
+                                        const double* bandwidth, int32_t* counts, void* stream) {
+    if (!pts || !ptr || !bandwidth || !counts || n_meshes <= 0 || n_all <= 0 || max_n <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(nms_counts_kernel, dim3(cdiv(max_n, 256), n_meshes), dim3(256), 0, s, pts, ptr, n_all, bandwidth, counts);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_nms_greedy_batched(const double* pts, const float* attn, const int32_t* ptr, int32_t n_meshes, int32_t n_all,
+                                        const double* bandwidth, const int32_t* order_local, double thrd_density, float thrd_attn,
+                                        uint8_t* alive, void* stream) {
+    if (!pts || !attn || !ptr || !bandwidth || !order_local || !alive || n_meshes <= 0 || n_all <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(nms_greedy_kernel, dim3(1, n_meshes), dim3(NMS_T), 0, s, pts, attn, ptr, n_all, bandwidth, order_local, thrd_density,
+                       thrd_attn, alive);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

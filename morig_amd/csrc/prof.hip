@@ -75,10 +75,10 @@ static const char* kSymbols[K_COUNT] = {
     "tile_kernel<32, 16, 1, 2, 0>", "tile_kernel<32, 32, 1, 2, 0>", "tile_kernel<64, 32, 1, 2, 0>", "tile_kernel<128, 32, 1, 2, 0>", "tile_kernel<256, 16, 1, 2, 0>",
     nullptr, nullptr, "rownorm_kernel", "cls_attention_kernel", nullptr,
     nullptr, nullptr, nullptr, nullptr, nullptr,
-    "tile_kernel<128, 32, 0, 0, 1>", "tile_kernel<64, 32, 0, 0, 1>", "tile_kernel<32, 32, 0, 0, 1>", "gemm16_dmap_kernel",
-    "tile_kernel<32, 32, 1, 2, 1>", "tile_kernel<64, 32, 1, 2, 1>", "edge_pp_kernel<128", "edge_ws_kernel<256", nullptr, "gemm16_dma_kernel<256, 256, 4, 2>",
+    "tile_kernel<128, 32, 0, 0, 1>", "tile_kernel<64, 32, 0, 0, 1>", "tile_kernel<32, 32, 0, 0, 1>", "gemm16_dmap_kernel<true>",
+    "tile_kernel<32, 32, 1, 2, 1>", "tile_kernel<64, 32, 1, 2, 1>", "edge_pp_kernel<128", "edge_ws_kernel<256", nullptr, "gemm16_dma_kernel<256, 256, 4, 2",
     nullptr, nullptr, nullptr,
-    "gemm16_dmap_kernel", "gemm16_dma_kernel<128, 128, 2, 2>", "edge_pp_kernel<256", "edge_ws_kernel<128", "edge_pc_kernel", "geo_ball_graph_kernel",
+    "gemm16_dmap_kernel<false>", "gemm16_dma_kernel<128, 128, 2, 2", "edge_pp_kernel<256", "edge_ws_kernel<128", "edge_pc_kernel", "geo_ball_graph_kernel",
 };
 
 }  // namespace morig

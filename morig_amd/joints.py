@@ -104,3 +104,73 @@ def extract_joints(shifted_pts, attn, vox=None, bandwidth_quantile: float = 0.04
     kept = nms_meanshift(modes, a, bw, threshold2)
     joints, side = flip(kept)
     return dict(joints=joints, side=side, bandwidth=float(bw.item()), modes=modes, attn=a)
+
+
+def extract_joints_batched(shifted_pts, attn, batch, vox=None, bandwidth_quantile: float = 0.04, threshold1: float = 0.1,
+                           threshold2: float = 0.02, max_iter: int = 30, num_graphs: Optional[int] = None):
+    """``extract_joints`` for ALL meshes of a batch at once (the reference loops over models, evaluate/eval_rigging.py:62-98):
+    shifted_pts [N, 3] / attn [N, 1] of the concatenated meshes, ``batch`` = PyG's sorted mesh index per vertex, ``vox`` = None or
+    one voxel object per mesh. Every O(n^2) stage -- bandwidth, mean-shift steps, neighbour counts, greedy suppression -- is ONE
+    launch set over all point sets (segment-aware kernels, csrc/joints.hip); per mesh the arithmetic is that of ``extract_joints``.
+    Three host round trips per batch instead of ~10 per mesh: the kept-point counts, the neighbour counts (numpy's
+    ``argsort(counts)[::-1]`` of cluster_utils.py:52 fixes the visiting order among equal counts, so that one call stays numpy,
+    per mesh) and the survivors. Returns one dict per mesh, as ``extract_joints``."""
+    ops = get_ops()
+    device = shifted_pts.device if torch.is_tensor(shifted_pts) else torch.device("cuda", torch.cuda.current_device())
+    pts = _dev_pts(shifted_pts, device)
+    a = _dev_attn(attn, device)
+    batch = batch.to(device)
+    B = int(num_graphs) if num_graphs is not None else int(batch.max().item()) + 1
+    # attention min-max normalised PER MESH in float32, as numpy does on each loaded array (eval_rigging.py:72)
+    amin = torch.full((B, 1), float("inf"), dtype=torch.float32, device=device).scatter_reduce(0, batch[:, None], a, "amin")
+    amax = torch.full((B, 1), float("-inf"), dtype=torch.float32, device=device).scatter_reduce(0, batch[:, None], a, "amax")
+    a = (a - amin[batch]) / (amax[batch] - amin[batch])
+    keep = a.squeeze(1) > threshold1
+    if vox is not None:
+        counts_v = torch.bincount(batch, minlength=B).tolist()
+        off = 0
+        for b, v in enumerate(vox):
+            if v is not None:
+                data = torch.as_tensor(np.ascontiguousarray(np.asarray(v.data, dtype=np.uint8))).to(device).reshape(-1)
+                keep[off:off + counts_v[b]] &= ops.inside_mask(pts[off:off + counts_v[b]].contiguous(), data, v.translate, v.scale, v.dims[0])
+            off += counts_v[b]
+    kb = batch[keep]
+    m = torch.bincount(kb, minlength=B)                                   # kept points per mesh
+    m_host = m.tolist()                                                   # host round trip 1
+    offs = torch.cumsum(m, 0) - m
+    # per mesh [kept ; x-mirrored kept] (eval_rigging.py:86-88), meshes concatenated
+    pos_in = torch.arange(kb.numel(), device=device) - offs[kb]
+    d1 = 2 * offs[kb] + pos_in
+    d2 = d1 + m[kb]
+    n2 = 2 * kb.numel()
+    P = torch.empty((n2, 3), dtype=torch.float64, device=device)
+    A = torch.empty((n2, 1), dtype=torch.float32, device=device)
+    pk, ak = pts[keep], a[keep]
+    P[d1] = pk
+    P[d2] = pk * torch.tensor([[-1.0, 1.0, 1.0]], dtype=torch.float64, device=device)
+    A[d1] = ak
+    A[d2] = ak
+    sizes = [2 * x for x in m_host]
+    ptr_host = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ptr = torch.from_numpy(ptr_host).to(device)
+    max_n = max(max(sizes), 1)
+    if n2 == 0:
+        return [dict(joints=np.zeros((0, 3)), side=np.zeros(0), bandwidth=float("nan"), modes=P, attn=A) for _ in range(B)]
+    bw = ops.knn_bandwidth_batched(P, ptr, max_n, bandwidth_quantile)
+    modes = ops.meanshift_batched(P, A.reshape(-1).contiguous(), ptr, max_n, bw, max_iter)
+    counts = ops.nms_counts_batched(modes, ptr, max_n, bw).cpu().numpy().astype(np.int64)     # host round trip 2
+    order = np.empty(n2, dtype=np.int32)
+    for b in range(B):
+        s, e = int(ptr_host[b]), int(ptr_host[b + 1])
+        order[s:e] = np.argsort(counts[s:e])[::-1]                        # cluster_utils.py:52, per mesh, local indices
+    alive = ops.nms_greedy_batched(modes, A.reshape(-1).contiguous(), ptr, bw, torch.from_numpy(order).to(device), threshold2, 0.7)
+    modes_h, alive_h, bw_h = modes.cpu().numpy(), alive.cpu().numpy(), bw.cpu().numpy()          # host round trip 3
+    out = []
+    for b in range(B):
+        s, e = int(ptr_host[b]), int(ptr_host[b + 1])
+        if e == s:
+            out.append(dict(joints=np.zeros((0, 3)), side=np.zeros(0), bandwidth=float("nan"), modes=modes[s:e], attn=A[s:e]))
+            continue
+        joints, side = flip(modes_h[s:e][alive_h[s:e]])
+        out.append(dict(joints=joints, side=side, bandwidth=float(bw_h[b]), modes=modes[s:e], attn=A[s:e]))
+    return out

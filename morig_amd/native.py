@@ -141,6 +141,12 @@ _SIGNATURES = {
     "morig_knn_bandwidth": (C.c_int, [c_f64p, C.c_int32, C.c_int32, c_f64p, c_f64p, C.c_void_p]),
     "morig_meanshift": (C.c_int, [c_f64p, c_f32p, C.c_int32, c_f64p, C.c_int32, c_f64p, c_f64p, c_f64p, c_i32p, C.c_void_p]),
     "morig_nms_counts": (C.c_int, [c_f64p, C.c_int32, c_f64p, c_i32p, C.c_void_p]),
+    "morig_knn_bandwidth_batched": (C.c_int, [c_f64p, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_f64p, c_f64p, C.c_void_p]),
+    "morig_meanshift_batched": (C.c_int, [c_f64p, c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, C.c_int32, c_f64p, c_f64p, c_f64p,
+                                          c_i32p, C.c_void_p]),
+    "morig_nms_counts_batched": (C.c_int, [c_f64p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, c_i32p, C.c_void_p]),
+    "morig_nms_greedy_batched": (C.c_int, [c_f64p, c_f32p, c_i32p, C.c_int32, C.c_int32, c_f64p, c_i32p, C.c_double, C.c_float, c_u8p,
+                                           C.c_void_p]),
     "morig_nms_greedy": (C.c_int, [c_f64p, c_f32p, C.c_int32, c_f64p, c_i32p, C.c_double, C.c_float, c_u8p, C.c_void_p]),
     "morig_gather_rows": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
@@ -886,6 +892,50 @@ class NativeOps:
         alive = torch.empty(n, dtype=torch.uint8, device=pts.device)
         check(self.lib.morig_nms_greedy(_p(pts), _p(attn), n, _p(bandwidth), _p(order), float(thrd_density), float(thrd_attn),
                                         _p(alive), _stream()), "morig_nms_greedy")
+        return alive.bool()
+
+    # -- the same stages over the point sets of several meshes (ptr: int32 [B + 1] row offsets on the device) ----------------
+    def knn_bandwidth_batched(self, pts: torch.Tensor, ptr: torch.Tensor, max_n: int, quantile: float) -> torch.Tensor:
+        _need_gpu(pts, ptr)
+        self._pts64(pts)
+        B = ptr.numel() - 1
+        ws = torch.empty(pts.shape[0], dtype=torch.float64, device=pts.device)
+        bw = torch.empty(B, dtype=torch.float64, device=pts.device)
+        check(self.lib.morig_knn_bandwidth_batched(_p(pts), _p(ptr), B, pts.shape[0], max_n, float(quantile), _p(ws), _p(bw), _stream()),
+              "morig_knn_bandwidth_batched")
+        return bw
+
+    def meanshift_batched(self, pts: torch.Tensor, weights: Optional[torch.Tensor], ptr: torch.Tensor, max_n: int,
+                          bandwidth: torch.Tensor, max_iter: int) -> torch.Tensor:
+        _need_gpu(pts, ptr, bandwidth)
+        self._pts64(pts)
+        B, n = ptr.numel() - 1, pts.shape[0]
+        if weights is not None:
+            assert weights.dtype == torch.float32 and weights.numel() == n and weights.is_contiguous()
+        a, b = torch.empty_like(pts), torch.empty_like(pts)
+        state = torch.empty(max(max_iter, 1) * B, dtype=torch.float64, device=pts.device)
+        in_a = C.c_int32(0)
+        check(self.lib.morig_meanshift_batched(_p(pts), _p(weights), _p(ptr), B, n, max_n, _p(bandwidth), max_iter, _p(a), _p(b),
+                                               _p(state), C.byref(in_a), _stream()), "morig_meanshift_batched")
+        return a if in_a.value else b
+
+    def nms_counts_batched(self, pts: torch.Tensor, ptr: torch.Tensor, max_n: int, bandwidth: torch.Tensor) -> torch.Tensor:
+        _need_gpu(pts, ptr, bandwidth)
+        self._pts64(pts)
+        counts = torch.empty(pts.shape[0], dtype=torch.int32, device=pts.device)
+        check(self.lib.morig_nms_counts_batched(_p(pts), _p(ptr), ptr.numel() - 1, pts.shape[0], max_n, _p(bandwidth), _p(counts),
+                                                _stream()), "morig_nms_counts_batched")
+        return counts
+
+    def nms_greedy_batched(self, pts: torch.Tensor, attn: torch.Tensor, ptr: torch.Tensor, bandwidth: torch.Tensor,
+                           order_local: torch.Tensor, thrd_density: float, thrd_attn: float) -> torch.Tensor:
+        _need_gpu(pts, attn, ptr, bandwidth, order_local)
+        self._pts64(pts)
+        n = pts.shape[0]
+        assert attn.dtype == torch.float32 and attn.numel() == n and order_local.dtype == torch.int32 and order_local.numel() == n
+        alive = torch.empty(n, dtype=torch.uint8, device=pts.device)
+        check(self.lib.morig_nms_greedy_batched(_p(pts), _p(attn), _p(ptr), ptr.numel() - 1, n, _p(bandwidth), _p(order_local),
+                                                float(thrd_density), float(thrd_attn), _p(alive), _stream()), "morig_nms_greedy_batched")
         return alive.bool()
 
     def gather_rows(self, src: Mat, idx: torch.Tensor, dst: Mat):

@@ -417,6 +417,45 @@ def _emu_nms_greedy(self, pts, attn, bandwidth, order, thrd_density, thrd_attn):
     return torch.from_numpy(alive)
 
 
+# batched forms: mesh b = rows [ptr[b], ptr[b + 1]); per mesh exactly the one-set emulation
+def _ranges(ptr):
+    p = ptr.tolist()
+    return [(p[b], p[b + 1]) for b in range(len(p) - 1)]
+
+
+def _emu_knn_bandwidth_batched(self, pts, ptr, max_n, quantile):
+    return torch.cat([_emu_knn_bandwidth(self, pts[s:e], max(int((e - s) * quantile), 1)) if e > s else torch.zeros(1, dtype=torch.float64)
+                      for s, e in _ranges(ptr)])
+
+
+def _emu_meanshift_batched(self, pts, weights, ptr, max_n, bandwidth, max_iter):
+    out = torch.empty_like(pts)
+    for b, (s, e) in enumerate(_ranges(ptr)):
+        if e > s:
+            out[s:e] = _emu_meanshift(self, pts[s:e], None if weights is None else weights[s:e], bandwidth[b:b + 1], max_iter)
+    return out
+
+
+def _emu_nms_counts_batched(self, pts, ptr, max_n, bandwidth):
+    out = torch.zeros(pts.shape[0], dtype=torch.int32)
+    for b, (s, e) in enumerate(_ranges(ptr)):
+        if e > s:
+            out[s:e] = _emu_nms_counts(self, pts[s:e], bandwidth[b:b + 1])
+    return out
+
+
+def _emu_nms_greedy_batched(self, pts, attn, ptr, bandwidth, order_local, thrd_density, thrd_attn):
+    out = torch.zeros(pts.shape[0], dtype=torch.bool)
+    for b, (s, e) in enumerate(_ranges(ptr)):
+        if e > s:
+            out[s:e] = _emu_nms_greedy(self, pts[s:e], attn[s:e], bandwidth[b:b + 1], order_local[s:e], thrd_density, thrd_attn)
+    return out
+
+
+EmuOps.knn_bandwidth_batched = _emu_knn_bandwidth_batched
+EmuOps.meanshift_batched = _emu_meanshift_batched
+EmuOps.nms_counts_batched = _emu_nms_counts_batched
+EmuOps.nms_greedy_batched = _emu_nms_greedy_batched
 EmuOps.inside_mask = _emu_inside_mask
 EmuOps.knn_bandwidth = _emu_knn_bandwidth
 EmuOps.meanshift = _emu_meanshift

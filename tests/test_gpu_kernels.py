@@ -607,6 +607,53 @@ def test_gemm_split_fp16_activation_layout(M, N, K):
     assert maxdiff(pg[present.to(DEV)], pw[present]) <= 2e-5 * max(1.0, pw[present].abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 1024, 867), (700, 512, 256), (4133, 256, 1024), (513, 1024, 64), (2600, 1024, 899)])
+@pytest.mark.parametrize("segs", ["one", "tiles", "ragged"])
+@pytest.mark.parametrize("y_split,relu", [(False, False), (True, True)])
+def test_gemm_dma_register_epilogue(M, N, K, segs, y_split, relu):
+    """the LDS-DMA GEMMs' store launches (gemm_dma.hip one tile per workgroup, gemm_dmap.hip persistent) run their MFMAs
+    transposed and store from registers (epilogue_store.h: store_tile_regs): bias and -- when a 256-row tile lies in one mesh --
+    the row bias are the accumulators' initial value ("one", "tiles": every tile in one mesh), otherwise the row bias is added
+    per row ("ragged": mesh boundaries inside tiles); fp32 and split-fp16 outputs, rows past M never written."""
+    from morig_amd import native
+    o = native.get_ops()
+    o.precision = "f16x3"
+    g = torch.Generator().manual_seed(M + K + len(segs))
+    Kp, Np = (K + 31) // 32 * 32, (N + 31) // 32 * 32
+    x = torch.zeros(M, Kp)
+    x[:, :K] = torch.randn(M, K, generator=g)
+    lin = _lin(N, K, 6, bn=relu)
+    if segs == "one":
+        seg = torch.zeros(M, dtype=torch.int32)
+    elif segs == "tiles":
+        seg = (torch.arange(M) // 512).int()
+    else:
+        seg = torch.sort(torch.randint(0, 9, (M,), generator=g))[0].int()
+    nseg = int(seg.max()) + 1
+    rb = torch.randn(nseg, N, generator=g)
+    xs = packing.split_f16(x).to(DEV)
+    for use_rb in (False, True):
+        want = torch.zeros(M, N)
+        kw = dict(rowbias=Mat.of(rb), seg=seg) if use_rb else {}
+        EmuOps().gemm(Mat.of(x, 0, K), lin, relu, Y=Mat.of(want), **kw)
+        kwg = dict(rowbias=Mat.of(rb.to(DEV)), seg=seg.to(DEV)) if use_rb else {}
+        if y_split:
+            ys = torch.full((M + 3, Np + 32), 5.0, device=DEV)
+            o.gemm(Mat.of(xs, 0, K), packing.to_device(lin, DEV), relu, Y=Mat.of(ys, 32, N, 0, M), x_split=True, y_split=True, **kwg)
+            torch.cuda.synchronize()
+            full = ys.cpu()
+            got = packing.unsplit_f16(full[:M].contiguous(), Np + 32)[:, 32:32 + N]
+            assert float((full[M:] - 5.0).abs().sum()) == 0 and float((full[:M, :32] - 5.0).abs().sum()) == 0     # window respected
+        else:
+            yb = torch.full((M + 3, N + 8), 5.0, device=DEV)
+            o.gemm(Mat.of(xs, 0, K), packing.to_device(lin, DEV), relu, Y=Mat.of(yb, 4, N, 0, M), x_split=True, **kwg)
+            torch.cuda.synchronize()
+            full = yb.cpu()
+            got = full[:M, 4:4 + N]
+            assert float((full[M:] - 5.0).abs().sum()) == 0 and float((full[:M, :4] - 5.0).abs().sum()) == 0 and float((full[:M, 4 + N:] - 5.0).abs().sum()) == 0
+        assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item()), (use_rb,)
+
+
 def test_copy2d_pad_plain_and_split():
     from morig_amd import native
     o = native.get_ops()

@@ -54,6 +54,64 @@ def test_extract_joints_host_logic(emulated_ops, name):
     _check_against_fixture(name, "cpu", 1e-11)
 
 
+def _check_batched(device, tol):
+    """both fixtures (different sizes, their own voxel grids) + an all-rejected mesh as ONE batch through extract_joints_batched:
+    per mesh the reference-generated fixture, as the one-mesh path"""
+    loaded = [_load(n) for n in ("joints_small", "joints_medium")]
+    meta = loaded[0][0]
+    pts = [a["shifted"] for _, a, _ in loaded]
+    att = [a["attn_raw"] for _, a, _ in loaded]
+    # third mesh: nothing passes the attention threshold except one point (min-max normalisation needs a range)
+    pts.append(np.random.default_rng(0).uniform(-0.2, 0.2, (50, 3)))
+    a3 = np.zeros((50, 1), dtype=np.float32); a3[7] = 1.0
+    att.append(a3)
+    voxs = [v for _, _, v in loaded] + [None]
+    batch = torch.cat([torch.full((len(p),), b, dtype=torch.long) for b, p in enumerate(pts)])
+    outs = J.extract_joints_batched(torch.from_numpy(np.concatenate(pts)).to(device), torch.from_numpy(np.concatenate(att)).to(device),
+                                    batch.to(device), voxs, meta["quantile"], meta["threshold1"], meta["threshold2"], meta["max_iter"],
+                                    num_graphs=3)
+    assert len(outs) == 3
+    for out, (_, a, _) in zip(outs, loaded):
+        assert out["bandwidth"] == pytest.approx(float(a["bandwidth"][0]), rel=1e-12)
+        assert np.array_equal(out["attn"].cpu().numpy(), a["attn_mirrored"])
+        assert np.abs(out["modes"].cpu().numpy() - a["modes"]).max() <= tol
+        assert out["joints"].shape == a["joints"].shape and np.abs(out["joints"] - a["joints"]).max() <= tol
+        assert np.array_equal(out["side"], a["side"])
+    one = J.extract_joints(pts[2], att[2], None, meta["quantile"], meta["threshold1"], meta["threshold2"], meta["max_iter"], device=device)
+    assert outs[2]["modes"].shape[0] == 2 and np.abs(outs[2]["joints"] - one["joints"]).max() <= tol
+
+
+def test_extract_joints_batched_host_logic(emulated_ops):
+    _check_batched("cpu", 1e-11)
+
+
+@pytest.mark.gpu
+def test_extract_joints_batched_on_gpu():
+    _check_batched("cuda:0", 1e-11)
+
+
+@pytest.mark.gpu
+def test_batched_joint_extraction_equals_per_mesh_at_bench_size():
+    """8 meshes x 4096 shifted points (+ mirror images), the workload of bench.py's secondary line: every mesh of the batched run
+    gives the joints of its own one-mesh run"""
+    rng = np.random.default_rng(5)
+    dev = torch.device("cuda:0")
+    P, A = [], []
+    for b in range(8):
+        centres = rng.uniform(-0.4, 0.4, (20, 3)); centres[:, 0] = -np.abs(centres[:, 0])
+        n = 4096 - 64 * b
+        P.append(centres[rng.integers(0, 20, n)] + rng.normal(0, 0.03, (n, 3)))
+        A.append((rng.random((n, 1)) ** 2).astype(np.float32))
+    batch = torch.cat([torch.full((len(p),), b, dtype=torch.long) for b, p in enumerate(P)]).to(dev)
+    outs = J.extract_joints_batched(torch.from_numpy(np.concatenate(P)).to(dev), torch.from_numpy(np.concatenate(A)).to(dev), batch,
+                                    None, 0.04, -1.0, 0.02, 30, num_graphs=8)
+    for b in range(8):
+        one = J.extract_joints(torch.from_numpy(P[b]).to(dev), torch.from_numpy(A[b]).to(dev), None, 0.04, -1.0, 0.02, 30)
+        assert outs[b]["bandwidth"] == one["bandwidth"]
+        assert torch.equal(outs[b]["modes"], one["modes"])
+        assert np.array_equal(outs[b]["joints"], one["joints"]) and np.array_equal(outs[b]["side"], one["side"])
+
+
 def test_flip_known_answer():
     j, side = J.flip(np.array([[-0.3, 1, 2], [0.01, 3, 4], [0.4, 5, 6], [-0.02, 7, 8]]))
     assert j.tolist() == [[-0.3, 1, 2], [0.0, 3, 4], [0.0, 7, 8], [0.3, 1, 2]] and side.tolist() == [-1, 0, 0, 1]

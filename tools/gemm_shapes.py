@@ -25,7 +25,7 @@ def main():
                 x, lin = a[0], a[1]
                 desc = f"M={x.rows} K={lin.K} N={lin.N} xs={int(bool(k.get('x_split')))} ys={int(bool(k.get('y_split')))} pool={int(k.get('pool') is not None)} rb={int(k.get('rowbias') is not None)}"
             elif name == "edgeconv":
-                desc = f"H={a[3].H if hasattr(a[3], 'H') else '?'}"
+                desc = f"H={a[3].H if hasattr(a[3], 'H') else '?'} rows={a[2].capacity} x{k.get('replicas', 1)} quad={int(a[2].quad)}"
             else:
                 desc = ""
             rows.append((name, desc, dt))
