@@ -235,13 +235,9 @@ __device__ __forceinline__ void store_tile_regs(const P& p, ep_f32x16 (&acc)[MT]
                 const int col = colw0 + c8;
                 if (!y16) {
                     ep_f32x4 w0 = {v[0], v[1], v[2], v[3]}, w1 = {v[4], v[5], v[6], v[7]};
-#ifdef MORIG_EPI_NT
-                    __builtin_nontemporal_store(w0, reinterpret_cast<ep_f32x4*>(yrow + col));
-                    __builtin_nontemporal_store(w1, reinterpret_cast<ep_f32x4*>(yrow + col + 4));
-#else
+                    // (plain stores: with the nontemporal hint the short-K launches ran 40 % SLOWER, profiles/r03e_epilogue_nt_ab.txt)
                     *reinterpret_cast<ep_f32x4*>(yrow + col) = w0;
                     *reinterpret_cast<ep_f32x4*>(yrow + col + 4) = w1;
-#endif
                 } else {
                     // split layout: each 32-column chunk is [32 hi halves | 32 lo halves]; my 8 columns never straddle a chunk
                     typedef __fp16 ep_h2 __attribute__((ext_vector_type(2)));
@@ -260,13 +256,8 @@ __device__ __forceinline__ void store_tile_regs(const P& p, ep_f32x16 (&acc)[MT]
                     }
                     if (!(am < 65000.f)) ovf = true;
                     char* o = reinterpret_cast<char*>(yrow) + (col >> 5) * 128 + (col & 31) * 2;
-#ifdef MORIG_EPI_NT
-                    __builtin_nontemporal_store(hw, reinterpret_cast<ep_b32x4*>(o));
-                    __builtin_nontemporal_store(lw, reinterpret_cast<ep_b32x4*>(o + 64));
-#else
                     *reinterpret_cast<ep_f16x8*>(o) = __builtin_bit_cast(ep_f16x8, hw);
                     *reinterpret_cast<ep_f16x8*>(o + 64) = __builtin_bit_cast(ep_f16x8, lw);
-#endif
                 }
             }
         }

@@ -331,10 +331,12 @@ class GCUMotion(NativeModule):
         return dict(vx=vx, xt=xt, xg=xg, vp=vp, pt=pt, pg=pg, mlp=packing.pack_mlp_layer(self.mlp[0]))
 
     def run(self, ops, pos: Mat, x: Mat, csr_tpl, csr_geo, out: Mat, replicas: int = 1, split: bool = False,
-            split_in=None, split_out=None):
+            split_in=None, split_out=None, pos_feat=None):
         """pos: [n, P] window; x: [R*n, C] window (replica-major); out: [R*n, O] window.
         split: x and out are windows in the split-fp16 activation layout (GEMM -> GEMM hand-off);
-        split_in / split_out override it for one side."""
+        split_in / split_out override it for one side.
+        pos_feat: (Mat [n, D], Mat [n, D]) = this unit's position-branch results on the tpl / geo graph, already computed by
+        ``run_pos_groups`` (paired with another unit's): copied into every replica instead of being computed here."""
         split_in = split if split_in is None else split_in
         split_out = split if split_out is None else split_out
         dev = x.base.device
@@ -345,19 +347,24 @@ class GCUMotion(NativeModule):
         ldo = 2 * H + 2 * D
         ab = ops.empty(M, 4 * H, dev)
         ops.gemm(x, pk["vx"], relu=False, Y=Mat.of(ab), x_split=split_in)
-        pab = ops.empty(n, 4 * D, dev)
-        ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
+        if pos_feat is None:
+            pab = ops.empty(n, 4 * D, dev)
+            ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
         ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
                      replicas=replicas, in_rep_stride=n, out_rep_stride=n)
         ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H + D, H),
                      replicas=replicas, in_rep_stride=n, out_rep_stride=n)
-        # position branch: independent of the keyframe -> computed once into replica 0, copied to the others
-        ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(ec, H, D, 0, n))
-        ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(ec, 2 * H + D, D, 0, n))
-        if replicas > 1:                                # one launch per column window instead of one per replica
-            ops.copy2d_rep(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, n, n), replicas - 1, n)
-            ops.copy2d_rep(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, n, n), replicas - 1, n)
+        # position branch: independent of the keyframe -> computed once, copied to every replica
+        if pos_feat is not None:
+            ops.copy2d_rep(pos_feat[0], Mat.of(ec, H, D, 0, n), replicas, n)
+            ops.copy2d_rep(pos_feat[1], Mat.of(ec, 2 * H + D, D, 0, n), replicas, n)
+        else:
+            ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(ec, H, D, 0, n))
+            ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(ec, 2 * H + D, D, 0, n))
+            if replicas > 1:                            # one launch per column window instead of one per replica
+                ops.copy2d_rep(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, n, n), replicas - 1, n)
+                ops.copy2d_rep(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, n, n), replicas - 1, n)
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split_out)
 
     def _forward(self, pos, x, tpl_edge_index, geo_edge_index):
@@ -370,6 +377,29 @@ class GCUMotion(NativeModule):
         self.run(ops, Mat.of(pos, 0, pk["vp"].K), Mat.of(x, 0, pk["vx"].K),
                  ops.csr_build(tpl_edge_index, n), ops.csr_build(geo_edge_index, n), Mat.of(out))
         return out
+
+
+def run_pos_groups(ops, packed_groups, pos: Mat, csr_tpl, csr_geo):
+    """The position branches of several GCUMotion units in pairs (packing.pack_pos_groups): ONE vertex GEMM for all pairs, then
+    per pair one 32-wide EdgeConv per graph. -> per covered unit (Mat tpl [n, D], Mat geo [n, D]), windows of one side buffer."""
+    vertex, edges, n_pairs = packed_groups
+    if n_pairs == 0:
+        return []
+    dev = pos.base.device
+    n = pos.rows
+    H = edges[0][0].H                               # 2 D
+    D = H // 2
+    pab = ops.empty(n, 4 * H * n_pairs, dev)        # per pair [A_tpl | B_tpl | A_geo | B_geo], H columns each
+    ops.gemm(pos, vertex, relu=False, Y=Mat.of(pab))
+    side = ops.empty(n, 2 * H * n_pairs, dev)       # per pair [tpl: unit 0, unit 1 | geo: unit 0, unit 1]
+    out = []
+    for g, (et, eg) in enumerate(edges):
+        c0 = 4 * H * g
+        ops.edgeconv(Mat.of(pab, c0, H), Mat.of(pab, c0 + H, H), csr_tpl, et, Mat.of(side, 2 * H * g, H))
+        ops.edgeconv(Mat.of(pab, c0 + 2 * H, H), Mat.of(pab, c0 + 3 * H, H), csr_geo, eg, Mat.of(side, 2 * H * g + H, H))
+        for j in range(2):
+            out.append((Mat.of(side, 2 * H * g + j * D, D), Mat.of(side, 2 * H * g + H + j * D, D)))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------

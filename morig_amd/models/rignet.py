@@ -22,7 +22,7 @@ from torch.nn import Linear, Sequential
 from .. import packing
 from ..native import Mat
 from ..runtime import get_ops
-from .basic_modules import MLP, GCUMotion, NativeModule, _padded_copy
+from .basic_modules import MLP, GCUMotion, NativeModule, _padded_copy, run_pos_groups
 
 __all__ = ["jointnet_motion", "masknet_motion", "skinnet_motion"]
 
@@ -141,9 +141,11 @@ class GCNRig(NativeModule):
         )
 
     def run(self, ops, pos4: torch.Tensor, write_feature, csr_tpl, csr_geo, seg: torch.Tensor, n_graphs: int,
-            replicas: int, out: Mat, csr_geo_wide=None, csr_tpl_wide=None):
+            replicas: int, out: Mat, csr_geo_wide=None, csr_tpl_wide=None, pos_feats=None):
         """pos4: [n, 4] (pos, 0); write_feature(window Mat [R*n, feat_slot], split) fills the feature slot
-        (zero padded); seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window."""
+        (zero padded); seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window.
+        pos_feats: per unit the position-branch results computed ahead by run_pos_groups (or None entries)."""
+        pf = list(pos_feats) if pos_feats is not None else [None, None, None]
         dev = pos4.device
         pk = self.packed(dev)
         n, R, F = pos4.shape[0], replicas, self.chn_feature
@@ -153,14 +155,17 @@ class GCNRig(NativeModule):
         ops.copy2d_rep(Mat.of(pos4), Mat.of(wide, self.POS, 32, 0, n), R, n, split=sp)       # the same positions in every replica
         write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
-        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp)
+        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp,
+                       pos_feat=pf[0])
         # the 128- and 256-wide layers take both graphs with 4-aligned segments (quad-reduced, single-pass epilogue of the
         # wave-specialised kernel: +12..18 % on the geo graph; on the tpl graph, in-degree 7 -> 8 rows, still -4 % since the
         # scans became cheap: 54.05 -> 53.35 ms per step); on the narrow layers the padding costs more than it saves
         cg = csr_geo_wide or csr_geo
         ct = csr_tpl_wide or csr_tpl
-        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, self.WIDTHS[0]), ct, cg, Mat.of(wide, self.X2, self.WIDTHS[1]), R, split=sp)
-        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, self.WIDTHS[1]), ct, cg, Mat.of(wide, self.X3, self.WIDTHS[2]), R, split=sp)
+        self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, self.WIDTHS[0]), ct, cg, Mat.of(wide, self.X2, self.WIDTHS[1]), R, split=sp,
+                       pos_feat=pf[1])
+        self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, self.WIDTHS[1]), ct, cg, Mat.of(wide, self.X3, self.WIDTHS[2]), R, split=sp,
+                       pos_feat=pf[2])
         pooled = ops.empty(R * n_graphs, 1024, dev)
         ops.gemm(Mat.of(wide, 0, self.POS), pk["glb"], relu=True, seg=seg, pool=pooled, x_split=sp)
         gb = ops.empty(R * n_graphs, 1024, dev)
@@ -191,6 +196,16 @@ class _MotionBackbone(NativeModule):
     """Shared front half of JointNetMotion / MaskNetMotion / SkinMotion: motionNet over the keyframes,
     row normalisation, aggregation (models/rignet.py:82-98, 115-131, 194-203)."""
 
+    def _pos_units(self):
+        """the GCUMotion units whose position branches see data.pos with 3 coordinates and D = 16: motionNet's, then the head's"""
+        return [self.motionNet.gcu_1, self.motionNet.gcu_2, self.motionNet.gcu_3]
+
+    def _pack(self):
+        import os
+        if os.environ.get("MORIG_POS_GROUPS", "1") == "0":
+            return dict(pos_groups=(None, [], 0))
+        return dict(pos_groups=packing.pack_pos_groups(self._pos_units()))
+
     def _motion(self, ops, data, input_flow, aggr_method, aggr_out_dim):
         dev = data.pos.device
         n = data.pos.shape[0]
@@ -211,8 +226,12 @@ class _MotionBackbone(NativeModule):
 
         C = self.motionNet.chn_output
         raw = ops.empty(T * n, C, dev)
+        # the position branches of motionNet's AND the head's units depend on positions and graphs only: all of them ahead, paired
+        # into 32-wide edge layers (packing.pack_pos_groups); a unit without a partner keeps its own 16-wide path
+        pos_feats = run_pos_groups(ops, self.packed(dev)["pos_groups"], Mat.of(pos4, 0, 3), csr_tpl, csr_geo)
+        pos_feats = pos_feats + [None] * (6 - len(pos_feats))
         self.motionNet.run(ops, pos4, write_flow, csr_tpl, csr_geo, seg_T, ng, T, Mat.of(raw), csr_geo_wide=csr_geo4,
-                           csr_tpl_wide=csr_tpl4)
+                           csr_tpl_wide=csr_tpl4, pos_feats=pos_feats[:3])
         motion_all = torch.empty((n, T, C), dtype=torch.float32, device=dev)
         ops.rownorm(Mat.of(raw), n, T, motion_all, T * C, C)          # F.normalize + torch.stack(dim=1)
 
@@ -227,11 +246,15 @@ class _MotionBackbone(NativeModule):
         ops.rownorm(Mat.of(pre), n, 1, motion_aggr, aggr_out_dim, 0)
         seg_1 = seg_T[:n]
         return dict(pos4=pos4, csr_tpl=csr_tpl, csr_geo=csr_geo, csr_geo4=csr_geo4, csr_tpl4=csr_tpl4, seg=seg_1, ng=ng, motion_all=motion_all,
-                    motion_aggr=motion_aggr)
+                    motion_aggr=motion_aggr, pos_feats=pos_feats[3:])
 
 
 class _MotionHead(_MotionBackbone):
     _head = None
+
+    def _pos_units(self):
+        head = getattr(self, self._head)
+        return super()._pos_units() + [head.gcu_1, head.gcu_2, head.gcu_3]
 
     def __init__(self, num_keyframes, chn_output, aggr_method, aggr="max"):
         super().__init__()
@@ -252,7 +275,7 @@ class _MotionHead(_MotionBackbone):
         aggr = st["motion_aggr"]
         out = torch.empty((n, head.chn_output), dtype=torch.float32, device=aggr.device)
         head.run(ops, st["pos4"], lambda w, sp: ops.copy2d_pad(Mat.of(aggr), w, split=sp), st["csr_tpl"], st["csr_geo"],
-                 st["seg"], st["ng"], 1, Mat.of(out), csr_geo_wide=st["csr_geo4"], csr_tpl_wide=st["csr_tpl4"])
+                 st["seg"], st["ng"], 1, Mat.of(out), csr_geo_wide=st["csr_geo4"], csr_tpl_wide=st["csr_tpl4"], pos_feats=st["pos_feats"])
         return st["motion_all"], aggr, out
 
 

@@ -158,6 +158,50 @@ def pack_edge_pair(mlps: Sequence[nn.Sequential]):
     return vertex, edges
 
 
+def pack_pos_groups(units):
+    """The POSITION branches (``nn_pos`` = MLP([2P, D, D]), D = 16) of several GCUMotion units that see the same positions and the
+    same two graphs (models/basic_modules.py:193-195, 212-215: the motion and the head network of a rig model, rignet.py:82-99).
+    Units are taken two at a time; a pair becomes ONE 32-wide edge layer per graph whose second Linear is block-diagonal:
+      vertex PackedLinear: pos -> per pair [A_tpl(2D) | B_tpl(2D) | A_geo(2D) | B_geo(2D)], A / B as pack_edge_pair builds them;
+      per pair (PackedEdge tpl, PackedEdge geo) of width 2D.
+    Six 16-wide EdgeConvs per graph (half of a 32-column MFMA tile each, 64-byte gathers) become three 32-wide ones.
+    Returns (vertex, [(edge_tpl, edge_geo)], n_pairs); an odd last unit is not covered (the caller runs it on its own)."""
+    n_pairs = len(units) // 2
+    if n_pairs == 0:
+        return None, [], 0
+    rows, biases, edges = [], [], []
+    D = units[0].edge_conv_tpl.nn_pos[0][0].weight.shape[0]
+    for g in range(n_pairs):
+        pair = units[2 * g: 2 * g + 2]
+        pe = []
+        for which in ("edge_conv_tpl", "edge_conv_geo"):
+            mlps = [getattr(u, which).nn_pos for u in pair]
+            A, B, bA, W2s, b2s, s2s, t2s = [], [], [], [], [], [], []
+            for m in mlps:
+                lin1, bn1, lin2, bn2 = m[0][0], m[0][2], m[1][0], m[1][2]
+                W1 = lin1.weight.detach().float()
+                assert W1.shape[0] == D and lin2.weight.shape == (D, D)
+                C = W1.shape[1] // 2
+                A.append(W1[:, :C] - W1[:, C:]); B.append(W1[:, C:]); bA.append(lin1.bias.detach().float())
+                s1, t1 = bn_affine(bn1)
+                s2, t2 = bn_affine(bn2)
+                Wf, bf = fold_hidden_affine(lin2.weight.detach().float(), lin2.bias.detach().float(), s1, t1)
+                W2s.append(Wf); b2s.append(bf); s2s.append(s2); t2s.append(t2)
+            rows += [torch.cat(A, 0), torch.cat(B, 0)]
+            biases += [torch.cat(bA, 0), torch.zeros(2 * D, dtype=torch.float32, device=rows[-1].device)]
+            H = 2 * D
+            W2 = torch.zeros((max(H, 32), _roundup(H, 32)), dtype=torch.float32, device=rows[-1].device)
+            W2[:D, :D] = W2s[0]
+            W2[D:H, D:H] = W2s[1]
+            W2 = W2.contiguous()
+            Hp = max(H, 32)
+            pe.append(PackedEdge(H, None, None, W2, _pad_vec(torch.cat(b2s), Hp), _pad_vec(torch.cat(s2s), Hp, 1.0), _pad_vec(torch.cat(t2s), Hp),
+                                 split_f16(W2) if H >= 32 else None))
+        edges.append((pe[0], pe[1]))
+    vertex = pack_linear(torch.cat(rows, 0), torch.cat(biases, 0))
+    return vertex, edges, n_pairs
+
+
 FUSED_POINTCONV_WIDTHS = ((32, 64), (64, 128))        # (H, H3) pairs morig_pointconv_fused is instantiated for
 
 
