@@ -175,6 +175,145 @@ __global__ __launch_bounds__(MS_TILE) void meanshift_step_kernel(const double* _
     }
 }
 
+// ---- mean-shift over SPATIALLY SORTED point sets (batched path): the kernel k_ij = max(h^2 - d_ij^2, 0) has compact support, and
+// with 4 % bandwidth quantiles ~95 % of the pairs contribute exactly 0. After a Morton sort (morig_morton_keys + a device sort,
+// once per call: points move by fractions of the bandwidth per step) 32 consecutive targets and 256 consecutive sources are
+// spatially compact, so a whole source tile is skipped when its bounding box is farther than h from the target block's: every
+// skipped pair has k_ij = 0 exactly, the sums only lose zero terms. Tile boxes are rebuilt before every step (points moved).
+__global__ __launch_bounds__(256) void tile_bbox_kernel(const double* __restrict__ src_all, const int* __restrict__ ptr, int n_all, int max_tiles,
+                                                        double* __restrict__ bbox) {
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    const int base = blockIdx.x * MS_TILE;
+    if (base >= n) return;
+    const int i = base + threadIdx.x;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    if (i < n) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) lo[a] = hi[a] = src_all[(size_t)(s0 + i) * 3 + a];
+    }
+    __shared__ double red[6][MS_TILE / 64];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double l = lo[a], h = hi[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { l = fmin(l, __shfl_xor(l, o)); h = fmax(h, __shfl_xor(h, o)); }
+        if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = l; red[3 + a][threadIdx.x >> 6] = h; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double v = red[threadIdx.x][0];
+        for (int q = 1; q < MS_TILE / 64; ++q) v = threadIdx.x < 3 ? fmin(v, red[threadIdx.x][q]) : fmax(v, red[threadIdx.x][q]);
+        bbox[((size_t)blockIdx.y * max_tiles + blockIdx.x) * 6 + threadIdx.x] = v;
+    }
+}
+
+__global__ __launch_bounds__(MS_TILE) void meanshift_step_sorted_kernel(const double* __restrict__ src_all, const float* __restrict__ w_all,
+                                                                        const int* __restrict__ ptr, int n_all,
+                                                                        const double* __restrict__ bandwidth_all, int t, int max_iter,
+                                                                        const double* __restrict__ bbox_all, int max_tiles,
+                                                                        double* __restrict__ state_all, double* __restrict__ dst_all) {
+    __shared__ double sx[MS_TILE], sy[MS_TILE], sz[MS_TILE], sw[MS_TILE];
+    __shared__ double part[MS_SL][4][MS_TGT];
+    __shared__ double tbox[6];
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    if ((int)blockIdx.x * MS_TGT >= n) return;
+    const double* src = src_all + (size_t)s0 * 3;
+    double* dst = dst_all + (size_t)s0 * 3;
+    const float* w = w_all ? w_all + s0 : nullptr;
+    const double* bbox = bbox_all + (size_t)blockIdx.y * max_tiles * 6;
+    double* state = state_all + (size_t)blockIdx.y * max_iter;
+    const int tg = threadIdx.x & (MS_TGT - 1), sl = threadIdx.x / MS_TGT;
+    const int j = blockIdx.x * MS_TGT + tg;
+    const bool live = j < n;
+    const bool active = sqrt(state[t - 1]) > 1e-3;              // block-uniform
+    const int jc = live ? j : n - 1;                            // dead lanes shadow the last point: they do not widen the box
+    const double px = src[(size_t)jc * 3], py = src[(size_t)jc * 3 + 1], pz = src[(size_t)jc * 3 + 2];
+    if (!active) {
+        if (live && sl == 0) { dst[(size_t)j * 3] = px; dst[(size_t)j * 3 + 1] = py; dst[(size_t)j * 3 + 2] = pz; }
+        return;
+    }
+    // bounding box of this block's 32 targets (the 32 tg lanes of slice 0 = lanes 0..31 of wave 0)
+    if (sl == 0) {
+        double l0 = px, l1 = py, l2 = pz, h0 = px, h1 = py, h2b = pz;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            l0 = fmin(l0, __shfl_xor(l0, o)); l1 = fmin(l1, __shfl_xor(l1, o)); l2 = fmin(l2, __shfl_xor(l2, o));
+            h0 = fmax(h0, __shfl_xor(h0, o)); h1 = fmax(h1, __shfl_xor(h1, o)); h2b = fmax(h2b, __shfl_xor(h2b, o));
+        }
+        if (tg == 0) { tbox[0] = l0; tbox[1] = l1; tbox[2] = l2; tbox[3] = h0; tbox[4] = h1; tbox[5] = h2b; }
+    }
+    __syncthreads();
+    const double h = bandwidth_all[blockIdx.y], h2 = __dmul_rn(h, h);
+    double ax = 0.0, ay = 0.0, az = 0.0, aw = 0.0;
+    const int n_tiles = (n + MS_TILE - 1) / MS_TILE;
+    for (int tile = 0; tile < n_tiles; ++tile) {
+        // box-to-box distance (block-uniform): farther than h -> every pair of this tile has k = 0
+        double gap2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double g = fmax(fmax(bbox[tile * 6 + a] - tbox[3 + a], tbox[a] - bbox[tile * 6 + 3 + a]), 0.0);
+            gap2 += g * g;
+        }
+        if (gap2 > h2) continue;
+        const int base = tile * MS_TILE;
+        const int i = base + threadIdx.x;
+        __syncthreads();
+        if (i < n) { sx[threadIdx.x] = src[(size_t)i * 3]; sy[threadIdx.x] = src[(size_t)i * 3 + 1]; sz[threadIdx.x] = src[(size_t)i * 3 + 2];
+                     sw[threadIdx.x] = w ? (double)w[i] : 1.0; }
+        __syncthreads();
+        const int lo = sl * MS_TGT, hi = min(lo + MS_TGT, n - base);
+        for (int r = lo; r < hi; ++r) {
+            double kk = __dsub_rn(h2, sqdist3d(sx[r], sy[r], sz[r], px, py, pz));
+            kk = kk > 0.0 ? kk : 0.0;
+            kk = __dmul_rn(kk, sw[r]);
+            aw = __dadd_rn(aw, kk);
+            ax = __dadd_rn(ax, __dmul_rn(kk, sx[r])); ay = __dadd_rn(ay, __dmul_rn(kk, sy[r])); az = __dadd_rn(az, __dmul_rn(kk, sz[r]));
+        }
+    }
+    part[sl][0][tg] = ax; part[sl][1][tg] = ay; part[sl][2][tg] = az; part[sl][3][tg] = aw;
+    __syncthreads();
+    double d2 = 0.0;
+    if (sl == 0) {
+        ax = ay = az = aw = 0.0;
+#pragma unroll
+        for (int q = 0; q < MS_SL; ++q) { ax += part[q][0][tg]; ay += part[q][1][tg]; az += part[q][2][tg]; aw += part[q][3][tg]; }
+        if (live) {
+            const double den = aw + 1e-10;
+            const double mx = 0.3 * (ax / den - px) + px, my = 0.3 * (ay / den - py) + py, mz = 0.3 * (az / den - pz) + pz;
+            dst[(size_t)j * 3] = mx; dst[(size_t)j * 3 + 1] = my; dst[(size_t)j * 3 + 2] = mz;
+            d2 = (mx - px) * (mx - px) + (my - py) * (my - py) + (mz - pz) * (mz - pz);
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) d2 += __shfl_xor(d2, o);
+        if (tg == 0) atomicAdd(&state[t], d2);
+    }
+}
+
+// Morton key of a point inside [-2, 2)^3 (10 bits per axis; coordinates outside are clamped), mesh index in the bits above
+__device__ __forceinline__ unsigned part1by2(unsigned v) {
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu; v = (v | (v << 8)) & 0x0300f00fu; v = (v | (v << 4)) & 0x030c30c3u; v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__global__ void morton_keys_kernel(const double* __restrict__ pts, const int* __restrict__ ptr, int n_meshes, int n_all, long long* __restrict__ keys) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_all) return;
+    int lo = 0, hi = n_meshes;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ptr[mid] <= i) lo = mid; else hi = mid; }
+    unsigned q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double v = (pts[(size_t)i * 3 + a] + 2.0) * 256.0;
+        v = v < 0.0 ? 0.0 : (v > 1023.0 ? 1023.0 : v);
+        q[a] = (unsigned)v;
+    }
+    keys[i] = ((long long)lo << 30) | (long long)(part1by2(q[0]) | (part1by2(q[1]) << 1) | (part1by2(q[2]) << 2));
+}
+
 __global__ void meanshift_state_init_kernel(double* __restrict__ state, int max_iter, int n_meshes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < max_iter * n_meshes) state[i] = (i % max_iter) == 0 ? 1e20 : 0.0;
@@ -371,5 +510,38 @@ extern "C" int morig_nms_greedy_batched(const double* pts, const float* attn, co
     hipLaunchKernelGGL(nms_greedy_kernel, dim3(1, n_meshes), dim3(NMS_T), 0, s, pts, attn, ptr, n_all, bandwidth, order_local, thrd_density,
                        thrd_attn, alive);
     MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_morton_keys(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int64_t* keys, void* stream) {
+    if (!pts || !ptr || !keys || n_meshes <= 0 || n_all <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    hipLaunchKernelGGL(morton_keys_kernel, dim3(cdiv(n_all, 256)), dim3(256), 0, s, pts, ptr, n_meshes, n_all, reinterpret_cast<long long*>(keys));
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_meanshift_sorted(const double* pts, const float* weights, const int32_t* ptr, int32_t n_meshes, int32_t n_all,
+                                      int32_t max_n, const double* bandwidth, int32_t max_iter, double* buf_a, double* buf_b,
+                                      double* state, double* bbox_ws, int32_t* result_in_a, void* stream) {
+    if (!pts || !ptr || !bandwidth || !buf_a || !buf_b || !state || !bbox_ws || !result_in_a || n_meshes <= 0 || n_all <= 0 || max_n <= 0 ||
+        max_iter < 1) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    const int max_tiles = cdiv(max_n, MS_TILE);
+    hipLaunchKernelGGL(meanshift_state_init_kernel, dim3(cdiv((long)max_iter * n_meshes, 256)), dim3(256), 0, s, state, max_iter, n_meshes);
+    MORIG_LAUNCH_CHECK();
+    MORIG_HIP_TRY(hipMemcpyAsync(buf_a, pts, sizeof(double) * 3 * (size_t)n_all, hipMemcpyDeviceToDevice, s));
+    double* cur = buf_a; double* nxt = buf_b;
+    for (int t = 1; t < max_iter; ++t) {
+        hipLaunchKernelGGL(tile_bbox_kernel, dim3(max_tiles, n_meshes), dim3(MS_TILE), 0, s, cur, ptr, n_all, max_tiles, bbox_ws);
+        MORIG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(meanshift_step_sorted_kernel, dim3(cdiv(max_n, MS_TGT), n_meshes), dim3(MS_TILE), 0, s, cur, weights, ptr, n_all,
+                           bandwidth, t, max_iter, bbox_ws, max_tiles, state, nxt);
+        MORIG_LAUNCH_CHECK();
+        double* tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *result_in_a = (cur == buf_a) ? 1 : 0;
     return MORIG_OK;
 }

@@ -157,7 +157,7 @@ def extract_joints_batched(shifted_pts, attn, batch, vox=None, bandwidth_quantil
     if n2 == 0:
         return [dict(joints=np.zeros((0, 3)), side=np.zeros(0), bandwidth=float("nan"), modes=P, attn=A) for _ in range(B)]
     bw = ops.knn_bandwidth_batched(P, ptr, max_n, bandwidth_quantile)
-    modes = ops.meanshift_batched(P, A.reshape(-1).contiguous(), ptr, max_n, bw, max_iter)
+    modes = ops.meanshift_batched_sorted(P, A.reshape(-1).contiguous(), ptr, max_n, bw, max_iter)
     counts = ops.nms_counts_batched(modes, ptr, max_n, bw).cpu().numpy().astype(np.int64)     # host round trip 2
     order = np.empty(n2, dtype=np.int32)
     for b in range(B):

@@ -144,6 +144,9 @@ _SIGNATURES = {
     "morig_knn_bandwidth_batched": (C.c_int, [c_f64p, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_double, c_f64p, c_f64p, C.c_void_p]),
     "morig_meanshift_batched": (C.c_int, [c_f64p, c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, C.c_int32, c_f64p, c_f64p, c_f64p,
                                           c_i32p, C.c_void_p]),
+    "morig_morton_keys": (C.c_int, [c_f64p, c_i32p, C.c_int32, C.c_int32, c_i64p, C.c_void_p]),
+    "morig_meanshift_sorted": (C.c_int, [c_f64p, c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, C.c_int32, c_f64p, c_f64p, c_f64p,
+                                         c_f64p, c_i32p, C.c_void_p]),
     "morig_nms_counts_batched": (C.c_int, [c_f64p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, c_i32p, C.c_void_p]),
     "morig_nms_greedy_batched": (C.c_int, [c_f64p, c_f32p, c_i32p, C.c_int32, C.c_int32, c_f64p, c_i32p, C.c_double, C.c_float, c_u8p,
                                            C.c_void_p]),
@@ -918,6 +921,28 @@ class NativeOps:
         check(self.lib.morig_meanshift_batched(_p(pts), _p(weights), _p(ptr), B, n, max_n, _p(bandwidth), max_iter, _p(a), _p(b),
                                                _p(state), C.byref(in_a), _stream()), "morig_meanshift_batched")
         return a if in_a.value else b
+
+    def meanshift_batched_sorted(self, pts: torch.Tensor, weights: Optional[torch.Tensor], ptr: torch.Tensor, max_n: int,
+                                 bandwidth: torch.Tensor, max_iter: int) -> torch.Tensor:
+        """meanshift_batched on Morton-sorted points with bounding-box culling of source tiles (csrc/joints.hip); the result is
+        returned in the caller's point order. Same sums up to the order of the additions (skipped pairs contribute exactly 0)."""
+        _need_gpu(pts, ptr, bandwidth)
+        self._pts64(pts)
+        B, n = ptr.numel() - 1, pts.shape[0]
+        keys = torch.empty(n, dtype=torch.int64, device=pts.device)
+        check(self.lib.morig_morton_keys(_p(pts), _p(ptr), B, n, _p(keys), _stream()), "morig_morton_keys")
+        perm = torch.argsort(keys)
+        ps = pts[perm].contiguous()
+        ws = None if weights is None else weights[perm].contiguous()
+        a, b = torch.empty_like(ps), torch.empty_like(ps)
+        state = torch.empty(max(max_iter, 1) * B, dtype=torch.float64, device=pts.device)
+        bbox = torch.empty(B * ((max_n + 255) // 256) * 6, dtype=torch.float64, device=pts.device)
+        in_a = C.c_int32(0)
+        check(self.lib.morig_meanshift_sorted(_p(ps), _p(ws), _p(ptr), B, n, max_n, _p(bandwidth), max_iter, _p(a), _p(b), _p(state),
+                                              _p(bbox), C.byref(in_a), _stream()), "morig_meanshift_sorted")
+        out = torch.empty_like(pts)
+        out[perm] = a if in_a.value else b
+        return out
 
     def nms_counts_batched(self, pts: torch.Tensor, ptr: torch.Tensor, max_n: int, bandwidth: torch.Tensor) -> torch.Tensor:
         _need_gpu(pts, ptr, bandwidth)

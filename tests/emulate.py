@@ -454,6 +454,7 @@ def _emu_nms_greedy_batched(self, pts, attn, ptr, bandwidth, order_local, thrd_d
 
 EmuOps.knn_bandwidth_batched = _emu_knn_bandwidth_batched
 EmuOps.meanshift_batched = _emu_meanshift_batched
+EmuOps.meanshift_batched_sorted = _emu_meanshift_batched
 EmuOps.nms_counts_batched = _emu_nms_counts_batched
 EmuOps.nms_greedy_batched = _emu_nms_greedy_batched
 EmuOps.inside_mask = _emu_inside_mask

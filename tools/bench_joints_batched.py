@@ -30,7 +30,9 @@ def timed(fn, reps=3):
 
 
 t_bw, bw = timed(lambda: ops.knn_bandwidth_batched(pts, ptr, 8192, 0.04))
-t_ms, modes = timed(lambda: ops.meanshift_batched(pts, att, ptr, 8192, bw, 30))
+t_ms0, modes0 = timed(lambda: ops.meanshift_batched(pts, att, ptr, 8192, bw, 30))
+t_ms, modes = timed(lambda: ops.meanshift_batched_sorted(pts, att, ptr, 8192, bw, 30))
+print(f"mean-shift plain {t_ms0:.2f} ms, Morton-sorted + culled {t_ms:.2f} ms, max |diff| {float((modes - modes0).abs().max()):.2e}")
 t_cnt, counts = timed(lambda: ops.nms_counts_batched(modes, ptr, 8192, bw))
 ch = counts.cpu().numpy().astype(np.int64)
 t0 = time.perf_counter()
