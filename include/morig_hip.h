@@ -239,6 +239,13 @@ int morig_frame_reduce(const float* x, int32_t n, int32_t T, int32_t C, int32_t 
  * CorrNet point branch (models/corrnet.py:50-73, models/basic_modules.py:66-138). Clouds are contiguous
  * row ranges given by int32 offset arrays ptr[n_clouds + 1] (PyG's sorted `batch` vector).
  */
+/* The plain AND the 4-aligned (MORIG_CSR_PAD4) CSR of one square graph from ONE pass over the COO: the count pass and the edge
+ * ranks inside a segment are shared, both fills happen in one kernel (the rig networks need both per graph and per forward:
+ * models/basic_modules.py:188-189 is normalised once instead of once per layer). Same results as two morig_csr_build_bipartite
+ * calls up to the order of a target's edges inside its segment. ws: 2 * n_nodes + 1 ints of scratch. */
+int morig_csr_build_dual(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes, int32_t* rowptr, int32_t* src_sorted,
+                         int32_t* dst_sorted, int32_t* rowptr4, int32_t* src_sorted4, int32_t* dst_sorted4, int32_t* ws,
+                         int32_t* status, void* stream);
 /* The same normalised CSR as morig_csr_build_bipartite(MORIG_CSR_SKIP_NEGATIVE) for the slot table morig_ball_query
  * writes (target k owns slots [k*max_nbrs, (k+1)*max_nbrs) of row 0 of `coo`, max_nbrs <= 64, unused = -1): counted
  * and filled per target without atomics (replaces torch_cluster.radius -> PointConv's remove/add_self_loops,

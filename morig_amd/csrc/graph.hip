@@ -115,6 +115,84 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E, int n
     }
 }
 
+// ---- dual build: the plain and the 4-aligned CSR of ONE graph from one count pass (the rig networks use both: the narrow layers
+// run on the plain one, the 128 / 256-wide kernels on the padded one). Segment lengths differ (d + 1 vs round4(d + 1)), edge ranks
+// inside a segment are shared: one atomic per edge claims rank k, the edge lands at rowptr[d] + k and rowptr4[d] + k.
+__global__ __launch_bounds__(SCAN_T) void scan2_reduce_kernel(const int* __restrict__ cnt, int n, int* __restrict__ bsum, int* __restrict__ bsum4) {
+    __shared__ int sh[SCAN_T / 64 + 1];
+    const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+    int v = 0, v4 = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) if (base + i < n) { const int c = cnt[base + i]; v += seg_len(c, 0); v4 += seg_len(c, 1); }
+    int tot, tot4;
+    (void)block_excl_scan(v, sh, &tot);
+    (void)block_excl_scan(v4, sh, &tot4);
+    if (threadIdx.x == 0) { bsum[blockIdx.x] = tot; bsum4[blockIdx.x] = tot4; }
+}
+
+__global__ __launch_bounds__(SCAN_T) void scan2_blocksums_kernel(int* bsum, int* bsum4, int nb, int* total_out, int* total4_out) {
+    __shared__ int sh[SCAN_T / 64 + 1];
+    int carry = 0, carry4 = 0;
+    for (int b0 = 0; b0 < nb; b0 += SCAN_T) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < nb ? bsum[i] : 0, v4 = i < nb ? bsum4[i] : 0;
+        int tot, tot4;
+        const int ex = block_excl_scan(v, sh, &tot);
+        const int ex4 = block_excl_scan(v4, sh, &tot4);
+        if (i < nb) { bsum[i] = carry + ex; bsum4[i] = carry4 + ex4; }
+        carry += tot; carry4 += tot4;
+    }
+    if (threadIdx.x == 0) { *total_out = carry; *total4_out = carry4; }
+}
+
+__global__ __launch_bounds__(SCAN_T) void scan2_apply_kernel(const int* __restrict__ cnt, int n, const int* __restrict__ bsum,
+                                                            const int* __restrict__ bsum4, int* __restrict__ rowptr, int* __restrict__ rowptr4) {
+    __shared__ int sh[SCAN_T / 64 + 1];
+    const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
+    int item[SCAN_I], item4[SCAN_I];
+    int v = 0, v4 = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        const int c = (base + i < n) ? cnt[base + i] : 0;
+        item[i] = (base + i < n) ? seg_len(c, 0) : 0; item4[i] = (base + i < n) ? seg_len(c, 1) : 0;
+        v += item[i]; v4 += item4[i];
+    }
+    int tot;
+    int run = bsum[blockIdx.x] + block_excl_scan(v, sh, &tot);
+    int run4 = bsum4[blockIdx.x] + block_excl_scan(v4, sh, &tot);
+#pragma unroll
+    for (int i = 0; i < SCAN_I; ++i) {
+        if (base + i < n) { rowptr[base + i] = run; rowptr4[base + i] = run4; }
+        run += item[i]; run4 += item4[i];
+    }
+}
+
+__global__ void csr_fill_dual_kernel(const int64_t* __restrict__ ei, int64_t E, int n, const int* __restrict__ cnt, int* __restrict__ rank,
+                                     const int* __restrict__ rowptr, int* __restrict__ srcS, int* __restrict__ dstS,
+                                     const int* __restrict__ rowptr4, int* __restrict__ srcS4, int* __restrict__ dstS4) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t total = E + n;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        if (e < E) {
+            const int64_t s64 = ei[e], d64 = ei[E + e];
+            if (s64 < 0 || s64 >= n || d64 < 0 || d64 >= n || s64 == d64) continue;
+            const int s = (int)s64, d = (int)d64;
+            const int k = atomicAdd(&rank[d], 1);
+            const int p = rowptr[d] + k, p4 = rowptr4[d] + k;
+            srcS[p] = s; dstS[p] = d;
+            srcS4[p4] = s; dstS4[p4] = d;
+        } else {
+            // node i: its self loop behind the cnt[i] real in-edges; the 4-aligned copy repeats it up to the segment's end
+            const int i = (int)(e - E);
+            const int c = cnt[i];
+            const int p = rowptr[i] + c;
+            srcS[p] = i; dstS[p] = i;
+            const int e4 = rowptr4[i] + seg_len(c, 1);
+            for (int q = rowptr4[i] + c; q < e4; ++q) { srcS4[q] = i; dstS4[q] = i; }
+        }
+    }
+}
+
 // after the fill pass cursor[i] = end of node i's real entries: repeat the self loop up to rowptr[i+1]
 __global__ void csr_pad_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ cursor,
                                int* __restrict__ srcS, int* __restrict__ dstS) {
@@ -433,6 +511,37 @@ extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_ed
         hipLaunchKernelGGL(csr_pad_kernel, dim3(grid_for(n_nodes)), dim3(256), 0, s, n_nodes, rowptr, cursor, src_sorted, dst_sorted);
         MORIG_LAUNCH_CHECK();
     }
+    return MORIG_OK;
+}
+
+extern "C" int morig_csr_build_dual(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes, int32_t* rowptr, int32_t* src_sorted,
+                                    int32_t* dst_sorted, int32_t* rowptr4, int32_t* src_sorted4, int32_t* dst_sorted4, int32_t* ws,
+                                    int32_t* status, void* stream) {
+    if (!rowptr || !src_sorted || !dst_sorted || !rowptr4 || !src_sorted4 || !dst_sorted4 || !ws || !status) return MORIG_E_INVALID;
+    if (n_edges < 0 || n_nodes <= 0 || (n_edges > 0 && !edge_index)) return MORIG_E_INVALID;
+    if (n_edges + 4 * (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nb = cdiv(n_nodes, SCAN_B);
+    int* cnt = ws;                                 // [n + 1]
+    int* rank = ws + (n_nodes + 1);                // [n]      (cleared together with cnt: one contiguous range)
+    int* bsum = dst_sorted;                        // scratch until the fill pass (capacity >= n_nodes >= nb)
+    int* bsum4 = dst_sorted4;
+    ProfScope ps(K_CSR, s, 0.0, 16.0 * n_edges * 2 + 16.0 * n_edges + 24.0 * n_nodes);
+    hipLaunchKernelGGL(csr_clear_kernel, dim3(grid_for(2 * n_nodes + 1)), dim3(256), 0, s, ws, 2 * n_nodes + 1, status);
+    MORIG_LAUNCH_CHECK();
+    if (n_edges > 0) {
+        hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, edge_index, n_edges, n_nodes, n_nodes, 0, cnt, status);
+        MORIG_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(scan2_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cnt, n_nodes, bsum, bsum4);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan2_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, bsum4, nb, rowptr + n_nodes, rowptr4 + n_nodes);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(scan2_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cnt, n_nodes, bsum, bsum4, rowptr, rowptr4);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(csr_fill_dual_kernel, dim3(grid_for(n_edges + n_nodes)), dim3(256), 0, s, edge_index, n_edges, n_nodes, cnt, rank,
+                       rowptr, src_sorted, dst_sorted, rowptr4, src_sorted4, dst_sorted4);
+    MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
 

@@ -73,7 +73,7 @@ static const char* kNames[K_COUNT] = {
 static const char* kSymbols[K_COUNT] = {
     "tile_kernel<128, 32, 0, 0, 0>", "tile_kernel<64, 32, 0, 0, 0>", "tile_kernel<32, 32, 0, 0, 0>", "tile_kernel<128, 32, 0, 1, 0>",
     "tile_kernel<32, 16, 1, 2, 0>", "tile_kernel<32, 32, 1, 2, 0>", "tile_kernel<64, 32, 1, 2, 0>", "tile_kernel<128, 32, 1, 2, 0>", "tile_kernel<256, 16, 1, 2, 0>",
-    nullptr, nullptr, "rownorm_kernel", "cls_attention_kernel", nullptr,
+    nullptr, nullptr, "rownorm", "cls_attention_kernel", nullptr,
     nullptr, nullptr, nullptr, nullptr, nullptr,
     "tile_kernel<128, 32, 0, 0, 1>", "tile_kernel<64, 32, 0, 0, 1>", "tile_kernel<32, 32, 0, 0, 1>", "gemm16_dmap_kernel<true>",
     "tile_kernel<32, 32, 1, 2, 1>", "tile_kernel<64, 32, 1, 2, 1>", "edge_pp_kernel<128", "edge_ws_kernel<256", nullptr, "gemm16_dma_kernel<256, 256, 4, 2",

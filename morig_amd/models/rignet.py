@@ -215,10 +215,9 @@ class _MotionBackbone(NativeModule):
         assert flow.shape[1] >= 3 * T
         pos4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
         ops.copy2d(Mat.of(data.pos.float().contiguous()), Mat.of(pos4, 0, 3))
-        csr_tpl = ops.csr_build(data.tpl_edge_index, n)
-        csr_geo = ops.csr_build(data.geo_edge_index, n)
-        csr_geo4 = ops.csr_build(data.geo_edge_index, n, pad4=True)
-        csr_tpl4 = ops.csr_build(data.tpl_edge_index, n, pad4=True)
+        # both CSR variants of a graph (plain for the narrow layers, 4-aligned for the 128 / 256-wide kernels) from ONE pass over its COO
+        csr_tpl, csr_tpl4 = ops.csr_build_dual(data.tpl_edge_index, n)
+        csr_geo, csr_geo4 = ops.csr_build_dual(data.geo_edge_index, n)
         seg_T = ops.make_seg(data.batch, ng, T)
 
         def write_flow(w: Mat, sp: bool):             # feature of replica t = input_flow[:, 3t:3t+3]  (:86), one launch

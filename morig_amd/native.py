@@ -100,6 +100,7 @@ _SIGNATURES = {
     "morig_ball_query": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, c_i64p, C.c_void_p]),
     "morig_radius_sample": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
                                       c_i64p, c_i32p, C.c_void_p]),
+    "morig_csr_build_dual": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_geo_ball_graph": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
                                        c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_geo_ball_graph_dist": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint32,
@@ -461,6 +462,29 @@ class NativeOps:
             self._edge_counts[key] = int(rowptr[-1].item())
         csr.edge_count = self._edge_counts.get(key, 0)
         return csr
+
+    def csr_build_dual(self, edge_index: torch.Tensor, n_nodes: int):
+        """-> (plain CSR, 4-aligned CSR) of one square graph from one pass over the COO (morig_csr_build_dual)."""
+        _need_gpu(edge_index)
+        ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
+        E = ei.shape[1]
+        dev = ei.device
+        cap, cap4 = E + n_nodes, E + 4 * n_nodes
+        rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        rowptr4 = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
+        src, dst = torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev)
+        src4, dst4 = torch.empty(cap4, dtype=torch.int32, device=dev), torch.empty(cap4, dtype=torch.int32, device=dev)
+        ws = torch.empty(2 * n_nodes + 1, dtype=torch.int32, device=dev)
+        status = torch.empty(1, dtype=torch.int32, device=dev)
+        check(self.lib.morig_csr_build_dual(_p(ei), E, n_nodes, _p(rowptr), _p(src), _p(dst), _p(rowptr4), _p(src4), _p(dst4), _p(ws),
+                                            _p(status), _stream()), "morig_csr_build_dual")
+        if getattr(self, "_csr_status", None) is not None:
+            self._csr_status.append(status)
+        key = (ei.data_ptr(), E, n_nodes)
+        a = CSR(rowptr, src, dst, n_nodes, cap, status)
+        b = CSR(rowptr4, src4, dst4, n_nodes, cap4, status, quad=True)
+        a.edge_count = b.edge_count = self._edge_counts.get(key, 0)
+        return a, b
 
     def csr_from_slots(self, coo: torch.Tensor, n_nodes: int, max_nbrs: int, n_src: int) -> CSR:
         """the bipartite CSR of a ball-query slot table (``ball_query`` output): same result as

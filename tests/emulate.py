@@ -54,6 +54,9 @@ class EmuOps:
         return CSR(rowptr.int(), torch.cat([src.int(), junk]), torch.cat([dst.int(), junk]), n_nodes, cap,
                    torch.zeros(1, dtype=torch.int32), edge_count=int(src.numel()), quad=pad4)
 
+    def csr_build_dual(self, edge_index, n_nodes):
+        return self.csr_build(edge_index, n_nodes), self.csr_build(edge_index, n_nodes, pad4=True)
+
     def csr_from_slots(self, coo, n_nodes, max_nbrs, n_src):
         assert coo.shape == (2, n_nodes * max_nbrs)
         return self.csr_build(coo, n_nodes, n_src=n_src, skip_negative=True)

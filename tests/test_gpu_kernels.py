@@ -62,6 +62,27 @@ def test_csr_build(ops, n, e, hub, pad4):
         assert int((got.rowptr.cpu() % 4).abs().sum()) == 0
 
 
+@pytest.mark.parametrize("n,e,hub", [(50, 300, None), (1000, 9000, 3), (4097, 30000, None), (7, 0, None), (2500, 40000, 11)])
+def test_csr_build_dual(ops, n, e, hub):
+    """morig_csr_build_dual: the plain and the 4-aligned CSR of one graph from one pass -- each equal to its own single build
+    (same rowptr, same destinations, same multiset of sources per segment), out-of-range indices flagged once for both"""
+    ei = _rand_graph(n, e, 5, hub) if e else torch.zeros((2, 0), dtype=torch.long)
+    a, b = ops.csr_build_dual(ei.to(DEV), n)
+    torch.cuda.synchronize()
+    assert int(a.status.item()) == 0 and b.quad and not a.quad
+    for got, pad4 in ((a, False), (b, True)):
+        want = ops.csr_build(ei.to(DEV), n, pad4=pad4)
+        assert torch.equal(got.rowptr, want.rowptr)
+        E = int(want.rowptr[-1])
+        assert torch.equal(got.dst[:E], want.dst[:E])
+        assert _segments(got, E) == _segments(want, E)
+    bad = ei.clone() if e else torch.tensor([[0], [0]])
+    bad[0, 0] = n + 5
+    a2, _ = ops.csr_build_dual(bad.to(DEV), n)
+    torch.cuda.synchronize()
+    assert int(a2.status.item()) != 0
+
+
 def test_csr_build_flags_bad_index(ops):
     ei = torch.tensor([[0, 1, 9], [1, 2, 0]])
     got = ops.csr_build(ei.to(DEV), 3)
@@ -249,6 +270,12 @@ def test_small_ops(ops):
     emu.rownorm(Mat.of(x), 37, 5, y_ref, 160, 32)
     ops.rownorm(Mat.of(x.to(DEV)), 37, 5, y, 160, 32)
     assert maxdiff(y, y_ref) <= 1e-6 and not torch.isnan(y).any()
+    for cols_n, rows_n in ((64, 1003), (33, 50), (32, 4099)):      # 16-byte vector kernel (32 / 64 columns) and the general one
+        xn = torch.randn(rows_n, cols_n + (4 - cols_n % 4) % 4, generator=g)
+        yn_ref, yn = torch.zeros(rows_n, cols_n), torch.zeros(rows_n, cols_n, device=DEV)
+        emu.rownorm(Mat.of(xn, 0, cols_n), rows_n, 1, yn_ref, cols_n, 0)
+        ops.rownorm(Mat.of(xn.to(DEV), 0, cols_n), rows_n, 1, yn, cols_n, 0)
+        assert maxdiff(yn, yn_ref) <= 1e-6
     xa = torch.nn.functional.normalize(torch.randn(70, 5, 32, generator=g), dim=2)
     gq, cls = torch.randn(2, 32, generator=g), torch.randn(32, generator=g)
     a_ref, a = torch.zeros(70, 64), torch.zeros(70, 64, device=DEV)
