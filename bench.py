@@ -246,7 +246,9 @@ def make_step(workload, data, dev, gather, model_only=False):
         model = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
         synth.load_recipe(model, 0, mild=True).to(dev)
         if model_only:
-            return lambda d: model(d, d.pred_flow)[2]
+            fn = lambda d: model(d, d.pred_flow)[2]
+            fn.model = model
+            return fn
         if os.environ.get("MORIG_BENCH_GUARD", "deferred") == "sync":
             def step():
                 motion_all, motion_aggr, pred_shift = model(data, data.pred_flow)
@@ -488,6 +490,19 @@ def main():
                     sdt, sper, _ = timed_run(lambda: st(d2), 30, 5)
                     sb[f"B{nb}"] = dict(ms_per_forward=round(sdt / 30 * 1e3, 3), ms_median=round(pct(sper, 0.5), 3),
                                          meshes_per_s=round(nb * 30 / sdt, 1))
+                    if nb in (1, 8):
+                        # the same forward as ONE captured HIP graph (morig_amd/serving.py), guard read after every replay
+                        from morig_amd.serving import CapturedForward
+                        cf = CapturedForward(st.model, d2, d2.pred_flow)
+
+                        def replay():
+                            o = cf.replay()
+                            assert cf.check()
+                            return o[2]
+                        gdt, _, _ = timed_run(replay, 30, 3)
+                        sb[f"B{nb}"]["hipgraph_ms_per_forward"] = round(gdt / 30 * 1e3, 3)
+                        sb[f"B{nb}"]["hipgraph_meshes_per_s"] = round(nb * 30 / gdt, 1)
+                        del cf
                     del d2
             sb["per_mesh_throughput_B8_over_B64"] = round(sb["B8"]["meshes_per_s"] / (B_local * args.steps / dt), 3)
             secondary["small_batch"] = dict(metric="jointnet_motion forward at 1 / 2 / 4 / 8 meshes per GPU (4 k-vert synthetic)", **sb)

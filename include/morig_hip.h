@@ -389,6 +389,23 @@ int morig_geo_ball_fill(const int32_t* slots, const int32_t* offsets, int32_t n_
                         int64_t* coo, int64_t n_out, void* stream);
 
 /* --------------------------------------------------------------------------------------------
+ * The path's one collective (the reference has no distributed code, this is the build's own sharding): meshes are
+ * sharded whole, one process per GPU, and the per-mesh output rows are all-gathered over RCCL / xGMI once per forward.
+ * The product's Python layer issues it through torch.distributed (backend "nccl" IS RCCL on ROCm: morig_amd/dist.py); these
+ * exports are the same collective for a host that owns its communicator: `comm` is an ncclComm_t created once per process
+ * (morig_rccl_unique_id on rank 0, the 128 bytes handed to every rank by the host's own means, then morig_rccl_comm_init).
+ * Equal row counts per rank: one morig_allgather_rows; ragged meshes: morig_allgather_counts first, then a padded gather.
+ * Status MORIG_E_HIP + morig_rccl_last_error() = the ncclResult_t. */
+#define MORIG_RCCL_UNIQUE_ID_BYTES 128
+int morig_rccl_unique_id(void* id_out /* MORIG_RCCL_UNIQUE_ID_BYTES */);
+int morig_rccl_comm_init(int32_t n_ranks, int32_t rank, const void* unique_id, void** comm_out);
+int morig_rccl_comm_destroy(void* comm);
+int morig_rccl_last_error(void);
+/* recv [n_ranks * rows][cols] <- every rank's send [rows][cols], rank-major (ncclAllGather on `stream`) */
+int morig_allgather_rows(void* comm, const float* send, float* recv, int64_t rows, int32_t cols, void* stream);
+int morig_allgather_counts(void* comm, const int64_t* send_one, int64_t* recv_n_ranks, void* stream);
+
+/* --------------------------------------------------------------------------------------------
  * Live per-kernel timing (HIP events on the launch stream) for bench.py's roofline object.
  */
 #define MORIG_PROF_KINDS 48

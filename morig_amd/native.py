@@ -163,6 +163,12 @@ _SIGNATURES = {
     "morig_rownorm": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
     "morig_cls_attention": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_frame_reduce": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_rccl_unique_id": (C.c_int, [C.c_void_p]),
+    "morig_rccl_comm_init": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "morig_rccl_comm_destroy": (C.c_int, [C.c_void_p]),
+    "morig_rccl_last_error": (C.c_int, []),
+    "morig_allgather_rows": (C.c_int, [C.c_void_p, c_f32p, c_f32p, C.c_int64, C.c_int32, C.c_void_p]),
+    "morig_allgather_counts": (C.c_int, [C.c_void_p, c_i64p, c_i64p, C.c_void_p]),
     "morig_prof_enable": (C.c_int, [C.c_int]),
     "morig_prof_reset": (C.c_int, []),
     "morig_prof_name": (C.c_char_p, [C.c_int]),

@@ -48,9 +48,11 @@ def _no_grad():
 def pytest_terminal_summary(terminalreporter):
     """parity report: worst absolute and scale-relative error per test (both readings of "within 1e-4 fp32")."""
     try:
-        from helpers import PARITY_LOG
+        from helpers import NOTES, PARITY_LOG
     except Exception:
         return
+    for line in NOTES:
+        terminalreporter.write_line("note: " + line)
     if not PARITY_LOG:
         return
     worst = {}

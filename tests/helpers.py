@@ -32,6 +32,7 @@ def excess(a, b, atol, rtol):
     return ((a - b).abs() - (atol + rtol * b.abs())).max().item()
 
 
+NOTES = []                 # free-text lines for the parity report (tests/conftest.py)
 PARITY_LOG = []            # (test id, abs err, |ref|inf, err / max(1, |ref|inf)) of every parity check; printed by conftest at the end
 
 
@@ -138,7 +139,10 @@ def check_full_size(model, meta, a, data, tol):
             top2 = (ov.double() @ op.double().t()).topk(2, dim=1).values          # one mesh, one cloud in these fixtures
             near_tie = (top2[:, 0] - top2[:, 1]) <= 4 * tol
             assert bool(near_tie[off].all()), "a visibility row differs although its nearest point is well separated"
-            assert float(off.float().mean()) <= 0.005, float(off.float().mean())
+            # measured on MI355X (r03): 3 of 4096 rows; the bound leaves one order of magnitude, not two
+            assert float(off.float().mean()) <= 0.002, float(off.float().mean())
+        NOTES.append("corrnet full-size visibility head: %d of %d rows excused as arg-max near-ties (fraction %.5f; bound 0.002)"
+                     % (int(off.sum()), off.numel(), float(off.float().mean())))
         assert rel_excess(vis[~off], ref_vis[~off], tol) <= 0
     else:
         _, aggr, last = model(data, data.pred_flow)

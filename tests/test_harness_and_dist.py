@@ -357,3 +357,19 @@ def test_rccl_ragged_gather_and_batchnorm_sums_on_one_gpu():
         assert p.returncode == 0 and "rccl ok" in p.stdout, p.stdout[-3000:]
     finally:
         os.unlink(f.name)
+
+
+@pytest.mark.gpu
+def test_c_abi_rccl_all_gather_on_one_gpu():
+    """the C-ABI's own RCCL wrapper (morig_rccl_unique_id / _comm_init / morig_allgather_rows) -- a communicator of
+    one rank on the one GPU a box has: the collective runs through librccl on the device stream and returns the rows"""
+    import torch
+    from morig_amd import dist as mdist
+    comm = mdist.RcclComm(1, 0, mdist.RcclComm.unique_id())
+    try:
+        t = torch.arange(5000 * 3, dtype=torch.float32, device="cuda").reshape(5000, 3)
+        out = comm.all_gather_rows(t)
+        torch.cuda.synchronize()
+        assert out.shape == (5000, 3) and torch.equal(out, t)
+    finally:
+        comm.close()
