@@ -139,9 +139,9 @@ def check_full_size(model, meta, a, data, tol):
             top2 = (ov.double() @ op.double().t()).topk(2, dim=1).values          # one mesh, one cloud in these fixtures
             near_tie = (top2[:, 0] - top2[:, 1]) <= 4 * tol
             assert bool(near_tie[off].all()), "a visibility row differs although its nearest point is well separated"
-            # measured on MI355X (r03): 3 of 4096 rows; the bound leaves one order of magnitude, not two
-            assert float(off.float().mean()) <= 0.002, float(off.float().mean())
-        NOTES.append("corrnet full-size visibility head: %d of %d rows excused as arg-max near-ties (fraction %.5f; bound 0.002)"
+            # measured on MI355X (r03j): 1 of 4096 rows (fraction 0.00024); the bound leaves a factor of four
+            assert float(off.float().mean()) <= 0.001, float(off.float().mean())
+        NOTES.append("corrnet full-size visibility head: %d of %d rows excused as arg-max near-ties (fraction %.5f; bound 0.001)"
                      % (int(off.sum()), off.numel(), float(off.float().mean())))
         assert rel_excess(vis[~off], ref_vis[~off], tol) <= 0
     else:
