@@ -5,6 +5,7 @@
 // scan of one point set (VALU fp64, candidates streamed through LDS) and keeps numpy's operation order where a
 // discrete decision depends on it (distance = ((dx^2 + dy^2) + dz^2), no FMA contraction; sqrt before "<= bandwidth").
 #include "common.h"
+#include <stdlib.h>
 
 // Every kernel in this file makes index decisions (arg-max, "< r^2", k nearest, voxel cells) or reproduces a summation order, so
 // products and sums round separately, as on the CPU: no fma contraction anywhere below. (hipcc's default contracts, and the
@@ -53,12 +54,21 @@ __device__ __forceinline__ void mesh_range(const int* __restrict__ ptr, int n, i
     if (ptr) { s = ptr[blockIdx.y]; e = ptr[blockIdx.y + 1]; } else { s = 0; e = n; }
 }
 
-// k of mesh b: the given k, or (quantile >= 0) sklearn's int(n_b * quantile) floored at 1 (estimate_bandwidth's n_neighbors)
+constexpr int KTH_SMALL = 8;
+// k of mesh b: the given k, or (quantile >= 0) sklearn's int(n_b * quantile) floored at 1 (estimate_bandwidth's n_neighbors).
+// EARLY: stop the radix passes as soon as the selected bin holds <= KTH_SMALL keys and pick the k-th among them from a list made
+// by one more pass (pass 5 + the list pass instead of 8 passes on the 4 % quantile of 8192 points: 38.6 -> 24.4 ms for 64 meshes).
+// Measured and not kept (profiles/r03m_kth_select_modes.txt): one aggregated atomic per wave and digit in the two top passes, where
+// nearly every key falls into one bin (the ballot loop costs more than the LDS unit's own same-address serialisation: 66.9 ms);
+// the points as three arrays instead of [n][3] (48.0 ms); 8 rows per workgroup sharing LDS tiles of candidates (53.7 ms).
+template <bool EARLY>
 __global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ pts_all, const int* __restrict__ ptr, int n_all, int k_given,
                                                      double quantile, double* __restrict__ kth_all) {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long s_prefix;
     __shared__ int s_k;
+    __shared__ unsigned long long s_list[KTH_SMALL];
+    __shared__ int s_nlist, s_stop;
     int s0, e0;
     mesh_range(ptr, n_all, s0, e0);
     const int n = e0 - s0;
@@ -69,7 +79,7 @@ __global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ 
     if (quantile >= 0.0) { k = (int)((double)n * quantile); if (k < 1) k = 1; }
     const int row = blockIdx.x, tid = threadIdx.x;
     const double px = pts[(size_t)row * 3], py = pts[(size_t)row * 3 + 1], pz = pts[(size_t)row * 3 + 2];
-    if (tid == 0) { s_prefix = 0ull; s_k = k; }
+    if (tid == 0) { s_prefix = 0ull; s_k = k; s_nlist = 0; s_stop = -1; }
     for (int pass = 7; pass >= 0; --pass) {
         hist[tid] = 0u;
         __syncthreads();
@@ -85,10 +95,38 @@ __global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ 
             int need = s_k; unsigned b = 0;
             while (b < 255u && (int)hist[b] < need) { need -= (int)hist[b]; ++b; }
             s_k = need; s_prefix = prefix | ((unsigned long long)b << (8 * pass));
+            if (pass == 0 || (EARLY && (int)hist[b] <= KTH_SMALL)) s_stop = pass;          // (pass 0: whatever is left is all equal)
         }
         __syncthreads();
+        if (s_stop >= 0) break;                                             // block-uniform
     }
-    if (tid == 0) kth[row] = sqrt(__longlong_as_double((long long)s_prefix));
+    if (!EARLY) {                                                           // all 8 passes ran: the prefix IS the key
+        if (tid == 0) kth[row] = sqrt(__longlong_as_double((long long)s_prefix));
+        return;
+    }
+    const int sp = s_stop;
+    const unsigned long long lmask = sp <= 0 ? ~0ull : (~0ull << (8 * sp));
+    const unsigned long long prefix = s_prefix;
+    for (int j = tid; j < n; j += 256) {
+        const unsigned long long key = (unsigned long long)__double_as_longlong(
+            sqdist3d(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], px, py, pz));
+        if ((key & lmask) == prefix) {
+            const int slot = atomicAdd(&s_nlist, 1);
+            if (slot < KTH_SMALL) s_list[slot] = key;                       // (more than KTH_SMALL only when all of them are equal)
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int m = s_nlist < KTH_SMALL ? s_nlist : KTH_SMALL;
+        unsigned long long v[KTH_SMALL];
+        for (int i = 0; i < KTH_SMALL; ++i) v[i] = i < m ? s_list[i] : ~0ull;
+        for (int i = 1; i < KTH_SMALL; ++i)
+            for (int q = i; q > 0 && v[q] < v[q - 1]; --q) { const unsigned long long t = v[q]; v[q] = v[q - 1]; v[q - 1] = t; }
+        int idx = s_k - 1;
+        if (idx < 0) idx = 0;
+        if (idx >= m) idx = m - 1;
+        kth[row] = sqrt(__longlong_as_double((long long)v[idx]));
+    }
 }
 
 // fixed-order sum (one workgroup): the bandwidth is deterministic from run to run
@@ -182,6 +220,7 @@ __global__ __launch_bounds__(MS_TILE) void meanshift_step_kernel(const double* _
 // skipped pair has k_ij = 0 exactly, the sums only lose zero terms. Tile boxes are rebuilt before every step (points moved).
 __global__ __launch_bounds__(256) void tile_bbox_kernel(const double* __restrict__ src_all, const int* __restrict__ ptr, int n_all, int max_tiles,
                                                         double* __restrict__ bbox) {
+    // one box per 64 consecutive sources (= the sources one wave of the step kernel takes from a 256-source tile)
     int s0, e0;
     mesh_range(ptr, n_all, s0, e0);
     const int n = e0 - s0;
@@ -193,19 +232,15 @@ __global__ __launch_bounds__(256) void tile_bbox_kernel(const double* __restrict
 #pragma unroll
         for (int a = 0; a < 3; ++a) lo[a] = hi[a] = src_all[(size_t)(s0 + i) * 3 + a];
     }
-    __shared__ double red[6][MS_TILE / 64];
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        double l = lo[a], h = hi[a];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { l = fmin(l, __shfl_xor(l, o)); h = fmax(h, __shfl_xor(h, o)); }
-        if ((threadIdx.x & 63) == 0) { red[a][threadIdx.x >> 6] = l; red[3 + a][threadIdx.x >> 6] = h; }
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
     }
-    __syncthreads();
-    if (threadIdx.x < 6) {
-        double v = red[threadIdx.x][0];
-        for (int q = 1; q < MS_TILE / 64; ++q) v = threadIdx.x < 3 ? fmin(v, red[threadIdx.x][q]) : fmax(v, red[threadIdx.x][q]);
-        bbox[((size_t)blockIdx.y * max_tiles + blockIdx.x) * 6 + threadIdx.x] = v;
+    if ((threadIdx.x & 63) == 0) {
+        double* bx = bbox + (((size_t)blockIdx.y * max_tiles + blockIdx.x) * 4 + (threadIdx.x >> 6)) * 6;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[3 + a] = hi[a]; }
     }
 }
 
@@ -224,7 +259,7 @@ __global__ __launch_bounds__(MS_TILE) void meanshift_step_sorted_kernel(const do
     const double* src = src_all + (size_t)s0 * 3;
     double* dst = dst_all + (size_t)s0 * 3;
     const float* w = w_all ? w_all + s0 : nullptr;
-    const double* bbox = bbox_all + (size_t)blockIdx.y * max_tiles * 6;
+    const double* bbox = bbox_all + (size_t)blockIdx.y * max_tiles * 24;      // 4 boxes of 64 sources per tile
     double* state = state_all + (size_t)blockIdx.y * max_iter;
     const int tg = threadIdx.x & (MS_TGT - 1), sl = threadIdx.x / MS_TGT;
     const int j = blockIdx.x * MS_TGT + tg;
@@ -250,21 +285,31 @@ __global__ __launch_bounds__(MS_TILE) void meanshift_step_sorted_kernel(const do
     const double h = bandwidth_all[blockIdx.y], h2 = __dmul_rn(h, h);
     double ax = 0.0, ay = 0.0, az = 0.0, aw = 0.0;
     const int n_tiles = (n + MS_TILE - 1) / MS_TILE;
+    const int wv = threadIdx.x >> 6;                               // this wave's 64 sources of a tile = slices 2 wv, 2 wv + 1
     for (int tile = 0; tile < n_tiles; ++tile) {
-        // box-to-box distance (block-uniform): farther than h -> every pair of this tile has k = 0
-        double gap2 = 0.0;
+        // box-to-box distances of the tile's four 64-source boxes (block-uniform): farther than h -> every pair has k = 0
+        bool near_any = false, near_mine = false;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            const double g = fmax(fmax(bbox[tile * 6 + a] - tbox[3 + a], tbox[a] - bbox[tile * 6 + 3 + a]), 0.0);
-            gap2 += g * g;
+        for (int q = 0; q < 4; ++q) {
+            const double* bx = bbox + ((size_t)tile * 4 + q) * 6;
+            double gap2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double g = fmax(fmax(bx[a] - tbox[3 + a], tbox[a] - bx[3 + a]), 0.0);
+                gap2 += g * g;
+            }
+            const bool nr = gap2 <= h2;
+            near_any = near_any || nr;
+            if (q == wv) near_mine = nr;
         }
-        if (gap2 > h2) continue;
+        if (!near_any) continue;
         const int base = tile * MS_TILE;
         const int i = base + threadIdx.x;
         __syncthreads();
         if (i < n) { sx[threadIdx.x] = src[(size_t)i * 3]; sy[threadIdx.x] = src[(size_t)i * 3 + 1]; sz[threadIdx.x] = src[(size_t)i * 3 + 2];
                      sw[threadIdx.x] = w ? (double)w[i] : 1.0; }
         __syncthreads();
+        if (!near_mine) continue;                                  // wave-uniform: this wave's 64 sources are all out of reach
         const int lo = sl * MS_TGT, hi = min(lo + MS_TGT, n - base);
         for (int r = lo; r < hi; ++r) {
             double kk = __dsub_rn(h2, sqdist3d(sx[r], sy[r], sz[r], px, py, pz));
@@ -416,7 +461,7 @@ extern "C" int morig_knn_bandwidth(const double* pts, int32_t n, int32_t k, doub
     if (!pts || !kth_ws || !bandwidth || n <= 0 || k < 1 || k > n) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    hipLaunchKernelGGL(kth_nn_kernel, dim3(n, 1), dim3(256), 0, s, pts, nullptr, n, k, -1.0, kth_ws);
+    hipLaunchKernelGGL(kth_nn_kernel<true>, dim3(n, 1), dim3(256), 0, s, pts, nullptr, n, k, -1.0, kth_ws);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_f64_kernel, dim3(1, 1), dim3(256), 0, s, kth_ws, nullptr, n, bandwidth);
     MORIG_LAUNCH_CHECK();
@@ -474,7 +519,7 @@ extern "C" int morig_knn_bandwidth_batched(const double* pts, const int32_t* ptr
     if (!pts || !ptr || !kth_ws || !bandwidth || n_meshes <= 0 || n_all <= 0 || max_n <= 0 || !(quantile >= 0.0)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    hipLaunchKernelGGL(kth_nn_kernel, dim3(max_n, n_meshes), dim3(256), 0, s, pts, ptr, n_all, 0, quantile, kth_ws);
+    hipLaunchKernelGGL(kth_nn_kernel<true>, dim3(max_n, n_meshes), dim3(256), 0, s, pts, ptr, n_all, 0, quantile, kth_ws);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_f64_kernel, dim3(1, n_meshes), dim3(256), 0, s, kth_ws, ptr, n_all, bandwidth);
     MORIG_LAUNCH_CHECK();

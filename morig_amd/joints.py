@@ -164,13 +164,17 @@ def extract_joints_batched(shifted_pts, attn, batch, vox=None, bandwidth_quantil
         s, e = int(ptr_host[b]), int(ptr_host[b + 1])
         order[s:e] = np.argsort(counts[s:e])[::-1]                        # cluster_utils.py:52, per mesh, local indices
     alive = ops.nms_greedy_batched(modes, A.reshape(-1).contiguous(), ptr, bw, torch.from_numpy(order).to(device), threshold2, 0.7)
-    modes_h, alive_h, bw_h = modes.cpu().numpy(), alive.cpu().numpy(), bw.cpu().numpy()          # host round trip 3
+    # host round trip 3: only the survivors travel (a few dozen rows per mesh), with their mesh index
+    mesh_of = torch.repeat_interleave(torch.arange(B, device=device), torch.as_tensor(sizes, device=device))
+    kept_h = torch.cat([modes[alive], mesh_of[alive].to(torch.float64)[:, None], bw[mesh_of[alive]][:, None]], dim=1).cpu().numpy()
+    bw_h = bw.cpu().numpy()
+    kept_mesh = kept_h[:, 3].astype(np.int64)
     out = []
     for b in range(B):
         s, e = int(ptr_host[b]), int(ptr_host[b + 1])
         if e == s:
             out.append(dict(joints=np.zeros((0, 3)), side=np.zeros(0), bandwidth=float("nan"), modes=modes[s:e], attn=A[s:e]))
             continue
-        joints, side = flip(modes_h[s:e][alive_h[s:e]])
+        joints, side = flip(kept_h[kept_mesh == b, :3])
         out.append(dict(joints=joints, side=side, bandwidth=float(bw_h[b]), modes=modes[s:e], attn=A[s:e]))
     return out

@@ -91,6 +91,32 @@ def test_extract_joints_batched_on_gpu():
 
 
 @pytest.mark.gpu
+def test_batched_bandwidth_selection_is_exact():
+    """the k-th nearest-neighbour distance (radix select, 8 rows per workgroup, early stop + short list) against torch.kthvalue of the
+    float64 distance matrix computed with the kernel's operation order: ragged meshes, duplicated points (mirror pairs: equal
+    distances), k = 1, tiny meshes"""
+    from morig_amd import native
+    ops = native.get_ops()
+    rng = np.random.default_rng(11)
+    dev = torch.device("cuda:0")
+    sets = [rng.normal(0, 0.1, (n, 3)) for n in (1000, 37, 2600, 9, 513)]
+    sets[2][1300:] = sets[2][:1300] * np.array([[-1, 1, 1]])              # mirror images
+    sets[1][5:10] = sets[1][0]                                              # exact duplicates
+    P = torch.from_numpy(np.concatenate(sets)).to(dev)
+    sizes = [len(x) for x in sets]
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    for q in (0.04, 0.3, 0.0):
+        bw = ops.knn_bandwidth_batched(P, ptr, max(sizes), q).cpu().numpy()
+        for b, x in enumerate(sets):
+            t = torch.from_numpy(x)
+            d = t[:, None, :] - t[None, :, :]
+            d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+            k = max(int(len(x) * q), 1)
+            want = float(torch.sqrt(torch.kthvalue(d2, k, dim=1).values).mean())
+            assert bw[b] == pytest.approx(want, rel=1e-13), (q, b)
+
+
+@pytest.mark.gpu
 def test_batched_joint_extraction_equals_per_mesh_at_bench_size():
     """8 meshes x 4096 shifted points (+ mirror images), the workload of bench.py's secondary line: every mesh of the batched run
     gives the joints of its own one-mesh run. (The batched mean-shift adds the same non-zero terms in Morton order and skips source
