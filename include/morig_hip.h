@@ -150,6 +150,28 @@ typedef struct morig_edgeconv_args {
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 
+/* The same EdgeConv for a vertex input of 3 channels (the position branches, models/basic_modules.py:193-195 `nn_pos([pos_i, pos_j - pos_i])`,
+ * and motionNet's first unit, whose feature is the 3-channel keyframe flow, models/rignet.py:86): the first Linear is evaluated inside the
+ * kernel from the two gathered endpoints -- z = relu(W1a x_i + W1b x_j + b1), W1a = W_a - W_b, W1b = W_b of the reference's
+ * Linear(6 -> H) on [x_i, x_j - x_i] -- so no per-vertex [A | B] table is written or gathered (2 x 16 bytes per edge row instead of
+ * 2 x 4 H). H == 32 (two 16-wide layers paired, or one 32-wide layer); BatchNorm-1 must be folded into W2 / b2 (packing.fold_hidden_affine).
+ *   X [rows][ldx] (ldx >= 4, 16-byte aligned rows; columns 0..2 used), replica r reads rows r * in_rep_stride + vertex;
+ *   W1a, W1b [32][4] (column 3 ignored), b1 [32]; everything else as morig_edgeconv_args. */
+typedef struct morig_edgeconv_x3_args {
+    int32_t H;
+    int32_t n_nodes, replicas;
+    int32_t in_rep_stride, out_rep_stride;
+    const float* X; int32_t ldx;
+    const float* W1a; const float* W1b; const float* b1;
+    const int32_t* rowptr; const int32_t* src_sorted; const int32_t* dst_sorted;
+    int32_t edge_capacity; int32_t edge_count;
+    const float* W2; int32_t ldw;
+    const float* b2; const float* s2; const float* t2;
+    float* out; int32_t ldo;
+    const void* W2_split; int32_t* overflow;
+} morig_edgeconv_x3_args;
+int morig_edgeconv_x3(const morig_edgeconv_x3_args* a, void* stream);
+
 /* PointConv (3-layer local_nn, models/basic_modules.py:72,82-84; PyG PointConv.message) in two passes:
  *   morig_edge_hidden : Z[e] = s2*relu(W2 (s1*relu(A_i + B_j) + t1) + b2) + t2 for every sorted edge e (< E');
  *                       same arguments as morig_edgeconv, `out` = Z [edge_capacity][ldo], replicas = 1

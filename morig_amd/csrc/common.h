@@ -15,7 +15,7 @@ enum Kind : int {
     K_GEMM16_BN128, K_GEMM16_BN64, K_GEMM16_BN32, K_GEMM16_POOL,
     K_EDGE16_H32, K_EDGE16_H64, K_EDGE16_H128, K_EDGE16_H256, K_POINTCONV16, K_GEMM16_DMA,
     K_COSINE_KNN, K_FLOW_VOTE, K_JOINTS,
-    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH,
+    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH, K_EDGE16_X3, K_EDGE_X3, K_EDGE16_X3P,
     K_COUNT
 };
 static_assert(K_COUNT <= MORIG_PROF_KINDS, "raise MORIG_PROF_KINDS");
@@ -72,6 +72,18 @@ int reserved_cus();
 int launch_edge_pp(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pp.hip (persistent)
 int launch_edge_ws(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_ws.hip (persistent, W2 resident in registers; 4-aligned CSR)
 int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); // gemm_dma.hip
+struct EdgeX3Params {
+    const float* X; int ldx;                       // [rows][ldx >= 4]: 3 input channels per vertex
+    const float* W1a; const float* W1b; const float* b1;      // [32][4], [32][4], [32]
+    const float* W2s; int ldw;                     // split-fp16 image of W2 [32][ldw]
+    const float* bias; const float* scale; const float* shift;
+    const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int cap;
+    int rep_in, rep_out, replicas;
+    float* Y; int ldy;
+    int* ovf;
+};
+
+int launch_edge_x3(const EdgeX3Params& p, int n_tiles_cap, hipStream_t s);      // edge_x3.hip (persistent 32-wide EdgeConv on 3-channel inputs)
 int launch_gemm16_dmap(const GemmDmaParams& p, hipStream_t s);                // gemm_dmap.hip (persistent, 256 x 256 tiles)
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

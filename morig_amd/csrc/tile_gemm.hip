@@ -39,7 +39,11 @@ typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));        // what __built
 //                the fp16 range; the loader raises `ovf` otherwise and the host re-runs in PREC_F32.
 enum { PREC_F32 = 0, PREC_F16X3 = 1 };
 
-enum { LOAD_DENSE = 0, LOAD_EDGE = 1 };
+// LOAD_EDGE3: an EdgeConv whose vertex input has 3 channels (positions; the keyframe flow of motionNet's first unit): instead of
+//             gathering the per-vertex first-layer terms A[dst], B[src] (2 x 4 H bytes per edge row) the loader gathers the two
+//             endpoints' 3 inputs (2 x 16 bytes) and evaluates the first Linear for its 4 hidden channels in registers
+//             (relu((Wa - Wb) x_i + Wb x_j + b): 28 fused multiply-adds per thread and row).
+enum { LOAD_DENSE = 0, LOAD_EDGE = 1, LOAD_EDGE3 = 2 };
 enum { MODE_STORE = 0, MODE_POOL = 1, MODE_EDGEMAX = 2 };
 
 struct TileParams {
@@ -50,6 +54,7 @@ struct TileParams {
     const float* X; int ldx;
     // edge loader
     const float* A; int lda; const float* B; int ldb;
+    const float* X3; int ldx3; const float* W1a; const float* W1b; const float* b1;     // LOAD_EDGE3: inputs [rows][ldx3 >= 4], [Hpad][4] weights
     const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
     const float* s1; const float* t1;
     // epilogue
@@ -72,7 +77,7 @@ static int debug_flags() {
 // them, so their register budget is capped for 4 (fp32, KC = 16: 6) waves per SIMD (measured -17..21 % at H = 32).
 // The dense fp32-X GEMM tile (BN = 128, KC = 32) likewise runs better at 3 waves per SIMD than at 2.
 template <int BN, int KC, int LOAD, int MODE, int PREC>
-__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD == LOAD_EDGE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC == PREC_F16X3) ? 3 :
+__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD != LOAD_DENSE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC == PREC_F16X3) ? 3 :
                                (BN == 64 && LOAD == LOAD_DENSE && MODE == MODE_STORE && PREC == PREC_F16X3) ? 4 : 1)) void tile_kernel(const TileParams p) {
     constexpr int BM = 128;
     constexpr int WN = (BN >= 128) ? 2 : 1;
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
     else { rep = lin / p.tiles_per_rep; tm = lin - rep * p.tiles_per_rep; tn = 0; }
     const int row0 = tm * BM;
 
-    constexpr bool EDGE_ROWS = (LOAD == LOAD_EDGE) || (MODE == MODE_EDGEMAX);   // tile rows = sorted edges
+    constexpr bool IS_EDGE = LOAD != LOAD_DENSE;                               // gathered edge rows (LOAD_EDGE, LOAD_EDGE3)
+    constexpr bool EDGE_ROWS = IS_EDGE || (MODE == MODE_EDGEMAX);               // tile rows = sorted edges
     // Edge tiles: the edge count, this thread's edge ids and the ids just outside the tile are all fetched before anything
     // waits (rows are clamped to the arrays' capacity p.M, validity is applied afterwards): ONE memory latency at tile
     // start instead of a chain of two or three. The neighbour ids decide in the epilogue whether the first / last
@@ -124,7 +130,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
         for (int i = 0; i < BM / (256 / (KC / 4)); ++i) {
             const int rc = min(row0 + lr + i * (256 / (KC / 4)), p.M - 1);
             ld_d[i] = p.dstS[rc];
-            ld_s[i] = (LOAD == LOAD_EDGE) ? p.srcS[rc] : 0;
+            ld_s[i] = IS_EDGE ? p.srcS[rc] : 0;
         }
         if (MODE == MODE_EDGEMAX) {
             const int dp = p.dstS[max(row0 - 1, 0)], da = p.dstS[min(row0 + BM, p.M - 1)];
@@ -158,16 +164,47 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
             const int d = va[i] ? ld_d[i] : -1;
             const int s = va[i] ? ld_s[i] : 0;
             const size_t base = (size_t)rep * p.rep_in;
-            pa[i] = p.A + (base + (va[i] ? d : 0)) * p.lda + 4 * lkq;
-            pb[i] = p.B + (base + s) * p.ldb + 4 * lkq;
+            if (LOAD == LOAD_EDGE3) {
+                pa[i] = p.X3 + (base + (va[i] ? d : 0)) * p.ldx3;
+                pb[i] = p.X3 + (base + s) * p.ldx3;
+            } else {
+                pa[i] = p.A + (base + (va[i] ? d : 0)) * p.lda + 4 * lkq;
+                pb[i] = p.B + (base + s) * p.ldb + 4 * lkq;
+            }
             if (lkq == 0) sseg[r] = d;
         }
     }
     const float* pw = p.W + (size_t)(tn * BN + lrow) * p.ldw + 4 * lkq;
 
+    // LOAD_EDGE3: first-layer rows [channel][8] = {W1a row (3), b1, W1b row (3), 0} in LDS (28 per-thread registers would spill the
+    // 128-VGPR budget that keeps 4 waves per SIMD); read channel by channel while staging, reused over the thread's PA rows
+    __shared__ __attribute__((aligned(16))) float w3[LOAD == LOAD_EDGE3 ? 32 * 8 : 4];
+    if (LOAD == LOAD_EDGE3) {
+        if (tid < 32) {
+            w3[tid * 8 + 0] = p.W1a[tid * 4 + 0]; w3[tid * 8 + 1] = p.W1a[tid * 4 + 1]; w3[tid * 8 + 2] = p.W1a[tid * 4 + 2]; w3[tid * 8 + 3] = p.b1[tid];
+            w3[tid * 8 + 4] = p.W1b[tid * 4 + 0]; w3[tid * 8 + 5] = p.W1b[tid * 4 + 1]; w3[tid * 8 + 6] = p.W1b[tid * 4 + 2]; w3[tid * 8 + 7] = 0.f;
+        }
+    }
     f32x4 ra[PA], rb[PA], rw[PB];
     f32x4 rs1 = {1.f, 1.f, 1.f, 1.f}, rt1 = {0.f, 0.f, 0.f, 0.f};      // hidden-layer affine of this thread's 4 k's
     auto fetch = [&](int k0) {
+        if (LOAD == LOAD_EDGE3) {                           // one chunk (K = H = 32): both endpoints' inputs, 16 bytes each
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                ra[i] = z; rb[i] = z;
+                if (va[i] && !(p.dbg & DBG_NO_GATHER)) {
+                    ra[i] = *reinterpret_cast<const f32x4*>(pa[i]);
+                    rb[i] = *reinterpret_cast<const f32x4*>(pb[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                if ((BN % RPP == 0 || lrow + i * RPP < BN) && !(p.dbg & DBG_NO_WLOAD))
+                    rw[i] = *reinterpret_cast<const f32x4*>(pw + (size_t)i * RPP * p.ldw + k0);
+            }
+            return;
+        }
         if (LOAD == LOAD_EDGE && p.s1 != nullptr && k0 + 4 * lkq < p.K) {   // NULL: affine already folded into W2/b2
             rs1 = *reinterpret_cast<const f32x4*>(p.s1 + k0 + 4 * lkq);
             rt1 = *reinterpret_cast<const f32x4*>(p.t1 + k0 + 4 * lkq);
@@ -180,7 +217,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
             const int k = (PREC == PREC_F16X3 && LOAD == LOAD_DENSE && p.x16) ? ((k0 + 4 * lkq) & ~31) : (k0 + 4 * lkq);
             if (va[i] && k < p.K && !(p.dbg & DBG_NO_GATHER)) {
                 ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
-                if (LOAD == LOAD_EDGE) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + k0);
+                if (IS_EDGE) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + k0);
             }
         }
 #pragma unroll
@@ -191,10 +228,27 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
     };
     auto stage = [&](int k0) {
         const int k = k0 + 4 * lkq;
+        f32x4 v3[PA];
+        if (LOAD == LOAD_EDGE3) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 wa = *reinterpret_cast<const f32x4*>(&w3[(4 * lkq + c) * 8]);        // W1a row, b1
+                const f32x4 ws = *reinterpret_cast<const f32x4*>(&w3[(4 * lkq + c) * 8 + 4]);    // W1b row
+#pragma unroll
+                for (int i = 0; i < PA; ++i) {
+                    float h = wa[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) h = fmaf(wa[j], ra[i][j], fmaf(ws[j], rb[i][j], h));
+                    v3[i][c] = va[i] ? fmaxf(h, 0.f) : 0.f;
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             f32x4 v = ra[i];
-            if (LOAD == LOAD_EDGE) {
+            if (LOAD == LOAD_EDGE3) {
+                v = v3[i];
+            } else if (LOAD == LOAD_EDGE) {
                 if (p.s1 != nullptr) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -794,4 +848,55 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         case 256: { ProfScope ps(K_EDGE_H256, s, flops, bytes); return launch_tile<256, 16, LOAD_EDGE, MODE_EDGEMAX>(p, nblocks, s); }
         default: return MORIG_E_UNSUPPORTED;
     }
+}
+
+// EdgeConv whose vertex input has 3 channels: first Linear evaluated in the loader from the gathered endpoints (LOAD_EDGE3), then the
+// 32-wide second layer + max exactly as morig_edgeconv. Replaces `morig_gemm` (K = 3 -> [A | B]) + `morig_edgeconv` for the position
+// branches (models/basic_modules.py:193-195: nn_pos([pos_i, pos_j - pos_i])) and for motionNet's first unit (nn_x on the 3-channel flow).
+extern "C" int morig_edgeconv_x3(const morig_edgeconv_x3_args* a, void* stream) {
+    if (!a || !a->X || !a->W1a || !a->W1b || !a->b1 || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
+    if (!a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
+    if (a->H != 32) return MORIG_E_UNSUPPORTED;
+    if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0 || a->ldx < 4 || (a->ldx & 3) || !aligned16(a->X)) return MORIG_E_INVALID;
+    if ((a->ldw & 3) || a->ldw < 32 || a->ldo < 32 || !aligned16(a->W2) || !aligned16(a->W1a) || !aligned16(a->W1b)) return MORIG_E_INVALID;
+    if (a->in_rep_stride < 0 || (a->replicas > 1 && a->out_rep_stride < a->n_nodes)) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    TileParams p = {};
+    p.M = a->edge_capacity; p.N = 32; p.K = 32;
+    p.W = a->W2; p.ldw = a->ldw;
+    p.bias = a->b2; p.scale = a->s2; p.shift = a->t2; p.relu = 1;
+    p.X3 = a->X; p.ldx3 = a->ldx; p.W1a = a->W1a; p.W1b = a->W1b; p.b1 = a->b1;
+    p.rowptr = a->rowptr; p.srcS = a->src_sorted; p.dstS = a->dst_sorted;
+    p.n_nodes = a->n_nodes; p.rep_in = a->in_rep_stride; p.rep_out = a->out_rep_stride;
+    p.Y = a->out; p.ldy = a->ldo;
+    p.tiles_per_rep = cdiv(a->edge_capacity, 128);
+    p.tiles_n = 1;
+    const bool f16 = a->W2_split != nullptr;
+    if (f16) {
+        if (!a->overflow || !aligned16(a->W2_split)) return MORIG_E_INVALID;
+        p.W = static_cast<const float*>(a->W2_split); p.ovf = a->overflow;
+    }
+    const int nblocks = p.tiles_per_rep * a->replicas;
+    { const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, 32, a->out, a->ldo, a->out_rep_stride,
+                                         a->replicas, s, 128);
+      if (st2 != MORIG_OK) return st2; }
+    const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
+    // algorithmic work: second layer 2 H^2 + first layer 2 * 6 * H per edge row; bytes: the two gathered 16-byte inputs
+    ProfScope ps(f16 ? K_EDGE16_X3 : K_EDGE_X3, s, E * (2.0 * 32 * 32 + 12.0 * 32), 32.0 * E);
+    // split-fp16 path: the persistent kernel (edge_x3.hip); MORIG_X3_TILE=1 keeps the one-tile-per-workgroup engine (A/B). The
+    // exact-fp32 path (MORIG_PRECISION=f32, or the re-run after a range overflow) stays on the tile engine.
+    static const bool want_tile = [] { const char* e = getenv("MORIG_X3_TILE"); return e && e[0] == '1'; }();
+    if (f16 && !want_tile && (a->ldo & 3) == 0 && aligned16(a->out)) {
+        EdgeX3Params q = {};
+        q.X = a->X; q.ldx = a->ldx; q.W1a = a->W1a; q.W1b = a->W1b; q.b1 = a->b1;
+        q.W2s = static_cast<const float*>(a->W2_split); q.ldw = a->ldw;
+        q.bias = a->b2; q.scale = a->s2; q.shift = a->t2;
+        q.rowptr = a->rowptr; q.srcS = a->src_sorted; q.dstS = a->dst_sorted; q.n_nodes = a->n_nodes; q.cap = a->edge_capacity;
+        q.rep_in = a->in_rep_stride; q.rep_out = a->out_rep_stride; q.replicas = a->replicas;
+        q.Y = a->out; q.ldy = a->ldo; q.ovf = a->overflow;
+        prof_retag(K_EDGE16_X3P);
+        return launch_edge_x3(q, nblocks, s);
+    }
+    return f16 ? launch_tile<32, 32, LOAD_EDGE3, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s)
+               : launch_tile<32, 32, LOAD_EDGE3, MODE_EDGEMAX>(p, nblocks, s);
 }

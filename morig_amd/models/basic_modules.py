@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import itertools
 import math
+import os
 import threading
 from typing import Optional
 
@@ -328,15 +329,26 @@ class GCUMotion(NativeModule):
     def _pack(self):
         vx, (xt, xg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_x, self.edge_conv_geo.nn_x])
         vp, (pt, pg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_pos, self.edge_conv_geo.nn_pos])
-        return dict(vx=vx, xt=xt, xg=xg, vp=vp, pt=pt, pg=pg, mlp=packing.pack_mlp_layer(self.mlp[0]))
+        pk = dict(vx=vx, xt=xt, xg=xg, vp=vp, pt=pt, pg=pg, mlp=packing.pack_mlp_layer(self.mlp[0]))
+        # a 3-channel feature with a 32-wide hidden layer (motionNet's first unit: the keyframe flow): the first Linear in the form
+        # morig_edgeconv_x3 evaluates in its loader
+        if xt.H == 32 and self.edge_conv_tpl.nn_x[0][0].weight.shape[1] == 6:
+            firsts = []
+            for ec in (self.edge_conv_tpl, self.edge_conv_geo):
+                W1 = ec.nn_x[0][0].weight.detach().float()
+                firsts.append(packing.pack_first_x3(W1[:, :3] - W1[:, 3:], W1[:, 3:], ec.nn_x[0][0].bias.detach().float()))
+            pk["x3t"], pk["x3g"] = firsts
+        return pk
 
     def run(self, ops, pos: Mat, x: Mat, csr_tpl, csr_geo, out: Mat, replicas: int = 1, split: bool = False,
-            split_in=None, split_out=None, pos_feat=None):
+            split_in=None, split_out=None, pos_feat=None, x3: Optional[Mat] = None):
         """pos: [n, P] window; x: [R*n, C] window (replica-major); out: [R*n, O] window.
         split: x and out are windows in the split-fp16 activation layout (GEMM -> GEMM hand-off);
         split_in / split_out override it for one side.
         pos_feat: (Mat [n, D], Mat [n, D]) = this unit's position-branch results on the tpl / geo graph, already computed by
-        ``run_pos_groups`` (paired with another unit's): copied into every replica instead of being computed here."""
+        ``run_pos_groups`` (paired with another unit's): copied into every replica instead of being computed here.
+        x3: the 3-channel feature as plain fp32 rows [R*n, 4] (first unit of motionNet): its two EdgeConvs then evaluate the first
+        Linear in-kernel from the gathered endpoints (morig_edgeconv_x3) and the [A | B] GEMM is not run."""
         split_in = split if split_in is None else split_in
         split_out = split if split_out is None else split_out
         dev = x.base.device
@@ -345,16 +357,22 @@ class GCUMotion(NativeModule):
         assert M == n * replicas
         H, D = pk["xt"].H, pk["pt"].H
         ldo = 2 * H + 2 * D
-        ab = ops.empty(M, 4 * H, dev)
-        ops.gemm(x, pk["vx"], relu=False, Y=Mat.of(ab), x_split=split_in)
+        use_x3 = x3 is not None and "x3t" in pk and hasattr(ops, "edgeconv_x3") and os.environ.get("MORIG_EDGE_X3", "1") != "0"
+        if not use_x3:
+            ab = ops.empty(M, 4 * H, dev)
+            ops.gemm(x, pk["vx"], relu=False, Y=Mat.of(ab), x_split=split_in)
         if pos_feat is None:
             pab = ops.empty(n, 4 * D, dev)
             ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
-        ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
-                     replicas=replicas, in_rep_stride=n, out_rep_stride=n)
-        ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H + D, H),
-                     replicas=replicas, in_rep_stride=n, out_rep_stride=n)
+        if use_x3:
+            ops.edgeconv_x3(x3, pk["x3t"], csr_tpl, pk["xt"], Mat.of(ec, 0, H), replicas=replicas, in_rep_stride=n, out_rep_stride=n)
+            ops.edgeconv_x3(x3, pk["x3g"], csr_geo, pk["xg"], Mat.of(ec, H + D, H), replicas=replicas, in_rep_stride=n, out_rep_stride=n)
+        else:
+            ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
+                         replicas=replicas, in_rep_stride=n, out_rep_stride=n)
+            ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H + D, H),
+                         replicas=replicas, in_rep_stride=n, out_rep_stride=n)
         # position branch: independent of the keyframe -> computed once, copied to every replica
         if pos_feat is not None:
             ops.copy2d_rep(pos_feat[0], Mat.of(ec, H, D, 0, n), replicas, n)
@@ -380,8 +398,11 @@ class GCUMotion(NativeModule):
 
 
 def run_pos_groups(ops, packed_groups, pos: Mat, csr_tpl, csr_geo):
-    """The position branches of several GCUMotion units in pairs (packing.pack_pos_groups): ONE vertex GEMM for all pairs, then
-    per pair one 32-wide EdgeConv per graph. -> per covered unit (Mat tpl [n, D], Mat geo [n, D]), windows of one side buffer."""
+    """The position branches of several GCUMotion units in pairs (packing.pack_pos_groups): per pair one 32-wide EdgeConv per graph.
+    With 3-channel positions the first Linear is evaluated inside the EdgeConv kernel from the gathered endpoints
+    (morig_edgeconv_x3: no per-vertex [A | B] table, 32 instead of 256 gathered bytes per edge row); wider position inputs (SkinNet's
+    33 channels are not paired: D = 64) would take one vertex GEMM for all pairs.
+    -> per covered unit (Mat tpl [n, D], Mat geo [n, D]), windows of one side buffer."""
     vertex, edges, n_pairs = packed_groups
     if n_pairs == 0:
         return []
@@ -389,14 +410,21 @@ def run_pos_groups(ops, packed_groups, pos: Mat, csr_tpl, csr_geo):
     n = pos.rows
     H = edges[0][0].H                               # 2 D
     D = H // 2
-    pab = ops.empty(n, 4 * H * n_pairs, dev)        # per pair [A_tpl | B_tpl | A_geo | B_geo], H columns each
-    ops.gemm(pos, vertex, relu=False, Y=Mat.of(pab))
+    x3 = pos.cols == 3 and pos.col0 == 0 and pos.ld % 4 == 0 and all(e[2] is not None for e in edges) and hasattr(ops, "edgeconv_x3") \
+        and os.environ.get("MORIG_EDGE_X3", "1") != "0"
     side = ops.empty(n, 2 * H * n_pairs, dev)       # per pair [tpl: unit 0, unit 1 | geo: unit 0, unit 1]
+    if not x3:
+        pab = ops.empty(n, 4 * H * n_pairs, dev)    # per pair [A_tpl | B_tpl | A_geo | B_geo], H columns each
+        ops.gemm(pos, vertex, relu=False, Y=Mat.of(pab))
     out = []
-    for g, (et, eg) in enumerate(edges):
-        c0 = 4 * H * g
-        ops.edgeconv(Mat.of(pab, c0, H), Mat.of(pab, c0 + H, H), csr_tpl, et, Mat.of(side, 2 * H * g, H))
-        ops.edgeconv(Mat.of(pab, c0 + 2 * H, H), Mat.of(pab, c0 + 3 * H, H), csr_geo, eg, Mat.of(side, 2 * H * g + H, H))
+    for g, (et, eg, ft, fg) in enumerate(edges):
+        if x3:
+            ops.edgeconv_x3(pos, ft, csr_tpl, et, Mat.of(side, 2 * H * g, H))
+            ops.edgeconv_x3(pos, fg, csr_geo, eg, Mat.of(side, 2 * H * g + H, H))
+        else:
+            c0 = 4 * H * g
+            ops.edgeconv(Mat.of(pab, c0, H), Mat.of(pab, c0 + H, H), csr_tpl, et, Mat.of(side, 2 * H * g, H))
+            ops.edgeconv(Mat.of(pab, c0 + 2 * H, H), Mat.of(pab, c0 + 3 * H, H), csr_geo, eg, Mat.of(side, 2 * H * g + H, H))
         for j in range(2):
             out.append((Mat.of(side, 2 * H * g + j * D, D), Mat.of(side, 2 * H * g + H + j * D, D)))
     return out

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import math
 
+from typing import Optional
+
 import numpy as np
 import torch
 from torch.nn import Linear, Sequential
@@ -141,10 +143,11 @@ class GCNRig(NativeModule):
         )
 
     def run(self, ops, pos4: torch.Tensor, write_feature, csr_tpl, csr_geo, seg: torch.Tensor, n_graphs: int,
-            replicas: int, out: Mat, csr_geo_wide=None, csr_tpl_wide=None, pos_feats=None):
+            replicas: int, out: Mat, csr_geo_wide=None, csr_tpl_wide=None, pos_feats=None, feat3: Optional[Mat] = None):
         """pos4: [n, 4] (pos, 0); write_feature(window Mat [R*n, feat_slot], split) fills the feature slot
         (zero padded); seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window.
-        pos_feats: per unit the position-branch results computed ahead by run_pos_groups (or None entries)."""
+        pos_feats: per unit the position-branch results computed ahead by run_pos_groups (or None entries).
+        feat3: a 3-channel feature once more as plain fp32 rows [R*n, 4] (gcu_1 then runs morig_edgeconv_x3 on it)."""
         pf = list(pos_feats) if pos_feats is not None else [None, None, None]
         dev = pos4.device
         pk = self.packed(dev)
@@ -156,7 +159,7 @@ class GCNRig(NativeModule):
         write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
         self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp,
-                       pos_feat=pf[0])
+                       pos_feat=pf[0], x3=feat3 if F == 3 else None)
         # the 128- and 256-wide layers take both graphs with 4-aligned segments (quad-reduced, single-pass epilogue of the
         # wave-specialised kernel: +12..18 % on the geo graph; on the tpl graph, in-degree 7 -> 8 rows, still -4 % since the
         # scans became cheap: 54.05 -> 53.35 ms per step); on the narrow layers the padding costs more than it saves
@@ -229,8 +232,12 @@ class _MotionBackbone(NativeModule):
         # into 32-wide edge layers (packing.pack_pos_groups); a unit without a partner keeps its own 16-wide path
         pos_feats = run_pos_groups(ops, self.packed(dev)["pos_groups"], Mat.of(pos4, 0, 3), csr_tpl, csr_geo)
         pos_feats = pos_feats + [None] * (6 - len(pos_feats))
+        # the 3-channel keyframe flows once more as plain fp32 rows [T n, 4]: motionNet's first unit evaluates its first edge Linear from
+        # the gathered endpoints (morig_edgeconv_x3) instead of gathering per-vertex [A | B] rows
+        flow4 = ops.empty(T * n, 4, dev)
+        ops.copy2d_rep(Mat.of(flow, 0, 3), Mat.of(flow4, 0, 4, 0, n), T, n, src_col_step=3)
         self.motionNet.run(ops, pos4, write_flow, csr_tpl, csr_geo, seg_T, ng, T, Mat.of(raw), csr_geo_wide=csr_geo4,
-                           csr_tpl_wide=csr_tpl4, pos_feats=pos_feats[:3])
+                           csr_tpl_wide=csr_tpl4, pos_feats=pos_feats[:3], feat3=Mat.of(flow4))
         motion_all = torch.empty((n, T, C), dtype=torch.float32, device=dev)
         ops.rownorm(Mat.of(raw), n, T, motion_all, T * C, C)          # F.normalize + torch.stack(dim=1)
 

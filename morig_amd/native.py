@@ -59,6 +59,22 @@ class EdgeConvArgs(C.Structure):
     ]
 
 
+class EdgeConvX3Args(C.Structure):
+    _fields_ = [
+        ("H", C.c_int32),
+        ("n_nodes", C.c_int32), ("replicas", C.c_int32),
+        ("in_rep_stride", C.c_int32), ("out_rep_stride", C.c_int32),
+        ("X", c_f32p), ("ldx", C.c_int32),
+        ("W1a", c_f32p), ("W1b", c_f32p), ("b1", c_f32p),
+        ("rowptr", c_i32p), ("src_sorted", c_i32p), ("dst_sorted", c_i32p),
+        ("edge_capacity", C.c_int32), ("edge_count", C.c_int32),
+        ("W2", c_f32p), ("ldw", C.c_int32),
+        ("b2", c_f32p), ("s2", c_f32p), ("t2", c_f32p),
+        ("out", c_f32p), ("ldo", C.c_int32),
+        ("W2_split", C.c_void_p), ("overflow", c_i32p),
+    ]
+
+
 class PointConvArgs(C.Structure):
     _fields_ = [
         ("A", c_f32p), ("lda", C.c_int32), ("B", c_f32p), ("ldb", C.c_int32),
@@ -93,6 +109,7 @@ _SIGNATURES = {
     "morig_csr_build_bipartite": (C.c_int, [c_i64p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_csr_from_slots": (C.c_int, [c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_gemm": (C.c_int, [C.POINTER(GemmArgs), C.c_void_p]),
+    "morig_edgeconv_x3": (C.c_int, [C.POINTER(EdgeConvX3Args), C.c_void_p]),
     "morig_edge_hidden": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
     "morig_segmax_gemm": (C.c_int, [C.POINTER(SegmaxArgs), C.c_void_p]),
     "morig_pointconv_fused": (C.c_int, [C.POINTER(PointConvArgs), C.c_void_p]),
@@ -571,6 +588,26 @@ class NativeOps:
         if self.fast and ec.W2split is not None:
             a.W2_split, a.overflow = ec.W2split.data_ptr(), self._flag(A.base.device).data_ptr()
         return a
+
+    def edgeconv_x3(self, X: Mat, first, csr: CSR, ec, out: Mat, replicas: int = 1, in_rep_stride: int = 0, out_rep_stride: int = 0):
+        """EdgeConv on a 3-channel vertex input with the first Linear evaluated in the kernel (morig_edgeconv_x3). X: [rows, >= 4]
+        window starting at column 0 of 16-byte aligned rows; first = (W1a [32, 4], W1b [32, 4], b1 [32]) from packing.pack_first_x3."""
+        _need_gpu(X.base, out.base)
+        assert ec.H == 32 and ec.s1 is None and X.col0 % 4 == 0 and X.ld % 4 == 0
+        a = EdgeConvX3Args()
+        a.H = 32
+        a.n_nodes, a.replicas = csr.n_nodes, replicas
+        a.in_rep_stride, a.out_rep_stride = in_rep_stride, out_rep_stride
+        a.X, a.ldx = X.ptr, X.ld
+        a.W1a, a.W1b, a.b1 = first[0].data_ptr(), first[1].data_ptr(), first[2].data_ptr()
+        a.rowptr, a.src_sorted, a.dst_sorted = csr.rowptr.data_ptr(), csr.src.data_ptr(), csr.dst.data_ptr()
+        a.edge_capacity, a.edge_count = csr.capacity, csr.edge_count
+        a.W2, a.ldw = ec.W2.data_ptr(), ec.W2.stride(0)
+        a.b2, a.s2, a.t2 = ec.b2.data_ptr(), ec.s2.data_ptr(), ec.t2.data_ptr()
+        a.out, a.ldo = out.ptr, out.ld
+        if self.fast and ec.W2split is not None:
+            a.W2_split, a.overflow = ec.W2split.data_ptr(), self._flag(X.base.device).data_ptr()
+        check(self.lib.morig_edgeconv_x3(C.byref(a), _stream()), "morig_edgeconv_x3")
 
     def edge_hidden(self, A: Mat, B: Mat, csr: CSR, ec, Z: Mat):
         """per-edge hidden activations Z [capacity, H] (rows >= E' untouched)."""

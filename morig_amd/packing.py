@@ -158,6 +158,18 @@ def pack_edge_pair(mlps: Sequence[nn.Sequential]):
     return vertex, edges
 
 
+def pack_first_x3(A: torch.Tensor, B: torch.Tensor, b: torch.Tensor):
+    """First edge Linear on a 3-channel input for morig_edgeconv_x3: (W1a [32, 4], W1b [32, 4], b1 [32]) from A = W_a - W_b, B = W_b
+    ([H <= 32, 3]) and the bias; rows past H and column 3 are zero."""
+    H = A.shape[0]
+    assert A.shape == (H, 3) and B.shape == (H, 3) and H <= 32
+    W1a = torch.zeros((32, 4), dtype=torch.float32, device=A.device)
+    W1b = torch.zeros((32, 4), dtype=torch.float32, device=A.device)
+    b1 = torch.zeros(32, dtype=torch.float32, device=A.device)
+    W1a[:H, :3], W1b[:H, :3], b1[:H] = A, B, b
+    return W1a.contiguous(), W1b.contiguous(), b1
+
+
 def pack_pos_groups(units):
     """The POSITION branches (``nn_pos`` = MLP([2P, D, D]), D = 16) of several GCUMotion units that see the same positions and the
     same two graphs (models/basic_modules.py:193-195, 212-215: the motion and the head network of a rig model, rignet.py:82-99).
@@ -169,7 +181,7 @@ def pack_pos_groups(units):
     n_pairs = len(units) // 2
     if n_pairs == 0:
         return None, [], 0
-    rows, biases, edges = [], [], []
+    rows, biases, edges, firsts = [], [], [], []
     D = units[0].edge_conv_tpl.nn_pos[0][0].weight.shape[0]
     for g in range(n_pairs):
         pair = units[2 * g: 2 * g + 2]
@@ -189,6 +201,7 @@ def pack_pos_groups(units):
                 W2s.append(Wf); b2s.append(bf); s2s.append(s2); t2s.append(t2)
             rows += [torch.cat(A, 0), torch.cat(B, 0)]
             biases += [torch.cat(bA, 0), torch.zeros(2 * D, dtype=torch.float32, device=rows[-1].device)]
+            firsts.append(pack_first_x3(torch.cat(A, 0), torch.cat(B, 0), torch.cat(bA, 0)) if A[0].shape[1] == 3 else None)
             H = 2 * D
             W2 = torch.zeros((max(H, 32), _roundup(H, 32)), dtype=torch.float32, device=rows[-1].device)
             W2[:D, :D] = W2s[0]
@@ -197,7 +210,8 @@ def pack_pos_groups(units):
             Hp = max(H, 32)
             pe.append(PackedEdge(H, None, None, W2, _pad_vec(torch.cat(b2s), Hp), _pad_vec(torch.cat(s2s), Hp, 1.0), _pad_vec(torch.cat(t2s), Hp),
                                  split_f16(W2) if H >= 32 else None))
-        edges.append((pe[0], pe[1]))
+        # (et, eg, first_tpl, first_geo): `first_*` = the first Linear in the form morig_edgeconv_x3 evaluates in its loader (P == 3)
+        edges.append((pe[0], pe[1], firsts[-2], firsts[-1]))
     vertex = pack_linear(torch.cat(rows, 0), torch.cat(biases, 0))
     return vertex, edges, n_pairs
 

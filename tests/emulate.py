@@ -132,6 +132,16 @@ class EmuOps:
             res = res.scatter_reduce(0, dst[:, None].expand(-1, H), z, reduce="amax", include_self=True)
             out.base[out.row0 + r * out_rep_stride: out.row0 + r * out_rep_stride + n, out.col0:out.col0 + H] = res
 
+    def edgeconv_x3(self, X: Mat, first, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0):
+        """first Linear on the gathered endpoints' 3 channels, then the 32-wide layer: A = W1a x + b1, B = W1b x per vertex"""
+        W1a, W1b, b1 = first
+        rows = X.base.shape[0] - X.row0
+        x = X.base[X.row0:X.row0 + rows, X.col0:X.col0 + 3]
+        ab = torch.zeros(rows, 64)
+        ab[:, :32] = x @ W1a[:, :3].t() + b1
+        ab[:, 32:] = x @ W1b[:, :3].t()
+        self.edgeconv(Mat.of(ab, 0, 32), Mat.of(ab, 32, 32), csr, ec, out, replicas, in_rep_stride, out_rep_stride)
+
     # -- small ops -----------------------------------------------------------------------------------
     def copy2d(self, src: Mat, dst: Mat):
         dst.view().copy_(src.view())

@@ -175,6 +175,34 @@ def _edge_pack(H, seed, folded=False):
     return pe
 
 
+@pytest.mark.parametrize("n,e,hub,reps,pad4", [(300, 2500, 5, 1, False), (1500, 9000, None, 3, False), (700, 5000, 3, 2, True), (5000, 60000, None, 1, True)])
+def test_edgeconv_x3(ops, n, e, hub, reps, pad4):
+    """morig_edgeconv_x3: a 32-wide EdgeConv on a 3-channel vertex input with the first Linear evaluated in the loader from the
+    gathered endpoints -- against the emulation's [A | B] form (A = W1a x + b1, B = W1b x per vertex, then the usual layer)"""
+    g = torch.Generator().manual_seed(n + reps)
+    ei = _rand_graph(n, e, 7, hub)
+    x = torch.zeros(reps * n, 4)
+    x[:, :3] = torch.randn(reps * n, 3, generator=g)
+    x[:, 3] = float("nan")                                      # column 3 must never enter the sum
+    W1a, W1b, b1 = torch.zeros(32, 4), torch.zeros(32, 4), torch.randn(32, generator=g) * 0.2
+    W1a[:, :3], W1b[:, :3] = torch.randn(32, 3, generator=g), torch.randn(32, 3, generator=g)
+    pe = _edge_pack(32, 21, folded=True)
+    emu = EmuOps()
+    want = torch.zeros(reps * n, 40)
+    emu.edgeconv_x3(Mat.of(x), (W1a, W1b, b1), emu.csr_build(ei, n, pad4=pad4), pe, Mat.of(want, 4, 32, 0, n), replicas=reps,
+                    in_rep_stride=n, out_rep_stride=n)
+    got = torch.zeros(reps * n, 40, device=DEV)
+    csr = ops.csr_build(ei.to(DEV), n, pad4=pad4)
+    ops.edgeconv_x3(Mat.of(x.to(DEV)), (W1a.to(DEV), W1b.to(DEV), b1.to(DEV)), csr, packing.to_device(pe, DEV),
+                    Mat.of(got, 4, 32, 0, n), replicas=reps, in_rep_stride=n, out_rep_stride=n)
+    torch.cuda.synchronize()
+    assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
+    again = torch.zeros(reps * n, 40, device=DEV)
+    ops.edgeconv_x3(Mat.of(x.to(DEV)), (W1a.to(DEV), W1b.to(DEV), b1.to(DEV)), csr, packing.to_device(pe, DEV),
+                    Mat.of(again, 4, 32, 0, n), replicas=reps, in_rep_stride=n, out_rep_stride=n)
+    assert torch.equal(got, again)
+
+
 @pytest.mark.parametrize("folded,pad4", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("H,ld_extra", [(16, 3), (32, 3), (64, 3), (128, 3), (256, 3), (128, 4), (256, 4)])
 @pytest.mark.parametrize("n,e,hub,reps,shared", [(300, 2500, 5, 1, False), (1500, 9000, None, 3, False), (700, 5000, 3, 2, True)])
