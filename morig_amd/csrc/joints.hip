@@ -129,6 +129,171 @@ __global__ __launch_bounds__(256) void kth_nn_kernel(const double* __restrict__ 
     }
 }
 
+// ---- the same selection, four points per workgroup and 12 key bits per pass ----
+// What the one-row kernel pays for: (1) its two top passes are degenerate -- squared distances inside a normalised mesh share
+// their sign and top exponent bits, so nearly every key lands in one bin and the LDS unit serialises 64 same-address atomics per
+// wave instruction; (2) every row streams the mesh's 24-byte points again (n x 24 B per row and pass out of L2: the address unit's
+// rate, not HBM's). Here a workgroup selects for FOUR rows at once -- a loaded candidate meets four row points held in
+// registers -- and the first pass looks at key bits 46..57 of the keys whose top six bits are 0b001111 (squared distances in
+// [2^-31, 2): six exponent bits + six mantissa bits = 64 bins per octave, so neighbouring distances spread over hundreds of bins);
+// keys below that range (the point itself, exact duplicates) are only counted, keys above need no count. At the 4 % quantile of
+// 8192 points the selected bin holds 2-5 keys, so the usual row takes ONE histogram pass + one list pass instead of three + one.
+// Bins are 16-bit halves of a word shared by two rows (n <= 65535; larger sets run the one-row kernel), padded by one word per
+// 64 so that the scan -- one wave per row, a lane sums 64 consecutive bins -- reads conflict-free. A row whose k-th key lies
+// outside the range of the first pass (k <= number of duplicates of the point; sets far larger than the unit box) is selected by
+// the generic 8 x 8-bit passes below, by the whole workgroup.
+constexpr int K4_R = 4, K4_LIST = 64, K4_BINS = 4096, K4_WORDS = K4_BINS + K4_BINS / 64;
+__device__ __forceinline__ int k4_idx(int b) { return b + (b >> 6); }
+__device__ __forceinline__ unsigned k4_half(unsigned w, int r) { return (r & 1) ? (w >> 16) : (w & 0xffffu); }
+
+__global__ __launch_bounds__(256) void kth_nn4_kernel(const double* __restrict__ pts_all, const int* __restrict__ ptr, int n_all, int k_given,
+                                                      double quantile, double* __restrict__ kth_all) {
+    __shared__ unsigned hist[K4_R / 2][K4_WORDS];
+    __shared__ unsigned long long s_list[K4_R][K4_LIST];
+    __shared__ unsigned long long s_prefix[K4_R];
+    __shared__ int s_k[K4_R], s_nlist[K4_R], s_state[K4_R], s_shift[K4_R];      // state: 0 selecting, 1 list pass next, 2 done, 3 generic
+    __shared__ unsigned s_lo[K4_R];
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    if ((int)blockIdx.x * K4_R >= n) return;
+    const double* pts = pts_all + (size_t)s0 * 3;
+    double* kth = kth_all + s0;
+    int k = k_given;
+    if (quantile >= 0.0) { k = (int)((double)n * quantile); if (k < 1) k = 1; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double px[K4_R], py[K4_R], pz[K4_R];
+#pragma unroll
+    for (int r = 0; r < K4_R; ++r) {                                           // rows past the end repeat the last one (never written)
+        const int row = min((int)blockIdx.x * K4_R + r, n - 1);
+        px[r] = pts[(size_t)row * 3]; py[r] = pts[(size_t)row * 3 + 1]; pz[r] = pts[(size_t)row * 3 + 2];
+    }
+    if (tid < K4_R) { s_prefix[tid] = 0ull; s_k[tid] = k; s_nlist[tid] = 0; s_state[tid] = 0; s_shift[tid] = 0; s_lo[tid] = 0u; }
+    unsigned long long pre[K4_R];
+    for (int p = 0; p < 5; ++p) {
+        const int shift = p < 4 ? 46 - 12 * p : 0, nbits = p < 4 ? 12 : 10, pshift = shift + nbits;
+        const unsigned bmask = (1u << nbits) - 1u;
+        for (int i = tid; i < (K4_R / 2) * K4_WORDS; i += 256) (&hist[0][0])[i] = 0u;
+        __syncthreads();
+        unsigned act = 0u;
+#pragma unroll
+        for (int r = 0; r < K4_R; ++r) { if (s_state[r] == 0) act |= 1u << r; pre[r] = s_prefix[r]; }
+        for (int j = tid; j < n; j += 256) {
+            const double qx = pts[(size_t)j * 3], qy = pts[(size_t)j * 3 + 1], qz = pts[(size_t)j * 3 + 2];
+#pragma unroll
+            for (int r = 0; r < K4_R; ++r) {
+                if (!((act >> r) & 1u)) continue;                              // block-uniform
+                const unsigned long long key = (unsigned long long)__double_as_longlong(sqdist3d(qx, qy, qz, px[r], py[r], pz[r]));
+                if (p == 0) {
+                    const unsigned top = (unsigned)(key >> 58);
+                    if (top == 0xFu) atomicAdd(&hist[r >> 1][k4_idx((int)((key >> 46) & 0xfffu))], 1u << (16 * (r & 1)));
+                    else if (top < 0xFu) atomicAdd(&s_lo[r], 1u);
+                } else if ((key >> pshift) == pre[r]) {
+                    atomicAdd(&hist[r >> 1][k4_idx((int)((unsigned)(key >> shift) & bmask))], 1u << (16 * (r & 1)));
+                }
+            }
+        }
+        __syncthreads();
+        if (wave < K4_R && ((act >> wave) & 1u)) {                             // wave r scans row r's bins
+            const int r = wave;
+            int need = s_k[r];
+            bool generic = false;
+            if (p == 0) { const int lo = (int)s_lo[r]; if (need <= lo) generic = true; else need -= lo; }
+            const int per = (1 << nbits) / 64;
+            unsigned tot = 0u;
+            for (int c = 0; c < per; ++c) tot += k4_half(hist[r >> 1][k4_idx(lane * per + c)], r);
+            unsigned inc = tot;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+            const unsigned total = __shfl(inc, 63);
+            if (!generic && need > (int)total) generic = true;                 // the k-th key lies above the range of pass 0
+            if (generic) { if (lane == 0) s_state[r] = 3; }
+            else {
+                const unsigned long long m = __ballot((int)inc >= need);
+                const int L = __ffsll((long long)m) - 1;
+                if (lane == L) {
+                    int rem = need - (int)(inc - tot), b = lane * per;
+                    unsigned v = 0u;
+                    for (int c = 0; c < per; ++c) {
+                        v = k4_half(hist[r >> 1][k4_idx(lane * per + c)], r);
+                        if (rem <= (int)v) { b = lane * per + c; break; }
+                        rem -= (int)v;
+                    }
+                    s_k[r] = rem;
+                    s_prefix[r] = (p == 0 ? (0xFull << 12) : (pre[r] << nbits)) | (unsigned long long)b;
+                    s_shift[r] = shift;
+                    s_state[r] = p == 4 ? 2 : ((int)v <= K4_LIST ? 1 : 0);     // (after the last pass the prefix IS the key)
+                }
+            }
+        }
+        __syncthreads();
+        bool more = false;
+#pragma unroll
+        for (int r = 0; r < K4_R; ++r) more = more || s_state[r] == 0;
+        if (!more) break;                                                      // block-uniform
+    }
+    // list pass: the keys of the selected bins, ranked by one wave per row
+    unsigned lst = 0u;
+    int sh[K4_R];
+#pragma unroll
+    for (int r = 0; r < K4_R; ++r) { if (s_state[r] == 1) lst |= 1u << r; pre[r] = s_prefix[r]; sh[r] = s_shift[r]; }
+    if (lst) {
+        for (int j = tid; j < n; j += 256) {
+            const double qx = pts[(size_t)j * 3], qy = pts[(size_t)j * 3 + 1], qz = pts[(size_t)j * 3 + 2];
+#pragma unroll
+            for (int r = 0; r < K4_R; ++r) {
+                if (!((lst >> r) & 1u)) continue;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(sqdist3d(qx, qy, qz, px[r], py[r], pz[r]));
+                if ((key >> sh[r]) == pre[r]) {
+                    const int slot = atomicAdd(&s_nlist[r], 1);
+                    if (slot < K4_LIST) s_list[r][slot] = key;
+                }
+            }
+        }
+        __syncthreads();
+        if (wave < K4_R && ((lst >> wave) & 1u)) {
+            const int r = wave, m = min(s_nlist[r], K4_LIST);
+            const unsigned long long v = lane < m ? s_list[r][lane] : ~0ull;
+            int rank = 0;
+            for (int j = 0; j < m; ++j) { const unsigned long long c = s_list[r][j]; rank += (c < v || (c == v && j < lane)) ? 1 : 0; }
+            int idx = s_k[r] - 1;
+            idx = idx < 0 ? 0 : (idx >= m ? m - 1 : idx);
+            if (lane < m && rank == idx) s_prefix[r] = v;
+        }
+        __syncthreads();
+    }
+    // rows outside pass 0's range: 8 passes of 8 bits from the top, one row at a time
+    for (int r = 0; r < K4_R; ++r) {
+        if (s_state[r] != 3) continue;                                         // block-uniform
+        unsigned* h = &hist[0][0];
+        __syncthreads();
+        if (tid == 0) { s_prefix[r] = 0ull; s_k[r] = k; }
+        for (int pass = 7; pass >= 0; --pass) {
+            h[tid] = 0u;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix[r];
+            const unsigned long long hi_mask = pass == 7 ? 0ull : (~0ull << (8 * (pass + 1)));
+            for (int j = tid; j < n; j += 256) {
+                const unsigned long long key = (unsigned long long)__double_as_longlong(
+                    sqdist3d(pts[(size_t)j * 3], pts[(size_t)j * 3 + 1], pts[(size_t)j * 3 + 2], px[r], py[r], pz[r]));
+                if ((key & hi_mask) == prefix) atomicAdd(&h[(key >> (8 * pass)) & 0xffu], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int need = s_k[r]; unsigned b = 0;
+                while (b < 255u && (int)h[b] < need) { need -= (int)h[b]; ++b; }
+                s_k[r] = need; s_prefix[r] = prefix | ((unsigned long long)b << (8 * pass));
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (tid < K4_R) {
+        const int row = (int)blockIdx.x * K4_R + tid;
+        if (row < n) kth[row] = sqrt(__longlong_as_double((long long)s_prefix[tid]));
+    }
+}
+
 // fixed-order sum (one workgroup): the bandwidth is deterministic from run to run
 // (per mesh: mean of its kth distances -> out[b])
 __global__ __launch_bounds__(256) void mean_f64_kernel(const double* __restrict__ x_all, const int* __restrict__ ptr, int n_all,
@@ -457,11 +622,18 @@ extern "C" int morig_inside_check(const double* pts, int32_t n, const uint8_t* v
     return MORIG_OK;
 }
 
+// four rows per workgroup (16-bit bins: sets of at most 65535 points); MORIG_KTH_ROWS=1 keeps the one-row kernel (A/B switch)
+static bool kth_four_rows(int max_n) {
+    static const int one = [] { const char* e = getenv("MORIG_KTH_ROWS"); return e && atoi(e) == 1 ? 1 : 0; }();
+    return !one && max_n <= 65535;
+}
+
 extern "C" int morig_knn_bandwidth(const double* pts, int32_t n, int32_t k, double* kth_ws, double* bandwidth, void* stream) {
     if (!pts || !kth_ws || !bandwidth || n <= 0 || k < 1 || k > n) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    hipLaunchKernelGGL(kth_nn_kernel<true>, dim3(n, 1), dim3(256), 0, s, pts, nullptr, n, k, -1.0, kth_ws);
+    if (kth_four_rows(n)) hipLaunchKernelGGL(kth_nn4_kernel, dim3(cdiv(n, K4_R), 1), dim3(256), 0, s, pts, nullptr, n, k, -1.0, kth_ws);
+    else hipLaunchKernelGGL(kth_nn_kernel<true>, dim3(n, 1), dim3(256), 0, s, pts, nullptr, n, k, -1.0, kth_ws);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_f64_kernel, dim3(1, 1), dim3(256), 0, s, kth_ws, nullptr, n, bandwidth);
     MORIG_LAUNCH_CHECK();
@@ -519,7 +691,9 @@ extern "C" int morig_knn_bandwidth_batched(const double* pts, const int32_t* ptr
     if (!pts || !ptr || !kth_ws || !bandwidth || n_meshes <= 0 || n_all <= 0 || max_n <= 0 || !(quantile >= 0.0)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    hipLaunchKernelGGL(kth_nn_kernel<true>, dim3(max_n, n_meshes), dim3(256), 0, s, pts, ptr, n_all, 0, quantile, kth_ws);
+    if (kth_four_rows(max_n))
+        hipLaunchKernelGGL(kth_nn4_kernel, dim3(cdiv(max_n, K4_R), n_meshes), dim3(256), 0, s, pts, ptr, n_all, 0, quantile, kth_ws);
+    else hipLaunchKernelGGL(kth_nn_kernel<true>, dim3(max_n, n_meshes), dim3(256), 0, s, pts, ptr, n_all, 0, quantile, kth_ws);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(mean_f64_kernel, dim3(1, n_meshes), dim3(256), 0, s, kth_ws, ptr, n_all, bandwidth);
     MORIG_LAUNCH_CHECK();

@@ -92,20 +92,26 @@ def test_extract_joints_batched_on_gpu():
 
 @pytest.mark.gpu
 def test_batched_bandwidth_selection_is_exact():
-    """the k-th nearest-neighbour distance (radix select, 8 rows per workgroup, early stop + short list) against torch.kthvalue of the
-    float64 distance matrix computed with the kernel's operation order: ragged meshes, duplicated points (mirror pairs: equal
-    distances), k = 1, tiny meshes"""
+    """the k-th nearest-neighbour distance (radix select: four rows per workgroup, 12 key bits per pass over the range [2^-31, 2) of
+    squared distances, short list; generic 8-bit passes for rows outside that range) against torch.kthvalue of the float64 distance
+    matrix computed with the kernel's operation order: ragged meshes, duplicated points (mirror pairs: equal distances), k = 1, tiny
+    meshes, a set 100 x larger than the unit box and one 10^-6 x smaller (both outside the first pass's range), coincident points,
+    quantiles up to 1"""
     from morig_amd import native
     ops = native.get_ops()
     rng = np.random.default_rng(11)
     dev = torch.device("cuda:0")
-    sets = [rng.normal(0, 0.1, (n, 3)) for n in (1000, 37, 2600, 9, 513)]
+    sets = [rng.normal(0, 0.1, (n, 3)) for n in (1000, 37, 2600, 9, 513, 300, 300, 70, 1, 2)]
     sets[2][1300:] = sets[2][:1300] * np.array([[-1, 1, 1]])              # mirror images
     sets[1][5:10] = sets[1][0]                                              # exact duplicates
+    sets[5] *= 1000.0                                                       # squared distances >= 2: above the first pass's range
+    sets[6] *= 1e-6                                                         # ... and below it
+    sets[7][:] = sets[7][0]                                                 # all points coincide
+    sets[0][:200] = np.round(sets[0][:200], 2)                              # a coarse lattice: many equal non-zero distances
     P = torch.from_numpy(np.concatenate(sets)).to(dev)
     sizes = [len(x) for x in sets]
     ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
-    for q in (0.04, 0.3, 0.0):
+    for q in (0.04, 0.3, 0.0, 0.9, 1.0):
         bw = ops.knn_bandwidth_batched(P, ptr, max(sizes), q).cpu().numpy()
         for b, x in enumerate(sets):
             t = torch.from_numpy(x)
