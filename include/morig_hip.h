@@ -373,8 +373,8 @@ int morig_nms_greedy_batched(const double* pts, const float* attn, const int32_t
 /* Mean-shift over SPATIALLY SORTED point sets: the caller sorts every mesh's points by morig_morton_keys (key = mesh index above a
  * 30-bit Morton code of the position inside [-2, 2)^3), runs morig_meanshift_sorted on the permuted points / weights and scatters the
  * result back. Source tiles whose bounding box lies farther than the bandwidth from a target block's are skipped: the skipped pairs
- * have kernel value 0 exactly, so the result is the unsorted one up to the order of the additions. bbox_ws: n_meshes * ceil(max_n / 256) * 24
- * doubles (one box per 64 sources). */
+ * have kernel value 0 exactly, so the result is the unsorted one up to the order of the additions. bbox_ws: 2 * n_meshes * ceil(max_n / 32) * 6
+ * doubles (one box per 32 consecutive points, two generations). */
 int morig_morton_keys(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int64_t* keys, void* stream);
 int morig_meanshift_sorted(const double* pts, const float* weights, const int32_t* ptr, int32_t n_meshes, int32_t n_all,
                            int32_t max_n, const double* bandwidth, int32_t max_iter, double* buf_a, double* buf_b,

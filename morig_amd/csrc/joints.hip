@@ -503,6 +503,157 @@ __global__ __launch_bounds__(MS_TILE) void meanshift_step_sorted_kernel(const do
     }
 }
 
+// ---- the sorted step at box granularity 32, without workgroup barriers in the pair loop ----
+// The step above tests four boxes of every 256-source tile in every thread (24 loads + ~50 operations per tile and thread: as much
+// work as the pairs that survive), stages whole tiles behind two barriers, and leaves a wave idle whenever its quarter of the tile
+// is out of reach. Here a box holds 32 consecutive (Morton-sorted) points, for sources and targets alike -- the workgroup's 32
+// targets ARE box blockIdx.x, and the workgroup writes the box of their NEW positions for the next step (two box buffers alternate;
+// no separate box kernel after the first step). One thread tests one source box, the near ones are compacted in order into a list
+// and dealt round-robin to the four waves. A wave stages a box in its own 1 KB of LDS (the next box's points are in flight in
+// registers meanwhile) and its lanes are 32 targets x 2 halves of 16 sources. Sources past the end of the set carry weight 0 and
+// finite coordinates: they add +0.0. Partial sums meet in a fixed order (deterministic; another order than the tile kernel's).
+constexpr int MSB = 32;
+__global__ __launch_bounds__(256) void box32_kernel(const double* __restrict__ src_all, const int* __restrict__ ptr, int n_all, int max_boxes,
+                                                    double* __restrict__ bbox) {
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    const int base = blockIdx.x * 256;
+    if (base >= n) return;
+    const int i = min(base + (int)threadIdx.x, n - 1);                        // lanes past the end shadow the last point
+    double lo[3], hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) lo[a] = hi[a] = src_all[(size_t)(s0 + i) * 3 + a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o)); }
+    }
+    const int box = (base + (int)threadIdx.x) / MSB;
+    if ((threadIdx.x & (MSB - 1)) == 0 && box * MSB < n) {
+        double* bx = bbox + ((size_t)blockIdx.y * max_boxes + box) * 6;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { bx[a] = lo[a]; bx[3 + a] = hi[a]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void meanshift_step_box_kernel(const double* __restrict__ src_all, const float* __restrict__ w_all,
+                                                                 const int* __restrict__ ptr, int n_all,
+                                                                 const double* __restrict__ bandwidth_all, int t, int max_iter,
+                                                                 const double* __restrict__ bbox_in_all, double* __restrict__ bbox_out_all,
+                                                                 int max_boxes, double* __restrict__ state_all, double* __restrict__ dst_all) {
+    __shared__ double stage[4][MSB][4];
+    __shared__ double part[8][4][MSB];
+    __shared__ unsigned long long s_mask[4];
+    __shared__ unsigned short s_near[256];
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    if ((int)blockIdx.x * MSB >= n) return;
+    const double* src = src_all + (size_t)s0 * 3;
+    double* dst = dst_all + (size_t)s0 * 3;
+    const float* w = w_all ? w_all + s0 : nullptr;
+    const double* bbox_in = bbox_in_all + (size_t)blockIdx.y * max_boxes * 6;
+    double* bbox_out = bbox_out_all + (size_t)blockIdx.y * max_boxes * 6;
+    double* state = state_all + (size_t)blockIdx.y * max_iter;
+    const int tid = threadIdx.x, tg = tid & (MSB - 1), sl = tid / MSB, wv = tid >> 6, lane = tid & 63, half = (tid >> 5) & 1;
+    const int j = blockIdx.x * MSB + tg;
+    const bool live = j < n;
+    const bool active = sqrt(state[t - 1]) > 1e-3;              // block-uniform
+    const int jc = live ? j : n - 1;                            // dead lanes shadow the last point
+    const double px = src[(size_t)jc * 3], py = src[(size_t)jc * 3 + 1], pz = src[(size_t)jc * 3 + 2];
+    if (!active) {
+        if (live && sl == 0) { dst[(size_t)j * 3] = px; dst[(size_t)j * 3 + 1] = py; dst[(size_t)j * 3 + 2] = pz; }
+        if (tid < 6) bbox_out[(size_t)blockIdx.x * 6 + tid] = bbox_in[(size_t)blockIdx.x * 6 + tid];
+        return;
+    }
+    double tb[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) tb[a] = bbox_in[(size_t)blockIdx.x * 6 + a];
+    const double h = bandwidth_all[blockIdx.y], h2 = __dmul_rn(h, h);
+    double ax = 0.0, ay = 0.0, az = 0.0, aw = 0.0;
+    const int n_boxes = (n + MSB - 1) / MSB;
+    for (int cb = 0; cb < n_boxes; cb += 256) {
+        const int b = cb + tid;
+        bool near = false;
+        if (b < n_boxes) {
+            const double* bx = bbox_in + (size_t)b * 6;
+            double gap2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double g = fmax(fmax(bx[a] - tb[3 + a], tb[a] - bx[3 + a]), 0.0);
+                gap2 += g * g;
+            }
+            near = gap2 <= h2;                                                 // farther than h box to box: every pair has k = 0
+        }
+        const unsigned long long mask = __ballot(near);
+        if (cb) __syncthreads();                                               // the previous chunk's list is consumed
+        if (lane == 0) s_mask[wv] = mask;
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int c = __popcll(s_mask[q]); if (q < wv) off += c; total += c; }
+        if (near) s_near[off + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+        __syncthreads();
+        // this wave's boxes: list entries wv, wv + 4, ...
+        int e = wv;
+        double rx = px, ry = py, rz = pz, rw = 0.0;
+        if (e < total && lane < MSB) {
+            const int i = (cb + (int)s_near[e]) * MSB + lane;
+            if (i < n) { rx = src[(size_t)i * 3]; ry = src[(size_t)i * 3 + 1]; rz = src[(size_t)i * 3 + 2]; rw = w ? (double)w[i] : 1.0; }
+        }
+        while (e < total) {
+            if (lane < MSB) { stage[wv][lane][0] = rx; stage[wv][lane][1] = ry; stage[wv][lane][2] = rz; stage[wv][lane][3] = rw; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            e += 4;
+            rx = px; ry = py; rz = pz; rw = 0.0;
+            if (e < total && lane < MSB) {
+                const int i = (cb + (int)s_near[e]) * MSB + lane;
+                if (i < n) { rx = src[(size_t)i * 3]; ry = src[(size_t)i * 3 + 1]; rz = src[(size_t)i * 3 + 2]; rw = w ? (double)w[i] : 1.0; }
+            }
+#pragma unroll
+            for (int r = 0; r < MSB / 2; ++r) {
+                const double* sp = stage[wv][half * (MSB / 2) + r];
+                const double qx = sp[0], qy = sp[1], qz = sp[2], qw = sp[3];
+                double kk = __dsub_rn(h2, sqdist3d(qx, qy, qz, px, py, pz));
+                kk = kk > 0.0 ? kk : 0.0;
+                kk = __dmul_rn(kk, qw);
+                aw = __dadd_rn(aw, kk);
+                ax = __dadd_rn(ax, __dmul_rn(kk, qx)); ay = __dadd_rn(ay, __dmul_rn(kk, qy)); az = __dadd_rn(az, __dmul_rn(kk, qz));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    part[sl][0][tg] = ax; part[sl][1][tg] = ay; part[sl][2][tg] = az; part[sl][3][tg] = aw;
+    __syncthreads();
+    if (sl == 0) {
+        ax = ay = az = aw = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { ax += part[q][0][tg]; ay += part[q][1][tg]; az += part[q][2][tg]; aw += part[q][3][tg]; }
+        const double den = aw + 1e-10;
+        const double mx = 0.3 * (ax / den - px) + px, my = 0.3 * (ay / den - py) + py, mz = 0.3 * (az / den - pz) + pz;
+        double d2 = 0.0;
+        if (live) {
+            dst[(size_t)j * 3] = mx; dst[(size_t)j * 3 + 1] = my; dst[(size_t)j * 3 + 2] = mz;
+            d2 = (mx - px) * (mx - px) + (my - py) * (my - py) + (mz - pz) * (mz - pz);
+        }
+        double l0 = mx, l1 = my, l2 = mz, h0 = mx, h1 = my, h2b = mz;          // (dead lanes moved with the last point)
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            d2 += __shfl_xor(d2, o);
+            l0 = fmin(l0, __shfl_xor(l0, o)); l1 = fmin(l1, __shfl_xor(l1, o)); l2 = fmin(l2, __shfl_xor(l2, o));
+            h0 = fmax(h0, __shfl_xor(h0, o)); h1 = fmax(h1, __shfl_xor(h1, o)); h2b = fmax(h2b, __shfl_xor(h2b, o));
+        }
+        if (tg == 0) {
+            atomicAdd(&state[t], d2);
+            double* bo = bbox_out + (size_t)blockIdx.x * 6;
+            bo[0] = l0; bo[1] = l1; bo[2] = l2; bo[3] = h0; bo[4] = h1; bo[5] = h2b;
+        }
+    }
+}
+
 // Morton key of a point inside [-2, 2)^3 (10 bits per axis; coordinates outside are clamped), mesh index in the bits above
 __device__ __forceinline__ unsigned part1by2(unsigned v) {
     v &= 0x3ffu;
@@ -748,18 +899,34 @@ extern "C" int morig_meanshift_sorted(const double* pts, const float* weights, c
         max_iter < 1) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
-    const int max_tiles = cdiv(max_n, MS_TILE);
+    static const int tiles = [] { const char* e = getenv("MORIG_MS_TILES"); return e && atoi(e) == 1 ? 1 : 0; }();   // A/B switch
+    const int max_tiles = cdiv(max_n, MS_TILE), max_boxes = cdiv(max_n, MSB);
     hipLaunchKernelGGL(meanshift_state_init_kernel, dim3(cdiv((long)max_iter * n_meshes, 256)), dim3(256), 0, s, state, max_iter, n_meshes);
     MORIG_LAUNCH_CHECK();
     MORIG_HIP_TRY(hipMemcpyAsync(buf_a, pts, sizeof(double) * 3 * (size_t)n_all, hipMemcpyDeviceToDevice, s));
     double* cur = buf_a; double* nxt = buf_b;
-    for (int t = 1; t < max_iter; ++t) {
-        hipLaunchKernelGGL(tile_bbox_kernel, dim3(max_tiles, n_meshes), dim3(MS_TILE), 0, s, cur, ptr, n_all, max_tiles, bbox_ws);
-        MORIG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(meanshift_step_sorted_kernel, dim3(cdiv(max_n, MS_TGT), n_meshes), dim3(MS_TILE), 0, s, cur, weights, ptr, n_all,
-                           bandwidth, t, max_iter, bbox_ws, max_tiles, state, nxt);
-        MORIG_LAUNCH_CHECK();
-        double* tmp = cur; cur = nxt; nxt = tmp;
+    if (tiles) {
+        for (int t = 1; t < max_iter; ++t) {
+            hipLaunchKernelGGL(tile_bbox_kernel, dim3(max_tiles, n_meshes), dim3(MS_TILE), 0, s, cur, ptr, n_all, max_tiles, bbox_ws);
+            MORIG_LAUNCH_CHECK();
+            hipLaunchKernelGGL(meanshift_step_sorted_kernel, dim3(cdiv(max_n, MS_TGT), n_meshes), dim3(MS_TILE), 0, s, cur, weights, ptr, n_all,
+                               bandwidth, t, max_iter, bbox_ws, max_tiles, state, nxt);
+            MORIG_LAUNCH_CHECK();
+            double* tmp = cur; cur = nxt; nxt = tmp;
+        }
+    } else {
+        double* box_cur = bbox_ws; double* box_nxt = bbox_ws + (size_t)n_meshes * max_boxes * 6;
+        if (max_iter > 1) {
+            hipLaunchKernelGGL(box32_kernel, dim3(cdiv(max_n, 256), n_meshes), dim3(256), 0, s, cur, ptr, n_all, max_boxes, box_cur);
+            MORIG_LAUNCH_CHECK();
+        }
+        for (int t = 1; t < max_iter; ++t) {
+            hipLaunchKernelGGL(meanshift_step_box_kernel, dim3(max_boxes, n_meshes), dim3(256), 0, s, cur, weights, ptr, n_all, bandwidth, t,
+                               max_iter, box_cur, box_nxt, max_boxes, state, nxt);
+            MORIG_LAUNCH_CHECK();
+            double* tmp = cur; cur = nxt; nxt = tmp;
+            tmp = box_cur; box_cur = box_nxt; box_nxt = tmp;
+        }
     }
     *result_in_a = (cur == buf_a) ? 1 : 0;
     return MORIG_OK;

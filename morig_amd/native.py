@@ -1003,7 +1003,7 @@ class NativeOps:
         ws = None if weights is None else weights[perm].contiguous()
         a, b = torch.empty_like(ps), torch.empty_like(ps)
         state = torch.empty(max(max_iter, 1) * B, dtype=torch.float64, device=pts.device)
-        bbox = torch.empty(B * ((max_n + 255) // 256) * 24, dtype=torch.float64, device=pts.device)
+        bbox = torch.empty(2 * B * ((max_n + 31) // 32) * 6, dtype=torch.float64, device=pts.device)
         in_a = C.c_int32(0)
         check(self.lib.morig_meanshift_sorted(_p(ps), _p(ws), _p(ptr), B, n, max_n, _p(bandwidth), max_iter, _p(a), _p(b), _p(state),
                                               _p(bbox), C.byref(in_a), _stream()), "morig_meanshift_sorted")
