@@ -376,6 +376,11 @@ int morig_nms_greedy_batched(const double* pts, const float* attn, const int32_t
  * have kernel value 0 exactly, so the result is the unsorted one up to the order of the additions. bbox_ws: 2 * n_meshes * ceil(max_n / 32) * 6
  * doubles (one box per 32 consecutive points, two generations). */
 int morig_morton_keys(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int64_t* keys, void* stream);
+/* morig_nms_counts_batched over point sets in the same sorted order (e.g. the modes as morig_meanshift_sorted leaves them): boxes
+ * of 32 consecutive points farther than the bandwidth from a target block's are skipped -- they hold no neighbour. Counts are
+ * integers: identical to the unsorted kernel's. bbox_ws: n_meshes * ceil(max_n / 32) * 6 doubles. */
+int morig_nms_counts_sorted(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int32_t max_n,
+                            const double* bandwidth, double* bbox_ws, int32_t* counts, void* stream);
 int morig_meanshift_sorted(const double* pts, const float* weights, const int32_t* ptr, int32_t n_meshes, int32_t n_all,
                            int32_t max_n, const double* bandwidth, int32_t max_iter, double* buf_a, double* buf_b,
                            double* state, double* bbox_ws, int32_t* result_in_a, void* stream);

@@ -680,6 +680,20 @@ __global__ void meanshift_state_init_kernel(double* __restrict__ state, int max_
     if (i < max_iter * n_meshes) state[i] = (i % max_iter) == 0 ? 1e20 : 0.0;
 }
 
+// "sqrt(d2) <= h" (numpy compares the ROOTED distance, cluster_utils.py:49, 57) without a square root per pair: correctly rounded
+// sqrt is monotone, so the pairs that pass are exactly those with d2 <= T, T = the largest double whose root is <= h. h * h is within
+// a few ulps of T; walk to it.
+__device__ __forceinline__ double sqrt_le_threshold(double h) {
+    double T = __dmul_rn(h, h);
+    for (int it = 0; it < 64 && sqrt(T) > h; ++it) T = __longlong_as_double(__double_as_longlong(T) - 1);
+    for (int it = 0; it < 64; ++it) {
+        const double u = __longlong_as_double(__double_as_longlong(T) + 1);
+        if (!(sqrt(u) <= h)) break;
+        T = u;
+    }
+    return T;
+}
+
 // ---- NMS (cluster_utils.py:48-51): neighbour counts within the bandwidth (the point itself included) ----
 __global__ __launch_bounds__(256) void nms_counts_kernel(const double* __restrict__ pts_all, const int* __restrict__ ptr, int n_all,
                                                          const double* __restrict__ bandwidth_all, int* __restrict__ counts_all) {
@@ -694,7 +708,7 @@ __global__ __launch_bounds__(256) void nms_counts_kernel(const double* __restric
     const int j = blockIdx.x * 256 + threadIdx.x;
     const bool live = j < n;
     const double px = live ? pts[(size_t)j * 3] : 0.0, py = live ? pts[(size_t)j * 3 + 1] : 0.0, pz = live ? pts[(size_t)j * 3 + 2] : 0.0;
-    const double h = bandwidth[0];
+    const double T = sqrt_le_threshold(bandwidth[0]);
     int c = 0;
     for (int base = 0; base < n; base += 256) {
         const int i = base + threadIdx.x;
@@ -702,9 +716,93 @@ __global__ __launch_bounds__(256) void nms_counts_kernel(const double* __restric
         if (i < n) { sx[threadIdx.x] = pts[(size_t)i * 3]; sy[threadIdx.x] = pts[(size_t)i * 3 + 1]; sz[threadIdx.x] = pts[(size_t)i * 3 + 2]; }
         __syncthreads();
         const int cnt = min(256, n - base);
-        for (int r = 0; r < cnt; ++r) c += sqrt(sqdist3d(sx[r], sy[r], sz[r], px, py, pz)) <= h ? 1 : 0;
+        for (int r = 0; r < cnt; ++r) c += sqdist3d(sx[r], sy[r], sz[r], px, py, pz) <= T ? 1 : 0;
     }
     if (live) counts[j] = c;
+}
+
+// the same counts over Morton-sorted point sets with box culling (the layout of meanshift_step_box_kernel: 32 targets per workgroup,
+// one thread tests one 32-point source box, near boxes dealt to the waves). The modes of a converged mean-shift sit in a few dozen
+// tight clusters, so a target block meets a few per cent of the boxes. A box farther than h (rooted gap, the same monotone chain of
+// roundings as a pair's distance: never larger than any of its pairs') holds no neighbour.
+__global__ __launch_bounds__(256) void nms_counts_box_kernel(const double* __restrict__ pts_all, const int* __restrict__ ptr, int n_all,
+                                                             const double* __restrict__ bandwidth_all, const double* __restrict__ bbox_all,
+                                                             int max_boxes, int* __restrict__ counts_all) {
+    __shared__ double stage[4][MSB][3];
+    __shared__ int part[8][MSB];
+    __shared__ unsigned long long s_mask[4];
+    __shared__ unsigned short s_near[256];
+    int s0, e0;
+    mesh_range(ptr, n_all, s0, e0);
+    const int n = e0 - s0;
+    if ((int)blockIdx.x * MSB >= n) return;
+    const double* src = pts_all + (size_t)s0 * 3;
+    const double* bbox = bbox_all + (size_t)blockIdx.y * max_boxes * 6;
+    const int tid = threadIdx.x, tg = tid & (MSB - 1), sl = tid / MSB, wv = tid >> 6, lane = tid & 63, half = (tid >> 5) & 1;
+    const int j = blockIdx.x * MSB + tg;
+    const int jc = j < n ? j : n - 1;
+    const double px = src[(size_t)jc * 3], py = src[(size_t)jc * 3 + 1], pz = src[(size_t)jc * 3 + 2];
+    double tb[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) tb[a] = bbox[(size_t)blockIdx.x * 6 + a];
+    const double T = sqrt_le_threshold(bandwidth_all[blockIdx.y]);
+    int c = 0;
+    const int n_boxes = (n + MSB - 1) / MSB;
+    for (int cb = 0; cb < n_boxes; cb += 256) {
+        const int b = cb + tid;
+        bool near = false;
+        if (b < n_boxes) {
+            const double* bx = bbox + (size_t)b * 6;
+            double gap2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double g = fmax(fmax(bx[a] - tb[3 + a], tb[a] - bx[3 + a]), 0.0);
+                gap2 += g * g;
+            }
+            near = gap2 <= T;
+        }
+        const unsigned long long mask = __ballot(near);
+        if (cb) __syncthreads();
+        if (lane == 0) s_mask[wv] = mask;
+        __syncthreads();
+        int off = 0, total = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int k = __popcll(s_mask[q]); if (q < wv) off += k; total += k; }
+        if (near) s_near[off + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)tid;
+        __syncthreads();
+        int e = wv;
+        double rx = 1e300, ry = 1e300, rz = 1e300;                             // past the end: infinitely far
+        if (e < total && lane < MSB) {
+            const int i = (cb + (int)s_near[e]) * MSB + lane;
+            if (i < n) { rx = src[(size_t)i * 3]; ry = src[(size_t)i * 3 + 1]; rz = src[(size_t)i * 3 + 2]; }
+        }
+        while (e < total) {
+            if (lane < MSB) { stage[wv][lane][0] = rx; stage[wv][lane][1] = ry; stage[wv][lane][2] = rz; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            e += 4;
+            rx = ry = rz = 1e300;
+            if (e < total && lane < MSB) {
+                const int i = (cb + (int)s_near[e]) * MSB + lane;
+                if (i < n) { rx = src[(size_t)i * 3]; ry = src[(size_t)i * 3 + 1]; rz = src[(size_t)i * 3 + 2]; }
+            }
+#pragma unroll
+            for (int r = 0; r < MSB / 2; ++r) {
+                const double* sp = stage[wv][half * (MSB / 2) + r];
+                c += sqdist3d(sp[0], sp[1], sp[2], px, py, pz) <= T ? 1 : 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    part[sl][tg] = c;
+    __syncthreads();
+    if (sl == 0 && j < n) {
+        int ct = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ct += part[q][tg];
+        counts_all[s0 + j] = ct;
+    }
 }
 
 // ---- NMS greedy pass (cluster_utils.py:54-64), one 1024-thread workgroup: points visited in `order`; a point still
@@ -718,7 +816,7 @@ __global__ __launch_bounds__(NMS_T) void nms_greedy_kernel(const double* __restr
                                                            double thrd_density, float thrd_attn, unsigned char* __restrict__ alive_all) {
     __shared__ int s_cnt[NMS_T / 64];
     __shared__ float s_att[NMS_T / 64];
-    __shared__ int s_alive_i;
+    __shared__ int s_first[NMS_T / 64];
     int s0, e0;
     mesh_range(ptr, n_all, s0, e0);
     const int n = e0 - s0;
@@ -726,27 +824,36 @@ __global__ __launch_bounds__(NMS_T) void nms_greedy_kernel(const double* __restr
     const float* attn = attn_all + s0;
     const int* order = order_all + s0;
     unsigned char* alive = alive_all + s0;
-    const int tid = threadIdx.x;
-    const double h = bandwidth_all[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double T = sqrt_le_threshold(bandwidth_all[blockIdx.y]);
     for (int r = tid; r < n; r += NMS_T) alive[r] = 1;
     __syncthreads();
-    for (int s = 0; s < n; ++s) {
-        const int i = order[s];
-        if (tid == 0) s_alive_i = alive[i];
+    // Only a few dozen of the n visits find their point still alive. The next one is found NMS_T order entries at a time (one per
+    // thread; the flags only change inside a visit) instead of one entry per barrier pair.
+    int s = 0;
+    while (s < n) {
+        const int cand = s + tid;
+        const bool al = cand < n && alive[order[cand]] != 0;
+        const unsigned long long m = __ballot(al);
+        if (lane == 0) s_first[wv] = m ? wv * 64 + (__ffsll((long long)m) - 1) : NMS_T;
         __syncthreads();
-        const bool go = s_alive_i != 0;
-        __syncthreads();                                   // s_alive_i is rewritten by the next iteration
-        if (!go) continue;
+        int first = NMS_T;
+#pragma unroll
+        for (int q = 0; q < NMS_T / 64; ++q) first = min(first, s_first[q]);
+        __syncthreads();                                   // s_first is rewritten by the next round
+        if (first == NMS_T) { s += NMS_T; continue; }      // block-uniform
+        s += first;
+        const int i = order[s];
         const double cx = pts[(size_t)i * 3], cy = pts[(size_t)i * 3 + 1], cz = pts[(size_t)i * 3 + 2];
         int c = 0; float am = -INFINITY;
         for (int r = tid; r < n; r += NMS_T) {
-            if (sqrt(sqdist3d(pts[(size_t)r * 3], pts[(size_t)r * 3 + 1], pts[(size_t)r * 3 + 2], cx, cy, cz)) <= h) {
+            if (sqdist3d(pts[(size_t)r * 3], pts[(size_t)r * 3 + 1], pts[(size_t)r * 3 + 2], cx, cy, cz) <= T) {
                 ++c; am = fmaxf(am, attn[r]); alive[r] = 0;
             }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); am = fmaxf(am, __shfl_xor(am, o)); }
-        if ((tid & 63) == 0) { s_cnt[tid >> 6] = c; s_att[tid >> 6] = am; }
+        if (lane == 0) { s_cnt[wv] = c; s_att[wv] = am; }
         __syncthreads();
         if (tid == 0) {
             int ct = 0; float at = -INFINITY;
@@ -754,6 +861,7 @@ __global__ __launch_bounds__(NMS_T) void nms_greedy_kernel(const double* __restr
             if (at > thrd_attn || (double)ct / (double)n > thrd_density) alive[i] = 1;
         }
         __syncthreads();
+        s += 1;
     }
 }
 
@@ -867,6 +975,20 @@ extern "C" int morig_nms_counts_batched(const double* pts, const int32_t* ptr, i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_JOINTS, s, 0.0, 0.0);
     hipLaunchKernelGGL(nms_counts_kernel, dim3(cdiv(max_n, 256), n_meshes), dim3(256), 0, s, pts, ptr, n_all, bandwidth, counts);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+// counts over Morton-sorted point sets (the order morig_meanshift_sorted works in): box culling, see nms_counts_box_kernel
+extern "C" int morig_nms_counts_sorted(const double* pts, const int32_t* ptr, int32_t n_meshes, int32_t n_all, int32_t max_n,
+                                       const double* bandwidth, double* bbox_ws, int32_t* counts, void* stream) {
+    if (!pts || !ptr || !bandwidth || !bbox_ws || !counts || n_meshes <= 0 || n_all <= 0 || max_n <= 0) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_JOINTS, s, 0.0, 0.0);
+    const int max_boxes = cdiv(max_n, MSB);
+    hipLaunchKernelGGL(box32_kernel, dim3(cdiv(max_n, 256), n_meshes), dim3(256), 0, s, pts, ptr, n_all, max_boxes, bbox_ws);
+    MORIG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nms_counts_box_kernel, dim3(max_boxes, n_meshes), dim3(256), 0, s, pts, ptr, n_all, bandwidth, bbox_ws, max_boxes, counts);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -13,6 +13,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
 import numpy as np
 import torch
 
@@ -106,6 +107,17 @@ def extract_joints(shifted_pts, attn, vox=None, bandwidth_quantile: float = 0.04
     return dict(joints=joints, side=side, bandwidth=float(bw.item()), modes=modes, attn=a)
 
 
+_POOL = None
+
+
+def _sort_pool():
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=max(1, min(8, (os.cpu_count() or 2) // 2)))
+    return _POOL
+
+
 def extract_joints_batched(shifted_pts, attn, batch, vox=None, bandwidth_quantile: float = 0.04, threshold1: float = 0.1,
                            threshold2: float = 0.02, max_iter: int = 30, num_graphs: Optional[int] = None):
     """``extract_joints`` for ALL meshes of a batch at once (the reference loops over models, evaluate/eval_rigging.py:62-98):
@@ -121,13 +133,15 @@ def extract_joints_batched(shifted_pts, attn, batch, vox=None, bandwidth_quantil
     a = _dev_attn(attn, device)
     batch = batch.to(device)
     B = int(num_graphs) if num_graphs is not None else int(batch.max().item()) + 1
-    # attention min-max normalised PER MESH in float32, as numpy does on each loaded array (eval_rigging.py:72)
-    amin = torch.full((B, 1), float("inf"), dtype=torch.float32, device=device).scatter_reduce(0, batch[:, None], a, "amin")
-    amax = torch.full((B, 1), float("-inf"), dtype=torch.float32, device=device).scatter_reduce(0, batch[:, None], a, "amax")
+    # attention min-max normalised PER MESH in float32, as numpy does on each loaded array (eval_rigging.py:72). `batch` is sorted
+    # (PyG), so the per-mesh extrema are segment reductions (a scatter with 64 target addresses serialises on its atomics: 3 ms each)
+    n_per = torch.bincount(batch, minlength=B)
+    amin = torch.segment_reduce(a.reshape(-1), "min", lengths=n_per, unsafe=True)[:, None]
+    amax = torch.segment_reduce(a.reshape(-1), "max", lengths=n_per, unsafe=True)[:, None]
     a = (a - amin[batch]) / (amax[batch] - amin[batch])
     keep = a.squeeze(1) > threshold1
     if vox is not None:
-        counts_v = torch.bincount(batch, minlength=B).tolist()
+        counts_v = n_per.tolist()
         off = 0
         for b, v in enumerate(vox):
             if v is not None:
@@ -157,12 +171,19 @@ def extract_joints_batched(shifted_pts, attn, batch, vox=None, bandwidth_quantil
     if n2 == 0:
         return [dict(joints=np.zeros((0, 3)), side=np.zeros(0), bandwidth=float("nan"), modes=P, attn=A) for _ in range(B)]
     bw = ops.knn_bandwidth_batched(P, ptr, max_n, bandwidth_quantile)
-    modes = ops.meanshift_batched_sorted(P, A.reshape(-1).contiguous(), ptr, max_n, bw, max_iter)
-    counts = ops.nms_counts_batched(modes, ptr, max_n, bw).cpu().numpy().astype(np.int64)     # host round trip 2
+    modes, counts_d = ops.meanshift_batched_sorted(P, A.reshape(-1).contiguous(), ptr, max_n, bw, max_iter, with_counts=True)
+    counts = counts_d.cpu().numpy().astype(np.int64)                        # host round trip 2
     order = np.empty(n2, dtype=np.int32)
-    for b in range(B):
+
+    def _order(b):
         s, e = int(ptr_host[b]), int(ptr_host[b + 1])
         order[s:e] = np.argsort(counts[s:e])[::-1]                        # cluster_utils.py:52, per mesh, local indices
+
+    if B >= 8:                                                            # numpy's sort releases the GIL: the meshes sort side by side
+        list(_sort_pool().map(_order, range(B)))
+    else:
+        for b in range(B):
+            _order(b)
     alive = ops.nms_greedy_batched(modes, A.reshape(-1).contiguous(), ptr, bw, torch.from_numpy(order).to(device), threshold2, 0.7)
     # host round trip 3: only the survivors travel (a few dozen rows per mesh), with their mesh index
     mesh_of = torch.repeat_interleave(torch.arange(B, device=device), torch.as_tensor(sizes, device=device))

@@ -166,6 +166,7 @@ _SIGNATURES = {
     "morig_meanshift_sorted": (C.c_int, [c_f64p, c_f32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, C.c_int32, c_f64p, c_f64p, c_f64p,
                                          c_f64p, c_i32p, C.c_void_p]),
     "morig_nms_counts_batched": (C.c_int, [c_f64p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, c_i32p, C.c_void_p]),
+    "morig_nms_counts_sorted": (C.c_int, [c_f64p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f64p, c_f64p, c_i32p, C.c_void_p]),
     "morig_nms_greedy_batched": (C.c_int, [c_f64p, c_f32p, c_i32p, C.c_int32, C.c_int32, c_f64p, c_i32p, C.c_double, C.c_float, c_u8p,
                                            C.c_void_p]),
     "morig_nms_greedy": (C.c_int, [c_f64p, c_f32p, C.c_int32, c_f64p, c_i32p, C.c_double, C.c_float, c_u8p, C.c_void_p]),
@@ -990,9 +991,11 @@ class NativeOps:
         return a if in_a.value else b
 
     def meanshift_batched_sorted(self, pts: torch.Tensor, weights: Optional[torch.Tensor], ptr: torch.Tensor, max_n: int,
-                                 bandwidth: torch.Tensor, max_iter: int) -> torch.Tensor:
-        """meanshift_batched on Morton-sorted points with bounding-box culling of source tiles (csrc/joints.hip); the result is
-        returned in the caller's point order. Same sums up to the order of the additions (skipped pairs contribute exactly 0)."""
+                                 bandwidth: torch.Tensor, max_iter: int, with_counts: bool = False):
+        """meanshift_batched on Morton-sorted points with bounding-box culling of source boxes (csrc/joints.hip); the result is
+        returned in the caller's point order. Same sums up to the order of the additions (skipped pairs contribute exactly 0).
+        with_counts: also the neighbour counts of the modes within the bandwidth (nms_counts_batched's integers), taken in the sorted
+        order with the same culling -> (modes, counts)."""
         _need_gpu(pts, ptr, bandwidth)
         self._pts64(pts)
         B, n = ptr.numel() - 1, pts.shape[0]
@@ -1007,9 +1010,17 @@ class NativeOps:
         in_a = C.c_int32(0)
         check(self.lib.morig_meanshift_sorted(_p(ps), _p(ws), _p(ptr), B, n, max_n, _p(bandwidth), max_iter, _p(a), _p(b), _p(state),
                                               _p(bbox), C.byref(in_a), _stream()), "morig_meanshift_sorted")
+        modes_sorted = a if in_a.value else b
         out = torch.empty_like(pts)
-        out[perm] = a if in_a.value else b
-        return out
+        out[perm] = modes_sorted
+        if not with_counts:
+            return out
+        cs = torch.empty(n, dtype=torch.int32, device=pts.device)
+        check(self.lib.morig_nms_counts_sorted(_p(modes_sorted), _p(ptr), B, n, max_n, _p(bandwidth), _p(bbox), _p(cs), _stream()),
+              "morig_nms_counts_sorted")
+        counts = torch.empty_like(cs)
+        counts[perm] = cs
+        return out, counts
 
     def nms_counts_batched(self, pts: torch.Tensor, ptr: torch.Tensor, max_n: int, bandwidth: torch.Tensor) -> torch.Tensor:
         _need_gpu(pts, ptr, bandwidth)

@@ -467,7 +467,14 @@ def _emu_nms_greedy_batched(self, pts, attn, ptr, bandwidth, order_local, thrd_d
 
 EmuOps.knn_bandwidth_batched = _emu_knn_bandwidth_batched
 EmuOps.meanshift_batched = _emu_meanshift_batched
-EmuOps.meanshift_batched_sorted = _emu_meanshift_batched
+
+
+def _emu_meanshift_batched_sorted(self, pts, weights, ptr, max_n, bandwidth, max_iter, with_counts=False):
+    modes = _emu_meanshift_batched(self, pts, weights, ptr, max_n, bandwidth, max_iter)
+    return (modes, _emu_nms_counts_batched(self, modes, ptr, max_n, bandwidth)) if with_counts else modes
+
+
+EmuOps.meanshift_batched_sorted = _emu_meanshift_batched_sorted
 EmuOps.nms_counts_batched = _emu_nms_counts_batched
 EmuOps.nms_greedy_batched = _emu_nms_greedy_batched
 EmuOps.inside_mask = _emu_inside_mask

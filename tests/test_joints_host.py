@@ -123,6 +123,49 @@ def test_batched_bandwidth_selection_is_exact():
 
 
 @pytest.mark.gpu
+def test_neighbour_counts_match_numpy_rooted_compare():
+    """counts within the bandwidth: the kernels compare d2 <= T (T = the largest double whose root is <= h) instead of
+    sqrt(d2) <= h, and the sorted form skips far boxes -- both must give numpy's integers, also when the bandwidth IS the rooted
+    distance of some pair (equality decides) and for bandwidth 0 on coincident points"""
+    from morig_amd import native
+    ops = native.get_ops()
+    rng = np.random.default_rng(23)
+    dev = torch.device("cuda:0")
+    sets = [rng.normal(0, 0.2, (n, 3)) for n in (700, 33, 1500, 64, 5)]
+    sets[2] = (sets[2][:20][rng.integers(0, 20, 1500)] + rng.normal(0, 1e-3, (1500, 3)))          # tight clusters, as modes are
+    sets[3][:] = sets[3][0]
+    P = torch.from_numpy(np.concatenate(sets)).to(dev)
+    sizes = [len(x) for x in sets]
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    hs = []
+    for x in sets:
+        d = np.sqrt(((x[:, None, :] - x[None, :, :]) ** 2).sum(-1))
+        hs.append(float(np.sort(d[0])[min(len(x) - 1, 7)]))                  # a distance that occurs: d == h for that pair
+    hs[3] = 0.0
+    bw = torch.tensor(hs, dtype=torch.float64, device=dev)
+    plain = ops.nms_counts_batched(P, ptr, max(sizes), bw).cpu().numpy()
+    keys = torch.empty(P.shape[0], dtype=torch.int64, device=dev)
+    native.check(ops.lib.morig_morton_keys(native._p(P), native._p(ptr), len(sets), P.shape[0], native._p(keys), native._stream()), "keys")
+    perm = torch.argsort(keys)
+    Ps = P[perm].contiguous()
+    cs = torch.empty(P.shape[0], dtype=torch.int32, device=dev)
+    bbox = torch.empty(len(sets) * ((max(sizes) + 31) // 32) * 6, dtype=torch.float64, device=dev)
+    native.check(ops.lib.morig_nms_counts_sorted(native._p(Ps), native._p(ptr), len(sets), P.shape[0], max(sizes), native._p(bw), native._p(bbox),
+                                                 native._p(cs), native._stream()), "counts_sorted")
+    srt = torch.empty_like(cs)
+    srt[perm] = cs
+    srt = srt.cpu().numpy()
+    off = 0
+    for b, x in enumerate(sets):
+        dx = x[:, None, :] - x[None, :, :]
+        d = np.sqrt((dx[..., 0] * dx[..., 0] + dx[..., 1] * dx[..., 1]) + dx[..., 2] * dx[..., 2])
+        want = (d <= hs[b]).sum(0)
+        assert (plain[off:off + len(x)] == want).all(), b
+        assert (srt[off:off + len(x)] == want).all(), b
+        off += len(x)
+
+
+@pytest.mark.gpu
 def test_batched_joint_extraction_equals_per_mesh_at_bench_size():
     """8 meshes x 4096 shifted points (+ mirror images), the workload of bench.py's secondary line: every mesh of the batched run
     gives the joints of its own one-mesh run. (The batched mean-shift adds the same non-zero terms in Morton order and skips source

@@ -34,6 +34,9 @@ t_ms0, modes0 = timed(lambda: ops.meanshift_batched(pts, att, ptr, 8192, bw, 30)
 t_ms, modes = timed(lambda: ops.meanshift_batched_sorted(pts, att, ptr, 8192, bw, 30))
 print(f"mean-shift plain {t_ms0:.2f} ms, Morton-sorted + culled {t_ms:.2f} ms, max |diff| {float((modes - modes0).abs().max()):.2e}")
 t_cnt, counts = timed(lambda: ops.nms_counts_batched(modes, ptr, 8192, bw))
+t_msc, (modes_c, counts_c) = timed(lambda: ops.meanshift_batched_sorted(pts, att, ptr, 8192, bw, 30, with_counts=True))
+print(f"neighbour counts: plain kernel {t_cnt:.2f} ms; in sorted order with box culling +{t_msc - t_ms:.2f} ms on top of the mean-shift; "
+      f"equal: {bool((counts_c == counts).all())}")
 ch = counts.cpu().numpy().astype(np.int64)
 t0 = time.perf_counter()
 order = np.concatenate([np.argsort(ch[b * 8192:(b + 1) * 8192])[::-1] for b in range(B)]).astype(np.int32)
