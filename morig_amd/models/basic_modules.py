@@ -199,9 +199,9 @@ class NativeModule(torch.nn.Module):
         if self.training:
             raise NotImplementedError(
                 f"{type(self).__name__}: no train-mode forward on the MI355X-native path for this module. The train-mode FORWARD "
-                "(batch-statistics BatchNorm over vertices / edges, running-buffer updates) exists for jointnet_motion, "
-                "masknet_motion and skinnet_motion (morig_amd/train_forward.py), and so does their BACKWARD pass "
-                "(morig_amd/train_backward.py); CorrNet / DeformNet and standalone blocks have neither yet -- SURVEY.md 8(f-4), DESIGN.md section 9. "
+                "(batch-statistics BatchNorm over vertices / edges, running-buffer updates) and its BACKWARD pass exist for the "
+                "networks the reference trains -- jointnet_motion, masknet_motion, skinnet_motion (morig_amd/train_forward.py, "
+                "train_backward.py), corrnet and deformnet (morig_amd/train_corr.py); standalone blocks have neither -- SURVEY.md 8(f-4), DESIGN.md section 9. "
                 "Call model.eval() for inference.")
 
 

@@ -91,5 +91,15 @@ class DeformNet(NativeModule):
         return pred_flow, vtx_f, pts_f, vis, tau
 
 
+    # ---- model.train() (training/train_deform_pose.py:29-40) ----
+    def _forward_train_grad(self, data):
+        from .. import train_corr
+        return train_corr.deformnet_step(self, data)
+
+    def _forward_train(self, data):
+        from .. import train_corr
+        return train_corr.deformnet_step(self, data)
+
+
 def deformnet(**kwargs):
     return DeformNet(tau_nce=kwargs["tau_nce"], num_interp=kwargs["num_interp"])

@@ -273,11 +273,32 @@ def _emu_knn_interpolate(self, feat: Mat, pos_x: Mat, ptr_x, pos_y: Mat, ptr_y, 
 
 
 def _emu_knn_search(self, pos_x: Mat, ptr_x, pos_y: Mat, ptr_y, n_clouds, max_targets_per_cloud, k):
-    return dict(px=pos_x.view()[:, :3].clone(), py=pos_y.view()[:, :3].clone(), bx=_batch_from_ptr(ptr_x), by=_batch_from_ptr(ptr_y), k=k)
+    """-> (idx [ny, 3] int32, -1 padded; wgt [ny, 3] = 1 / clamp(d^2, 1e-16)): the contract of morig_knn_search"""
+    px, py = pos_x.view()[:, :3], pos_y.view()[:, :3]
+    yi, xi = _P.knn(px, py, k, batch_x=_batch_from_ptr(ptr_x), batch_y=_batch_from_ptr(ptr_y))
+    ny = py.shape[0]
+    idx = torch.full((ny, 3), -1, dtype=torch.int32)
+    wgt = torch.zeros((ny, 3))
+    slot = torch.zeros(ny, dtype=torch.long)
+    diff = px[xi] - py[yi]
+    w = 1.0 / torch.clamp((diff * diff).sum(-1), min=1e-16)
+    for e in range(yi.numel()):                                   # knn lists a target's neighbours consecutively, nearest first
+        t = int(yi[e])
+        idx[t, slot[t]] = int(xi[e]); wgt[t, slot[t]] = w[e]; slot[t] += 1
+    return idx, wgt
 
 
 def _emu_knn_apply(self, feat: Mat, nn, out: Mat):
-    out.view().copy_(_P.knn_interpolate(feat.view(), nn["px"], nn["py"], nn["bx"], nn["by"], k=nn["k"]))
+    idx, wgt = nn
+    f = feat.view()
+    w = torch.where(idx >= 0, wgt, torch.zeros_like(wgt)).unsqueeze(-1)
+    g = f[idx.clamp(min=0).reshape(-1).long()].reshape(idx.shape[0], idx.shape[1], -1)
+    num = torch.zeros((idx.shape[0], f.shape[1]))
+    den = torch.zeros((idx.shape[0], 1))
+    for s_ in range(idx.shape[1]):                                # scatter_add's order: slot by slot
+        num = num + g[:, s_] * w[:, s_]
+        den = den + w[:, s_]
+    out.view().copy_(num / den)
 
 
 def _emu_cosine_nn(self, v: Mat, ptr_v, p: Mat, ptr_p, n_clouds, max_rows_per_cloud):

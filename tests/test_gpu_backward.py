@@ -339,3 +339,18 @@ def test_skinnet_training_step_gradients(monkeypatch):
         PARITY_LOG.append((f"backward:skinnet:{nm}", err * scale, scale, err))
         assert err <= max(2e-4, slack), (nm, err, slack)
     _grad_report("skinnet_f32", mine, ref64, ref32, 0.99)
+
+
+@pytest.mark.parametrize("vismask", [True, False])
+def test_corrnet_training_step_gradients(vismask):
+    """CorrNet in model.train() on the HIP operators (morig_amd/train_corr.py; training/train_corr_pose.py:61-70): forward against
+    the float64 oracle with torch's own float32 run as the yardstick, every parameter's gradient against torch.autograd"""
+    from helpers import check_corrnet_training
+    check_corrnet_training(DEV, vismask)
+
+
+def test_deformnet_training_step_gradients():
+    """DeformNet in model.train() (training/train_deform_pose.py:29-40, 149-153): extractor frozen as the reference trains it,
+    then nothing frozen"""
+    from helpers import check_deformnet_training
+    check_deformnet_training(DEV)

@@ -227,9 +227,22 @@ def test_train_mode_forward_host_wiring(emulated_ops, name):
 
 
 def test_train_mode_modules_without_a_train_path_say_so(emulated_ops):
-    m = models.corrnet(input_feature=3, output_feature=64, temprature=0.07).train()
+    m = bm.SAModule(0.5, 0.2, bm.MLP([3, 8, 8]), 16).train()
     with pytest.raises(NotImplementedError, match="BACKWARD|train-mode"):
-        m(None, True)
+        m(None, torch.zeros(4, 3), torch.zeros(4, dtype=torch.long))
+
+
+@pytest.mark.parametrize("vismask", [True, False])
+def test_corrnet_training_step_host_wiring(emulated_ops, vismask):
+    """SURVEY 8 f-4 / VERDICT r2 missing #4: CorrNet in model.train() through the module API on the emulated op layer
+    (tests/helpers.py::check_corrnet_training; the same check runs on the HIP operators in tests/test_gpu_backward.py)"""
+    from helpers import check_corrnet_training
+    check_corrnet_training("cpu", vismask)
+
+
+def test_deformnet_training_step_host_wiring(emulated_ops):
+    from helpers import check_deformnet_training
+    check_deformnet_training("cpu")
 
 
 def test_modules_pickle_and_deepcopy_without_device_caches(emulated_ops):
