@@ -554,6 +554,32 @@ def main():
             torch.cuda.empty_cache()
         except Exception as e:                                   # the secondary lines never take the headline line down
             secondary["train_step"] = dict(error=repr(e)[:300])
+        # CorrNet in model.train() (morig_amd/train_corr.py; training/train_corr_pose.py:61-70): forward with batch statistics over
+        # vertices, mesh edges and ball-query edges, a stand-in loss on the three outputs, backward -- 8 pairs of a 4 k-vertex mesh
+        # and an 8 k-point cloud
+        try:
+            from morig_amd import models as _models, synth
+            nbc = 8
+            dc = build_batch([3000 + i for i in range(nbc)], args.n_side, with_skin=False, n_pts=8192, dev=dev)
+            cm = _models.corrnet(input_feature=3, output_feature=64, temprature=0.07).train()
+            synth.load_recipe(cm, 0, mild=True).to(dev)
+
+            def corr_train_step():
+                for p_ in cm.parameters():
+                    p_.grad = None
+                ov, op, vis, _ = cm(dc, True)
+                loss = (ov[:, ::7] ** 2).mean() + (op[:, ::5] ** 2).mean() + (vis ** 2).mean()
+                loss.backward()
+                return loss
+            with torch.enable_grad():
+                sdt, _, _ = timed_run(corr_train_step, n_secondary, 1)
+            secondary["corrnet_train_step"] = dict(metric="pairs/sec corrnet TRAINING step (train-mode forward + backward, no optimizer), 4 k-vert mesh + 8 k-point cloud per pair",
+                                                   value=round(nbc * n_secondary / sdt, 2), unit="pairs/s", ms_per_step=round(sdt / n_secondary * 1e3, 3),
+                                                   steps=n_secondary, warmup=1, batch=nbc, config="SURVEY 8(f-4); exact-fp32 MFMA contractions")
+            del cm, dc
+            torch.cuda.empty_cache()
+        except Exception as e:
+            secondary["corrnet_train_step"] = dict(error=repr(e)[:300])
         # the joint extraction that follows the networks (evaluate/eval_rigging.py:72-95): per mesh 4096 shifted points
         # + their mirror images, bandwidth, 29 weighted mean-shift steps, NMS, flip -- for ALL meshes of the batch at once
         # (segment-aware kernels), next to the one-mesh-per-call form the reference has
