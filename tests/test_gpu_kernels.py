@@ -629,6 +629,55 @@ def test_split_fp16_overflow_is_flagged_and_forward_falls_back():
     assert maxdiff(got, want) <= 1e-4 * max(1.0, want.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 544), (1100, 256, 288), (1024, 256, 64), (33000, 512, 96), (2049, 768, 320)])
+@pytest.mark.parametrize("y_split,relu,bn", [(False, True, True), (True, True, True), (False, False, False)])
+def test_gemm_fp32_x_producer_consumer(M, N, K, y_split, relu, bn):
+    """gemm_x32.hip: fp32 X, N a multiple of 256, K a multiple of 32 -- persistent producer / consumer waves (the GCU vertex MLP
+    shapes K = 544 -> 512 and 288 -> 256 among them): ragged last row tile, fp32 and split-layout outputs, plain Linear"""
+    from morig_amd import native
+    o = native.get_ops()
+    o.precision = "f16x3"
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K + 4, generator=g) * 3.0
+    x[:, K:] = float("nan")                                  # nothing beyond K may be read into the sums
+    lin = _lin(N, K, 7, bn)
+    want = torch.zeros(M, N)
+    EmuOps().gemm(Mat.of(x, 0, K), lin, relu, Y=Mat.of(want))
+    xg, ling = x.to(DEV), packing.to_device(lin, DEV)
+    if y_split:
+        ys = torch.zeros(M, N + 32, device=DEV)
+        o.gemm(Mat.of(xg, 0, K), ling, relu, Y=Mat.of(ys, 32, N), y_split=True)
+        torch.cuda.synchronize()
+        got = packing.unsplit_f16(ys.cpu(), N + 32)[:, 32:32 + N]
+        assert float(ys[:, :32].abs().sum()) == 0
+    else:
+        yb = torch.zeros(M, N + 8, device=DEV)
+        o.gemm(Mat.of(xg, 0, K), ling, relu, Y=Mat.of(yb, 4, N))
+        torch.cuda.synchronize()
+        got = yb[:, 4:4 + N].cpu()
+        assert float(yb[:, :4].abs().sum()) == 0 and float(yb[:, 4 + N:].abs().sum()) == 0
+    assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_gemm_fp32_x_runs_on_the_producer_consumer_kernel():
+    """the dispatcher picks gemm_x32_pc_kernel for the GCU vertex-MLP shape (profiling kind gemm_f16x3_x32pc)"""
+    from morig_amd import native
+    o = native.get_ops()
+    o.precision = "f16x3"
+    lin = packing.to_device(_lin(512, 544, 3, True), DEV)
+    x = torch.randn(4096, 544, device=DEV)
+    y = torch.zeros(4096, 512, device=DEV)
+    native.prof_reset()
+    native.prof_enable(True)
+    try:
+        o.gemm(Mat.of(x), lin, True, Y=Mat.of(y))
+        torch.cuda.synchronize()
+        kinds = native.prof_collect()
+    finally:
+        native.prof_enable(False)
+    assert "gemm_f16x3_x32pc" in kinds and kinds["gemm_f16x3_x32pc"]["symbol"] == "gemm_x32_pc_kernel", kinds
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 512, 544), (1000, 1024, 867), (129, 64, 64), (4096, 256, 1024)])
 def test_gemm_split_fp16_activation_layout(M, N, K):
     """X consumed and Y produced in the split-fp16 activation layout (chunk = [32 hi | 32 lo])."""
