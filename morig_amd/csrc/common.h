@@ -15,7 +15,7 @@ enum Kind : int {
     K_GEMM16_BN128, K_GEMM16_BN64, K_GEMM16_BN32, K_GEMM16_POOL,
     K_EDGE16_H32, K_EDGE16_H64, K_EDGE16_H128, K_EDGE16_H256, K_POINTCONV16, K_GEMM16_DMA,
     K_COSINE_KNN, K_FLOW_VOTE, K_JOINTS,
-    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH, K_EDGE16_X3, K_EDGE_X3, K_EDGE16_X3P, K_GEMM16_X32PC,
+    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH, K_EDGE16_X3, K_EDGE_X3, K_EDGE16_X3P,
     K_COUNT
 };
 static_assert(K_COUNT <= MORIG_PROF_KINDS, "raise MORIG_PROF_KINDS");
@@ -72,8 +72,6 @@ int reserved_cus();
 int launch_edge_pp(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pp.hip (persistent)
 int launch_edge_ws(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_ws.hip (persistent, W2 resident in registers; 4-aligned CSR)
 int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); // gemm_dma.hip
-bool gemm_x32_pc_takes(int M, int N, int K, bool rowbias);                   // gemm_x32.hip: fp32 X, producer / consumer waves
-int launch_gemm_x32_pc(const GemmDmaParams& p, hipStream_t s);
 struct EdgeX3Params {
     const float* X; int ldx;                       // [rows][ldx >= 4]: 3 input channels per vertex
     const float* W1a; const float* W1b; const float* b1;      // [32][4], [32][4], [32]

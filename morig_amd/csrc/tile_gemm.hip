@@ -673,15 +673,6 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         ProfScope ps(K_GEMM16_DMA, s, flops, bytes);
         return launch_gemm16_dma(q, tiles_m, s);
     }
-    if (f16 && !a->x_split && gemm_x32_pc_takes(a->M, a->N, a->K, a->rowbias != nullptr)) {
-        // fp32 X, wide output: persistent producer / consumer waves (gemm_x32.hip) -- X is converted once per 256 output columns
-        GemmDmaParams q = {};
-        q.M = a->M; q.N = a->N; q.K = a->K; q.X = a->X; q.ldx = a->ldx; q.W = p.W; q.ldw = p.ldw;
-        q.bias = a->bias; q.scale = a->scale; q.shift = a->shift; q.relu = a->relu;
-        q.Y = a->Y; q.ldy = a->ldy; q.y16 = a->y_split ? 1 : 0; q.ovf = a->overflow;
-        ProfScope ps(K_GEMM16_X32PC, s, flops, bytes);
-        return launch_gemm_x32_pc(q, s);
-    }
     if (a->N > 64) {
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_BN128 : K_GEMM_BN128, s, flops, bytes);
