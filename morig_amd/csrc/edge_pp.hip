@@ -50,16 +50,9 @@ __device__ __forceinline__ void pp_barrier() {
 #define PP_TS(k) do { } while (0)
 #endif
 
-// NPW: producer waves. 4: as described above. 8 (H = 128 on 4-aligned CSRs only): the producers are that kernel's critical path --
-// per tile their gathers, adds and splits take longer than the consumers' MFMAs -- so the same work is
-// spread over twice the waves (two per SIMD beside one consumer: an in-order wave waiting for its own loads or LDS round trips
-// leaves the issue slots to its neighbour); 12 waves per workgroup, 170 registers per wave.
-template <int H, bool QUAD, int NPW = 4>
-__global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcParams p) {
-    static_assert(NPW == 4 || (NPW == 8 && QUAD && H == 128), "8 producer waves: quad-mode H = 128 only");
+template <int H, bool QUAD>
+__global__ __launch_bounds__(512, 2) void edge_pp_kernel(const EdgePcParams p) {
     constexpr int BM = 128, KC = 32, LDB = 144;         // LDB: bytes per LDS row = [32 hi | 32 lo | 16 pad]
-    constexpr int RS = 8 * NPW;                         // tile rows one producer pass covers (8 threads per row)
-    constexpr int NI = BM / RS;                         // producer passes per chunk
     constexpr int NT = H / 64;                          // consumer wave tile: 64 rows x H/2 cols
     constexpr int MT = 2;
     constexpr int NCHUNK = H / KC;
@@ -70,7 +63,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcPar
     constexpr int ZQ = H + 4;                           // quad mode: 32 quad-rows x H columns (+4: 16-byte rows, 2-way store conflicts only)
     constexpr int ZC = 64, ZLD = ZC + 1;                // general mode: 128 rows x 64 columns per pass
     constexpr int ZB = (32 * ZQ > BM * ZLD ? 32 * ZQ : BM * ZLD) * 4;
-    constexpr int ATAB = QUAD ? NPW * 1024 : 0;         // quad mode: per producer wave, (32 / NPW) quads x 128 B of A rows for one chunk (1 KB slots)
+    constexpr int ATAB = QUAD ? 4 * 1024 : 0;           // quad mode: per producer wave, 8 quads x 128 B of A rows for one chunk
     __shared__ __attribute__((aligned(16))) char smem[WRESB + 2 * STAGE + ZB + 2 * BM * 4 + 32 + 3 * H * 4 + ATAB];
     char* wres = smem;                                  // [chunk][row][LDB]
     char* aring = smem + WRESB;
@@ -243,8 +236,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcPar
         if (p.dbg & 1) return;
         if constexpr (QUAD && H == 128) {                   // the consumer waves scan 6 quad-rows each; the producers, which are the
             if constexpr (!is_producer) scan_quad(rep, sseg, fc, lc, IC<6>{}, wave);     // critical path, stage the next tile's
-            else if constexpr (NPW == 4) scan_quad(rep, sseg, fc, lc, IC<2>{}, 12 + (wave - 4));   // chunk 1 first and then take 2
-            else scan_quad(rep, sseg, fc, lc, IC<1>{}, 24 + (wave - 4));                 // (8 producer waves: 1) each
+            else scan_quad(rep, sseg, fc, lc, IC<2>{}, 12 + (wave - 4));                 // chunk 1 first and then take 2 each
             return;
         }
         if constexpr (QUAD) {                               // H = 256: the consumers scan alone (8 each), the producers only stage
@@ -265,30 +257,30 @@ __global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcPar
     };
 
     if (producer) {
-        // ---------------- producers: 64 NPW threads, thread (row = pt/8 + RS i, 16-byte piece = pt%8) ----------------
+        // ---------------- producers: 256 threads, thread (row = pt/8 + 32 i, 16-byte piece = pt%8) ----------------
         const int pt = tid - 256;
         const int lrow = pt >> 3, lkq = pt & 7;
-        unsigned oa[NI], ob[NI];                             // byte offsets of this thread's NI gathered rows (< 4 GB per replica)
+        unsigned oa[4], ob[4];                               // byte offsets of this thread's 4 gathered rows (< 4 GB per replica)
         // quad mode (4-aligned segments): the four rows of a quad share their destination, so A[dst] is fetched once
         // per QUAD: this lane loads piece (lane & 7) of quad qe of its own wave's 8 quads into a 1 KB per-wave LDS
         // table, from which the wave's threads take the A piece of each of their 4 rows (1 gather + 4 ds_reads
         // instead of 4 gathers per chunk)
-        const int pw4 = pt >> 6;                             // producer wave; it holds 2 quads of every pass: lanes 16 i + 8 q + piece
-        const int qe = (RS / 4) * ((lane >> 4) & (NI - 1)) + 2 * pw4 + ((lane >> 3) & 1);     // (NPW = 8: lanes 32.. repeat lanes 0..31)
+        const int pw4 = pt >> 6;
+        const int qe = 8 * ((lane >> 4) & 3) + 2 * pw4 + ((lane >> 3) & 1);
         char* atab_w = atab + pw4 * 1024;
         const char* atab_r = atab_w + ((pt >> 5) & 1) * 128 + lkq * 16;      // + 256 i
         unsigned oq = 0; int nq = 0;
         f32x4 ta[2];
         const char* abase = reinterpret_cast<const char*>(p.A);             // + replica offset: wave-uniform, lives in SGPRs
         const char* bbase = reinterpret_cast<const char*>(p.B);
-        int nd[NI], ns[NI], nprev, nlast, nafter;           // next tile's indices, in flight
+        int nd[4], ns[4], nprev, nlast, nafter;             // next tile's indices, in flight
         int nrow0 = 0, nrep = 0;
         auto load_indices = [&](int j) __attribute__((always_inline)) {
             const int t = tile_of(j);
             nrep = t / tpr; nrow0 = (t - nrep * tpr) * BM;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int row = min(nrow0 + lrow + RS * i, Etot - 1);
+            for (int i = 0; i < 4; ++i) {
+                const int row = min(nrow0 + lrow + 32 * i, Etot - 1);
                 if constexpr (!QUAD) nd[i] = p.dstS[row];
                 ns[i] = p.srcS[row];
             }
@@ -302,12 +294,12 @@ __global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcPar
             bbase = reinterpret_cast<const char*>(p.B + (size_t)nrep * p.rep_in * p.ldb);
             int* sseg = sseg_all + (j & 1) * BM;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const bool valid = nrow0 + lrow + RS * i < Etot;
+            for (int i = 0; i < 4; ++i) {
+                const bool valid = nrow0 + lrow + 32 * i < Etot;
                 if constexpr (!QUAD) oa[i] = ((unsigned)nd[i] * (unsigned)p.lda + 4u * lkq) * 4u;   // rows past the end re-read the
                 ob[i] = ((unsigned)ns[i] * (unsigned)p.ldb + 4u * lkq) * 4u;          // last edge: finite, ignored by the scan (id -1)
                 if (p.dbg & 4) oa[i] = ob[i] = 16u * lkq;                              // ablation: every gather hits row 0
-                if constexpr (!QUAD) { if (lkq == 0) sseg[lrow + RS * i] = valid ? nd[i] : -1; }
+                if constexpr (!QUAD) { if (lkq == 0) sseg[lrow + 32 * i] = valid ? nd[i] : -1; }
             }
             if constexpr (QUAD) {
                 oq = ((unsigned)nq * (unsigned)p.lda + 4u * lkq) * 4u;
@@ -325,26 +317,26 @@ __global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcPar
         };
         const unsigned ow = ((unsigned)lrow * (unsigned)p.ldw + 4u * lkq) * 4u;
         const char* wbase = reinterpret_cast<const char*>(p.W);
-        constexpr int PW = H / RS;                          // W2 passes of RS rows
-        f32x4 ra[2][NI], rb[2][NI], rw[PW];                 // gathers: two chunks in flight; W2 (L2-resident): one
+        constexpr int PW = H / 32;                          // W2 passes of 32 rows
+        f32x4 ra[2][4], rb[2][4], rw[PW];                   // gathers: two chunks in flight; W2 (L2-resident): one
         auto fetch_w = [&](int c) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 unsigned o = ow;
                 asm volatile("" : "+v"(o));                 // keep the (scalar base + 32-bit lane offset) form: no hoisted 64-bit VGPR pairs
-                rw[i] = *reinterpret_cast<const f32x4*>(wbase + (size_t)i * RS * p.ldw * 4 + c * KC * 4 + o);
+                rw[i] = *reinterpret_cast<const f32x4*>(wbase + (size_t)i * 32 * p.ldw * 4 + c * KC * 4 + o);
             }
         };
         auto stage_w = [&](int c) __attribute__((always_inline)) {
             char* sB = WRES ? wres + c * (H * LDB) : aring + (c & 1) * STAGE + BM * LDB;
 #pragma unroll
-            for (int i = 0; i < PW; ++i) *reinterpret_cast<f32x4*>(sB + (lrow + RS * i) * LDB + 16 * lkq) = rw[i];
+            for (int i = 0; i < PW; ++i) *reinterpret_cast<f32x4*>(sB + (lrow + 32 * i) * LDB + 16 * lkq) = rw[i];
         };
         float amax = 0.f;
         auto fetch_g = [&](int c, auto setc) __attribute__((always_inline)) {
             constexpr int S = decltype(setc)::value;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 if constexpr (!QUAD) ra[S][i] = *reinterpret_cast<const f32x4*>(abase + c * KC * 4 + oa[i]);
                 rb[S][i] = *reinterpret_cast<const f32x4*>(bbase + c * KC * 4 + ob[i]);
             }
@@ -353,14 +345,14 @@ __global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcPar
         auto stage_a = [&](int c, auto setc) __attribute__((always_inline)) {
             constexpr int S = decltype(setc)::value;
             char* sA = aring + (c & 1) * STAGE;
-            f32x4 qa[NI];
+            f32x4 qa[4];
             if constexpr (QUAD) {                           // same-wave LDS hand-over: the LDS executes a wave's operations in order
-                *reinterpret_cast<f32x4*>(atab_w + (lane & (16 * NI - 1)) * 16) = ta[S];
+                *reinterpret_cast<f32x4*>(atab_w + lane * 16) = ta[S];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) qa[i] = *reinterpret_cast<const f32x4*>(atab_r + 256 * i);
+                for (int i = 0; i < 4; ++i) qa[i] = *reinterpret_cast<const f32x4*>(atab_r + 256 * i);
             }
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 f32x4 v;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = fmaxf((QUAD ? qa[i][q] : ra[S][i][q]) + rb[S][i][q], 0.f);
@@ -371,7 +363,7 @@ __global__ __launch_bounds__(256 + 64 * NPW) void edge_pp_kernel(const EdgePcPar
                 split_pair_f16(v[2], v[3], h1, l1);
                 h[0] = h0; h[1] = h1; l[0] = l0; l[1] = l1;
                 amax = fmaxf(amax, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));               // v >= 0 after the ReLU
-                char* rowp = sA + (lrow + RS * i) * LDB + 8 * lkq;
+                char* rowp = sA + (lrow + 32 * i) * LDB + 8 * lkq;
                 *reinterpret_cast<b32x2*>(rowp) = h;
                 *reinterpret_cast<b32x2*>(rowp + 64) = l;
             }
@@ -516,10 +508,8 @@ int launch_edge_pp(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     if (avail < 8) avail = 8;
     const int grid = nblocks < avail ? ((nblocks + 7) / 8) * 8 : avail;  // one persistent workgroup per CU, multiple of 8 (XCDs)
 #define PP_LAUNCH(HH, QQ) hipLaunchKernelGGL((edge_pp_kernel<HH, QQ>), dim3(grid), dim3(512), 0, s, p)
-    static const bool p8 = [] { const char* e = getenv("MORIG_PP_PRODUCERS"); return !e || atoi(e) != 4; }();   // A/B switch: 4 = the 8-wave form
     if (p.H == 256 && p.quad) PP_LAUNCH(256, true);
     else if (p.H == 256) PP_LAUNCH(256, false);
-    else if (p.H == 128 && p.quad && p8) hipLaunchKernelGGL((edge_pp_kernel<128, true, 8>), dim3(grid), dim3(768), 0, s, p);
     else if (p.H == 128 && p.quad) PP_LAUNCH(128, true);
     else if (p.H == 128) PP_LAUNCH(128, false);
     else return MORIG_E_UNSUPPORTED;
