@@ -166,6 +166,45 @@ def test_neighbour_counts_match_numpy_rooted_compare():
 
 
 @pytest.mark.gpu
+def test_sorted_kernels_on_large_and_ragged_sets():
+    """point sets beyond one 256-box chunk (20 000 and 9 000 points next to a 40-point one): the box-granular mean-shift and the
+    culled neighbour counts walk several chunks of source boxes per target block; beyond 65 535 points the bandwidth selection
+    takes the one-row kernel (16-bit bins no longer hold the counts). Against the plain (unsorted, unculled) kernels."""
+    from morig_amd import native
+    ops = native.get_ops()
+    rng = np.random.default_rng(41)
+    dev = torch.device("cuda:0")
+    sizes = [20000, 40, 9000]
+    sets = []
+    for n in sizes:
+        c = rng.uniform(-0.4, 0.4, (12, 3))
+        sets.append(c[rng.integers(0, 12, n)] + rng.normal(0, 0.04, (n, 3)))
+    P = torch.from_numpy(np.concatenate(sets)).to(dev)
+    A = torch.from_numpy((rng.random(sum(sizes)) ** 2).astype(np.float32)).to(dev)
+    ptr = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=dev)
+    bw = ops.knn_bandwidth_batched(P, ptr, max(sizes), 0.02)
+    plain = ops.meanshift_batched(P, A, ptr, max(sizes), bw, 12)
+    modes, counts = ops.meanshift_batched_sorted(P, A, ptr, max(sizes), bw, 12, with_counts=True)
+    assert float((modes - plain).abs().max()) <= 1e-11
+    want = ops.nms_counts_batched(modes, ptr, max(sizes), bw)
+    assert bool((counts == want).all())
+    # 70 000 points in one set: the one-row selection kernel; every 977th row against torch.kthvalue
+    big = torch.from_numpy(rng.normal(0, 0.2, (70000, 3))).to(dev)
+    pb = torch.tensor([0, 70000], dtype=torch.int32, device=dev)
+    k = int(70000 * 0.001)
+    kth = torch.empty(70000, dtype=torch.float64, device=dev)
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    native.check(ops.lib.morig_knn_bandwidth_batched(native._p(big), native._p(pb), 1, 70000, 70000, 0.001, native._p(kth), native._p(out),
+                                                     native._stream()), "bandwidth")
+    rows = torch.arange(0, 70000, 977, device=dev)
+    d = big[rows][:, None, :] - big[None, :, :]
+    d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+    ref = torch.sqrt(torch.kthvalue(d2, k, dim=1).values)
+    assert torch.equal(kth[rows], ref)
+    assert float(out[0]) == pytest.approx(float(kth.mean()), rel=1e-12)
+
+
+@pytest.mark.gpu
 def test_batched_joint_extraction_equals_per_mesh_at_bench_size():
     """8 meshes x 4096 shifted points (+ mirror images), the workload of bench.py's secondary line: every mesh of the batched run
     gives the joints of its own one-mesh run. (The batched mean-shift adds the same non-zero terms in Morton order and skips source
