@@ -457,6 +457,13 @@ int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const int32_t* ro
 /* x[r][c] <- scale[c] * x[r][c] + shift[c], in place (BatchNorm once its statistics are known) */
 int morig_col_affine(float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, const float* scale,
                      const float* shift, void* stream);
+/* BatchNorm1d in training mode after the column statistics (torch.nn.functional.batch_norm; models/basic_modules.py:31-36): the batch
+ * affine s = gamma / sqrt(var + eps), t = beta - mean * s, rstd = 1 / sqrt(var + eps) (may be NULL), and -- when running_mean /
+ * running_var are given -- their update with momentum and the UNBIASED variance (count: [1] float on the device, the rows the
+ * statistics were taken over), num_batches_tracked += 1 (may be NULL). gamma / beta NULL: 1 / 0. */
+int morig_bn_finalize(const float* mean, const float* var, const float* count, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                      float* s, float* t, float* rstd, int32_t n, void* stream);
 /* Z[e] = relu(A[dst_e] + B[src_e]) for the E' = rowptr[n_nodes] edges of a CSR: the first edge ReLU
  * (models/basic_modules.py:193-195 after the per-vertex split of Linear1), materialised for its batch statistics */
 int morig_edge_gather_relu(const float* A, int32_t lda, const float* B, int32_t ldb, const int32_t* rowptr, int32_t n_nodes,

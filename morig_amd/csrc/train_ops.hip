@@ -161,6 +161,44 @@ extern "C" int morig_col_affine(float* x, int32_t ldx, int32_t rows, const int32
     return MORIG_OK;
 }
 
+// ---- BatchNorm1d in training mode, everything that follows the column statistics in ONE launch (torch.nn.functional.batch_norm
+// semantics; models/basic_modules.py:31-36 has momentum = 0.1): the batch affine s = gamma / sqrt(var + eps), t = beta - mean s
+// (biased variance normalises), rstd for the backward, and the running-buffer update with the UNBIASED variance. As torch
+// elementwise calls this was a dozen launches per BatchNorm layer, 182 layers per JointNetMotion step. ----
+__global__ void bn_finalize_kernel(const float* __restrict__ mean, const float* __restrict__ var, const float* __restrict__ count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+                                   float* __restrict__ s, float* __restrict__ t, float* __restrict__ rstd, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && nbt) nbt[0] += 1;
+    if (i >= n) return;
+    const float v = var[i], m = mean[i];
+    const float sd = __fsqrt_rn(v + eps);
+    const float sc = __fdiv_rn(gamma ? gamma[i] : 1.f, sd);
+    s[i] = sc;
+    t[i] = (beta ? beta[i] : 0.f) - m * sc;
+    if (rstd) rstd[i] = __fdiv_rn(1.f, sd);
+    if (running_mean && running_var) {
+        const float c = count[0];
+        const float unbiased = v * (c / fmaxf(c - 1.f, 1.f));
+        running_mean[i] = running_mean[i] * (1.f - momentum) + m * momentum;
+        running_var[i] = running_var[i] * (1.f - momentum) + unbiased * momentum;
+    }
+}
+
+extern "C" int morig_bn_finalize(const float* mean, const float* var, const float* count, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                                 float* s, float* t, float* rstd, int32_t n, void* stream) {
+    if (!mean || !var || !s || !t || n <= 0 || (running_mean == nullptr) != (running_var == nullptr)) return MORIG_E_INVALID;
+    if (running_mean && !count) return MORIG_E_INVALID;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_MISC, st, 0.0, 32.0 * n);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, mean, var, count, gamma, beta, eps, momentum, running_mean,
+                       running_var, reinterpret_cast<long long*>(num_batches_tracked), s, t, rstd, n);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
 extern "C" int morig_edge_gather_relu(const float* A, int32_t lda, const float* B, int32_t ldb, const int32_t* rowptr, int32_t n_nodes,
                                       const int32_t* src_sorted, const int32_t* dst_sorted, int32_t edge_capacity, int32_t H,
                                       float* Z, int32_t ldz, void* stream) {

@@ -125,6 +125,8 @@ _SIGNATURES = {
     "morig_geo_ball_fill": (C.c_int, [c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i64p, C.c_int64, C.c_void_p]),
     "morig_col_stats": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_void_p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "morig_col_affine": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    "morig_bn_finalize": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
+                                    C.c_int32, C.c_void_p]),
     "morig_edge_gather_relu": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
                                          c_f32p, C.c_int32, C.c_void_p]),
     "morig_segmax_affine": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
@@ -702,6 +704,25 @@ class NativeOps:
         _need_gpu(X.base, scale, shift)
         assert scale.numel() >= X.cols and shift.numel() >= X.cols and scale.dtype == shift.dtype == torch.float32
         check(self.lib.morig_col_affine(X.ptr, X.ld, X.rows, _p(rows_dev), X.cols, _p(scale), _p(shift), _stream()), "morig_col_affine")
+
+    def bn_finalize(self, bn, mean: torch.Tensor, var: torch.Tensor, count: torch.Tensor):
+        """BatchNorm1d ``bn`` in training mode after its column statistics, ONE launch: -> (s, t, rstd); the running buffers and
+        num_batches_tracked move in place (``bn.momentum`` must be a number)."""
+        _need_gpu(mean, var, count)
+        n = mean.numel()
+        dev = mean.device
+        out = torch.empty((3, n), dtype=torch.float32, device=dev)
+        track = bn.track_running_stats and bn.running_mean is not None
+        g = bn.weight.detach() if bn.weight is not None else None
+        b = bn.bias.detach() if bn.bias is not None else None
+        for x in (g, b, bn.running_mean if track else None, bn.running_var if track else None):
+            assert x is None or (x.dtype == torch.float32 and x.is_contiguous() and x.device == dev)
+        assert mean.dtype == var.dtype == count.dtype == torch.float32 and mean.is_contiguous() and var.is_contiguous()
+        check(self.lib.morig_bn_finalize(_p(mean), _p(var), _p(count), _p(g), _p(b), float(bn.eps), float(bn.momentum if track else 0.0),
+                                         _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
+                                         _p(bn.num_batches_tracked) if track else None, _p(out[0]), _p(out[1]), _p(out[2]), n, _stream()),
+              "morig_bn_finalize")
+        return out[0], out[1], out[2]
 
     def edge_gather_relu(self, A: Mat, B: Mat, csr: CSR, Z: Mat):
         _need_gpu(A.base, B.base, Z.base)

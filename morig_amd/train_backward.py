@@ -93,10 +93,10 @@ class DenseTrain(torch.autograd.Function):
         y = _buf(xa.shape[0], N, dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=True, Y=Mat.of(y, 0, N))
         mean, var, cnt, share = batch_moments(ops, Mat.of(y, 0, N))
-        s, t = _bn_train(bn, mean, var, cnt)
+        s, t, rstd = _bn_train(bn, mean, var, cnt, want_rstd=True)
         z = y.clone()
         ops.col_affine(Mat.of(z, 0, N), s, t)
-        ctx.save_for_backward(xa, weight, y, mean, torch.rsqrt(var + bn.eps), gamma)
+        ctx.save_for_backward(xa, weight, y, mean, rstd, gamma)
         ctx.dims = (K, N)
         ctx.share = share
         return z[:, :N]
@@ -171,7 +171,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         z1 = _buf(csr.capacity, H, dev)
         ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H))
         mean1, var1, cnt, share1 = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live)
-        s1, t1 = _bn_train(bn1, mean1, var1, cnt)
+        s1, t1, rstd1 = _bn_train(bn1, mean1, var1, cnt, want_rstd=True)
         Hp, Kp = max(H, 32), (H + 31) // 32 * 32
         W2p = torch.zeros((Hp, Kp), dtype=torch.float32, device=dev)
         W2p[:H, :H] = W2.detach().float()
@@ -180,10 +180,10 @@ class EdgeMLPTrain(torch.autograd.Function):
         z2 = _buf(csr.capacity, H, dev)
         ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
         mean2, var2, cnt2, share2 = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
-        s2, t2 = _bn_train(bn2, mean2, var2, cnt2)
+        s2, t2, rstd2 = _bn_train(bn2, mean2, var2, cnt2, want_rstd=True)
         out = _buf(n, H, dev)
         arg = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2)
-        ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, torch.rsqrt(var1 + bn1.eps), mean2, torch.rsqrt(var2 + bn2.eps), g1, g2, s1, t1, arg)
+        ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg)
         ctx.csr = csr
         ctx.dims = (n, C, H)
         ctx.shares = (share1, share2)

@@ -70,19 +70,25 @@ def sync_backward_sums(sdz: torch.Tensor, sdzx: torch.Tensor, share):
     return (gs * share).contiguous(), (gx * share).contiguous(), gs, gx
 
 
-def _bn_train(bn: BatchNorm1d, mean: torch.Tensor, var: torch.Tensor, count: torch.Tensor):
+def _bn_train(bn: BatchNorm1d, mean: torch.Tensor, var: torch.Tensor, count: torch.Tensor, want_rstd: bool = False):
     """batch-statistics affine (s, t) of a BatchNorm1d in training mode + its running-buffer update
-    (torch.nn.functional.batch_norm semantics: biased variance normalises, unbiased variance is tracked)."""
+    (torch.nn.functional.batch_norm semantics: biased variance normalises, unbiased variance is tracked); want_rstd: also
+    1 / sqrt(var + eps) for the backward. One native launch (morig_bn_finalize) when the layer has a numeric momentum --
+    the reference's MLP() has 0.1; the cumulative-average form (momentum=None) reads the batch counter on the host and stays torch."""
+    tracking = bn.track_running_stats and bn.running_mean is not None
+    if bn.momentum is not None or not tracking:
+        from .runtime import get_ops
+        s, t, rstd = get_ops().bn_finalize(bn, mean.contiguous(), var.contiguous(), count)
+        return (s, t, rstd) if want_rstd else (s, t)
     with torch.no_grad():
         s = bn.weight.detach().float() / torch.sqrt(var + bn.eps)
         t = bn.bias.detach().float() - mean * s
-        if bn.track_running_stats and bn.running_mean is not None:
-            bn.num_batches_tracked += 1
-            m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            unbiased = var * (count / torch.clamp(count - 1.0, min=1.0))
-            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
-            bn.running_var.mul_(1.0 - m).add_(unbiased, alpha=m)
-    return s.contiguous(), t.contiguous()
+        bn.num_batches_tracked += 1
+        m = 1.0 / float(bn.num_batches_tracked)
+        unbiased = var * (count / torch.clamp(count - 1.0, min=1.0))
+        bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+        bn.running_var.mul_(1.0 - m).add_(unbiased, alpha=m)
+    return (s.contiguous(), t.contiguous(), torch.rsqrt(var + bn.eps)) if want_rstd else (s.contiguous(), t.contiguous())
 
 
 def _pad_to(v: torch.Tensor, n: int, fill: float) -> torch.Tensor:

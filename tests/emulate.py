@@ -664,6 +664,23 @@ EmuOps.edge_scatter_backward = _emu_edge_scatter_backward
 EmuOps.gemm_tn = _emu_gemm_tn
 EmuOps._flag = _emu_flag
 EmuOps.col_stats = _emu_col_stats
+
+
+def _emu_bn_finalize(self, bn, mean, var, count):
+    with torch.no_grad():
+        sd = torch.sqrt(var + bn.eps)
+        s = (bn.weight.detach().float() if bn.weight is not None else torch.ones_like(var)) / sd
+        t = (bn.bias.detach().float() if bn.bias is not None else torch.zeros_like(var)) - mean * s
+        if bn.track_running_stats and bn.running_mean is not None:
+            bn.num_batches_tracked += 1
+            m = float(bn.momentum)
+            unbiased = var * (count / torch.clamp(count - 1.0, min=1.0))
+            bn.running_mean.mul_(1.0 - m).add_(mean, alpha=m)
+            bn.running_var.mul_(1.0 - m).add_(unbiased, alpha=m)
+    return s.contiguous(), t.contiguous(), (1.0 / sd).contiguous()
+
+
+EmuOps.bn_finalize = _emu_bn_finalize
 EmuOps.col_affine = _emu_col_affine
 EmuOps.edge_gather_relu = _emu_edge_gather_relu
 EmuOps.segmax_affine = _emu_segmax_affine

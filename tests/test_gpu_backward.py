@@ -109,6 +109,33 @@ def test_column_statistics_kernels(rows, cols, ld, c0):
         assert none is None and torch.equal(only, sdz)
 
 
+@pytest.mark.parametrize("n,affine,track", [(1, True, True), (130, True, True), (1024, False, True), (77, True, False)])
+def test_bn_finalize_is_functional_batch_norm(n, affine, track):
+    """morig_bn_finalize against torch.nn.functional.batch_norm in training mode: the normalised output through (s, t), rstd, the
+    running buffers (unbiased variance, momentum 0.1) and num_batches_tracked"""
+    ops = native.get_ops()
+    g = torch.Generator().manual_seed(n)
+    rows = 57
+    x = torch.randn(rows, n, generator=g) * 2.0 + 0.5
+    bn = torch.nn.BatchNorm1d(n, affine=affine, track_running_stats=track)
+    if affine:
+        with torch.no_grad():
+            bn.weight.copy_(torch.randn(n, generator=g)); bn.bias.copy_(torch.randn(n, generator=g))
+    ref = copy.deepcopy(bn).train()
+    want = ref(x)
+    bn = bn.to(DEV)
+    mean = x.mean(0).to(DEV)
+    var = x.var(0, unbiased=False).to(DEV)
+    cnt = torch.tensor([float(rows)], device=DEV)
+    s, t, rstd = ops.bn_finalize(bn, mean, var, cnt)
+    got = x.to(DEV) * s + t
+    assert _rel(got, want) <= 1e-5
+    assert _rel(rstd, torch.rsqrt(x.var(0, unbiased=False) + bn.eps)) <= 1e-6
+    if track:
+        assert _rel(bn.running_mean, ref.running_mean) <= 1e-6 and _rel(bn.running_var, ref.running_var) <= 1e-6
+        assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
 @pytest.mark.parametrize("rows,K,N", [(700, 35, 64), (4096, 832, 128), (257, 3, 16), (513, 20, 30)])
 def test_dense_block_backward(rows, K, N):
     layer = _randomise(nets.mlp_stack([K, N]), K)[0].train()
