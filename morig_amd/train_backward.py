@@ -27,6 +27,7 @@ from __future__ import annotations
 import contextlib
 import math
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -72,24 +73,68 @@ def _pack_f32(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
     return packing.to_device(packing.pack_linear(weight.detach().float(), None if bias is None else bias.detach().float(), split=False), dev)
 
 
-def _gemm_f32(ops, X: Mat, weight: torch.Tensor, n_out: int) -> torch.Tensor:
-    """X @ weight^T on the fp32 MFMA path -> [rows, ld4(n_out)] (columns >= n_out are padding)"""
+def _gemm_f32(ops, X: Mat, weight, n_out: int) -> torch.Tensor:
+    """X @ weight^T on the fp32 MFMA path -> [rows, ld4(n_out)] (columns >= n_out are padding); ``weight``: a tensor, or an
+    already packed Linear (``_pack_f32``)"""
     dev = X.base.device
     out = _buf(X.rows, n_out, dev)
-    ops.gemm(X, _pack_f32(weight, None, dev), relu=False, Y=Mat.of(out, 0, n_out))
+    pk = weight if isinstance(weight, packing.PackedLinear) else _pack_f32(weight, None, dev)
+    ops.gemm(X, pk, relu=False, Y=Mat.of(out, 0, n_out))
     return out
+
+
+# Kernel-layout images of the weights, per nn.Module and valid while the parameters they were made from are unchanged: packing a
+# Linear is ~10 small launches (zero-padded copy, padded bias / scale / shift vectors), a training step packs ~230 of them forwards
+# and again, transposed, backwards -- and motionNet's layers run five times per step on the same weights (measured: ~4 000 of the
+# step's 9 300 launches). Keyed on (data_ptr, _version) of the parameters: optimizer.step() updates in place and bumps the version,
+# load_state_dict() copies in place likewise. (Edits through ``.data`` bypass the counter: call ``clear_pack_cache()`` after them.)
+_PACKS = weakref.WeakKeyDictionary()
+
+
+class _Packs:
+    __slots__ = ("d", "__weakref__")
+
+    def __init__(self):
+        self.d = {}
+
+    def get(self, key, params, build):
+        ver = tuple((q.data_ptr(), q._version, q.device) for q in params if q is not None) + (train_fast(),)
+        hit = self.d.get(key)
+        if hit is None or hit[0] != ver:
+            hit = self.d[key] = (ver, build())
+        return hit[1]
+
+
+class _NoPacks:
+    @staticmethod
+    def get(key, params, build):
+        return build()
+
+
+def packs_of(module):
+    """the pack cache of one nn.Module (a Linear, or a Seq(Linear, ReLU, BN) layer); MORIG_TRAIN_PACK_CACHE=0 switches it off"""
+    if os.environ.get("MORIG_TRAIN_PACK_CACHE", "1") == "0":
+        return _NoPacks
+    c = _PACKS.get(module)
+    if c is None:
+        c = _PACKS[module] = _Packs()
+    return c
+
+
+def clear_pack_cache():
+    _PACKS.clear()
 
 
 class DenseTrain(torch.autograd.Function):
     """one ``Seq(Linear, ReLU, BatchNorm1d)`` of MLP() with batch statistics (models/basic_modules.py:31-36)"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, bn):
+    def forward(ctx, x, weight, bias, gamma, beta, bn, packs=_NoPacks):
         ops = get_ops()
         dev = x.device
         xa = _rows16(x)
         K, N = x.shape[1], weight.shape[0]
-        pk = _pack_fwd(weight, bias, dev)
+        pk = packs.get("fwd", (weight, bias), lambda: _pack_fwd(weight, bias, dev))
         y = _buf(xa.shape[0], N, dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=True, Y=Mat.of(y, 0, N))
         mean, var, cnt, share = batch_moments(ops, Mat.of(y, 0, N))
@@ -99,6 +144,7 @@ class DenseTrain(torch.autograd.Function):
         ctx.save_for_backward(xa, weight, y, mean, rstd, gamma)
         ctx.dims = (K, N)
         ctx.share = share
+        ctx.packs = packs
         return z[:, :N]
 
     @staticmethod
@@ -116,24 +162,28 @@ class DenseTrain(torch.autograd.Function):
         ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), ksdz, ksdzx, DU)
         db, _ = ops.bn_backward_stats(DU)
         dW = ops.gemm_tn(DU, Mat.of(xa, 0, K))
-        dX = _gemm_f32(ops, DU, weight.detach().t().contiguous(), K)[:, :K] if ctx.needs_input_grad[0] else None
-        return dX, dW, db, sdzx, sdz, None
+        dX = None
+        if ctx.needs_input_grad[0]:
+            wt = ctx.packs.get("wT", (weight,), lambda: _pack_f32(weight.detach().t().contiguous(), None, dev))
+            dX = _gemm_f32(ops, DU, wt, K)[:, :K]
+        return dX, dW, db, sdzx, sdz, None, None
 
 
 class NativeLinear(torch.autograd.Function):
     """a bare ``Linear`` (the last layer of mlp_transform, models/rignet.py:57): forward and both gradient GEMMs native"""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, packs=_NoPacks):
         ops = get_ops()
         dev = x.device
         xa = _rows16(x)
         K, N = x.shape[1], weight.shape[0]
-        pk = _pack_fwd(weight, bias, dev)
+        pk = packs.get("fwd", (weight, bias), lambda: _pack_fwd(weight, bias, dev))
         y = _buf(xa.shape[0], N, dev)
         ops.gemm(Mat.of(xa, 0, K), pk, relu=False, Y=Mat.of(y, 0, N))
         ctx.save_for_backward(xa, weight)
         ctx.dims = (K, N, bias is not None)
+        ctx.packs = packs
         return y[:, :N]
 
     @staticmethod
@@ -145,8 +195,11 @@ class NativeLinear(torch.autograd.Function):
         DY = Mat.of(dya, 0, N)
         db = ops.bn_backward_stats(DY)[0] if has_bias else None
         dW = ops.gemm_tn(DY, Mat.of(xa, 0, K))
-        dX = _gemm_f32(ops, DY, weight.detach().t().contiguous(), K)[:, :K] if ctx.needs_input_grad[0] else None
-        return dX, dW, db
+        dX = None
+        if ctx.needs_input_grad[0]:
+            wt = ctx.packs.get("wT", (weight,), lambda: _pack_f32(weight.detach().t().contiguous(), None, dy.device))
+            dX = _gemm_f32(ops, DY, wt, K)[:, :K]
+        return dX, dW, db, None
 
 
 class EdgeMLPTrain(torch.autograd.Function):
@@ -154,16 +207,18 @@ class EdgeMLPTrain(torch.autograd.Function):
     edges (models/basic_modules.py:153-155 / 192-195 in training mode); ``csr``: the unpadded CSR of the loop-normalised graph."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, bn1, bn2, csr: CSR):
+    def forward(ctx, x, W1, b1, g1, be1, W2, b2, g2, be2, bn1, bn2, csr: CSR, packs=_NoPacks):
         assert not csr.quad, "batch statistics over edges need every edge exactly once"
         ops = get_ops()
         dev = x.device
         xa = _rows16(x)
         n, C = x.shape
         H = W1.shape[0]
-        W1f = W1.detach().float()
-        Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)                      # [A | B] = x Wv^T + [b1 | 0]
-        vertex = _pack_fwd(Wv, torch.cat([b1.detach().float(), torch.zeros(H, device=W1.device)], 0), dev)
+        def vertex_pack():
+            W1f = W1.detach().float()
+            Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)                  # [A | B] = x Wv^T + [b1 | 0]
+            return _pack_fwd(Wv, torch.cat([b1.detach().float(), torch.zeros(H, device=W1.device)], 0), dev)
+        vertex = packs.get("vertex", (W1, b1), vertex_pack)
         ab = _buf(n, 2 * H, dev)
         ops.gemm(Mat.of(xa, 0, C), vertex, relu=False, Y=Mat.of(ab, 0, 2 * H))
         A, B = Mat.of(ab, 0, H), Mat.of(ab, H, H)
@@ -173,10 +228,13 @@ class EdgeMLPTrain(torch.autograd.Function):
         mean1, var1, cnt, share1 = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live)
         s1, t1, rstd1 = _bn_train(bn1, mean1, var1, cnt, want_rstd=True)
         Hp, Kp = max(H, 32), (H + 31) // 32 * 32
-        W2p = torch.zeros((Hp, Kp), dtype=torch.float32, device=dev)
-        W2p[:H, :H] = W2.detach().float()
-        pe = packing.PackedEdge(H, _pad_to(s1, Kp, 1.0), _pad_to(t1, Kp, 0.0), W2p.contiguous(), _pad_to(b2.detach().float(), Hp, 0.0),
-                                torch.ones(Hp, device=dev), torch.zeros(Hp, device=dev), None)
+
+        def w2_pack():
+            W2p = torch.zeros((Hp, Kp), dtype=torch.float32, device=dev)
+            W2p[:H, :H] = W2.detach().float()
+            return W2p.contiguous(), _pad_to(b2.detach().float(), Hp, 0.0), torch.ones(Hp, device=dev), torch.zeros(Hp, device=dev)
+        W2p, b2p, ones, zeros = packs.get("w2", (W2, b2), w2_pack)
+        pe = packing.PackedEdge(H, _pad_to(s1, Kp, 1.0), _pad_to(t1, Kp, 0.0), W2p, b2p, ones, zeros, None)
         z2 = _buf(csr.capacity, H, dev)
         ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
         mean2, var2, cnt2, share2 = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
@@ -187,6 +245,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         ctx.csr = csr
         ctx.dims = (n, C, H)
         ctx.shares = (share1, share2)
+        ctx.packs = packs
         return out[:, :H]
 
     @staticmethod
@@ -209,7 +268,8 @@ class EdgeMLPTrain(torch.autograd.Function):
         db2, _ = ops.bn_backward_stats(DU2, rows_dev=e_live)
         # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
         dW2 = ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]
-        dh = _gemm_f32(ops, DU2, W2.detach().t().contiguous(), H)                      # d(s1 Z1 + t1)  [capacity, H]
+        w2t = ctx.packs.get("w2T", (W2,), lambda: _pack_f32(W2.detach().t().contiguous(), None, dev))
+        dh = _gemm_f32(ops, DU2, w2t, H)                                               # d(s1 Z1 + t1)  [capacity, H]
         DH = Mat.of(dh, 0, H)
         # BatchNorm1 + ReLU over the edges
         sdz1, sdzx1 = ops.bn_backward_stats(DH, Z1, mean1, rstd1, rows_dev=e_live)
@@ -224,10 +284,12 @@ class EdgeMLPTrain(torch.autograd.Function):
         dW1 = torch.cat([dWv[:H], dWv[H:] - dWv[:H]], 1)                               # back to [W_a | W_b]: W_v = [[W_a - W_b], [W_b]]
         dX = None
         if ctx.needs_input_grad[0]:                       # (positions and input features are leaves without a gradient)
-            W1f = W1.detach().float()
-            Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)
-            dX = _gemm_f32(ops, DAB, Wv.t().contiguous(), C)[:, :C]
-        return dX, dW1, db1, sdzx1, sdz1, dW2, db2, sdzx2, sdz2, None, None, None
+            def wvt_pack():
+                W1f = W1.detach().float()
+                Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)
+                return _pack_f32(Wv.t().contiguous(), None, dev)
+            dX = _gemm_f32(ops, DAB, ctx.packs.get("wvT", (W1,), wvt_pack), C)[:, :C]
+        return dX, dW1, db1, sdzx1, sdz1, dW2, db2, sdzx2, sdz2, None, None, None, None
 
 
 class SegMaxPool(torch.autograd.Function):
@@ -280,13 +342,18 @@ class RowGather(torch.autograd.Function):
 
 # ---- the reference's modules, composed from the blocks above (parameters are the module's own nn.Parameters) -------------------
 def mlp_layer(x, layer):
-    return DenseTrain.apply(x, layer[0].weight, layer[0].bias, layer[2].weight, layer[2].bias, layer[2])
+    return DenseTrain.apply(x, layer[0].weight, layer[0].bias, layer[2].weight, layer[2].bias, layer[2], packs_of(layer))
+
+
+def linear(x, lin):
+    """a bare nn.Linear on the native forward / backward GEMMs"""
+    return NativeLinear.apply(x, lin.weight, lin.bias, packs_of(lin))
 
 
 def edge_mlp(x, csr: CSR, mlp):
     l1, l2 = mlp[0], mlp[1]
     return EdgeMLPTrain.apply(x, l1[0].weight, l1[0].bias, l1[2].weight, l1[2].bias, l2[0].weight, l2[0].bias, l2[2].weight, l2[2].bias,
-                              l1[2], l2[2], csr)
+                              l1[2], l2[2], csr, packs_of(mlp))
 
 
 def edgeconvmotion(ec, pos, x, csr: CSR):
@@ -309,7 +376,7 @@ def gcnrig(net, pos, feature, csr_tpl: CSR, csr_geo: CSR, batch, mesh_ptr, n_gra
     g = SegMaxPool.apply(mlp_layer(torch.cat([a, b, c], 1), net.mlp_glb[0]), mesh_ptr, n_graphs)
     x5 = torch.cat([RowGather.apply(g, batch, n_graphs), pos, feature, a, b, c], 1)                              # repeat_interleave over sorted batch ids (:64)
     h = mlp_layer(mlp_layer(x5, tr[0][0]), tr[0][1])
-    return NativeLinear.apply(h, tr[1].weight, tr[1].bias)
+    return linear(h, tr[1])
 
 
 def temporal_attn(attn, x):
@@ -407,7 +474,7 @@ def skinnet_inner(net, data, motion, st):
     x3 = gcumotion(net.gcu3, raw, x2, st["csr_tpl"], st["csr_geo"])
     cb = net.cls_branch
     h = mlp_layer(mlp_layer(torch.cat([x3, RowGather.apply(g, st["batch"], st["ng"])], 1), cb[0][0]), cb[0][1])
-    return NativeLinear.apply(h, cb[1].weight, cb[1].bias)
+    return linear(h, cb[1])
 
 
 def skin_motion_step(model, data, input_flow):

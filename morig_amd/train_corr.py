@@ -3,7 +3,7 @@ callers training/train_corr_pose.py:61-70, train_corr_shape.py, train_deform_pos
 
 Composition of the autograd blocks of ``train_backward.py`` -- ``DenseTrain`` (one ``Seq(Linear, ReLU, BatchNorm1d)`` with batch
 statistics: native forward, native dX / dW / BatchNorm backward), ``EdgeMLPTrain`` (EdgeConv's per-edge MLP with statistics over
-the edges and arg-max routed max aggregation), ``SegMaxPool`` / ``RowGather`` (pooling and its broadcast), ``NativeLinear`` -- in
+the edges and arg-max routed max aggregation), ``SegMaxPool`` / ``RowGather`` (pooling and its broadcast), ``NativeLinear`` (``linear``) -- in
 the order of /root/reference/models/corrnet.py:37-77 and models/deformnet.py:40-99:
 
   vertex branch   GCU x 4 (models/basic_modules.py:165-177: two EdgeConvs on [x_i ‖ x_j - x_i], concatenated, MLP) -> mlp_glb ->
@@ -29,7 +29,7 @@ import torch.nn.functional as F
 
 from .native import Mat
 from .runtime import get_ops
-from .train_backward import NativeLinear, RowGather, SegMaxPool, edge_mlp, gcnrig, mlp_layer
+from .train_backward import RowGather, SegMaxPool, edge_mlp, gcnrig, linear, mlp_layer
 
 
 def _mlp(x, layers):
@@ -60,7 +60,7 @@ def vertex_branch(net, data, st):
     g = SegMaxPool.apply(mlp_layer(cat, net.vtx_mlp_glb[0]), st["ptr_v"], st["B"])
     x6 = torch.cat([RowGather.apply(g, st["vtx_batch"], st["B"]), vtx, cat], 1)                    # corrnet.py:45-46
     h = _mlp(x6, net.vtx_mlp[0])
-    return F.normalize(NativeLinear.apply(h, net.vtx_mlp[1].weight, net.vtx_mlp[1].bias), dim=1)
+    return F.normalize(linear(h, net.vtx_mlp[1]), dim=1)
 
 
 def set_abstraction(mod, x, pos4, pos_new4, ptr, out_ptr, B):
@@ -116,7 +116,7 @@ def point_branch(net, data, plan):
     f2 = propagate(net.pts_fp2_module, f3, 2, x1)
     f1 = propagate(net.pts_fp1_module, f2, 1, None)
     h = _mlp(f1, net.pts_mlp[0])
-    return F.normalize(NativeLinear.apply(h, net.pts_mlp[1].weight, net.pts_mlp[1].bias), dim=1)
+    return F.normalize(linear(h, net.pts_mlp[1]), dim=1)
 
 
 def _state(net, data, random_start):
@@ -172,7 +172,7 @@ def _corrnet(net, data, train_vismask, st):
         b = out_pts.index_select(0, nn.long())
         comb = torch.cat([out_vtx, b, (out_vtx * b).sum(1, keepdim=True)], 1)                    # corrnet.py:65
         h = _mlp(comb, net.lin_vismask[0])
-        vis = NativeLinear.apply(h, net.lin_vismask[1].weight, net.lin_vismask[1].bias)
+        vis = linear(h, net.lin_vismask[1])
     return out_vtx, out_pts, vis
 
 

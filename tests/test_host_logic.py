@@ -245,6 +245,32 @@ def test_deformnet_training_step_host_wiring(emulated_ops):
     check_deformnet_training("cpu")
 
 
+def test_training_pack_cache_follows_parameter_updates(emulated_ops):
+    """the per-module cache of kernel-layout weights (train_backward.packs_of) is keyed on the parameters' version counters: an
+    in-place update (optimizer.step(), load_state_dict) must repack, a repeated forward must not"""
+    from morig_amd import train_backward as TB
+    layer = bm.MLP([6, 8])[0].train()
+    x = torch.randn(20, 6, requires_grad=True)
+    with torch.enable_grad():
+        a = TB.mlp_layer(x, layer)
+        cache = TB.packs_of(layer)
+        first = cache.d["fwd"][1]
+        b = TB.mlp_layer(x, layer)
+        assert cache.d["fwd"][1] is first and torch.equal(a, b)
+        opt = torch.optim.SGD(layer.parameters(), lr=0.5)
+        b.sum().backward()
+        with torch.no_grad():
+            layer[0].weight.grad = torch.ones_like(layer[0].weight)
+        opt.step()
+        assert cache.d["wT"][1] is not None                  # the backward's transposed image sits beside the forward's
+        c = TB.mlp_layer(x, layer)
+        assert cache.d["fwd"][1] is not first and not torch.equal(b, c)
+        fresh = copy_module = bm.MLP([6, 8])[0].train()
+        fresh.load_state_dict(layer.state_dict())
+        fresh[2].running_mean.copy_(layer[2].running_mean); fresh[2].running_var.copy_(layer[2].running_var)
+        assert torch.allclose(TB.mlp_layer(x, fresh), TB.mlp_layer(x, layer), atol=1e-6)
+
+
 def test_modules_pickle_and_deepcopy_without_device_caches(emulated_ops):
     """whole-model torch.save / deepcopy after a forward must not drag the kernel-layout cache, HIP streams or the
     last host plan along."""
