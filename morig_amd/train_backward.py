@@ -436,13 +436,15 @@ def _motion_backbone(model, data, input_flow, st, aggr_method):
     return motion_all, F.normalize(aggr, dim=1)
 
 
-def _guarded_step(data, body):
-    """run ``body(st)`` on the model's device. The CSR status words of the graph build are read BEFORE the body runs (an
-    out-of-range edge index raises like the reference's index error, and nothing has touched the BatchNorm buffers yet); the
-    split-fp16 range flag is cleared before and checked after (only MORIG_TRAIN_PRECISION=f16x3 can raise it -- by then the
-    running buffers of this step have moved, as they would have in a step that ends in a NaN loss)."""
+def _guarded_step(data, body, state=None, dev=None):
+    """run ``body(st)`` on the model's device, ``st = state(data)`` (default: ``graph_state``). The CSR status words of the graph
+    build are read BEFORE the body runs (an out-of-range edge index raises like the reference's index error, and nothing has
+    touched the BatchNorm buffers yet); the split-fp16 range flag is cleared before and checked after (only
+    MORIG_TRAIN_PRECISION=f16x3 can raise it -- by then the running buffers of this step have moved, as they would have in a step
+    that ends in a NaN loss)."""
     ops = get_ops()
-    dev = data.pos.device
+    dev = data.pos.device if dev is None else dev
+    state = graph_state if state is None else state
     from .native import MorigNativeError
     with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
         flag = ops._flag(dev)
@@ -451,7 +453,7 @@ def _guarded_step(data, body):
         if collect:
             ops._csr_status = []
         try:
-            st = graph_state(data)
+            st = state(data)
         finally:
             stats = None
             if collect:

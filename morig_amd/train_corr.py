@@ -22,14 +22,12 @@ tensors. There is no CPU fallback: the op layer raises without the HIP library.
 """
 from __future__ import annotations
 
-import contextlib
-
 import torch
 import torch.nn.functional as F
 
 from .native import Mat
 from .runtime import get_ops
-from .train_backward import RowGather, SegMaxPool, edge_mlp, gcnrig, linear, mlp_layer
+from .train_backward import RowGather, SegMaxPool, _guarded_step, edge_mlp, gcnrig, linear, mlp_layer
 
 
 def _mlp(x, layers):
@@ -136,29 +134,9 @@ def _state(net, data, random_start):
 
 
 def _guarded(data, net, random_start, body):
-    """as train_backward._guarded_step: CSR status words read BEFORE any BatchNorm buffer moves, range flag checked after"""
-    ops = get_ops()
-    dev = data.vtx.device
-    from .native import MorigNativeError
-    with (torch.cuda.device(dev) if dev.type == "cuda" else contextlib.nullcontext()):
-        flag = ops._flag(dev)
-        flag.zero_()
-        collect = getattr(ops, "_csr_status", None) is None and hasattr(ops, "_state")
-        if collect:
-            ops._csr_status = []
-        try:
-            st = _state(net, data, random_start)
-            stats = list(ops._csr_status) if collect else None
-        finally:
-            if collect:
-                ops._csr_status = None
-        if stats and any(w != 0 for w in torch.cat(stats).tolist()):
-            raise MorigNativeError("edge_index out of range for the vertex count it was built with (train-mode step)")
-        out = body(st)
-        if int(flag.item()) != 0:
-            raise MorigNativeError("an operand left the split-fp16 range in the train-mode forward: unset MORIG_TRAIN_PRECISION "
-                                   "(the default runs the train-mode contractions on the exact-fp32 MFMA kernels)")
-    return out
+    """train_backward._guarded_step with this file's batch state: CSR status words read BEFORE any BatchNorm buffer moves, range
+    flag checked after"""
+    return _guarded_step(data, body, state=lambda d: _state(net, d, random_start), dev=data.vtx.device)
 
 
 def _corrnet(net, data, train_vismask, st):
