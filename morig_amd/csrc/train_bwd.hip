@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void edge_scatter_bwd_kernel(const float* __re
 // dimensional and XCD-aware: hardware block id i runs on XCD i % 8, so block i takes logical tile (i % 8) * per_xcd + i / 8 and
 // the tiles of one row chunk -- which read the same rows of A and B -- share one XCD's L2 (in tile-major order every XCD
 // streamed the whole of B: 2 GB of L2 misses for a 32768 x 1024 x 1800 weight gradient whose operands are 370 MB).
-constexpr int TN_T = 128, TN_R = 32;
+constexpr int TN_T = 128, TN_R = 16;      // (rows per stage; two stages: the LDS footprint of the old single 32-row stage, 4 workgroups per CU)
 typedef float tn_f32x16 __attribute__((ext_vector_type(16)));
 typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
 
@@ -251,7 +251,10 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                                                       int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
                                                       int n_tiles, int k_tiles, int chunks, int per_xcd,
                                                       float* __restrict__ part /* [chunks][N][K] */) {
-    __shared__ __attribute__((aligned(16))) float sA[TN_R][TN_T + 4], sB[TN_R][TN_T + 4];
+    // two LDS stages: the rows of stage s + 1 are written (from the registers a fetch filled one stage earlier) BETWEEN the MFMAs of
+    // stage s, one barrier per stage. With one stage and two barriers every wave stopped issuing MFMAs for the write phase: 27 % of
+    // the kernel (measurement builds -DTN_NO_LDSW / TN_NO_GLOBAL / TN_NO_MFMA, profiles/r03ac_gemm_tn_ablations.txt).
+    __shared__ __attribute__((aligned(16))) float sA[2][TN_R][TN_T + 4], sB[2][TN_R][TN_T + 4];
     const int rows = rows_dev ? *rows_dev : rows_host;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     // 32-column sub-tiles that lie wholly past N / K (narrow layers: H = 16, 32; K = 3 position inputs) are skipped (wave-uniform)
     const bool on_a[2] = {n0 + wn < N, n0 + wn + 32 < N}, on_b[2] = {k0 + wk < K, k0 + wk + 32 < K};
     tn_f32x4 va[TN_R / 8], vb[TN_R / 8];
-    auto fetch = [&](int r0) {                                      // global -> registers (in flight under the MFMAs of the previous stage)
+    auto fetch = [&](int r0) {                                      // global -> registers (in flight under the MFMAs of a whole stage)
 #pragma unroll
         for (int p = 0; p < TN_R / 8; ++p) {
             const int r = r0 + p * 8 + lr;
@@ -289,29 +292,48 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             }
         }
     };
-    if (r_begin < r_end) fetch(r_begin);
-    for (int r0 = r_begin; r0 < r_end; r0 += TN_R) {
-        __syncthreads();
+    auto put = [&](int st, int p) __attribute__((always_inline)) {
+#ifndef TN_NO_LDSW                                      // (measurement builds, tools/build_variant.sh)
+        *reinterpret_cast<tn_f32x4*>(&sA[st][p * 8 + lr][lc]) = va[p];
+        *reinterpret_cast<tn_f32x4*>(&sB[st][p * 8 + lr][lc]) = vb[p];
+#endif
+    };
+    if (r_begin < r_end) {
+        fetch(r_begin);
 #pragma unroll
-        for (int p = 0; p < TN_R / 8; ++p) {
-            *reinterpret_cast<tn_f32x4*>(&sA[p * 8 + lr][lc]) = va[p];
-            *reinterpret_cast<tn_f32x4*>(&sB[p * 8 + lr][lc]) = vb[p];
-        }
-        __syncthreads();
-        if (r0 + TN_R < r_end) fetch(r0 + TN_R);
-#pragma unroll 4
+        for (int p = 0; p < TN_R / 8; ++p) put(0, p);
+#ifndef TN_NO_GLOBAL
+        if (r_begin + TN_R < r_end) fetch(r_begin + TN_R);
+#endif
+    }
+    __syncthreads();
+    int st = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += TN_R, st ^= 1) {
+        const bool more = r0 + TN_R < r_end;                        // block-uniform
+#pragma unroll
         for (int kk = 0; kk < TN_R; kk += 2) {
             float fa[2], fb[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) fa[a] = on_a[a] ? sA[kk + hi][wn + a * 32 + l31] : 0.f;
+            for (int a = 0; a < 2; ++a) fa[a] = on_a[a] ? sA[st][kk + hi][wn + a * 32 + l31] : 0.f;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) fb[b] = on_b[b] ? sB[kk + hi][wk + b * 32 + l31] : 0.f;
+            for (int b = 0; b < 2; ++b) fb[b] = on_b[b] ? sB[st][kk + hi][wk + b * 32 + l31] : 0.f;
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
+#ifndef TN_NO_MFMA
                     if (on_a[a] && on_b[b]) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+#else
+                    acc[a][b][0] += fa[a] * fb[b];
+#endif
+            // the next stage's rows go to the other buffer behind the first k-steps' MFMAs (their issue slots are free while the
+            // matrix pipe works), then the fetch of the stage after it
+            if (more && kk < 2 * (TN_R / 8)) put(st ^ 1, kk >> 1);
+#ifndef TN_NO_GLOBAL
+            if (kk == 2 * (TN_R / 8) && more && r0 + 2 * TN_R < r_end) fetch(r0 + 2 * TN_R);
+#endif
         }
+        __syncthreads();                                             // stage st consumed by every wave, stage st ^ 1 written
     }
     float* o = part + (size_t)bz * N * K;
 #pragma unroll
@@ -348,7 +370,7 @@ static int tn_chunks(int rows, int N, int K) {
     const int tiles = cdiv(N, TN_T) * cdiv(K, TN_T);
     int chunks = cdiv(1024, tiles);                                   // ~4 workgroups per CU ...
     if (chunks > 512) chunks = 512;                                   // ... and at most 64 additions per lane of the reduction
-    const int max_chunks = cdiv(rows > 0 ? rows : 1, 4 * TN_R);       // at least 128 rows per chunk
+    const int max_chunks = cdiv(rows > 0 ? rows : 1, 128);            // at least 128 rows per chunk
     if (chunks > max_chunks) chunks = max_chunks;
     return chunks < 1 ? 1 : chunks;
 }
