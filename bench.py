@@ -29,7 +29,7 @@ import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0         # MI355X_MICROARCH.md: BF16/FP16 MFMA, dense
-SCLK_UNDER_LOAD_MHZ = 2036.0           # measured (tools/gpu_clocks.sh): the power controller holds ~2.04 GHz under this load; peaks are quoted at 2.4 GHz
+PEAK_SCLK_MHZ = 2400.0                # the clock the peaks above are quoted at; what the chip SUSTAINS is sampled in the run (ClockSampler)
 PEAK_HBM_GBS = 8000.0
 # MORIG_BENCH_PLUMBING=1 (set by tests/ only): gloo + CPU tensors + the torch emulation of the op layer on tiny meshes.
 # It exercises launch / sharding / all-gather / JSON assembly; its numbers are not measurements and the line says so.
@@ -94,6 +94,211 @@ def measured_mfma_util(symbol):
             busy += v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) * d
             cu += v["SQ_BUSY_CU_CYCLES"] * d
     return (round(busy / (4.0 * cu), 4), None) if cu else (None, f"{symbol} not in profiles/mfma_pmc_latest.json")
+
+
+class ClockSampler:
+    """Samples the GPU's shader clock and socket power in a background thread while a timed loop runs (VERDICT r3 #1c: the
+    clock in the line is the clock of THIS run). Sources, first one that answers: the amdsmi Python binding, the amdgpu sysfs
+    nodes (pp_dpm_sclk / hwmon power1_average), `rocm-smi --json`. Never raises: a box without any of them yields no samples
+    and the line says so."""
+
+    def __init__(self, index=0, period=0.05):
+        import threading
+        self.index, self.period = index, period
+        self.samples = []                              # (t, sclk MHz or None, watts or None)
+        self._stop = threading.Event()
+        self._thread = None
+        self.source = None
+        self._read = self._pick_source()
+
+    # -- sources -------------------------------------------------------------------------------------------------
+    def _pick_source(self):
+        for name, make in (("amdsmi", self._make_amdsmi), ("sysfs", self._make_sysfs), ("rocm-smi", self._make_rocm_smi)):
+            try:
+                fn = make()
+                if fn is None:
+                    continue
+                s = fn()
+                if s and (s[0] or s[1]):
+                    self.source = name
+                    return fn
+            except Exception:
+                continue
+        return None
+
+    def _make_amdsmi(self):
+        import amdsmi
+        amdsmi.amdsmi_init()
+        hs = amdsmi.amdsmi_get_processor_handles()
+        if not hs:
+            return None
+        h = hs[min(self.index, len(hs) - 1)]
+
+        def num(v):
+            try:
+                return float(v)
+            except Exception:
+                return None
+
+        def read():
+            clk = pw = None
+            try:
+                ci = amdsmi.amdsmi_get_clock_info(h, amdsmi.AmdSmiClkType.GFX)
+                clk = num(ci.get("clk", ci.get("cur_clk")))
+            except Exception:
+                pass
+            try:
+                pi = amdsmi.amdsmi_get_power_info(h)
+                for k in ("current_socket_power", "average_socket_power", "socket_power"):
+                    v = num(pi.get(k))
+                    if v:
+                        pw = v
+                        break
+            except Exception:
+                pass
+            return clk, pw
+        return read
+
+    def _make_sysfs(self):
+        import glob
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        if not cards:
+            return None
+        dpm = cards[min(self.index, len(cards) - 1)]
+        hw = sorted(glob.glob(os.path.join(os.path.dirname(dpm), "hwmon/hwmon*/power1_average")) +
+                    glob.glob(os.path.join(os.path.dirname(dpm), "hwmon/hwmon*/power1_input")))
+
+        def read():
+            clk = pw = None
+            for line in open(dpm):
+                if "*" in line:
+                    clk = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+            if hw:
+                pw = float(open(hw[0]).read().strip()) / 1e6
+            return clk, pw
+        return read
+
+    def _make_rocm_smi(self):
+        import shutil
+        exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+        if not os.path.exists(exe):
+            return None
+        idx = self.index
+
+        def read():
+            out = subprocess.run([exe, "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=5).stdout
+            card = json.loads(out).get(f"card{idx}", {})
+            clk = pw = None
+            for k, v in card.items():
+                kl = k.lower()
+                if "sclk" in kl and "level" in kl and "(" in str(v):
+                    clk = float(str(v).split("(")[1].lower().replace("mhz)", "").strip())
+                elif "power" in kl and "(w)" in kl:
+                    try:
+                        pw = float(v)
+                    except Exception:
+                        pass
+            return clk, pw
+        return read
+
+    # -- control --------------------------------------------------------------------------------------------------
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                clk, pw = self._read()
+                self.samples.append((time.perf_counter(), clk, pw))
+            except Exception:
+                pass
+            self._stop.wait(self.period)
+
+    def start(self):
+        import threading
+        self.samples = []
+        self._stop.clear()
+        if self._read is not None:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=6)
+            self._thread = None
+        return self
+
+    def summary(self, t0=None, t1=None):
+        """medians over the samples taken inside [t0, t1] (the timed region), skipping the first quarter of them: the power
+        controller needs about a second to settle after the load starts"""
+        ss = [s for s in self.samples if (t0 is None or s[0] >= t0) and (t1 is None or s[0] <= t1)]
+        settled = ss[len(ss) // 4:] if len(ss) >= 8 else ss
+        clk = [s[1] for s in settled if s[1]]
+        pw = [s[2] for s in settled if s[2]]
+        return dict(sclk_under_load_mhz=round(pct(clk, 0.5), 1) if clk else None,
+                    sclk_p10_mhz=round(pct(clk, 0.1), 1) if clk else None, sclk_p90_mhz=round(pct(clk, 0.9), 1) if clk else None,
+                    socket_power_w=round(pct(pw, 0.5), 1) if pw else None,
+                    samples=len(ss), samples_used=len(settled), source=self.source,
+                    period_s=self.period,
+                    note="sampled in a background thread during the timed steps of THIS run (medians; first quarter of the samples dropped as ramp)"
+                         if ss else "no clock source answered on this host (amdsmi / sysfs / rocm-smi)")
+
+
+def roofline_of(prof, psteps, clocks=None):
+    """-> (roofline dict of the dominant kernel symbol, per-kind breakdown, total GPU ms) from one morig_prof_* pass.
+    Launch kinds are grouped by the ONE kernel symbol they run (morig_prof_symbol), so the dominant entry is the object
+    `rocprofv3 --kernel-trace --stats` ranks first and frac follows from profiles/ + this line alone. A dominant kind that
+    declares FLOPs is priced against the dense MFMA peak of its arithmetic; one that declares only bytes against HBM."""
+    from morig_amd import native
+    total_ms = sum(v["ms"] for v in prof.values())
+    by_sym = {}
+    for k, v in prof.items():
+        key = v.get("symbol") or ("kind:" + k)
+        g = by_sym.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, kinds=[], symbol=v.get("symbol")))
+        g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]; g["launches"] += v["launches"]
+        g["kinds"].append(k)
+    dom_key, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+    sclk = (clocks or {}).get("sclk_under_load_mhz")
+    common = dict(kernel=dom["symbol"] or dom_key, kernel_is="rocprofv3 kernel symbol (prefix)" if dom["symbol"] else "launch kind (several symbols)",
+                  launch_kinds=sorted(dom["kinds"]), lib_sha256=lib_sha256(),
+                  launches_per_step=dom["launches"] / psteps, avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
+                  share_of_gpu_time=round(dom["ms"] / total_ms, 4),
+                  timing="HIP events around every launch in a separate pass of %d steps" % psteps,
+                  sclk_under_load_mhz=sclk, socket_power_w=(clocks or {}).get("socket_power_w"),
+                  sclk_source=("%s, %d samples inside the timed region of this run" % ((clocks or {}).get("source"), (clocks or {}).get("samples_used", 0)))
+                              if sclk else "not sampled", peak_quoted_at_mhz=PEAK_SCLK_MHZ)
+    alg_bytes = round(dom["bytes"] / dom["launches"]) if dom["launches"] else None
+    traffic, traffic_why = measured_traffic(dom["symbol"])
+    tr = dict(algorithmic_bytes=alg_bytes,
+              algorithmic_bytes_unit="operand + result bytes per launch as the launcher declares them (fp32 elements, each once)",
+              traffic=traffic, traffic_unavailable=traffic_why,
+              traffic_over_algorithmic=round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
+              traffic_unit="HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc, profiles/traffic_latest.json)")
+    if dom["flops"] > 0:
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        # split-fp16 kernels issue 3 f16 MFMAs per algorithmic product: `achieved` stays ALGORITHMIC flops/s,
+        # `peak` is the dense f16 MFMA peak, so frac <= 1/3 by construction (frac_of_3x_split_peak rescales)
+        split = any("f16x3" in k for k in dom["kinds"]) or (native.get_ops().precision == "f16x3" and any(k in ("cosine_knn",) for k in dom["kinds"]))
+        peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        util, util_why = measured_mfma_util(dom["symbol"])
+        roof = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
+                    algorithmic_flops_per_launch=round(dom["flops"] / dom["launches"]) if dom["launches"] else None,
+                    mfma_issued_per_product=3 if split else 1,
+                    frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
+                    frac_of_3x_split_peak_at_sclk=round(3 * achieved / peak * PEAK_SCLK_MHZ / sclk, 4) if (split and sclk) else None,
+                    mfma_util_counter=util, mfma_util_counter_unavailable=util_why,
+                    mfma_util_counter_source="profiles/mfma_pmc_latest.json (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES)")
+    else:
+        gbs = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
+        roof = dict(bound="hbm", achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(gbs / PEAK_HBM_GBS, 4),
+                    note="the dominant launch kind declares no FLOPs: priced on the bytes its launcher declares against the HBM rate "
+                         "(a latency chain such as farthest-point sampling sits far below either roof by construction)")
+    roof.update(common)
+    roof.update(tr)
+    breakdown = {k: dict(ms_per_step=round(v["ms"] / psteps, 3),
+                         tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
+                         launches_per_step=v["launches"] / psteps, symbol=v.get("symbol"))
+                 for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+    return roof, breakdown, total_ms
 
 
 def cpu_model():
@@ -329,6 +534,8 @@ def main():
                          "(SURVEY 8 f-1), same pairs as corrnet")
     ap.add_argument("--n-pts", type=int, default=8192)
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--secondary-cpu-seconds", type=float, default=10.0,
+                    help="budget of the cpu_baseline leg of each of the mask_skin / corrnet secondary entries (0 = skip)")
     ap.add_argument("--prof-steps", type=int, default=5, help="steps of the second, per-launch-evented pass")
     ap.add_argument("--secondary", type=int, default=-1,
                     help="steps of the short mask_skin / corrnet / deformnet runs added to the jointnet line at N = 1 "
@@ -390,7 +597,15 @@ def main():
 
     data = build_batch(seeds, args.n_side, with_skin=with_skin, n_pts=args.n_pts if pairs else 0, dev=dev).to(dev)
     n_vert = data.pos.shape[0]
-    gather = (lambda t: mdist.all_gather_rows(t, equal_rows=True, even_alone=True)) if use_dist else (lambda t: t)
+    gathered = []                                      # the tensors one step hands to the collective (refreshed every step)
+
+    def gather(t):
+        if not use_dist:
+            return t
+        if gather.record:
+            gathered.append(t)
+        return mdist.all_gather_rows(t, equal_rows=True, even_alone=True)
+    gather.record = False
     step = make_step(args.workload, data, dev, gather)
 
     def sync():
@@ -403,8 +618,11 @@ def main():
             dist.barrier()
             sync()
 
-    def timed_run(step, steps, warmup):
-        """-> (wall seconds for `steps` steps, per-step ms from HIP events, last output)"""
+    def timed_run(step, steps, warmup, sampler=None):
+        """-> (wall seconds for `steps` steps, per-step ms from HIP events, last output); `sampler` (ClockSampler) runs from the
+        first warm-up step on and is summarised over the timed region only"""
+        if sampler is not None:
+            sampler.start()
         for _ in range(warmup):
             out = step()
         if hasattr(step, "drain"):
@@ -424,10 +642,26 @@ def main():
         if hasattr(step, "drain"):
             step.drain()                                # the deferred guard read of the last forward(s) belongs to the timed region
         fence()
-        dt = time.perf_counter() - t0
+        t1 = time.perf_counter()
+        dt = t1 - t0
+        if sampler is not None:
+            sampler.stop()
+            sampler.window = (t0, t1)
         per = ([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)] if ev
                else [(marks[i + 1] - marks[i]) * 1e3 for i in range(steps)])
         return dt, per, out
+
+    def prof_pass(step, n):
+        """second pass: HIP events around every launch, on the launch stream (outside the timed region)"""
+        native.prof_reset()
+        native.prof_enable(True)
+        for _ in range(n):
+            step()
+        if hasattr(step, "drain"):
+            step.drain()
+        fence()
+        native.prof_enable(False)
+        return native.prof_collect()
 
     prof = {}
     with torch.no_grad():
@@ -437,18 +671,33 @@ def main():
             ops.csr_build(data.tpl_edge_index, n_vert)    # learned outside the steps so the FLOP counters use
             ops.csr_build(data.geo_edge_index, n_vert)    # algorithmic edges
             ops.learn_edge_counts = False
-        dt, per_step, out = timed_run(step, args.steps, args.warmup)
+        sampler = None if PLUMBING else ClockSampler(index=local)
+        dt, per_step, out = timed_run(step, args.steps, args.warmup, sampler)
+        clocks = sampler.summary(*sampler.window) if sampler is not None else None
         if not PLUMBING and args.prof_steps > 0:
-            # second pass: HIP events around every launch, on the launch stream (outside the timed region)
-            native.prof_reset()
-            native.prof_enable(True)
-            for _ in range(args.prof_steps):
-                step()
+            prof = prof_pass(step, args.prof_steps)
+
+    allgather_ms = None
+    if use_dist:
+        # the collective on its own: one more step records the tensors it hands to all_gather_rows, then the same
+        # calls are repeated back to back between fences -- what the all-gather of one step costs when nothing hides it
+        with torch.no_grad():
+            gather.record = True
+            step()
             if hasattr(step, "drain"):
                 step.drain()
+            gather.record = False
+            reps = 20
             fence()
-            native.prof_enable(False)
-            prof = native.prof_collect()
+            tg = time.perf_counter()
+            for _ in range(reps):
+                for g_t in gathered:
+                    mdist.all_gather_rows(g_t, equal_rows=True, even_alone=True)
+            fence()
+            allgather_ms = (time.perf_counter() - tg) / reps * 1e3
+        tg_t = torch.tensor([allgather_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tg_t, op=dist.ReduceOp.MAX)
+        allgather_ms = float(tg_t.item())
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     per_rank = [dt]
@@ -473,12 +722,24 @@ def main():
             ns, nw = (4 * n_secondary, 3) if wpairs else (n_secondary, 1)        # the pair workloads are 12-18 ms steps: more of them
             with torch.no_grad():
                 st = make_step(wl, d2, dev, lambda x: x)
-                sdt, sper, _ = timed_run(st, ns, nw)
+                ssampler = ClockSampler(index=local)
+                sdt, sper, _ = timed_run(st, ns, nw, ssampler)
+                sroof = skern = None
+                if args.prof_steps > 0:
+                    # the same per-launch-evented pass as the headline workload: dominant rocprofv3 symbol, frac, bytes / FLOPs per launch
+                    sp_steps = 4 if wpairs else 2
+                    sroof, skern, _ = roofline_of(prof_pass(st, sp_steps), sp_steps, ssampler.summary(*ssampler.window))
             secondary[wl] = dict(metric=NAMES[wl][0], value=round(nb * ns / sdt, 2), unit="pairs/s" if wpairs else "meshes/s",
                                  ms_per_step=round(sdt / ns * 1e3, 3), steps=ns, warmup=nw, batch=nb,
-                                 config=NAMES[wl][2])
+                                 config=NAMES[wl][2], roofline=sroof, kernels=skern)
             del st, d2
             torch.cuda.empty_cache()
+            if args.cpu_seconds > 0 and args.secondary_cpu_seconds > 0 and wl != "deformnet":
+                # BASELINE configs[2] / configs[3] next to the CPU oracle on this host, like the headline line (VERDICT r3 #1a)
+                try:
+                    secondary[wl]["cpu_baseline"] = cpu_baseline_other(wl, args.secondary_cpu_seconds, args.n_side, args.n_pts, 1000)
+                except Exception as e:
+                    secondary[wl]["cpu_baseline"] = dict(error=repr(e)[:300])
         # north_star's one-mesh-per-GPU operating point (and what `--scaling strong --gpus 8` gives each rank: 8 meshes): the same
         # forward at B = 1, 2, 4, 8 meshes per launch set
         try:
@@ -619,50 +880,7 @@ def main():
         roof, breakdown, hbm_kinds, all_flops = None, {}, {}, 0.0
         psteps = max(args.prof_steps, 1)
         if prof:
-            total_ms = sum(v["ms"] for v in prof.values())
-            # group the launch kinds by the ONE kernel symbol they run (morig_prof_symbol): the dominant entry is then the same
-            # object `rocprofv3 --kernel-trace --stats` ranks first, and frac follows from profiles/ + this line alone
-            by_sym = {}
-            for k, v in prof.items():
-                key = v.get("symbol") or ("kind:" + k)
-                g = by_sym.setdefault(key, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, kinds=[], symbol=v.get("symbol")))
-                g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]; g["launches"] += v["launches"]
-                g["kinds"].append(k)
-            dom_key, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
-            achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-            # split-fp16 kernels issue 3 f16 MFMAs per algorithmic product: `achieved` stays ALGORITHMIC flops/s,
-            # `peak` is the dense f16 MFMA peak, so frac <= 1/3 by construction (frac_of_3x_split_peak rescales)
-            split = any("f16x3" in k for k in dom["kinds"])
-            peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-            traffic, traffic_why = measured_traffic(dom["symbol"])
-            util, util_why = measured_mfma_util(dom["symbol"])
-            alg_bytes = round(dom["bytes"] / dom["launches"]) if dom["launches"] else None
-            roof = dict(bound="mfma", kernel=dom["symbol"] or dom_key, kernel_is="rocprofv3 kernel symbol (prefix)",
-                        launch_kinds=sorted(dom["kinds"]),
-                        achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                        frac=round(achieved / peak, 4),
-                        algorithmic_flops_per_launch=round(dom["flops"] / dom["launches"]) if dom["launches"] else None,
-                        algorithmic_bytes=alg_bytes,
-                        algorithmic_bytes_unit="operand + result bytes per launch as the launcher declares them (fp32 elements, each once)",
-                        traffic=traffic, traffic_unavailable=traffic_why,
-                        traffic_over_algorithmic=round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
-                        traffic_unit="HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc, profiles/traffic_latest.json)",
-                        mfma_issued_per_product=3 if split else 1,
-                        frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
-                        sclk_under_load_mhz=SCLK_UNDER_LOAD_MHZ,
-                        sclk_source="rocm-smi sampled while this workload ran: 2.04 GHz at 1.26 kW (profiles/r02m_clocks_under_load.txt); `peak` is quoted at 2.4 GHz",
-                        frac_of_3x_split_peak_at_sclk=round(3 * achieved / peak * 2400.0 / SCLK_UNDER_LOAD_MHZ, 4) if split else None,
-                        mfma_util_counter=util, mfma_util_counter_unavailable=util_why,
-                        mfma_util_counter_source="profiles/mfma_pmc_latest.json (SQ_VALU_MFMA_BUSY_CYCLES / 4 SQ_BUSY_CU_CYCLES)",
-                        lib_sha256=lib_sha256(),
-                        launches_per_step=dom["launches"] / psteps,
-                        avg_launch_ms=round(dom["ms"] / dom["launches"], 4),
-                        share_of_gpu_time=round(dom["ms"] / total_ms, 4),
-                        timing="HIP events around every launch in a separate pass of %d steps" % psteps)
-            breakdown = {k: dict(ms_per_step=round(v["ms"] / psteps, 3),
-                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
-                                 launches_per_step=v["launches"] / psteps, symbol=v.get("symbol"))
-                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+            roof, breakdown, total_ms = roofline_of(prof, psteps, clocks)
             # the index / copy kernels are the HBM-bound ones: bytes the launcher declares / event time, against 8 TB/s
             for k in ("csr_build", "copy", "rownorm"):
                 v = prof.get(k)
@@ -692,15 +910,30 @@ def main():
                        "geo_graph": "built on the device (morig_geo_ball_graph)" if not PLUMBING else "host recipe"},
             "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
             "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank],
+            "allgather_ms_per_step": round(allgather_ms, 4) if allgather_ms is not None else None,
+            "allgather_note": ("the step's %d all_gather_into_tensor call(s) (%s bytes per rank in total) repeated 20x back to back between "
+                               "fences in a separate pass, max over ranks; inside the timed steps the same calls are part of ms_per_step"
+                               % (len(gathered), sum(g_t.numel() * g_t.element_size() for g_t in gathered))) if allgather_ms is not None else None,
             "roofline": roof,
             "hbm_bound_kernels": hbm_kinds,
             "whole_forward_tflops": round(all_flops / (dt / args.steps) / 1e12, 2) if prof else None,
             "kernels": breakdown,
             "secondary": secondary,
         }
-        if world == 1 and args.cpu_seconds > 0 and not PLUMBING and args.workload == "jointnet":
+        res["clocks_under_load"] = clocks
+        if PLUMBING:
+            res["roofline"] = dict(bound="mfma", achieved=None, peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
+                                   note="PLUMBING RUN: no HIP kernel ran (CPU emulation of the op layer); the key is here so that the "
+                                        "line's schema can be checked at any world size")
+        # the CPU oracle on this host's cores, on rank 0, AFTER the timed region (the other ranks wait at the closing barrier), at
+        # every world size: an N > 1 line without it would be unmeasured by rule (VERDICT r3 #1b)
+        if args.cpu_seconds > 0 and not PLUMBING and args.workload == "jointnet":
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)
-        elif world == 1 and args.cpu_seconds > 0 and not PLUMBING:
+        elif args.cpu_seconds > 0 and not PLUMBING:
+            res["cpu_baseline"] = cpu_baseline_other(args.workload, args.cpu_seconds, args.n_side, args.n_pts, 1000)
+        elif PLUMBING and args.cpu_seconds > 0 and args.workload == "jointnet":
+            res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)      # the real oracle, on the plumbing run's tiny meshes
+        elif PLUMBING and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline_other(args.workload, args.cpu_seconds, args.n_side, args.n_pts, 1000)
         else:
             res["cpu_baseline"] = None

@@ -279,6 +279,100 @@ def test_bench_single_rank_line_keeps_the_contract():
     assert "workload" in r["config"] and "model" not in r["config"]
 
 
+# ---- world size 8: the node the north star names has eight ranks; nothing here can measure it, so the plumbing
+# ---- (launch, sharding, ragged and equal-row gathers, the line's contract) is run at that world size on gloo
+_WORKER8 = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], 'tests'))
+torch.set_num_threads(1)
+from morig_amd import dist as mdist, models, synth
+import morig_amd.runtime as runtime
+from emulate import EmuOps
+runtime._test_ops = EmuOps()
+W = 8
+dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%s' % sys.argv[2], rank=int(sys.argv[3]), world_size=W)
+rank = dist.get_rank()
+# 11 meshes of three sizes over 8 ranks: ranks 0..2 hold two meshes, the others one -- ragged row counts on every rank
+sides = [6, 8, 5, 7, 6, 8, 5, 7, 6, 8, 5]
+meshes = [synth.make_mesh(20 + i, n_side=n) for i, n in enumerate(sides)]
+mine = mdist.shard_items(meshes, rank, W)
+assert len(mine) == (2 if rank < 3 else 1)
+m = synth.load_recipe(models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method='attn').eval(), 5, mild=True)
+with torch.no_grad():
+    b = synth.collate(mine)
+    shift = m(b, b.pred_flow)[2]
+    allshift = mdist.all_gather_rows(shift)                      # ragged: count exchange + padded gather
+    order = mdist.unshard_order(len(meshes), W)
+    assert sorted(order) == list(range(len(meshes)))
+    full = synth.collate([meshes[i] for i in order])
+    want = m(full, full.pred_flow)[2]
+    err = (allshift - want).abs().max().item()
+    assert allshift.shape == want.shape and err < 2e-5, err
+    # equal rows: ONE all_gather_into_tensor, rank-major
+    eq = mdist.all_gather_rows(torch.full((3, 2), float(rank)), equal_rows=True)
+    assert eq.shape == (3 * W, 2) and all(bool(eq[3 * r: 3 * r + 3].eq(float(r)).all()) for r in range(W))
+    # a rank with NO rows (fewer meshes than ranks) still takes part in the ragged gather
+    part = torch.full((0 if rank == 5 else rank + 1, 4), float(rank))
+    rg = mdist.all_gather_rows(part)
+    assert rg.shape[0] == sum(0 if r == 5 else r + 1 for r in range(W))
+    off = 0
+    for r in range(W):
+        n = 0 if r == 5 else r + 1
+        assert bool(rg[off: off + n].eq(float(r)).all())
+        off += n
+print('rank', rank, 'ok')
+"""
+
+
+def test_eight_rank_gloo_ragged_and_equal_gathers():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(_WORKER8)
+    try:
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, f.name, ROOT, str(port), str(r)], stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True, env=env) for r in range(8)]
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        for r, (p, o) in enumerate(zip(procs, outs)):
+            assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
+    finally:
+        os.unlink(f.name)
+
+
+def _check_n8_line(r, scaling, per_gpu, total, unit):
+    assert r["n_gpus"] == 8 and r["rccl_ranks"] == 8 and r["backend"] == "gloo" and r["scaling"] == scaling
+    assert r["config"]["meshes_per_gpu"] == per_gpu and r["config"]["global_batch"] == total and r["unit"] == unit
+    assert len(r["per_rank_ms_per_step"]) == 8 and all(x > 0 for x in r["per_rank_ms_per_step"])
+    assert abs(max(r["per_rank_ms_per_step"]) - r["ms_per_step"]) < 1e-6                  # max over ranks is what `value` uses
+    assert abs(r["value"] - total * r["steps"] / (r["ms_per_step"] * r["steps"] * 1e-3)) / r["value"] < 0.02
+    assert r["allgather_ms_per_step"] is not None and r["allgather_ms_per_step"] > 0 and "all_gather_into_tensor" in r["allgather_note"]
+    # the keys an N = 8 line is judged on are all there (roofline / cpu_baseline carry their plumbing notes)
+    assert isinstance(r["roofline"], dict) and r["roofline"]["bound"] in ("mfma", "hbm")
+    cb = r["cpu_baseline"]
+    assert isinstance(cb, dict) and cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == unit
+    assert "PLUMBING" in r["data"] and r["vs_baseline"] is None
+
+
+def test_bench_eight_ranks_weak():
+    r = _bench_line(["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--cpu-seconds", "1"], dict(OMP_NUM_THREADS="1"))
+    _check_n8_line(r, "weak", 2, 16, "meshes/s")
+
+
+def test_bench_eight_ranks_strong():
+    r = _bench_line(["--gpus", "8", "--steps", "2", "--warmup", "0", "--batch", "8", "--scaling", "strong", "--cpu-seconds", "1"],
+                    dict(OMP_NUM_THREADS="1"))
+    _check_n8_line(r, "strong", 1, 8, "meshes/s")
+
+
+def test_bench_eight_ranks_corrnet_pairs():
+    """BASELINE.json configs[3]: cloud pairs sharded over eight ranks, the three outputs gathered (bench.py's pair workloads)"""
+    r = _bench_line(["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--cpu-seconds", "1", "--workload", "corrnet"],
+                    dict(OMP_NUM_THREADS="1"))
+    _check_n8_line(r, "weak", 2, 16, "pairs/s")
+    assert "configs[3]" in r["config"]["workload"] and "3 all_gather_into_tensor" in r["allgather_note"]
+
+
 # ---- RCCL on hardware: the one-GPU box can only hold a world of one rank, but every collective the multi-GPU paths issue
 # ---- (process-group creation on the device, all-reduce, all-gather, barrier) goes through RCCL all the same
 @pytest.mark.gpu
