@@ -372,6 +372,44 @@ def test_ball_query_and_bipartite_csr_bit_exact(ops):
         assert torch.equal(cs.dst.cpu()[:E].long(), torch.repeat_interleave(torch.arange(cen.shape[0]), (cw.rowptr[1:] - cw.rowptr[:-1]).long()))
 
 
+def test_point_kernels_known_answers_ties_and_over_full_balls(ops):
+    """The hand-computed known answers of tests/test_oracle_kat.py (VERDICT r3 #4c) on the HIP kernels themselves, so the device
+    path is pinned to the published torch_cluster / PyG behaviour directly and not only through the restated oracle:
+    over-full ball with coincident points (first 64 hits in index order, strict <), FPS arg-max ties (lowest index), and the
+    bipartite self-loop step of PointConv (raw pair (k, k) dropped, (k, k) appended for every target k)."""
+    # -- radius: 6 far-ish points first, one at exactly r, then 32 coincident pairs at distance 0.1
+    far = [[0.9, 0.0, 0.0]] * 3 + [[0.0, 0.9, 0.0]] * 3
+    x = torch.zeros(71, 4)
+    x[:, :3] = torch.tensor(far + [[1.0, 0.0, 0.0]] + [[0.1, 0.0, 0.0], [0.0, 0.1, 0.0]] * 32)
+    y = torch.zeros(1, 4)
+    ptr_x, ptr_y = torch.tensor([0, 71], dtype=torch.int32), torch.tensor([0, 1], dtype=torch.int32)
+    coo = ops.ball_query(Mat.of(x.to(DEV), 0, 3), ptr_x.to(DEV), Mat.of(y.to(DEV), 0, 3), ptr_y.to(DEV), 1, 1.0, 64).cpu()
+    assert coo[0].tolist() == [0, 1, 2, 3, 4, 5] + list(range(7, 65)) and coo[1].tolist() == [0] * 64
+    coo = ops.ball_query(Mat.of(x.to(DEV), 0, 3), ptr_x.to(DEV), Mat.of(y.to(DEV), 0, 3), ptr_y.to(DEV), 1, 1.0, 16).cpu()
+    assert coo[0].tolist() == [0, 1, 2, 3, 4, 5] + list(range(7, 17))
+    # -- FPS ties: start 0, the extremes -2 / +2 tie -> lower index; then the mid points -1 / +1 tie -> lower index
+    for pts, extremes in (([[0.0, 0, 0], [-2.0, 0, 0], [2.0, 0, 0], [1.0, 0, 0], [-1.0, 0, 0], [0.0, 0.5, 0]], [-2.0, 1.0]),
+                          ([[0.0, 0, 0], [2.0, 0, 0], [-2.0, 0, 0], [-1.0, 0, 0], [1.0, 0, 0], [0.0, 0.5, 0]], [2.0, -1.0])):
+        p4 = torch.zeros(6, 4)
+        p4[:, :3] = torch.tensor(pts)
+        got = ops.fps(Mat.of(p4.to(DEV), 0, 3), torch.tensor([0, 6], dtype=torch.int32, device=DEV),
+                      torch.tensor([0, 4], dtype=torch.int32, device=DEV), None, 1, 6, 4).cpu()
+        assert got.tolist() == [0, 1, 2, 3]
+        assert [p4[1, 0].item(), p4[3, 0].item()] == extremes
+    # -- bipartite self loops, N_src = 5 > N_dst = 2: raw (1, 1) dropped, (0, 0) and (1, 1) appended -> target 0 hears {4, 0},
+    #    target 1 hears {3, 1}
+    ei = torch.tensor([[4, 1, 3], [0, 1, 1]])
+    c = ops.csr_build(ei.to(DEV), 2, n_src=5)
+    torch.cuda.synchronize()
+    assert int(c.status.item()) == 0 and c.rowptr.cpu().tolist() == [0, 2, 4]
+    assert sorted(c.src.cpu()[:2].tolist()) == [0, 4] and sorted(c.src.cpu()[2:4].tolist()) == [1, 3]
+    assert c.dst.cpu()[:4].tolist() == [0, 0, 1, 1]
+    # fewer sources than targets does not occur on the path (centres are sampled FROM the sources): the C-ABI refuses it
+    from morig_amd import native
+    with pytest.raises(native.MorigNativeError):
+        ops.csr_build(torch.tensor([[1, 0, 1], [0, 2, 2]], device=DEV), 4, n_src=2)
+
+
 @pytest.mark.parametrize("H,N3", [(32, 64), (64, 128), (256, 256)])
 def test_pointconv_two_pass(ops, H, N3):
     g = torch.Generator().manual_seed(H)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from helpers import POINT_MODULE_CASES, check_point_module, data_from, rel_excess
+from helpers import POINT_MODULE_CASES, check_point_module, data_from, maxdiff, rel_excess
 from morig_amd import models, synth
 from morig_amd.models import basic_modules as bm, rignet as rn
 
@@ -373,6 +373,35 @@ def test_headline_batch_64_meshes_contains_the_golden_mesh_and_is_deterministic(
     sl = slice(37 * n, 38 * n)
     assert rel_excess(aggr[sl], a["motion_aggr"], TOL) <= 0
     assert rel_excess(shift[sl], a["pred_shift"], TOL) <= 0
+
+
+def test_mask_skin_batch_64_contains_the_golden_mesh():
+    """BASELINE.json configs[2] at its stated size (VERDICT r3 #4a): masknet_motion + skinnet_motion over ONE batch of 64 meshes x
+    4096 vertices, as bench.py's `mask_skin` workload runs them, with the committed harsh-recipe 4096-vertex golden mesh at
+    position 21: its rows must equal the outputs of the reference's own models on that mesh alone, and two runs of the whole
+    batch must be bit-identical."""
+    import bench
+    mm, ma = load_golden("masknet_4k_harsh")
+    sm, sa = load_golden("skinnet_4k_harsh")
+    assert mm["mesh_seed"] == sm["mesh_seed"] and mm["n_side"] == sm["n_side"]
+    slot, n = 21, mm["n_side"] ** 2
+    seeds = [2100 + i for i in range(64)]
+    seeds[slot] = mm["mesh_seed"]
+    d = bench.build_batch(seeds, mm["n_side"], with_skin=True).to(DEV)
+    sl = slice(slot * n, (slot + 1) * n)
+    assert maxdiff(d.pos[sl][:8], ma["pos_check"]) == 0
+    step = mm["row_step"]
+    for meta, a, key in ((mm, ma, "pred_mask"), (sm, sa, "skin_cls_pred")):
+        m = models.__dict__[meta["arch"]](**meta["kwargs"]).eval()
+        synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
+        _, aggr, last = m(d, d.pred_flow)
+        _, aggr2, last2 = m(d, d.pred_flow)
+        assert torch.equal(last, last2) and torch.equal(aggr, aggr2), key
+        assert last.shape[0] == 64 * n and bool(torch.isfinite(last).all())
+        assert rel_excess(aggr[sl][::step], a["motion_aggr_rows"], TOL) <= 0, key
+        assert rel_excess(last[sl], a[key], TOL) <= 0, key
+        del m, aggr, last, aggr2, last2
+        torch.cuda.empty_cache()
 
 
 def test_batch_past_the_32_bit_row_offsets_still_equals_the_golden():
