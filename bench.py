@@ -257,6 +257,19 @@ def roofline_of(prof, psteps, clocks=None):
         g["ms"] += v["ms"]; g["flops"] += v["flops"]; g["bytes"] += v["bytes"]; g["launches"] += v["launches"]
         g["kinds"].append(k)
     dom_key, dom = max(by_sym.items(), key=lambda kv: kv[1]["ms"])
+    chain = None
+    if dom["flops"] <= 0 and dom["bytes"] <= 0:
+        # the largest entry declares neither FLOPs nor bytes: a dependent-latency chain (farthest-point sampling: m arg-max steps
+        # per cloud on ONE CU each, 32 of 256 CUs busy, on its own stream beside the other branch) -- no roof applies to it. It is
+        # reported as such, and the roofline object describes the largest kernel that HAS a roof.
+        chain = dict(kind=dom_key, kernel_is="launch kind (latency chain: neither the HBM nor the MFMA roof applies)",
+                     ms_per_step=round(dom["ms"] / psteps, 3), launches_per_step=dom["launches"] / psteps,
+                     share_of_gpu_time=round(dom["ms"] / total_ms, 4),
+                     note="event time of a kernel that runs CONCURRENTLY with the other stream's kernels: its share of the summed "
+                          "event times overstates its share of the step")
+        rest = {k: v for k, v in by_sym.items() if v["flops"] > 0 or v["bytes"] > 0}
+        if rest:
+            dom_key, dom = max(rest.items(), key=lambda kv: kv[1]["ms"])
     sclk = (clocks or {}).get("sclk_under_load_mhz")
     common = dict(kernel=dom["symbol"] or dom_key, kernel_is="rocprofv3 kernel symbol (prefix)" if dom["symbol"] else "launch kind (several symbols)",
                   launch_kinds=sorted(dom["kinds"]), lib_sha256=lib_sha256(),
@@ -294,6 +307,8 @@ def roofline_of(prof, psteps, clocks=None):
                          "(a latency chain such as farthest-point sampling sits far below either roof by construction)")
     roof.update(common)
     roof.update(tr)
+    if chain is not None:
+        roof["largest_entry_is_a_latency_chain"] = chain
     breakdown = {k: dict(ms_per_step=round(v["ms"] / psteps, 3),
                          tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 else 0.0,
                          launches_per_step=v["launches"] / psteps, symbol=v.get("symbol"))

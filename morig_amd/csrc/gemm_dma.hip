@@ -324,7 +324,20 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
     // they hide), so it takes the pooled launches and the deep, wide stores only. MORIG_DMA_PERSIST=0 / 1 forces never / always.
     static const int persist = [] { const char* e = getenv("MORIG_DMA_PERSIST"); return e ? (e[0] == '0' ? 0 : 2) : 1; }();
     const bool deep_wide = p.pool != nullptr || (p.K >= 768 && p.N >= 1024);
-    if (mode == 256 && p.N % 256 == 0 && p.K > 32 && (persist == 2 || (persist == 1 && deep_wide))) {
+    // the persistent STORE kernel has only the register epilogue (16-byte vector stores to Y, 16-byte loads of rowbias): an output
+    // or row-bias that is not 16-byte aligned stays on the one-tile kernel below, whose <.., false> form stores scalars
+    const bool vec_ok = p.pool != nullptr ||
+                        ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0 &&
+                         (!p.rowbias || ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0 && (p.ld_rowbias & 3) == 0)));
+    if (mode == 256 && p.N % 256 == 0 && p.K > 32 && vec_ok && (persist == 2 || (persist == 1 && deep_wide))) {
+        // MORIG_GEMM_PP=1: the ping-pong schedule (gemm_pp.hip: the two waves of a SIMD alternate MFMA and load slots) for the same
+        // launches; 0 = the in-phase persistent kernel (gemm_dmap.hip)
+        const char* e_pp = getenv("MORIG_GEMM_PP");             // read per launch: the parity test flips it inside one process
+        const bool pingpong = e_pp ? e_pp[0] != '0' : MORIG_GEMM_PP_DEFAULT;
+        if (pingpong) {
+            prof_retag(p.pool ? K_GEMM16_PP_POOL : K_GEMM16_PP);
+            return launch_gemm16_pp(p0, s);
+        }
         if (!p.pool) prof_retag(K_GEMM16_DMAP);       // the pooled kind already names this kernel
         return launch_gemm16_dmap(p0, s);
     }

@@ -128,16 +128,37 @@ def extract_joints_batched(shifted_pts, attn, batch, vox=None, bandwidth_quantil
     ``argsort(counts)[::-1]`` of cluster_utils.py:52 fixes the visiting order among equal counts, so that one call stays numpy,
     per mesh) and the survivors. Returns one dict per mesh, as ``extract_joints``."""
     ops = get_ops()
-    device = shifted_pts.device if torch.is_tensor(shifted_pts) else torch.device("cuda", torch.cuda.current_device())
+    # device resolution as in extract_joints: a CUDA tensor's own device, else the current one; the native launches go to the
+    # CURRENT device's stream, so a tensor on another GPU switches the current device for the call
+    from . import runtime
+    if runtime._test_ops is not None and torch.is_tensor(shifted_pts) and not shifted_pts.is_cuda:
+        device = shifted_pts.device                      # tests/ only: host logic on the CPU emulation of the op layer
+    else:
+        device = (shifted_pts.device if torch.is_tensor(shifted_pts) and shifted_pts.is_cuda
+                  else torch.device("cuda", torch.cuda.current_device()))
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        if torch.cuda.current_device() != device.index:
+            with torch.cuda.device(device):
+                return extract_joints_batched(shifted_pts, attn, batch, vox, bandwidth_quantile, threshold1, threshold2, max_iter, num_graphs)
     pts = _dev_pts(shifted_pts, device)
     a = _dev_attn(attn, device)
-    batch = batch.to(device)
-    B = int(num_graphs) if num_graphs is not None else int(batch.max().item()) + 1
+    batch = torch.as_tensor(batch).to(device)
+    B = int(num_graphs) if num_graphs is not None else (int(batch.max().item()) + 1 if batch.numel() else 0)
+    if B == 0 or pts.shape[0] == 0:
+        return [dict(joints=np.zeros((0, 3)), side=np.zeros(0), bandwidth=float("nan"),
+                     modes=torch.zeros((0, 3), dtype=torch.float64, device=device),
+                     attn=torch.zeros((0, 1), dtype=torch.float32, device=device)) for _ in range(B)]
     # attention min-max normalised PER MESH in float32, as numpy does on each loaded array (eval_rigging.py:72). `batch` is sorted
     # (PyG), so the per-mesh extrema are segment reductions (a scatter with 64 target addresses serialises on its atomics: 3 ms each)
     n_per = torch.bincount(batch, minlength=B)
     amin = torch.segment_reduce(a.reshape(-1), "min", lengths=n_per, unsafe=True)[:, None]
     amax = torch.segment_reduce(a.reshape(-1), "max", lengths=n_per, unsafe=True)[:, None]
+    # a mesh WITHOUT vertices has an empty segment (+inf / -inf extrema): nothing indexes those rows (`batch` never names the
+    # mesh), but they must not stay non-finite in case a later reduction touches the whole column
+    empty = (n_per == 0)[:, None]
+    amin = torch.where(empty, torch.zeros_like(amin), amin)
+    amax = torch.where(empty, torch.ones_like(amax), amax)
     a = (a - amin[batch]) / (amax[batch] - amin[batch])
     keep = a.squeeze(1) > threshold1
     if vox is not None:

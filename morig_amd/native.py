@@ -1022,7 +1022,7 @@ class NativeOps:
         B, n = ptr.numel() - 1, pts.shape[0]
         keys = torch.empty(n, dtype=torch.int64, device=pts.device)
         check(self.lib.morig_morton_keys(_p(pts), _p(ptr), B, n, _p(keys), _stream()), "morig_morton_keys")
-        perm = torch.argsort(keys)
+        perm = torch.argsort(keys, stable=True)       # mirrored points on the x = 0 plane share a Morton key: a stable order keeps the fp64 summation order, and with it the modes' last bits, the same from run to run
         ps = pts[perm].contiguous()
         ws = None if weights is None else weights[perm].contiguous()
         a, b = torch.empty_like(ps), torch.empty_like(ps)

@@ -99,10 +99,18 @@ class _Packs:
 
     def get(self, key, params, build):
         ver = tuple((q.data_ptr(), q._version, q.device) for q in params if q is not None) + (train_fast(),)
+        if _PACK_DEBUG:
+            # MORIG_TRAIN_PACK_DEBUG=1: the (storage, version) key cannot see a write through `.data` (an EMA copy, `p.data.clamp_()`):
+            # those leave _version alone. The debug key adds a checksum of the values (one device reduction + host read per lookup --
+            # slow, for hunting a stale pack); without it call clear_pack_cache() after any such write.
+            ver = ver + tuple(float(q.detach().double().sum().item()) + float(q.detach().double().abs().sum().item()) for q in params if q is not None)
         hit = self.d.get(key)
         if hit is None or hit[0] != ver:
             hit = self.d[key] = (ver, build())
         return hit[1]
+
+
+_PACK_DEBUG = os.environ.get("MORIG_TRAIN_PACK_DEBUG", "0") == "1"
 
 
 class _NoPacks:
@@ -122,6 +130,9 @@ def packs_of(module):
 
 
 def clear_pack_cache():
+    """Drop every cached kernel-layout weight image. The cache follows optimizer steps on its own (in-place updates bump the
+    parameters' version counters); call this after writing parameters THROUGH `.data` (EMA copies, clamps, manual loads), which
+    no version counter records -- or run with MORIG_TRAIN_PACK_DEBUG=1 to have every lookup verify a checksum."""
     _PACKS.clear()
 
 
@@ -160,13 +171,14 @@ class DenseTrain(torch.autograd.Function):
         du = torch.empty_like(y) if y.shape[1] == N else torch.zeros_like(y)
         DU = Mat.of(du, 0, N)
         ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), ksdz, ksdzx, DU)
-        db, _ = ops.bn_backward_stats(DU)
-        dW = ops.gemm_tn(DU, Mat.of(xa, 0, K))
+        # a frozen layer (requires_grad False: e.g. train_deform_pose.py's frozen corr_extractor) pays for no weight-gradient GEMM
+        db = ops.bn_backward_stats(DU)[0] if ctx.needs_input_grad[2] else None
+        dW = ops.gemm_tn(DU, Mat.of(xa, 0, K)) if ctx.needs_input_grad[1] else None
         dX = None
         if ctx.needs_input_grad[0]:
             wt = ctx.packs.get("wT", (weight,), lambda: _pack_f32(weight.detach().t().contiguous(), None, dev))
             dX = _gemm_f32(ops, DU, wt, K)[:, :K]
-        return dX, dW, db, sdzx, sdz, None, None
+        return dX, dW, db, (sdzx if ctx.needs_input_grad[3] else None), (sdz if ctx.needs_input_grad[4] else None), None, None
 
 
 class NativeLinear(torch.autograd.Function):
@@ -193,8 +205,8 @@ class NativeLinear(torch.autograd.Function):
         K, N, has_bias = ctx.dims
         dya = _rows16(dy)
         DY = Mat.of(dya, 0, N)
-        db = ops.bn_backward_stats(DY)[0] if has_bias else None
-        dW = ops.gemm_tn(DY, Mat.of(xa, 0, K))
+        db = ops.bn_backward_stats(DY)[0] if (has_bias and ctx.needs_input_grad[2]) else None
+        dW = ops.gemm_tn(DY, Mat.of(xa, 0, K)) if ctx.needs_input_grad[1] else None
         dX = None
         if ctx.needs_input_grad[0]:
             wt = ctx.packs.get("wT", (weight,), lambda: _pack_f32(weight.detach().t().contiguous(), None, dy.device))
@@ -265,9 +277,10 @@ class EdgeMLPTrain(torch.autograd.Function):
         du2 = _buf(z2.shape[0], H, dev)                 # (the kernel zeroes the rows past E': they feed the dX GEMM below)
         DU2 = Mat.of(du2, 0, H)
         ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2)
-        db2, _ = ops.bn_backward_stats(DU2, rows_dev=e_live)
+        need = ctx.needs_input_grad                      # (x, W1, b1, g1, be1, W2, b2, g2, be2, ...): frozen layers skip their dW GEMMs
+        db2 = ops.bn_backward_stats(DU2, rows_dev=e_live)[0] if (need[5] or need[6]) else None
         # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
-        dW2 = ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]
+        dW2 = (ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]) if need[5] else None
         w2t = ctx.packs.get("w2T", (W2,), lambda: _pack_f32(W2.detach().t().contiguous(), None, dev))
         dh = _gemm_f32(ops, DU2, w2t, H)                                               # d(s1 Z1 + t1)  [capacity, H]
         DH = Mat.of(dh, 0, H)
@@ -279,9 +292,11 @@ class EdgeMLPTrain(torch.autograd.Function):
         dab = _buf(n, 2 * H, dev)                       # dA is written whole, dB is cleared by the operator
         ops.edge_scatter_backward(DH, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H))
         DAB = Mat.of(dab, 0, 2 * H)
-        db1, _ = ops.bn_backward_stats(Mat.of(dab, 0, H))
-        dWv = ops.gemm_tn(DAB, Mat.of(xa, 0, C))                                       # [2H, C]
-        dW1 = torch.cat([dWv[:H], dWv[H:] - dWv[:H]], 1)                               # back to [W_a | W_b]: W_v = [[W_a - W_b], [W_b]]
+        db1 = ops.bn_backward_stats(Mat.of(dab, 0, H))[0] if need[2] else None
+        dW1 = None
+        if need[1]:
+            dWv = ops.gemm_tn(DAB, Mat.of(xa, 0, C))                                   # [2H, C]
+            dW1 = torch.cat([dWv[:H], dWv[H:] - dWv[:H]], 1)                           # back to [W_a | W_b]: W_v = [[W_a - W_b], [W_b]]
         dX = None
         if ctx.needs_input_grad[0]:                       # (positions and input features are leaves without a gradient)
             def wvt_pack():
@@ -289,7 +304,8 @@ class EdgeMLPTrain(torch.autograd.Function):
                 Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)
                 return _pack_f32(Wv.t().contiguous(), None, dev)
             dX = _gemm_f32(ops, DAB, ctx.packs.get("wvT", (W1,), wvt_pack), C)[:, :C]
-        return dX, dW1, db1, sdzx1, sdz1, dW2, db2, sdzx2, sdz2, None, None, None, None
+        return (dX, dW1, db1, (sdzx1 if need[3] else None), (sdz1 if need[4] else None), dW2, (db2 if need[6] else None),
+                (sdzx2 if need[7] else None), (sdz2 if need[8] else None), None, None, None, None)
 
 
 class SegMaxPool(torch.autograd.Function):

@@ -9,5 +9,5 @@ mkdir -p ../lib/variants /tmp/morig_variants
 obj=/tmp/morig_variants/${name}_${src%.hip}.o
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function "$@" -c $src -o $obj
 others=$(ls *.o | grep -v "^${src%.hip}.o$")
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $others $obj -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib -o ../lib/variants/lib_$name.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $others $obj -ldl -o ../lib/variants/lib_$name.so
 echo built lib_$name.so
