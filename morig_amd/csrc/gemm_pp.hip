@@ -32,6 +32,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void glb_void_t;
 
+#ifndef PP_AX
+#define PP_AX 6
+#endif
 struct GemmPpHot { int M, K, ldx, ldw, tiles_n; const float* X; const float* W; const int* seg; };
 typedef __attribute__((address_space(4))) const GemmDmaParams* pp_kernarg_t;
 
@@ -45,7 +48,7 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const GemmDmaParams) {
     constexpr int WNW = BN / (32 * NT);          // 2 waves along N
     constexpr int STAGE = (BM + BN) * 128;       // 64 KB: X tile + W tile of one 32-column chunk
     constexpr int PANEL = 3 * BN;                // floats: [bias (+ row bias) | scale | shift] of a tile's columns
-    constexpr int AX = 6, BX = 8 - AX;           // one-KiB pieces of X (and as many of W) per wave and chunk: group A / group B
+    constexpr int AX = PP_AX, BX = 8 - AX;           // one-KiB pieces of X (and as many of W) per wave and chunk: group A / group B
     __shared__ __attribute__((aligned(128))) char smem[2 * STAGE + (POOL ? 0 : 2 * PANEL * 4)];
     float* pan = reinterpret_cast<float*>(smem + 2 * STAGE);
 
@@ -139,21 +142,27 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const GemmDmaParams) {
         if constexpr (POOL) c = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w, c, 0, 0, 0);
         else                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, x, c, 0, 0, 0);
     };
+    // A compute slot is ONE wave feeding the SIMD's matrix pipe: consecutive MFMAs must not wait for each other, so each split
+    // term sweeps all eight accumulators of the wave tile before the next term touches them again (dependent MFMAs 8 apart; with
+    // the in-phase kernel's 2-apart order a lone wave left the pipe idle between them: first A/B, profiles/r04b_*). Per accumulator
+    // the order of its additions is unchanged (k16 step, then lo*hi, hi*lo, hi*hi): results stay bit-identical to gemm_dmap.hip.
     auto compute = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const Frag& f = fr[s2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt0 = 0; nt0 < NT; nt0 += 2) {
-                    const Frag& f = fr[s2];
-                    mm(f.al[mt], f.bh[nt0],     acc[mt][nt0]);
-                    mm(f.al[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1]);
-                    mm(f.ah[mt], f.bl[nt0],     acc[mt][nt0]);
-                    mm(f.ah[mt], f.bl[nt0 + 1], acc[mt][nt0 + 1]);
-                    mm(f.ah[mt], f.bh[nt0],     acc[mt][nt0]);
-                    mm(f.ah[mt], f.bh[nt0 + 1], acc[mt][nt0 + 1]);
-                }
+                for (int nt = 0; nt < NT; ++nt) mm(f.al[mt], f.bh[nt], acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mm(f.ah[mt], f.bl[nt], acc[mt][nt]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) mm(f.ah[mt], f.bh[nt], acc[mt][nt]);
+        }
     };
     // ---- store variant: the column constants of one tile (as gemm_dmap.hip) ----
     float pv0 = 0.f, pv1 = 0.f;
@@ -292,6 +301,9 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const GemmDmaParams) {
             const int st = (g + c) & 1;
             const bool panel_now = !POOL && c == cP && has_next;
             // ---------------- load slot L(c) ----------------
+#ifdef PP_PRIO
+            __builtin_amdgcn_s_setprio(PP_PRIO);             // the loading wave's LDS / VMEM issue ahead of the partner's MFMA stream
+#endif
             if (panel_now) panel_fetch(nlin, slow_next);
             if (grpB) {                          // B's pieces must land inside this slot: out first
                 if (c + 1 < nchunk) dma_share(xb, wb, row0, c + 1, st ^ 1);
@@ -315,6 +327,9 @@ __global__ __launch_bounds__(512) void gemm16_pp_kernel(const GemmDmaParams) {
             a_skips = false;
             __builtin_amdgcn_sched_barrier(0);
             // ---------------- compute slot C(c) ----------------
+#ifdef PP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             compute();
             __builtin_amdgcn_sched_barrier(0);
             if (!grpB) {
