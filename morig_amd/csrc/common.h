@@ -15,7 +15,7 @@ enum Kind : int {
     K_GEMM16_BN128, K_GEMM16_BN64, K_GEMM16_BN32, K_GEMM16_POOL,
     K_EDGE16_H32, K_EDGE16_H64, K_EDGE16_H128, K_EDGE16_H256, K_POINTCONV16, K_GEMM16_DMA,
     K_COSINE_KNN, K_FLOW_VOTE, K_JOINTS,
-    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH, K_EDGE16_X3, K_EDGE_X3, K_EDGE16_X3P, K_GEMM16_PP, K_GEMM16_PP_POOL,
+    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH, K_EDGE16_X3, K_EDGE_X3, K_EDGE16_X3P,
     K_COUNT
 };
 static_assert(K_COUNT <= MORIG_PROF_KINDS, "raise MORIG_PROF_KINDS");
@@ -85,10 +85,6 @@ struct EdgeX3Params {
 
 int launch_edge_x3(const EdgeX3Params& p, int n_tiles_cap, hipStream_t s);      // edge_x3.hip (persistent 32-wide EdgeConv on 3-channel inputs)
 int launch_gemm16_dmap(const GemmDmaParams& p, hipStream_t s);                // gemm_dmap.hip (persistent, 256 x 256 tiles)
-int launch_gemm16_pp(const GemmDmaParams& p, hipStream_t s);                  // gemm_pp.hip (persistent, ping-pong wave roles)
-#ifndef MORIG_GEMM_PP_DEFAULT
-#define MORIG_GEMM_PP_DEFAULT false
-#endif
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

@@ -330,14 +330,8 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
                         ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0 &&
                          (!p.rowbias || ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0 && (p.ld_rowbias & 3) == 0)));
     if (mode == 256 && p.N % 256 == 0 && p.K > 32 && vec_ok && (persist == 2 || (persist == 1 && deep_wide))) {
-        // MORIG_GEMM_PP=1: the ping-pong schedule (gemm_pp.hip: the two waves of a SIMD alternate MFMA and load slots) for the same
-        // launches; 0 = the in-phase persistent kernel (gemm_dmap.hip)
-        const char* e_pp = getenv("MORIG_GEMM_PP");             // read per launch: the parity test flips it inside one process
-        const bool pingpong = e_pp ? e_pp[0] != '0' : MORIG_GEMM_PP_DEFAULT;
-        if (pingpong) {
-            prof_retag(p.pool ? K_GEMM16_PP_POOL : K_GEMM16_PP);
-            return launch_gemm16_pp(p0, s);
-        }
+        // (a ping-pong schedule for these launches -- the two waves of a SIMD alternating 48-MFMA slots and load slots, gemm_pp.hip in
+        // commit a267b6e -- was built, bit-identical, and measured 3-11 % slower: profiles/r04b..r04d, DESIGN section 5 [r04])
         if (!p.pool) prof_retag(K_GEMM16_DMAP);       // the pooled kind already names this kernel
         return launch_gemm16_dmap(p0, s);
     }

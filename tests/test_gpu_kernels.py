@@ -778,72 +778,6 @@ def test_gemm_dma_register_epilogue(M, N, K, segs, y_split, relu):
         assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item()), (use_rb,)
 
 
-@pytest.mark.parametrize("M,N,K,mode", [(70001, 1024, 867, "store"), (66000, 1024, 832, "pool"), (40000, 1024, 899, "store_split"),
-                                        (3000, 1024, 64, "pool"), (999, 2048, 800, "store")])
-def test_gemm_ping_pong_schedule_equals_in_phase_kernel(M, N, K, mode):
-    """gemm_pp.hip (the two waves of a SIMD alternate MFMA and load slots) against gemm_dmap.hip (all waves in phase) on launches
-    long enough that every workgroup walks several tiles: the two schedules issue the same MFMAs in the same order per
-    accumulator, so the results must be BIT-identical; a row sample is also held to the CPU emulation. Ragged mesh ids (row bias
-    per row inside some tiles, folded into the accumulators in others), a last row tile past M, fp32 and split outputs."""
-    import os
-    from morig_amd import native
-    o = native.get_ops()
-    o.precision = "f16x3"
-    g = torch.Generator().manual_seed(M + K)
-    Kp, Np = (K + 31) // 32 * 32, (N + 31) // 32 * 32
-    x = torch.zeros(M, Kp)
-    x[:, :K] = torch.randn(M, K, generator=g)
-    lin = _lin(N, K, 8, bn=True)
-    nseg = 11
-    seg = torch.sort(torch.randint(0, nseg, (M,), generator=g))[0].int()
-    seg[: min(M, 3000)] = 0                                     # the first tiles lie in one mesh: row bias = initial accumulator value
-    seg[-1] = nseg - 1
-    rb = torch.randn(nseg, N, generator=g)
-    xs = packing.split_f16(x).to(DEV)
-    ling = packing.to_device(lin, DEV)
-    outs = {}
-    prev = os.environ.get("MORIG_GEMM_PP")
-    try:
-        for pp in ("0", "1"):
-            os.environ["MORIG_GEMM_PP"] = pp
-            if mode == "pool":
-                out = torch.zeros(nseg, N, device=DEV)
-                o.gemm(Mat.of(xs, 0, K), ling, True, seg=seg.to(DEV), pool=out, x_split=True)
-            elif mode == "store":
-                out = torch.full((M + 2, N + 8), 7.0, device=DEV)
-                o.gemm(Mat.of(xs, 0, K), ling, True, Y=Mat.of(out, 4, N, 0, M), x_split=True, rowbias=Mat.of(rb.to(DEV)), seg=seg.to(DEV))
-            else:
-                out = torch.full((M + 2, Np + 32), 7.0, device=DEV)
-                o.gemm(Mat.of(xs, 0, K), ling, True, Y=Mat.of(out, 32, N, 0, M), x_split=True, y_split=True)
-            torch.cuda.synchronize()
-            outs[pp] = out.cpu()
-    finally:
-        if prev is None:
-            os.environ.pop("MORIG_GEMM_PP", None)
-        else:
-            os.environ["MORIG_GEMM_PP"] = prev
-    assert torch.equal(outs["0"], outs["1"])
-    got = outs["1"]
-    rows = torch.unique(torch.cat([torch.arange(0, M, max(1, M // 97)), torch.arange(max(0, M - 300), M), torch.arange(0, min(M, 300))]))
-    if mode == "pool":
-        want = torch.zeros(nseg, N)
-        EmuOps().gemm(Mat.of(x, 0, K), lin, True, seg=seg, pool=want)
-        present = torch.unique(seg.long())
-        assert maxdiff(got[present], want[present]) <= 2e-5 * max(1.0, want[present].abs().max().item())
-        return
-    xr = x[rows].contiguous()
-    want = torch.zeros(rows.numel(), N)
-    kw = dict(rowbias=Mat.of(rb), seg=seg[rows].contiguous()) if mode == "store" else {}
-    EmuOps().gemm(Mat.of(xr, 0, K), lin, True, Y=Mat.of(want), **kw)
-    if mode == "store":
-        sub = got[:M, 4:4 + N][rows]
-        assert float((got[M:] - 7.0).abs().sum()) == 0 and float((got[:M, :4] - 7.0).abs().sum()) == 0
-    else:
-        sub = packing.unsplit_f16(got[:M].contiguous(), Np + 32)[:, 32:32 + N][rows]
-        assert float((got[M:] - 7.0).abs().sum()) == 0 and float((got[:M, :32] - 7.0).abs().sum()) == 0
-    assert maxdiff(sub, want) <= 2e-5 * max(1.0, want.abs().max().item())
-
-
 def test_copy2d_pad_plain_and_split():
     from morig_amd import native
     o = native.get_ops()
