@@ -552,22 +552,34 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
 
 // Rows of `out` whose segment straddles a 128-edge tile boundary are combined with integer-atomic float max
 // by the two (or more) tiles involved: only THOSE rows need the identity pattern 0xFFFFFFFF beforehand.
-__global__ __launch_bounds__(64) void init_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
-                                                                int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out,
-                                                                int tile_rows) {
-    const int e = (blockIdx.x + 1) * tile_rows;
+// [r04] one WAVE per boundary, four boundaries per 256-thread workgroup, 16-byte stores where the row allows them: the H = 256
+// launches used to start 410 k workgroups of 64 threads that stored 4 bytes per thread and pass (0.41 ms per step in total).
+__global__ __launch_bounds__(256) void init_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
+                                                                 int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out,
+                                                                 int tile_rows, int n_bound) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (b >= n_bound) return;
+    const int e = (b + 1) * tile_rows;
     if (e >= rowptr[n_nodes]) return;
     const int d = dstS[e];
     if (rowptr[d] >= e) return;                       // a segment starts exactly on the boundary: no sharing
-    unsigned* o = reinterpret_cast<unsigned*>(out + ((size_t)blockIdx.y * rep_out + d) * ldo);
-    for (int c = threadIdx.x; c < H; c += 64) o[c] = 0xFFFFFFFFu;
+    float* orow = out + ((size_t)blockIdx.y * rep_out + d) * ldo;
+    if (((reinterpret_cast<uintptr_t>(orow) | (uintptr_t)(H * 4)) & 15) == 0) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4* o4 = reinterpret_cast<u32x4*>(orow);
+        for (int c = lane; c < H / 4; c += 64) o4[c] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    } else {
+        unsigned* o = reinterpret_cast<unsigned*>(orow);
+        for (int c = lane; c < H; c += 64) o[c] = 0xFFFFFFFFu;
+    }
 }
 
 static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
                               int rep_out, int slots, hipStream_t s, int tile_rows = 128) {
     const int nb = cdiv(edge_capacity, tile_rows) - 1;
     if (nb <= 0) return MORIG_OK;
-    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(nb, slots), dim3(64), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out, tile_rows);
+    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(cdiv(nb, 4), slots), dim3(256), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out,
+                       tile_rows, nb);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
