@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
             }
             float* o = obase + (size_t)sg * p.ldy;
             const bool partial = (b == 0 && first_cont) || (e == NQ && last_cont);
-            if (partial) {
+            if (partial && !(p.dbg & 32)) {               // (dbg 32: timing experiment -- plain stores, wrong results on shared rows)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
             } else {
@@ -440,9 +440,11 @@ int launch_edge_ws(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
     if (!p.quad) return MORIG_E_UNSUPPORTED;
-    // (a four-wave / 512-register form of this kernel -- a wave owns 64 output columns, half the LDS fragment traffic; edge_w4.hip in
-    // commit f2666b4, bit-identical -- measured 7-10 % slower: a lone wave per SIMD pays every LDS-DMA issue, conversion burst and the
-    // quad epilogue as bubbles of its own matrix pipe; ablations in profiles/r04e..r04g, DESIGN section 5 [r04])
+    if (p.H == 256) {
+        // MORIG_EDGE_W4: the four-wave, 512-register form (edge_w4.hip); read per launch so that one process can compare the two
+        const char* e_w4 = getenv("MORIG_EDGE_W4");
+        if (e_w4 ? e_w4[0] != '0' : MORIG_EDGE_W4_DEFAULT) { prof_retag(K_EDGE16_H256_W4); return launch_edge_w4(p0, nblocks, s); }
+    }
     int ncu = cu_count_of_current_device();
     ncu = ncu > 8 ? (ncu / 8) * 8 : 8;
 #ifdef MORIG_WS_TRACE
