@@ -289,17 +289,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // per step -- traced: 1 800 of a tile's 13 000 cycles, fully exposed on a one-wave-per-SIMD kernel.
     // The quads of a 32 x 32 tile are worked on side by side (one after the other the compiler reused one temporary for all sixteen
     // quads and every instruction waited for its predecessor: ~1 200 cycles per tile, traced).
+    // what the epilogue of a tile needs besides its accumulators -- the quad rows' destination ids, segment starts, the segments
+    // this wave stores (round robin), continuation flags, the replica -- is read and derived in the tile's LAST interval (prep_epi,
+    // in the tail behind the interval's MFMAs), so that neither write_z nor scan starts with an LDS round trip and a division
+    unsigned eSTART = 0u, eMINE = 0u;
+    int esv = -1, erep = 0;
+    bool efirst = false, elast = false;
+    auto prep_epi = [&](int t, int slot) __attribute__((always_inline)) {
+        const int* sq = sq_all + slot * 32;
+        const int ql = lane & (NQ - 1);
+        esv = sq[ql];
+        const int sp = sq[ql > 0 ? ql - 1 : 0];
+        efirst = sflag[slot * 2] != 0; elast = sflag[slot * 2 + 1] != 0;
+        erep = t / tpr;
+        eSTART = (unsigned)__ballot(lane < NQ && (ql == 0 || esv != sp));        // wave-uniform: bit R = a segment starts at quad row R
+        const unsigned valid = (unsigned)__ballot(lane < NQ && esv >= 0);
+        // the tile's segments are dealt round-robin to the four waves: segment k (in start order) belongs to wave k & 3
+        unsigned todo = eSTART & valid, mine = 0u;
+        int k = 0;
+        while (todo) {
+            const unsigned low = todo & (0u - todo);
+            if ((k & (NW - 1)) == wave) mine |= low;
+            todo ^= low;
+            ++k;
+        }
+        eMINE = mine;
+    };
     auto write_z = [&](int slot) __attribute__((always_inline)) {
         // the min / max below read the accumulators from inline assembly: ordered behind the MFMAs, wait states by hand
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) asm volatile("s_nop 15" : "+v"(acc[mt][ct]));
-        const int* sq = sq_all + slot * 32;
-        const int ql = lane & (NQ - 1);
-        const int sv = sq[ql];
-        const int sp = sq[ql > 0 ? ql - 1 : 0];
-        const unsigned START = (unsigned)__ballot(lane < NQ && (ql == 0 || sv != sp));      // wave-uniform: bit R = a segment starts at quad row R
+        (void)slot;
+        const unsigned START = eSTART;
         float val[NQ];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -356,34 +379,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     // segments are dealt round-robin to the four waves (segment k in start order belongs to wave k & 3); a lane holds VEC adjacent columns
     auto scan = [&](int t, int slot) __attribute__((always_inline)) {
         typedef float fvec __attribute__((ext_vector_type(VEC)));
+        (void)t; (void)slot;
         if (p.dbg & 1) return;
-        const int rep = t / tpr;
-        const int* sq = sq_all + slot * 32;
-        const bool first_cont = sflag[slot * 2] != 0, last_cont = sflag[slot * 2 + 1] != 0;
         const float* zl = Z + VEC * lane;
-        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + VEC * lane;
-        const int ql = lane & (NQ - 1);
-        const int sv = sq[ql];
-        const int sp = sq[ql > 0 ? ql - 1 : 0];
-        const unsigned START = (unsigned)__ballot(lane < NQ && (ql == 0 || sv != sp));
-        const unsigned VALID = (unsigned)__ballot(lane < NQ && sv >= 0);
+        float* obase = p.Y + (size_t)erep * p.rep_out * p.ldy + VEC * lane;
+        const unsigned START = eSTART;
 #ifdef W4_TRACE
         if (t == tile_of(4) && blockIdx.x == 8 && lane == 0) p.trace[wave * 32 + 22] = __builtin_readcyclecounter();
 #endif
-        unsigned todo = START & VALID;
-        int k = 0;
-        while (todo) {                                                       // wave-uniform: SALU bit walking
-            const int b = __builtin_ctz(todo);
-            todo &= todo - 1u;
-            const bool is_mine = (k & (NW - 1)) == wave;
-            ++k;
-            if (!is_mine) continue;
+        unsigned mine = eMINE;
+        while (mine) {                                                       // wave-uniform: SALU bit walking
+            const int b = __builtin_ctz(mine);
+            mine &= mine - 1u;
             const unsigned later = b < 31 ? (START & ~((2u << b) - 1u)) : 0u;
             const int e = later ? __builtin_ctz(later) : NQ;                 // the segment covers quad rows [b, e)
-            const int sg = __builtin_amdgcn_readlane(sv, b);
+            const int sg = __builtin_amdgcn_readlane(esv, b);
             const fvec m = *reinterpret_cast<const fvec*>(zl + (e - 1) * ZQ);
             float* o = obase + (size_t)sg * p.ldy;
-            const bool partial = (b == 0 && first_cont) || (e == NQ && last_cont);
+            const bool partial = (b == 0 && efirst) || (e == NQ && elast);
             if (partial && !(p.dbg & 32)) {               // (dbg 32: timing experiment -- plain stores, wrong results on shared rows)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
@@ -470,7 +483,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         W4_TS(5 * c + 4);
         dma1(W4C<cd>{}, W4C<4>{}, rs_d);                   // the A quads last
         if constexpr (c == 1) W4_TS(23);
-        if constexpr (c == 3) load_indices(j + 2);
+        if constexpr (c == 3) { load_indices(j + 2); prep_epi(tile_of(j), j % 3); }
         rs = rs_v;
         if constexpr (c == 1) { if (j > 0) scan(tile_of(j - 1), (j - 1) % 3); }
         if constexpr (c == 1) W4_TS(21);

@@ -287,6 +287,9 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
                 Z[((wm * MT + mt) * 8 + 2 * q + hi) * ZQ + col] = fmaxf(x + b, 0.f) * sc + sh;
             }
     };
+    // ([r04] measured and not adopted here, profiles/r04r_*: segments dealt round-robin to the waves instead of by quad-row ownership,
+    // and the four quads of a tile worked on side by side in write_z -- 2.18 vs 2.14 ms on the geo graph, 1.17 vs 1.12 ms on tpl: with a
+    // partner wave on the SIMD the epilogue's latency chains are already covered, the extra bit walking is not)
     // segmented max over the NQ quad rows of a finished tile: a wave owns NQ/8 quad rows and every segment that STARTS
     // there; a lane holds VEC adjacent columns; two ballots list the segment starts (same scheme as edge_pp.hip)
     auto scan = [&](int t, int slot) __attribute__((always_inline)) {
