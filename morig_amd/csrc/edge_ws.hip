@@ -443,11 +443,11 @@ int launch_edge_ws(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
     if (!p.quad) return MORIG_E_UNSUPPORTED;
-    if (p.H == 256) {
-        // MORIG_EDGE_W4: the four-wave, 512-register form (edge_w4.hip); read per launch so that one process can compare the two
-        const char* e_w4 = getenv("MORIG_EDGE_W4");
-        if (e_w4 ? e_w4[0] != '0' : MORIG_EDGE_W4_DEFAULT) { prof_retag(K_EDGE16_H256_W4); return launch_edge_w4(p0, nblocks, s); }
-    }
+    // ([r04] a four-wave / 512-register form of this kernel -- a wave owns 64 output columns: W2 in 256 AGPRs, half the LDS fragment
+    // traffic; edge_w4.hip in commit b3bd7ab, bit-identical to this one -- reached this kernel's main-loop time and lost 5 % overall: a
+    // lone wave per SIMD has nobody to hide the quad epilogue, the scan and the per-tile bookkeeping behind (3 500 of a tile's 14 000
+    // cycles, cycle-stamped), and a second accumulator set to overlap them does not fit beside W2. Traces and A/Bs: profiles/r04e..r04t,
+    // DESIGN section 5 [r04])
     int ncu = cu_count_of_current_device();
     ncu = ncu > 8 ? (ncu / 8) * 8 : 8;
 #ifdef MORIG_WS_TRACE

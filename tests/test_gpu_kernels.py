@@ -257,52 +257,6 @@ def test_edgeconv_persistent_many_tiles(ops, H, pad4):
     assert torch.equal(out[:n], out[n:])                      # replicas of one input: identical bits
 
 
-@pytest.mark.parametrize("n,e,reps,shared,neg", [(20000, 300000, 2, True, False), (700, 5000, 2, False, True), (50000, 350000, 5, False, False),
-                                                 (300, 2500, 1, False, False)])
-def test_edgeconv_four_wave_kernel_equals_eight_wave_kernel(n, e, reps, shared, neg):
-    """edge_w4.hip (four waves of 512 registers, a wave owns 64 output columns) against edge_ws.hip (eight waves, 32 columns each)
-    on H = 256 / 4-aligned CSRs: same tiles, same order of additions per accumulator -> BIT-identical outputs; and against the
-    emulation. Many tiles per workgroup, a destination longer than several tiles, replicas, negative BatchNorm scales."""
-    import os
-    from morig_amd import native
-    o = native.get_ops()
-    o.precision = "f16x3"
-    H = 256
-    g = torch.Generator().manual_seed(n + reps)
-    ei = _rand_graph(n, e, 31, hub=min(777, n - 1))
-    if n >= 20000:
-        ei = torch.cat([ei, torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 1234)])], dim=1)
-    rows_in = n if shared else n * reps
-    ab = torch.randn(rows_in, 2 * H, generator=g)
-    ec = _edge_pack(H, 5, folded=True)
-    if neg:
-        ec.s2 = torch.where(torch.arange(ec.s2.numel()) % 3 == 0, -ec.s2.abs(), ec.s2)
-    emu = EmuOps()
-    out_ref = torch.zeros(n * reps, H)
-    emu.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), emu.csr_build(ei, n), ec, Mat.of(out_ref), replicas=reps,
-                 in_rep_stride=0 if shared else n, out_rep_stride=n)
-    csr = o.csr_build(ei.to(DEV), n, pad4=True)
-    abg, ecg = ab.to(DEV), packing.to_device(ec, DEV)
-    outs = {}
-    prev = os.environ.get("MORIG_EDGE_W4")
-    try:
-        for w4 in ("0", "1"):
-            os.environ["MORIG_EDGE_W4"] = w4
-            out = torch.full((n * reps, H), float("nan"), device=DEV)
-            o.edgeconv(Mat.of(abg, 0, H), Mat.of(abg, H, H), csr, ecg, Mat.of(out), replicas=reps,
-                       in_rep_stride=0 if shared else n, out_rep_stride=n)
-            torch.cuda.synchronize()
-            outs[w4] = out.cpu()
-    finally:
-        if prev is None:
-            os.environ.pop("MORIG_EDGE_W4", None)
-        else:
-            os.environ["MORIG_EDGE_W4"] = prev
-    assert not torch.isnan(outs["1"]).any()
-    assert torch.equal(outs["0"], outs["1"])
-    assert maxdiff(outs["1"], out_ref) <= 2e-5 * max(1.0, out_ref.abs().max().item())
-
-
 def test_edgeconv_sign_cases(ops):
     """negative BN scales (max of a decreasing function) and all-negative outputs (the integer-atomic
     max identity must not leak)."""
