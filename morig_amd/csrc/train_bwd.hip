@@ -20,6 +20,7 @@
 //   morig_gemm_tn                  C[N x K] = A^T B over the rows (fp32 MFMA, 32x32x2: both operands are read row-major, a lane
 //                                  takes one float of each), row range split over workgroups, partials summed in a fixed order
 #include "common.h"
+#include <stdlib.h>
 
 namespace morig {
 
@@ -347,6 +348,134 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
             }
 }
 
+// ---- the same contraction on the matrix cores' 16-bit rate: C = A^T B with every operand split into two bf16 halves ------------------
+// [r04] Gradients span the float32 exponent range (1e-8 .. 1e+4 inside one step), which rules the fp16 split of the forward path
+// out; bf16 keeps float32's exponent, so x = hi + lo with hi = bf16(x) truncated, lo = bf16(x - hi) rounded to nearest carries
+// ~16 mantissa bits with no range guard, and  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_bf16 (float32 accumulation) runs at
+// 16/3 = 5.3x the rate of the exact-float32 MFMA above. (The weight gradient is a sum over thousands of rows: 2^-16 per
+// product is far inside the 2e-4-of-scale criterion of the block tests; MORIG_TRAIN_BWD=f32 keeps the exact kernel.)
+// With the contraction over ROWS both MFMA operands need 8 CONSECUTIVE ROWS of one column per lane, i.e. the transposed tile:
+// a loader thread owns a 4 x 4 block (4 rows x 4 columns: one float4 per row, 128 contiguous bytes per row and 8 lanes), splits
+// it, transposes it in registers and writes 4 + 4 eight-byte pieces into the LDS image  sT[column][32 rows hi | 32 rows lo]
+// (row pitch 144 bytes: the 8-byte writes of a half-wave -- row group fastest -- and the 16-byte fragment reads of 16 lanes both
+// fall on distinct banks). Tiles, chunking over the rows, XCD-aware tile order and the fixed-order reduction are gemm_tn's.
+constexpr int TN16_R = 32;                // rows per stage = two 16-row MFMA steps
+constexpr int TN16_P = 144;               // bytes per column of the transposed image: 64 hi + 64 lo + 16 pad
+typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned tn_u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split_bf16(float x, unsigned& hi, unsigned& lo) {
+    const unsigned xb = __float_as_uint(x);
+    hi = xb >> 16;                                                    // truncated: lo absorbs the remainder exactly
+    const float r = x - __uint_as_float(xb & 0xffff0000u);            // exact in float32
+    const unsigned rb = __float_as_uint(r);
+    lo = (rb + 0x7fffu + ((rb >> 16) & 1u)) >> 16;                    // round to nearest even (an unbiased split)
+}
+
+__global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
+                                                        int n_tiles, int k_tiles, int chunks, int per_xcd,
+                                                        float* __restrict__ part /* [chunks][N][K] */) {
+    __shared__ __attribute__((aligned(16))) char sA[2][TN_T * TN16_P], sB[2][TN_T * TN16_P];
+    const int rows = rows_dev ? *rows_dev : rows_host;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= n_tiles * k_tiles * chunks) return;
+    const int bx = logical % n_tiles, by = (logical / n_tiles) % k_tiles, bz = logical / (n_tiles * k_tiles);
+    const int n0 = bx * TN_T, k0 = by * TN_T;
+    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int r_begin = bz * chunk_rows, r_end = min(r_begin + chunk_rows, rows);
+    tn_f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const int rg = tid & 7, cg = tid >> 3;                            // loader: rows 4 rg .. + 3 of the stage, columns 4 cg .. + 3 of the tile
+    const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    const bool b_vec = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+    const bool on_a[2] = {n0 + wn < N, n0 + wn + 32 < N}, on_b[2] = {k0 + wk < K, k0 + wk + 32 < K};
+    tn_f32x4 va[4], vb[4];
+    auto fetch = [&](int r0) {                                        // global -> registers (in flight under the MFMAs of a whole stage)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + 4 * rg + i;
+            va[i] = tn_f32x4{0.f, 0.f, 0.f, 0.f}; vb[i] = tn_f32x4{0.f, 0.f, 0.f, 0.f};
+            if (r < r_end) {
+                const float* pa = A + (size_t)r * lda + n0 + 4 * cg;
+                const float* pb = B + (size_t)r * ldb + k0 + 4 * cg;
+                if (a_vec && n0 + 4 * cg + 4 <= N) va[i] = *reinterpret_cast<const tn_f32x4*>(pa);
+                else { for (int q = 0; q < 4; ++q) if (n0 + 4 * cg + q < N) va[i][q] = pa[q]; }
+                if (b_vec && k0 + 4 * cg + 4 <= K) vb[i] = *reinterpret_cast<const tn_f32x4*>(pb);
+                else { for (int q = 0; q < 4; ++q) if (k0 + 4 * cg + q < K) vb[i][q] = pb[q]; }
+            }
+        }
+    };
+    // split, transpose the 4 x 4 block and write column q's four rows as one 8-byte piece each for hi and lo
+    auto put_one = [&](char* base, const tn_f32x4 (&v)[4], int q) __attribute__((always_inline)) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split_bf16(v[i][q], h[i], l[i]);
+        char* col = base + (4 * cg + q) * TN16_P + 8 * rg;
+        *reinterpret_cast<tn_u32x2*>(col) = tn_u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
+        *reinterpret_cast<tn_u32x2*>(col + 64) = tn_u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+    };
+    auto put = [&](int st, int q) __attribute__((always_inline)) { put_one(sA[st], va, q); put_one(sB[st], vb, q); };
+    if (r_begin < r_end) {
+        fetch(r_begin);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) put(0, q);
+        if (r_begin + TN16_R < r_end) fetch(r_begin + TN16_R);
+    }
+    __syncthreads();
+    int st = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += TN16_R, st ^= 1) {
+        const bool more = r0 + TN16_R < r_end;                        // block-uniform
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {                              // the stage's two 16-row steps
+            tn_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const char* pa = sA[st] + (wn + a * 32 + l31) * TN16_P + 32 * s2 + 16 * hi;
+                ah[a] = *reinterpret_cast<const tn_bf16x8*>(pa);
+                al[a] = *reinterpret_cast<const tn_bf16x8*>(pa + 64);
+            }
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const char* pb = sB[st] + (wk + b * 32 + l31) * TN16_P + 32 * s2 + 16 * hi;
+                bh[b] = *reinterpret_cast<const tn_bf16x8*>(pb);
+                bl[b] = *reinterpret_cast<const tn_bf16x8*>(pb + 64);
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    if (on_a[a] && on_b[b]) {
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+            // the next stage's block goes to the other buffer behind this step's MFMAs (two columns per step), then the fetch of the
+            // stage after it
+            if (more) { put(st ^ 1, 2 * s2); put(st ^ 1, 2 * s2 + 1); }
+            if (s2 == 1 && more && r0 + 2 * TN16_R < r_end) fetch(r0 + 2 * TN16_R);
+        }
+        __syncthreads();                                              // stage st consumed by every wave, stage st ^ 1 written
+    }
+    float* o = part + (size_t)bz * N * K;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, k = k0 + wk + b * 32 + l31;
+                if (n < N && k < K) o[(size_t)n * K + k] = acc[a][b][r];
+            }
+}
+
 // partial tiles -> C: 32 output elements x 8 chunk lanes per block; lane j adds chunks j, j + 8, ... in order, the eight lane sums
 // are combined as a fixed tree (deterministic; the chain per lane is <= 64 additions)
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, int N, int K,
@@ -497,12 +626,20 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
     const int chunks = tn_chunks(rows, N, K);
     if (workspace_floats < (int64_t)chunks * N * K) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int chunk_rows = cdiv(cdiv(rows > 0 ? rows : 1, chunks), TN_R) * TN_R;
+    // MORIG_TRAIN_BWD=f32: the exact-float32 MFMA kernel; default: the bf16 x 3 split (gemm_tn16_kernel). Read per call: the tests flip it.
+    const char* e_bwd = getenv("MORIG_TRAIN_BWD");
+    const bool split16 = !(e_bwd && e_bwd[0] == 'f');
+    const int RS = split16 ? TN16_R : TN_R;
+    const int chunk_rows = cdiv(cdiv(rows > 0 ? rows : 1, chunks), RS) * RS;
     ProfScope ps(K_MISC, s, 2.0 * rows * (double)N * K, 4.0 * rows * ((double)N + K));
     const int n_tiles = cdiv(N, TN_T), k_tiles = cdiv(K, TN_T);
     const int per_xcd = cdiv((long)n_tiles * k_tiles * chunks, 8);
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles, k_tiles,
-                       chunks, per_xcd, workspace);
+    if (split16)
+        hipLaunchKernelGGL(gemm_tn16_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles,
+                           k_tiles, chunks, per_xcd, workspace);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles, k_tiles,
+                           chunks, per_xcd, workspace);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((int)(((int64_t)N * K + 31) / 32)), dim3(256), 0, s, workspace, chunks, N, K, out, ldo);
     MORIG_LAUNCH_CHECK();

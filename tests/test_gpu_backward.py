@@ -63,19 +63,35 @@ def _graph(n, e, seed):
     return torch.stack([torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)])
 
 
-@pytest.mark.parametrize("rows,N,K", [(1000, 32, 7), (5000, 130, 259), (40000, 256, 64), (333, 1, 1), (70000, 512, 835)])
-def test_gemm_tn(rows, N, K):
+@pytest.mark.parametrize("bwd,tol", [("f32", 2e-6), ("bf16x3", 2e-5)])
+@pytest.mark.parametrize("rows,N,K,spread", [(1000, 32, 7, 0), (5000, 130, 259, 0), (40000, 256, 64, 0), (333, 1, 1, 0), (70000, 512, 835, 0),
+                                             (30000, 128, 256, 12)])
+def test_gemm_tn(rows, N, K, spread, bwd, tol, monkeypatch):
+    """C = A^T B over the rows (the weight gradient): the exact-float32 MFMA kernel (MORIG_TRAIN_BWD=f32) to 2e-6, the default bf16 x 3
+    split kernel to 2e-5 of the result's scale -- also on operands whose columns span 24 orders of magnitude (`spread`: column c scaled
+    by 10^(-spread .. +spread), the range gradients live in and an fp16 split could not hold), with odd shapes, a device-side live row
+    count and bit-identical repeats."""
+    monkeypatch.setenv("MORIG_TRAIN_BWD", bwd)
     ops = native.get_ops()
     g = torch.Generator().manual_seed(rows)
     A = torch.randn(rows, (N + 3) // 4 * 4, generator=g)
     B = torch.randn(rows, K + 5, generator=g)
+    if spread:
+        A[:, :N] *= 10.0 ** torch.linspace(-spread, spread, N)
+        B[:, :K] *= 10.0 ** torch.linspace(spread, -spread, K)
     want = A[:, :N].double().t() @ B[:, :K].double()
     got = ops.gemm_tn(Mat.of(A.to(DEV), 0, N), Mat.of(B.to(DEV), 0, K))
-    assert _rel(got, want) <= 2e-6
+    # every entry against the scale of ITS dot product, |a_n| |b_k| (with `spread` the result spans 48 orders of magnitude; a 1 x 1
+    # product has nothing else to be measured against)
+    ref_scale = A[:, :N].double().norm(dim=0)[:, None] * B[:, :K].double().norm(dim=0)[None, :]
+    assert float(((got.cpu().double() - want).abs() / ref_scale).max()) <= tol
+    if not spread:
+        assert _rel(got, want) <= 10 * tol
     live = torch.tensor([rows // 3], dtype=torch.int32, device=DEV)        # device-side row count (E' of a CSR)
     got = ops.gemm_tn(Mat.of(A.to(DEV), 0, N), Mat.of(B.to(DEV), 0, K), rows_dev=live)
     want = A[: rows // 3, :N].double().t() @ B[: rows // 3, :K].double()
-    assert _rel(got, want) <= 2e-6
+    ref_scale = A[: rows // 3, :N].double().norm(dim=0)[:, None] * B[: rows // 3, :K].double().norm(dim=0)[None, :]
+    assert float(((got.cpu().double() - want).abs() / ref_scale).max()) <= tol
     again = ops.gemm_tn(Mat.of(A.to(DEV), 0, N), Mat.of(B.to(DEV), 0, K), rows_dev=live)
     assert torch.equal(got, again), "fixed summation order"
 
