@@ -107,7 +107,12 @@ typedef struct morig_gemm_args {
     float* pool; int32_t ld_pool; int32_t n_seg;  /* optional [n_seg][ld_pool] column max per segment; a segment without rows
                                                    * receives 0 (torch_scatter's fill) */
     /* optional fast path (see "split-fp16" below): W_split has the shape/stride of W; overflow is an int32
-     * on the device that the kernel sets to 1 if an operand left the fp16 range (result then invalid). */
+     * on the device that the kernel sets to 1 if an operand left the fp16 range (result then invalid).
+     * W_split WITHOUT an overflow word (overflow = NULL) selects the bf16 split instead: W_split then holds
+     * bf16 halves (hi = bf16(w), lo = bf16(w - hi), same layout), X is split the same way in the kernel and the
+     * three products run on v_mfma_f32_32x32x16_bf16 -- bf16 keeps float32's exponent range, so there is no range
+     * condition to report; ~16 mantissa bits per operand. Plain stores only (no pool, no split activations):
+     * the gradient contractions of the training path (dX = dU W). */
     const void* W_split; int32_t* overflow;
     /* split-fp16 ACTIVATIONS (only with W_split): a matrix window whose first column and row stride are
      * multiples of 32 floats and whose every aligned 32-column chunk holds [32 halves hi | 32 halves lo].
@@ -510,7 +515,9 @@ int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, const int32_t*
 int morig_edge_scatter_backward(const float* dG, int32_t ldg, const int32_t* rowptr, const int32_t* src_sorted, int32_t n_nodes,
                                 int32_t n_src_nodes, int32_t H, float* dA, int32_t lda, float* dB, int32_t ldb, void* stream);
 /* out[N][K] = A^T B over the rows (A [rows][N], B [rows][K], fp32 MFMA): the weight gradient dW = dU^T X. The row range is split
- * over workgroups and the partial products are summed in a fixed order. workspace: morig_gemm_tn_workspace(rows, N, K) floats. */
+ * over workgroups and the partial products are summed in a fixed order. workspace: morig_gemm_tn_workspace(rows, N, K) floats.
+ * Arithmetic: bf16 x 3 split MFMAs by default (both operands split in the kernel: ~16 mantissa bits, float32 exponent range, 2x the
+ * exact kernel's rate); the environment variable MORIG_TRAIN_BWD=f32 selects the exact-float32 MFMA kernel. */
 int64_t morig_gemm_tn_workspace(int32_t rows, int32_t N, int32_t K);
 int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t rows, const int32_t* rows_dev, int32_t N, int32_t K,
                   float* workspace, int64_t workspace_floats, float* out, int32_t ldo, void* stream);

@@ -136,6 +136,20 @@ __device__ inline void split_pair_f16(float v0, float v1, float& hi, float& lo) 
 }
 #endif
 
+// bf16 counterpart (gradient contractions: bf16 keeps float32's exponent range, no range guard): hi = bf16(v), lo = bf16(v - hi), both
+// rounded to nearest even by v_cvt_pk_bf16_f32 (one instruction per pair); ~16 mantissa bits per operand
+#ifdef __HIPCC__
+__device__ inline void split_pair_bf16(float v0, float v1, float& hi, float& lo) {
+    typedef __bf16 split_b2 __attribute__((ext_vector_type(2)));
+    const split_b2 h = {(__bf16)v0, (__bf16)v1};
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    hi = __builtin_bit_cast(float, h);
+    const float r0 = v0 - __uint_as_float(hb << 16), r1 = v1 - __uint_as_float(hb & 0xffff0000u);
+    const split_b2 l = {(__bf16)r0, (__bf16)r1};
+    lo = __builtin_bit_cast(float, l);
+}
+#endif
+
 // V consecutive floats of a row (V = 4: one 16-byte access; V = 1: any alignment). vec4_ok(): the host-side predicate
 template <int V> struct VecF { float v[V]; };
 #ifdef __HIPCC__

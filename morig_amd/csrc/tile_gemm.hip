@@ -37,7 +37,8 @@ typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));        // what __built
 //                16 k = 5.3x the fp32-MFMA rate). fp16 products are exact in fp32, the dropped lo*lo term
 //                and the rounding of lo are both ~2^-22 relative: fp32-class accuracy. |x| must stay below
 //                the fp16 range; the loader raises `ovf` otherwise and the host re-runs in PREC_F32.
-enum { PREC_F32 = 0, PREC_F16X3 = 1 };
+enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16X3 = 2 };   // BF16X3 [r04]: the same 3-MFMA split on bf16 halves (float32 exponent range: the
+                                                          // backward contractions, whose operands are gradients); dense fp32-X stores only
 
 // LOAD_EDGE3: an EdgeConv whose vertex input has 3 channels (positions; the keyframe flow of motionNet's first unit): instead of
 //             gathering the per-vertex first-layer terms A[dst], B[src] (2 x 4 H bytes per edge row) the loader gathers the two
@@ -77,8 +78,8 @@ static int debug_flags() {
 // them, so their register budget is capped for 4 (fp32, KC = 16: 6) waves per SIMD (measured -17..21 % at H = 32).
 // The dense fp32-X GEMM tile (BN = 128, KC = 32) likewise runs better at 3 waves per SIMD than at 2.
 template <int BN, int KC, int LOAD, int MODE, int PREC>
-__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD != LOAD_DENSE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC == PREC_F16X3) ? 3 :
-                               (BN == 64 && LOAD == LOAD_DENSE && MODE == MODE_STORE && PREC == PREC_F16X3) ? 4 : 1)) void tile_kernel(const TileParams p) {
+__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD != LOAD_DENSE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC != PREC_F32) ? 3 :
+                               (BN == 64 && LOAD == LOAD_DENSE && MODE == MODE_STORE && PREC != PREC_F32) ? 4 : 1)) void tile_kernel(const TileParams p) {
     constexpr int BM = 128;
     constexpr int WN = (BN >= 128) ? 2 : 1;
     constexpr int WM = 4 / WN;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
             }
             if (PREC == PREC_F32) {
                 *reinterpret_cast<f32x4*>(&sA[(lrow + i * RPP) * LDK + 4 * lkq]) = v;
-            } else if (LOAD == LOAD_DENSE && p.x16) {
+            } else if (PREC == PREC_F16X3 && LOAD == LOAD_DENSE && p.x16) {
                 // the producer already wrote [32 halves hi | 32 halves lo] per 32-column chunk: plain copy
                 *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 16 * lkq) = ra[i];
             } else {
@@ -275,11 +276,16 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
                 typedef float b32x2 __attribute__((ext_vector_type(2)));
                 b32x2 h, l;
                 float h0, h1, l0, l1;
-                split_pair_f16(v[0], v[1], h0, l0);
-                split_pair_f16(v[2], v[3], h1, l1);
+                if (PREC == PREC_BF16X3) {
+                    split_pair_bf16(v[0], v[1], h0, l0);
+                    split_pair_bf16(v[2], v[3], h1, l1);
+                } else {
+                    split_pair_f16(v[0], v[1], h0, l0);
+                    split_pair_f16(v[2], v[3], h1, l1);
+                    const float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                    if (!(amax < 65000.f)) *p.ovf = 1;                 // also catches NaN
+                }
                 h[0] = h0; h[1] = h1; l[0] = l0; l[1] = l1;
-                const float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                if (!(amax < 65000.f)) *p.ovf = 1;                     // also catches NaN
                 char* rowp = reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 128 * (lkq >> 3) + 8 * (lkq & 7);
                 *reinterpret_cast<b32x2*>(rowp) = h;
                 *reinterpret_cast<b32x2*>(rowp + 64) = l;
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
         __syncthreads();
         if (c + 1 < nchunk) fetch((c + 1) * KC);
         if (p.dbg & DBG_NO_MFMA) continue;
-        if (PREC == PREC_F16X3) {
+        if (PREC != PREC_F32) {
             const char* a0 = reinterpret_cast<const char*>(sA) + (wm * MT * 32 + l31) * (LDK * 4) + 16 * hi;
             const char* b0 = reinterpret_cast<const char*>(sB) + (wn * NT * 32 + l31) * (LDK * 4) + 16 * hi;
 #pragma unroll
@@ -330,9 +336,18 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        if (PREC == PREC_BF16X3) {
+                            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+                            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[mt]), xl = __builtin_bit_cast(bf16x8, al[mt]);
+                            const bf16x8 wh = __builtin_bit_cast(bf16x8, bh[nt]), wl = __builtin_bit_cast(bf16x8, bl[nt]);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, wh, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wl, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, wh, acc[mt][nt], 0, 0, 0);
+                        } else {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        }
                     }
             }
             continue;
@@ -639,8 +654,12 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
     const double bytes = 4.0 * ((double)a->M * a->K + (double)a->N * a->K + (pool ? 0.0 : (double)a->M * a->N));
 
     const bool f16 = a->W_split != nullptr;
+    // [r04] W_split WITHOUT an overflow word = the bf16 split (W_split then holds bf16 halves; bf16 has float32's exponent range, so
+    // there is no range guard to report through): fp32 X, fp32 Y, plain stores -- the backward contractions
+    const bool bf16 = f16 && a->overflow == nullptr;
     if (f16) {
-        if (!a->overflow || !aligned16(a->W_split)) return MORIG_E_INVALID;
+        if (!aligned16(a->W_split)) return MORIG_E_INVALID;
+        if (bf16 && (pool || a->x_split || a->y_split)) return MORIG_E_UNSUPPORTED;
         p.W = static_cast<const float*>(a->W_split); p.ovf = a->overflow;
     }
     // 64-deep K chunks halve the barriers per MFMA on the split-fp16 path (needs weights padded to 64 in K)
@@ -684,6 +703,13 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         q.Y = a->Y; q.ldy = a->ldy; q.y16 = a->y_split ? 1 : 0; q.tiles_n = cdiv(a->N, 128); q.ovf = a->overflow;
         ProfScope ps(K_GEMM16_DMA, s, flops, bytes);
         return launch_gemm16_dma(q, tiles_m, s);
+    }
+    if (bf16) {
+        ProfScope ps(K_MISC, s, flops, bytes);
+        if (a->N > 64) { p.tiles_n = cdiv(a->N, 128); return launch_tile<128, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X3>(p, tiles_m * p.tiles_n, s); }
+        p.tiles_n = 1;
+        if (a->N > 32) return launch_tile<64, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X3>(p, tiles_m, s);
+        return launch_tile<32, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X3>(p, tiles_m, s);
     }
     if (a->N > 64) {
         p.tiles_n = cdiv(a->N, 128);

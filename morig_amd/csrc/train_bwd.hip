@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 
 // ---- the same contraction on the matrix cores' 16-bit rate: C = A^T B with every operand split into two bf16 halves ------------------
 // [r04] Gradients span the float32 exponent range (1e-8 .. 1e+4 inside one step), which rules the fp16 split of the forward path
-// out; bf16 keeps float32's exponent, so x = hi + lo with hi = bf16(x) truncated, lo = bf16(x - hi) rounded to nearest carries
+// out; bf16 keeps float32's exponent, so x = hi + lo with hi = bf16(x), lo = bf16(x - hi), both rounded to nearest, carries
 // ~16 mantissa bits with no range guard, and  hi*hi + hi*lo + lo*hi  on v_mfma_f32_32x32x16_bf16 (float32 accumulation) runs at
 // 16/3 = 5.3x the rate of the exact-float32 MFMA above. (The weight gradient is a sum over thousands of rows: 2^-16 per
 // product is far inside the 2e-4-of-scale criterion of the block tests; MORIG_TRAIN_BWD=f32 keeps the exact kernel.)
@@ -364,12 +364,16 @@ constexpr int TN16_P = 144;               // bytes per column of the transposed 
 typedef __bf16 tn_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned tn_u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void split_bf16(float x, unsigned& hi, unsigned& lo) {
-    const unsigned xb = __float_as_uint(x);
-    hi = xb >> 16;                                                    // truncated: lo absorbs the remainder exactly
-    const float r = x - __uint_as_float(xb & 0xffff0000u);            // exact in float32
-    const unsigned rb = __float_as_uint(r);
-    lo = (rb + 0x7fffu + ((rb >> 16) & 1u)) >> 16;                    // round to nearest even (an unbiased split)
+// two values -> (packed bf16 hi pair, packed bf16 lo pair): hi = bf16(x) and lo = bf16(x - hi), both rounded to nearest even by the
+// hardware conversion (v_cvt_pk_bf16_f32 on gfx950: one instruction per PAIR; the bit-twiddled form cost 8 VALU per element and made
+// the kernel VALU-bound); x - hi is exact in float32
+typedef __bf16 tn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const tn_bf16x2 h = {(__bf16)x0, (__bf16)x1};
+    hi = __builtin_bit_cast(unsigned, h);
+    const float r0 = x0 - __uint_as_float(hi << 16), r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+    const tn_bf16x2 l = {(__bf16)r0, (__bf16)r1};
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
 __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
@@ -415,12 +419,12 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
     };
     // split, transpose the 4 x 4 block and write column q's four rows as one 8-byte piece each for hi and lo
     auto put_one = [&](char* base, const tn_f32x4 (&v)[4], int q) __attribute__((always_inline)) {
-        unsigned h[4], l[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) split_bf16(v[i][q], h[i], l[i]);
+        unsigned h01, l01, h23, l23;
+        split_pair_bf16(v[0][q], v[1][q], h01, l01);
+        split_pair_bf16(v[2][q], v[3][q], h23, l23);
         char* col = base + (4 * cg + q) * TN16_P + 8 * rg;
-        *reinterpret_cast<tn_u32x2*>(col) = tn_u32x2{h[0] | (h[1] << 16), h[2] | (h[3] << 16)};
-        *reinterpret_cast<tn_u32x2*>(col + 64) = tn_u32x2{l[0] | (l[1] << 16), l[2] | (l[3] << 16)};
+        *reinterpret_cast<tn_u32x2*>(col) = tn_u32x2{h01, h23};
+        *reinterpret_cast<tn_u32x2*>(col + 64) = tn_u32x2{l01, l23};
     };
     auto put = [&](int st, int q) __attribute__((always_inline)) { put_one(sA[st], va, q); put_one(sB[st], vb, q); };
     if (r_begin < r_end) {

@@ -561,7 +561,11 @@ class NativeOps:
         if pool is not None:
             assert pool.shape[1] >= lin.N and pool.is_contiguous()
             a.pool, a.ld_pool, a.n_seg = pool.data_ptr(), pool.stride(0), pool.shape[0]
-        if self.fast and lin.Wsplit is not None:
+        if getattr(lin, "Wsplit_bf16", None) is not None:
+            # the bf16 split (no range guard: W_split without an overflow word, include/morig_hip.h): whatever self.precision says
+            assert pool is None and not x_split and not y_split
+            a.W_split, a.overflow = lin.Wsplit_bf16.data_ptr(), 0
+        elif self.fast and lin.Wsplit is not None:
             a.W_split, a.overflow = lin.Wsplit.data_ptr(), self._flag(X.base.device).data_ptr()
         a.x_split, a.y_split = int(x_split), int(y_split)
         check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")

@@ -44,6 +44,7 @@ class PackedLinear:
     N: int
     K: int
     Wsplit: Optional[torch.Tensor] = None   # split-fp16 image of W (same shape/stride), None = fp32 only
+    Wsplit_bf16: Optional[torch.Tensor] = None   # split-bf16 image (gradient contractions, train_backward.py): takes precedence when set
 
 
 @dataclass
@@ -73,6 +74,18 @@ def split_f16(Wp: torch.Tensor) -> Optional[torch.Tensor]:
         return None
     hi = Wp.half()
     lo = (Wp - hi.float()).half()
+    img = torch.stack([hi.view(N, Kp // 32, 32), lo.view(N, Kp // 32, 32)], dim=2)     # [N, Kc, 2, 32] halves
+    return img.reshape(N, Kp * 2).contiguous().view(torch.float32)
+
+
+def split_bf16(Wp: torch.Tensor) -> torch.Tensor:
+    """Split-bf16 image of a packed weight matrix, same layout as ``split_f16`` with bf16 halves: hi = bf16(w), lo = bf16(w - hi), both
+    rounded to nearest even (what v_cvt_pk_bf16_f32 does to the activations in the kernel). bf16 has float32's exponent range: no
+    range condition (the operands of the backward contractions are gradients)."""
+    N, Kp = Wp.shape
+    assert Kp % 32 == 0
+    hi = Wp.to(torch.bfloat16)
+    lo = (Wp - hi.float()).to(torch.bfloat16)
     img = torch.stack([hi.view(N, Kp // 32, 32), lo.view(N, Kp // 32, 32)], dim=2)     # [N, Kc, 2, 32] halves
     return img.reshape(N, Kp * 2).contiguous().view(torch.float32)
 

@@ -73,6 +73,20 @@ def _pack_f32(weight: torch.Tensor, bias: Optional[torch.Tensor], dev):
     return packing.to_device(packing.pack_linear(weight.detach().float(), None if bias is None else bias.detach().float(), split=False), dev)
 
 
+def bwd_split() -> bool:
+    """MORIG_TRAIN_BWD=f32: the gradient contractions (dX = dU W, dW = dU^T X) on the exact-float32 MFMA kernels; default: the
+    bf16 x 3 split (bf16 keeps float32's exponent range, which gradients need; ~16 mantissa bits per operand, 16/3 of the fp32-MFMA rate)"""
+    return not os.environ.get("MORIG_TRAIN_BWD", "bf16x3").startswith("f")
+
+
+def _pack_bwd(weight: torch.Tensor, dev):
+    """a packed Linear for a gradient GEMM dX = dU W^T-form: fp32 image always, plus the split-bf16 image unless MORIG_TRAIN_BWD=f32"""
+    pk = packing.pack_linear(weight.detach().float(), None, split=False)
+    if bwd_split():
+        pk.Wsplit_bf16 = packing.split_bf16(pk.W)
+    return packing.to_device(pk, dev)
+
+
 def _gemm_f32(ops, X: Mat, weight, n_out: int) -> torch.Tensor:
     """X @ weight^T on the fp32 MFMA path -> [rows, ld4(n_out)] (columns >= n_out are padding); ``weight``: a tensor, or an
     already packed Linear (``_pack_f32``)"""
@@ -98,7 +112,7 @@ class _Packs:
         self.d = {}
 
     def get(self, key, params, build):
-        ver = tuple((q.data_ptr(), q._version, q.device) for q in params if q is not None) + (train_fast(),)
+        ver = tuple((q.data_ptr(), q._version, q.device) for q in params if q is not None) + (train_fast(), bwd_split())
         if _PACK_DEBUG:
             # MORIG_TRAIN_PACK_DEBUG=1: the (storage, version) key cannot see a write through `.data` (an EMA copy, `p.data.clamp_()`):
             # those leave _version alone. The debug key adds a checksum of the values (one device reduction + host read per lookup --
@@ -176,7 +190,7 @@ class DenseTrain(torch.autograd.Function):
         dW = ops.gemm_tn(DU, Mat.of(xa, 0, K)) if ctx.needs_input_grad[1] else None
         dX = None
         if ctx.needs_input_grad[0]:
-            wt = ctx.packs.get("wT", (weight,), lambda: _pack_f32(weight.detach().t().contiguous(), None, dev))
+            wt = ctx.packs.get("wT", (weight,), lambda: _pack_bwd(weight.detach().t().contiguous(), dev))
             dX = _gemm_f32(ops, DU, wt, K)[:, :K]
         return dX, dW, db, (sdzx if ctx.needs_input_grad[3] else None), (sdz if ctx.needs_input_grad[4] else None), None, None
 
@@ -209,7 +223,7 @@ class NativeLinear(torch.autograd.Function):
         dW = ops.gemm_tn(DY, Mat.of(xa, 0, K)) if ctx.needs_input_grad[1] else None
         dX = None
         if ctx.needs_input_grad[0]:
-            wt = ctx.packs.get("wT", (weight,), lambda: _pack_f32(weight.detach().t().contiguous(), None, dy.device))
+            wt = ctx.packs.get("wT", (weight,), lambda: _pack_bwd(weight.detach().t().contiguous(), dy.device))
             dX = _gemm_f32(ops, DY, wt, K)[:, :K]
         return dX, dW, db, None
 
@@ -281,7 +295,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         db2 = ops.bn_backward_stats(DU2, rows_dev=e_live)[0] if (need[5] or need[6]) else None
         # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
         dW2 = (ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]) if need[5] else None
-        w2t = ctx.packs.get("w2T", (W2,), lambda: _pack_f32(W2.detach().t().contiguous(), None, dev))
+        w2t = ctx.packs.get("w2T", (W2,), lambda: _pack_bwd(W2.detach().t().contiguous(), dev))
         dh = _gemm_f32(ops, DU2, w2t, H)                                               # d(s1 Z1 + t1)  [capacity, H]
         DH = Mat.of(dh, 0, H)
         # BatchNorm1 + ReLU over the edges
@@ -302,7 +316,7 @@ class EdgeMLPTrain(torch.autograd.Function):
             def wvt_pack():
                 W1f = W1.detach().float()
                 Wv = torch.cat([W1f[:, :C] - W1f[:, C:], W1f[:, C:]], 0)
-                return _pack_f32(Wv.t().contiguous(), None, dev)
+                return _pack_bwd(Wv.t().contiguous(), dev)
             dX = _gemm_f32(ops, DAB, ctx.packs.get("wvT", (W1,), wvt_pack), C)[:, :C]
         return (dX, dW1, db1, (sdzx1 if need[3] else None), (sdz1 if need[4] else None), dW2, (db2 if need[6] else None),
                 (sdzx2 if need[7] else None), (sdz2 if need[8] else None), None, None, None, None)
