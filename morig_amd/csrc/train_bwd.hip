@@ -466,7 +466,10 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
             if (more) { put(st ^ 1, 2 * s2); put(st ^ 1, 2 * s2 + 1); }
             if (s2 == 1 && more && r0 + 2 * TN16_R < r_end) fetch(r0 + 2 * TN16_R);
         }
-        __syncthreads();                                              // stage st consumed by every wave, stage st ^ 1 written
+        // stage st consumed by every wave, stage st ^ 1 written. A raw barrier: __syncthreads() would also drain vmcnt, i.e. wait for
+        // the global loads of the stage AFTER the next one, which were issued a moment ago and have a whole stage to arrive
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
     }
     float* o = part + (size_t)bz * N * K;
 #pragma unroll
