@@ -496,20 +496,37 @@ int morig_bn_backward_stats(const float* dz, int32_t ldz, const float* y, int32_
 int morig_bn_relu_backward(const float* dz, int32_t ldz, const float* y, int32_t ldy, int32_t rows, const int32_t* rows_dev,
                            int32_t cols, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
                            const float* sum_dzx, float* du, int32_t ldu, void* stream);
-/* morig_segmax_affine that also records which row won: arg[v][c] = row index (first on ties), -1 for an empty segment */
+/* morig_segmax_affine that also records which row won: arg[v][c] = row index (first on ties), -1 for an empty segment; zwin
+ * (NULL or [n_segments][ldw]) receives Z[arg[v][c]][c], the winner's value in front of the affine (0 for an empty segment): the
+ * backward statistics then need no gather. Few long segments (per-mesh pooling) and many short ones (edges) take different kernels. */
 int morig_segmax_affine_arg(const float* Z, int32_t ldz, const int32_t* rowptr, int32_t n_segments, int32_t H, const float* scale,
-                            const float* shift, float* out, int32_t ldo, int32_t* arg, int32_t ld_arg, void* stream);
+                            const float* shift, float* out, int32_t ldo, int32_t* arg, int32_t ld_arg, float* zwin, int32_t ldw,
+                            void* stream);
 /* the two BatchNorm sums for the BatchNorm in FRONT of a max aggregation, from the per-segment gradient dout [n_segments][cols]
- * and the arg-max table (the per-row gradient is one-hot per (segment, column) and never materialised); Z = BatchNorm input rows */
+ * and the arg-max table (the per-row gradient is one-hot per (segment, column) and never materialised); the BatchNorm input of
+ * the winning rows comes from zwin [n_segments][ldw] when given (coalesced), otherwise it is gathered from the rows Z */
 int morig_segmax_bn_backward_stats(const float* dout, int32_t ldd, const int32_t* arg, int32_t ld_arg, const float* Z, int32_t ldz,
-                                   int32_t n_segments, int32_t cols, const float* mean, const float* rstd, double* workspace,
-                                   int64_t workspace_doubles, float* sum_dz, float* sum_dzx, void* stream);
+                                   const float* zwin, int32_t ldw, int32_t n_segments, int32_t cols, const float* mean,
+                                   const float* rstd, double* workspace, int64_t workspace_doubles, float* sum_dz, float* sum_dzx,
+                                   void* stream);
 /* du[e][c] for every row e < rowptr[n_segments] (seg_of_row[e] = its segment): the BatchNorm (+ the ReLU in front of it when
- * relu != 0) applied to that one-hot gradient; n = rowptr[n_segments]. Rows rowptr[n_segments] <= e < row_capacity are set to 0. */
+ * relu != 0) applied to that one-hot gradient; n = rowptr[n_segments]. Rows rowptr[n_segments] <= e < row_capacity are set to 0.
+ * sum_du (NULL or [cols]): the column sums of du over the live rows, fp64 accumulation in a fixed order (the bias gradient of the
+ * Linear behind the BatchNorm, from the same pass); workspace: >= ceil(row_capacity / slab) * 2 * cols doubles as in
+ * morig_bn_backward_stats, needed only with sum_du. */
 int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, const int32_t* arg, int32_t ld_arg, const float* Z, int32_t ldz,
                                   const int32_t* rowptr, int32_t n_segments, const int32_t* seg_of_row, int32_t row_capacity,
                                   int32_t cols, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
-                                  const float* sum_dzx, int32_t relu, float* du, int32_t ldu, void* stream);
+                                  const float* sum_dzx, int32_t relu, float* du, int32_t ldu, double* workspace,
+                                  int64_t workspace_doubles, float* sum_du, void* stream);
+/* morig_bn_relu_backward and morig_edge_scatter_backward in one, deterministic: with d[e] = [Y > 0] gamma rstd (dG - sum_dz / n -
+ * xhat sum_dzx / n) (n = rowptr[n_nodes]; mean == NULL: d = dG), dA[v] = sum of d over the CSR segment of v and dB[u] = sum of d
+ * over the edges out of u, walked through the transposed graph: rowptr_t [n_src_nodes + 1], perm_t[k] = row e of the k-th edge in
+ * (source, row) order. d is evaluated where it is summed and never stored; both sums run in a fixed order (no atomics). */
+int morig_edge_bn_scatter_backward(const float* dG, int32_t ldg, const float* Y, int32_t ldy, const int32_t* rowptr,
+                                   const int32_t* rowptr_t, const int32_t* perm_t, int32_t n_nodes, int32_t n_src_nodes, int32_t H,
+                                   const float* mean, const float* rstd, const float* gamma, const float* sum_dz, const float* sum_dzx,
+                                   float* dA, int32_t lda, float* dB, int32_t ldb, void* stream);
 /* backward of Z[e] = A[dst_e] + B[src_e]: dA[v] = sum of dG over the CSR segment of v (fixed order), dB[u] = sum of dG over the
  * edges with source u (float atomics: summation order, hence the last bits, vary run to run). dB ([n_src_nodes][ldb]) is zeroed here. */
 int morig_edge_scatter_backward(const float* dG, int32_t ldg, const int32_t* rowptr, const int32_t* src_sorted, int32_t n_nodes,

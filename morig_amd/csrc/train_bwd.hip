@@ -27,7 +27,8 @@ namespace morig {
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dz, int ldz, const float* __restrict__ y, int ldy,
                                                              int rows_host, const int* __restrict__ rows_dev, int cols, int slab_rows,
                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                             double* __restrict__ part /* [slabs][2][cols] */) {
+                                                             double* __restrict__ part /* [slabs][2][cols] */,
+                                                             const int* __restrict__ live /* NULL, or: entries < 0 drop dz */, int ld_live) {
     const int rows = rows_dev ? *rows_dev : rows_host;
     const int c0 = blockIdx.x * 64;
     const int quads = min(16, (cols - c0 + 3) >> 2);
@@ -46,7 +47,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 #pragma unroll 4
             for (int r = r0 + rl; r < r1; r += RL) {
                 const float4 g4 = *reinterpret_cast<const float4*>(dz + (size_t)r * ldz + c);
-                const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+                float g[4] = {g4.x, g4.y, g4.z, g4.w};
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (live[(size_t)r * ld_live + c + j] < 0) g[j] = 0.f;
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[0][j] += (double)g[j];
                 if (y) {
@@ -61,7 +66,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (c + j < cols) {
-                        const float g = dz[(size_t)r * ldz + c + j];
+                        const float g = (live && live[(size_t)r * ld_live + c + j] < 0) ? 0.f : dz[(size_t)r * ldz + c + j];
                         acc[0][j] += (double)g;
                         if (y) acc[1][j] += (double)(g * ((y[(size_t)r * ldy + c + j] - m[j]) * rs[j]));
                     }
@@ -111,7 +116,8 @@ __global__ void bn_relu_bwd_kernel(const float* dz, int ldz, const float* __rest
 template <int V>
 __global__ __launch_bounds__(256) void segmax_arg_kernel(const float* __restrict__ Z, int ldz, const int* __restrict__ rowptr, int n_seg,
                                                          int H, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         float* __restrict__ out, int ldo, int* __restrict__ arg, int ld_arg) {
+                                                         float* __restrict__ out, int ldo, int* __restrict__ arg, int ld_arg,
+                                                         float* __restrict__ zwin, int ldw) {
     const int qn = H / V;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)n_seg * qn) return;
@@ -123,22 +129,23 @@ __global__ __launch_bounds__(256) void segmax_arg_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < V; ++j) { m.v[j] = 0.f; arg[(size_t)v * ld_arg + c + j] = -1; }
         stv<V>(out + (size_t)v * ldo + c, m);
+        if (zwin) stv<V>(zwin + (size_t)v * ldw + c, m);
         return;
     }
-    VecF<V> s, sh;
+    VecF<V> s, sh, zw;
 #pragma unroll
     for (int j = 0; j < V; ++j) { s.v[j] = scale ? scale[c + j] : 1.f; sh.v[j] = shift ? shift[c + j] : 0.f; }
     {
         const VecF<V> z = ldv<V>(Z + (size_t)e0 * ldz + c);
 #pragma unroll
-        for (int j = 0; j < V; ++j) { m.v[j] = z.v[j] * s.v[j] + sh.v[j]; a[j] = e0; }
+        for (int j = 0; j < V; ++j) { m.v[j] = z.v[j] * s.v[j] + sh.v[j]; a[j] = e0; zw.v[j] = z.v[j]; }
     }
     for (int e = e0 + 1; e < e1; ++e) {
         const VecF<V> z = ldv<V>(Z + (size_t)e * ldz + c);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
             const float w = z.v[j] * s.v[j] + sh.v[j];
-            if (w > m.v[j]) { m.v[j] = w; a[j] = e; }                // strict: the first maximum keeps the gradient
+            if (w > m.v[j]) { m.v[j] = w; a[j] = e; zw.v[j] = z.v[j]; }   // strict: the first maximum keeps the gradient
         }
     }
     stv<V>(out + (size_t)v * ldo + c, m);
@@ -146,6 +153,72 @@ __global__ __launch_bounds__(256) void segmax_arg_kernel(const float* __restrict
 #pragma unroll
     for (int j = 0; j < V; ++j) ab.v[j] = __int_as_float(a[j]);
     stv<V>(reinterpret_cast<float*>(arg) + (size_t)v * ld_arg + c, ab);
+    if (zwin) stv<V>(zwin + (size_t)v * ldw + c, zw);
+}
+
+// FEW, LONG segments (the per-mesh pooling: 8 segments of 4 096 rows; one thread per (segment, V columns) would walk them serially
+// on a handful of waves: 1.1 ms per call): one workgroup per (segment, 16 columns), 16 V row lanes with four loads in flight each,
+// then a tree over the row lanes in LDS. Same result as the serial walk: the largest value, on ties the LOWEST row.
+template <int V>
+__global__ __launch_bounds__(256) void segmax_arg_long_kernel(const float* __restrict__ Z, int ldz, const int* __restrict__ rowptr, int H,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ out, int ldo, int* __restrict__ arg, int ld_arg,
+                                                              float* __restrict__ zwin, int ldw) {
+    constexpr int CG = 16 / V, RL = 256 / CG;
+    const int v = blockIdx.y;
+    const int cg = threadIdx.x % CG, rl = threadIdx.x / CG;
+    const int cl = cg * V, c = blockIdx.x * 16 + cl;
+    const int e0 = rowptr[v], e1 = rowptr[v + 1];
+    float m[V], zw[V], s[V], sh[V];
+    int a[V];
+    const bool on = c + V <= H;                                      // (H is a multiple of V: a column group is in or out as a whole)
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        m[j] = 0.f; zw[j] = 0.f; a[j] = -1;
+        s[j] = (on && scale) ? scale[c + j] : 1.f; sh[j] = (on && shift) ? shift[c + j] : 0.f;
+    }
+    if (on) {
+        auto take = [&](const VecF<V>& z, int e) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float w = z.v[j] * s[j] + sh[j];
+                if (a[j] < 0 || w > m[j]) { m[j] = w; a[j] = e; zw[j] = z.v[j]; }
+            }
+        };
+        int e = e0 + rl;
+        for (; e + 3 * RL < e1; e += 4 * RL) {
+            const VecF<V> z0 = ldv<V>(Z + (size_t)e * ldz + c), z1 = ldv<V>(Z + (size_t)(e + RL) * ldz + c);
+            const VecF<V> z2 = ldv<V>(Z + (size_t)(e + 2 * RL) * ldz + c), z3 = ldv<V>(Z + (size_t)(e + 3 * RL) * ldz + c);
+            take(z0, e); take(z1, e + RL); take(z2, e + 2 * RL); take(z3, e + 3 * RL);
+        }
+        for (; e < e1; e += RL) take(ldv<V>(Z + (size_t)e * ldz + c), e);
+    }
+    __shared__ float sm[RL][16], sz[RL][16];
+    __shared__ int sa[RL][16];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sm[rl][cl + j] = m[j]; sz[rl][cl + j] = zw[j]; sa[rl][cl + j] = a[j]; }
+    __syncthreads();
+    for (int h = RL / 2; h > 0; h >>= 1) {
+        if (rl < h) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float mo = sm[rl + h][cl + j]; const int ao = sa[rl + h][cl + j];
+                const float mm = sm[rl][cl + j]; const int am = sa[rl][cl + j];
+                if (ao >= 0 && (am < 0 || mo > mm || (mo == mm && ao < am))) {
+                    sm[rl][cl + j] = mo; sa[rl][cl + j] = ao; sz[rl][cl + j] = sz[rl + h][cl + j];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && on) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            out[(size_t)v * ldo + c + j] = sm[0][cl + j];
+            arg[(size_t)v * ld_arg + c + j] = sa[0][cl + j];
+            if (zwin) zwin[(size_t)v * ldw + c + j] = sz[0][cl + j];
+        }
+    }
 }
 
 // sums over SEGMENTS of the one-hot row gradient: dz[arg[v][c]][c] = dout[v][c]
@@ -178,40 +251,72 @@ __global__ __launch_bounds__(256) void segmax_bwd_partial_kernel(const float* __
     }
 }
 
+// One workgroup per (64 columns, slab of rows), threads as in bn_bwd_partial_kernel (column quads x row lanes); besides du it leaves
+// the fp64 column sums of du over its slab (= the bias gradient of the Linear behind this BatchNorm: no second pass over du).
 template <int V>
-__global__ void segmax_bn_relu_bwd_kernel(const float* __restrict__ dout, int ldd, const int* __restrict__ arg, int ld_arg,
+__global__ __launch_bounds__(256) void segmax_bn_relu_bwd_kernel(const float* __restrict__ dout, int ldd, const int* __restrict__ arg, int ld_arg,
                                           const float* __restrict__ Z, int ldz, const int* __restrict__ rowptr, int n_seg,
-                                          const int* __restrict__ seg_of_row, int row_capacity, int cols,
+                                          const int* __restrict__ seg_of_row, int row_capacity, int cols, int slab_rows,
                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                           const float* __restrict__ gamma, const float* __restrict__ sum_dz,
-                                          const float* __restrict__ sum_dzx, int relu, float* __restrict__ du, int ldu) {
+                                          const float* __restrict__ sum_dzx, int relu, float* __restrict__ du, int ldu,
+                                          double* __restrict__ part /* NULL or [slabs][2][cols] */) {
     const int rows = rowptr[n_seg];
     const float inv_n = rows > 0 ? 1.f / (float)rows : 0.f;
-    const int qn = cols / V;
-    const int64_t total = (int64_t)row_capacity * qn;            // rows past the live count are zeroed: du feeds a GEMM over the capacity
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t e = i / qn; const int c = (int)(i - e * qn) * V;
-        VecF<V> o;
-        if (e >= rows) {
+    const int c0 = blockIdx.x * 64;
+    const int quads = min(16, (cols - c0 + 3) >> 2);
+    const int RL = 256 / quads;
+    const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
+    const int c = c0 + q * 4;
+    const int r0 = blockIdx.y * slab_rows, r1 = min(r0 + slab_rows, row_capacity);   // rows past the live count are zeroed: du feeds a GEMM over the capacity
+    double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (rl < RL) {
+        float m[4], rs[4], grs[4], k0[4], k1[4];
 #pragma unroll
-            for (int j = 0; j < V; ++j) o.v[j] = 0.f;
-            stv<V>(du + e * ldu + c, o);
-            continue;
+        for (int j = 0; j < 4; ++j) {
+            const bool in = c + j < cols;
+            m[j] = in ? mean[c + j] : 0.f; rs[j] = in ? rstd[c + j] : 0.f; grs[j] = in ? gamma[c + j] * rs[j] : 0.f;
+            k0[j] = in ? sum_dz[c + j] * inv_n : 0.f; k1[j] = in ? sum_dzx[c + j] * inv_n : 0.f;
         }
-        const int v = seg_of_row[e];
-        const VecF<V> zv = ldv<V>(Z + e * ldz + c);
-        const VecF<V> dv = ldv<V>(dout + (size_t)v * ldd + c);
-        const VecF<V> av = ldv<V>(reinterpret_cast<const float*>(arg) + (size_t)v * ld_arg + c);       // (row indices, moved as bits)
+        for (int e = r0 + rl; e < r1; e += RL) {
+            if (e >= rows) {
+                if (V == 4) *reinterpret_cast<float4*>(du + (size_t)e * ldu + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+                else
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            const float xh = (zv.v[j] - mean[c + j]) * rstd[c + j];
-            const float dzv = __float_as_int(av.v[j]) == (int)e ? dv.v[j] : 0.f;
-            const float g = gamma[c + j] * rstd[c + j] * (dzv - sum_dz[c + j] * inv_n - xh * (sum_dzx[c + j] * inv_n));
-            o.v[j] = (!relu || zv.v[j] > 0.f) ? g : 0.f;
+                    for (int j = 0; j < 4; ++j) if (c + j < cols) du[(size_t)e * ldu + c + j] = 0.f;
+                continue;
+            }
+            const int v = seg_of_row[e];
+            float zv[4], dv[4], o[4]; int av[4];
+            if (V == 4) {
+                const float4 z4 = *reinterpret_cast<const float4*>(Z + (size_t)e * ldz + c);
+                const float4 d4 = *reinterpret_cast<const float4*>(dout + (size_t)v * ldd + c);
+                const int4 a4 = *reinterpret_cast<const int4*>(arg + (size_t)v * ld_arg + c);
+                zv[0] = z4.x; zv[1] = z4.y; zv[2] = z4.z; zv[3] = z4.w; dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w;
+                av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool in = c + j < cols;
+                    zv[j] = in ? Z[(size_t)e * ldz + c + j] : 0.f; dv[j] = in ? dout[(size_t)v * ldd + c + j] : 0.f;
+                    av[j] = in ? arg[(size_t)v * ld_arg + c + j] : -1;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (zv[j] - m[j]) * rs[j];
+                const float dzv = av[j] == e ? dv[j] : 0.f;
+                const float g = grs[j] * (dzv - k0[j] - xh * k1[j]);
+                o[j] = (!relu || zv[j] > 0.f) ? g : 0.f;
+                acc[0][j] += (double)o[j];
+            }
+            if (V == 4) *reinterpret_cast<float4*>(du + (size_t)e * ldu + c) = make_float4(o[0], o[1], o[2], o[3]);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < cols) du[(size_t)e * ldu + c + j] = o[j];
         }
-        stv<V>(du + e * ldu + c, o);
     }
+    if (part) stats_block_store(acc, quads, RL, q, rl, c0, cols, blockIdx.y, part);
 }
 
 // dA[v] = sum over the rows of segment v (fixed order); dB[src(e)] += dG[e] (atomics). One thread per (segment, V columns).
@@ -234,6 +339,65 @@ __global__ __launch_bounds__(256) void edge_scatter_bwd_kernel(const float* __re
         for (int j = 0; j < V; ++j) { s.v[j] += g.v[j]; atomicAdd(pb + j, g.v[j]); }
     }
     stv<V>(dA + (size_t)v * lda + c, s);
+}
+
+// The backward of Z[e] = relu(A[dst_e] + B[src_e]) with the BatchNorm behind it, WITHOUT materialising the per-edge gradient and
+// without atomics: d[e] = [y > 0] gamma rstd (g - sum_dz / n - xhat sum_dzx / n) is evaluated where it is summed, once in the CSR
+// order of the targets (dA[v]) and once in the order of the TRANSPOSED graph (dB[u] = sum over perm[k], k in the segment of u in
+// rowptr_t: the edges out of u in ascending row order). Both sums run in a fixed order. mean == NULL: d[e] = g[e] (the plain
+// scatter). One thread per (vertex, V columns).
+template <int V>
+__global__ __launch_bounds__(256) void edge_bn_scatter_bwd_kernel(const float* __restrict__ dG, int ldg, const float* __restrict__ Y, int ldy,
+                                                                  const int* __restrict__ rowptr, const int* __restrict__ rowptr_t,
+                                                                  const int* __restrict__ perm_t, int n_nodes, int n_src, int H,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ sum_dz,
+                                                                  const float* __restrict__ sum_dzx, float* __restrict__ dA, int lda,
+                                                                  float* __restrict__ dB, int ldb) {
+    const int qn = H / V;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nmax = max(n_nodes, n_src);
+    if (t >= (int64_t)nmax * qn) return;
+    const int v = (int)(t / qn), c = (int)(t - (int64_t)v * qn) * V;
+    const int rows = rowptr[n_nodes];
+    const float inv_n = rows > 0 ? 1.f / (float)rows : 0.f;
+    VecF<V> m, rs, grs, k0, k1;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+        m.v[j] = mean ? mean[c + j] : 0.f; rs.v[j] = mean ? rstd[c + j] : 0.f; grs.v[j] = mean ? gamma[c + j] * rs.v[j] : 1.f;
+        k0.v[j] = mean ? sum_dz[c + j] * inv_n : 0.f; k1.v[j] = mean ? sum_dzx[c + j] * inv_n : 0.f;
+    }
+    auto grad = [&](int e, VecF<V>& acc) {
+        const VecF<V> g = ldv<V>(dG + (size_t)e * ldg + c);
+        if (mean) {
+            const VecF<V> y = ldv<V>(Y + (size_t)e * ldy + c);
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float xh = (y.v[j] - m.v[j]) * rs.v[j];
+                const float d = grs.v[j] * (g.v[j] - k0.v[j] - xh * k1.v[j]);
+                acc.v[j] += y.v[j] > 0.f ? d : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) acc.v[j] += g.v[j];
+        }
+    };
+    if (v < n_nodes) {
+        VecF<V> a;
+#pragma unroll
+        for (int j = 0; j < V; ++j) a.v[j] = 0.f;
+        const int e1 = rowptr[v + 1];
+        for (int e = rowptr[v]; e < e1; ++e) grad(e, a);
+        stv<V>(dA + (size_t)v * lda + c, a);
+    }
+    if (v < n_src) {
+        VecF<V> b;
+#pragma unroll
+        for (int j = 0; j < V; ++j) b.v[j] = 0.f;
+        const int k1e = rowptr_t[v + 1];
+        for (int k = rowptr_t[v]; k < k1e; ++k) grad(perm_t[k], b);
+        stv<V>(dB + (size_t)v * ldb + c, b);
+    }
 }
 
 // ---- C = A^T B over the rows -----------------------------------------------------------------------------------------------
@@ -526,7 +690,7 @@ extern "C" int morig_bn_backward_stats(const float* dz, int32_t ldz, const float
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 8.0 * rows * (double)cols);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols, slab_rows,
-                       mean, rstd, workspace);
+                       mean, rstd, workspace, (const int*)nullptr, 0);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, y ? sum_dzx : nullptr);
     MORIG_LAUNCH_CHECK();
@@ -554,32 +718,47 @@ extern "C" int morig_bn_relu_backward(const float* dz, int32_t ldz, const float*
 
 extern "C" int morig_segmax_affine_arg(const float* Z, int32_t ldz, const int32_t* rowptr, int32_t n_segments, int32_t H,
                                        const float* scale, const float* shift, float* out, int32_t ldo, int32_t* arg, int32_t ld_arg,
-                                       void* stream) {
+                                       float* zwin, int32_t ldw, void* stream) {
     if (!Z || !rowptr || !out || !arg || n_segments <= 0 || H <= 0 || ldz < H || ldo < H || ld_arg < H) return MORIG_E_INVALID;
-    if ((scale == nullptr) != (shift == nullptr)) return MORIG_E_INVALID;
+    if ((scale == nullptr) != (shift == nullptr) || (zwin && ldw < H)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 0.0);
-    const bool v4 = (H & 3) == 0 && vec4_ptr(Z, ldz) && vec4_ptr(out, ldo) && vec4_ptr(arg, ld_arg);
-    const int blocks = cdiv((long)n_segments * (H / (v4 ? 4 : 1)), 256);
+    const bool v4 = (H & 3) == 0 && vec4_ptr(Z, ldz) && vec4_ptr(out, ldo) && vec4_ptr(arg, ld_arg) && (!zwin || vec4_ptr(zwin, ldw));
+    const long threads = (long)n_segments * (H / (v4 ? 4 : 1));
+    if (threads < 32768 && n_segments <= 65535) {        // too few (segment, column group) pairs to fill the chip: the segments are what is long
+        const dim3 grid(cdiv(H, 16), n_segments);
+        if (v4) hipLaunchKernelGGL(segmax_arg_long_kernel<4>, grid, dim3(256), 0, s, Z, ldz, rowptr, H, scale, shift, out, ldo, arg, ld_arg,
+                                   zwin, ldw);
+        else hipLaunchKernelGGL(segmax_arg_long_kernel<1>, grid, dim3(256), 0, s, Z, ldz, rowptr, H, scale, shift, out, ldo, arg, ld_arg,
+                                zwin, ldw);
+        MORIG_LAUNCH_CHECK();
+        return MORIG_OK;
+    }
+    const int blocks = cdiv(threads, 256);
     if (v4) hipLaunchKernelGGL(segmax_arg_kernel<4>, dim3(blocks), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale, shift, out, ldo,
-                               arg, ld_arg);
+                               arg, ld_arg, zwin, ldw);
     else hipLaunchKernelGGL(segmax_arg_kernel<1>, dim3(blocks), dim3(256), 0, s, Z, ldz, rowptr, n_segments, H, scale, shift, out, ldo,
-                            arg, ld_arg);
+                            arg, ld_arg, zwin, ldw);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
 
 extern "C" int morig_segmax_bn_backward_stats(const float* dout, int32_t ldd, const int32_t* arg, int32_t ld_arg, const float* Z,
-                                              int32_t ldz, int32_t n_segments, int32_t cols, const float* mean, const float* rstd,
-                                              double* workspace, int64_t workspace_doubles, float* sum_dz, float* sum_dzx, void* stream) {
-    if (!dout || !arg || !Z || !mean || !rstd || !workspace || !sum_dz || !sum_dzx) return MORIG_E_INVALID;
-    if (n_segments <= 0 || cols <= 0 || ldd < cols || ld_arg < cols || ldz < cols) return MORIG_E_INVALID;
+                                              int32_t ldz, const float* zwin, int32_t ldw, int32_t n_segments, int32_t cols,
+                                              const float* mean, const float* rstd, double* workspace, int64_t workspace_doubles,
+                                              float* sum_dz, float* sum_dzx, void* stream) {
+    if (!dout || !arg || (!Z && !zwin) || !mean || !rstd || !workspace || !sum_dz || !sum_dzx) return MORIG_E_INVALID;
+    if (n_segments <= 0 || cols <= 0 || ldd < cols || ld_arg < cols || (zwin ? ldw < cols : ldz < cols)) return MORIG_E_INVALID;
     const int slab_rows = stats_slab_rows(n_segments);
     const int slabs = cdiv(n_segments, slab_rows);
     if (workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 12.0 * n_segments * (double)cols);
-    hipLaunchKernelGGL(segmax_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, n_segments,
+    // with the winners' values at hand (the forward kept them per segment) these are the plain BatchNorm sums over the segment rows,
+    // all reads coalesced; without, every (segment, column) fetches its own row of Z
+    if (zwin) hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dout, ldd, zwin, ldw, n_segments,
+                                 (const int*)nullptr, cols, slab_rows, mean, rstd, workspace, arg, ld_arg);
+    else hipLaunchKernelGGL(segmax_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, n_segments,
                        cols, slab_rows, mean, rstd, workspace);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, sum_dzx);
@@ -591,19 +770,25 @@ extern "C" int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, con
                                              int32_t ldz, const int32_t* rowptr, int32_t n_segments, const int32_t* seg_of_row,
                                              int32_t row_capacity, int32_t cols, const float* mean, const float* rstd, const float* gamma,
                                              const float* sum_dz, const float* sum_dzx, int32_t relu, float* du, int32_t ldu,
-                                             void* stream) {
+                                             double* workspace, int64_t workspace_doubles, float* sum_du, void* stream) {
     if (!dout || !arg || !Z || !rowptr || !seg_of_row || !mean || !rstd || !gamma || !sum_dz || !sum_dzx || !du) return MORIG_E_INVALID;
     if (n_segments <= 0 || row_capacity <= 0 || cols <= 0 || ldd < cols || ld_arg < cols || ldz < cols || ldu < cols) return MORIG_E_INVALID;
+    const int slab_rows = stats_slab_rows(row_capacity);
+    const int slabs = cdiv(row_capacity, slab_rows);
+    if (sum_du && (!workspace || workspace_doubles < (int64_t)slabs * 2 * cols)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool v4 = (cols & 3) == 0 && vec4_ptr(Z, ldz) && vec4_ptr(du, ldu) && vec4_ptr(dout, ldd) && vec4_ptr(arg, ld_arg);
-    int64_t blocks = ((int64_t)row_capacity * (cols / (v4 ? 4 : 1)) + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
     ProfScope ps(K_MISC, s, 0.0, 16.0 * row_capacity * (double)cols);
-    if (v4) hipLaunchKernelGGL(segmax_bn_relu_bwd_kernel<4>, dim3((int)blocks), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, rowptr,
-                               n_segments, seg_of_row, row_capacity, cols, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu);
-    else hipLaunchKernelGGL(segmax_bn_relu_bwd_kernel<1>, dim3((int)blocks), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, rowptr,
-                            n_segments, seg_of_row, row_capacity, cols, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu);
+    double* part = sum_du ? workspace : nullptr;
+    if (v4) hipLaunchKernelGGL(segmax_bn_relu_bwd_kernel<4>, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, rowptr,
+                               n_segments, seg_of_row, row_capacity, cols, slab_rows, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu, part);
+    else hipLaunchKernelGGL(segmax_bn_relu_bwd_kernel<1>, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, rowptr,
+                            n_segments, seg_of_row, row_capacity, cols, slab_rows, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu, part);
     MORIG_LAUNCH_CHECK();
+    if (sum_du) {
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_du, (float*)nullptr);
+        MORIG_LAUNCH_CHECK();
+    }
     return MORIG_OK;
 }
 
@@ -618,6 +803,26 @@ extern "C" int morig_edge_scatter_backward(const float* dG, int32_t ldg, const i
     // instructions per row -- measured 4x slower)
     hipLaunchKernelGGL(edge_scatter_bwd_kernel<1>, dim3(cdiv((long)n_nodes * H, 256)), dim3(256), 0, s, dG, ldg, rowptr, src_sorted, n_nodes, H,
                        dA, lda, dB, ldb);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_edge_bn_scatter_backward(const float* dG, int32_t ldg, const float* Y, int32_t ldy, const int32_t* rowptr,
+                                             const int32_t* rowptr_t, const int32_t* perm_t, int32_t n_nodes, int32_t n_src_nodes,
+                                             int32_t H, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
+                                             const float* sum_dzx, float* dA, int32_t lda, float* dB, int32_t ldb, void* stream) {
+    if (!dG || !rowptr || !rowptr_t || !perm_t || !dA || !dB || n_nodes <= 0 || n_src_nodes <= 0 || H <= 0) return MORIG_E_INVALID;
+    if (ldg < H || lda < H || ldb < H) return MORIG_E_INVALID;
+    if (mean && (!Y || !rstd || !gamma || !sum_dz || !sum_dzx || ldy < H)) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_MISC, s, 0.0, 0.0);
+    const bool v4 = (H & 3) == 0 && vec4_ptr(dG, ldg) && vec4_ptr(dA, lda) && vec4_ptr(dB, ldb) && (!mean || vec4_ptr(Y, ldy));
+    const int nmax = n_nodes > n_src_nodes ? n_nodes : n_src_nodes;
+    const int blocks = cdiv((long)nmax * (H / (v4 ? 4 : 1)), 256);
+    if (v4) hipLaunchKernelGGL(edge_bn_scatter_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dG, ldg, Y, ldy, rowptr, rowptr_t, perm_t, n_nodes,
+                               n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb);
+    else hipLaunchKernelGGL(edge_bn_scatter_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dG, ldg, Y, ldy, rowptr, rowptr_t, perm_t, n_nodes,
+                            n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -135,12 +135,15 @@ _SIGNATURES = {
     "morig_bn_relu_backward": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
                                          c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_segmax_affine_arg": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, c_i32p,
-                                          C.c_int32, C.c_void_p]),
-    "morig_segmax_bn_backward_stats": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p,
-                                                 c_f32p, C.c_void_p, C.c_int64, c_f32p, c_f32p, C.c_void_p]),
+                                          C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
+    "morig_segmax_bn_backward_stats": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
+                                                 C.c_int32, c_f32p, c_f32p, C.c_void_p, C.c_int64, c_f32p, c_f32p, C.c_void_p]),
     "morig_segmax_bn_relu_backward": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, c_i32p,
                                                 C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32,
-                                                C.c_void_p]),
+                                                C.c_void_p, C.c_int64, c_f32p, C.c_void_p]),
+    "morig_edge_bn_scatter_backward": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int32, C.c_int32,
+                                                 C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32,
+                                                 C.c_void_p]),
     "morig_edge_scatter_backward": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p,
                                               C.c_int32, C.c_void_p]),
     "morig_gemm_tn_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
@@ -283,6 +286,23 @@ class CSR:
     status: torch.Tensor      # int32 [1], non-zero = index out of range (read once per forward by NativeOps.guarded)
     edge_count: int = 0       # exact E' when known (accounting only)
     quad: bool = False        # segments padded to multiples of 4 (MORIG_CSR_PAD4)
+    _transposed: Optional[tuple] = None
+
+    def transposed(self, n_src: Optional[int] = None):
+        """-> (rowptr_t int32 [n_src + 1], perm_t int32 [capacity]): the same edges grouped by SOURCE, perm_t[k] = the row of this CSR
+        holding the k-th edge in (source, row) order -- what ``edge_bn_scatter_backward`` walks to sum the gradient of the source
+        side in a fixed order. Built once per graph with stream-ordered torch calls (stable sort; no host read: the live row count
+        stays on the device, rows past it sort behind every vertex)."""
+        n_src = self.n_nodes if n_src is None else n_src
+        if self._transposed is None or self._transposed[0] != n_src:
+            dev = self.src.device
+            live = self.rowptr[self.n_nodes]
+            pos = torch.arange(self.capacity, device=dev)
+            keys = torch.where(pos < live, self.src.long().clamp(0, n_src), torch.full((), n_src, dtype=torch.int64, device=dev))
+            skeys, order = torch.sort(keys, stable=True)
+            rowptr_t = torch.searchsorted(skeys, torch.arange(n_src + 1, device=dev)).int()
+            self._transposed = (n_src, rowptr_t.contiguous(), order.int().contiguous())
+        return self._transposed[1], self._transposed[2]
 
 
 def _p(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -763,36 +783,62 @@ class NativeOps:
         check(self.lib.morig_bn_relu_backward(dz.ptr, dz.ld, y.ptr, y.ld, dz.rows, _p(rows_dev), dz.cols, _p(mean), _p(rstd), _p(gamma),
                                               _p(sum_dz), _p(sum_dzx), du.ptr, du.ld, _stream()), "morig_bn_relu_backward")
 
-    def segmax_affine_arg(self, Z: Mat, rowptr: torch.Tensor, n_segments: int, out: Mat, scale=None, shift=None) -> torch.Tensor:
-        """segmax_affine + the winning row per (segment, column): int32 [n_segments, cols], -1 for empty segments."""
+    def segmax_affine_arg(self, Z: Mat, rowptr: torch.Tensor, n_segments: int, out: Mat, scale=None, shift=None, want_zwin: bool = False):
+        """segmax_affine + the winning row per (segment, column): int32 [n_segments, cols], -1 for empty segments. want_zwin: also the
+        winners' values in front of the affine, float32 [n_segments, cols] -> (arg, zwin)."""
         _need_gpu(Z.base, rowptr, out.base)
         assert rowptr.dtype == torch.int32 and out.rows == n_segments and out.cols == Z.cols
         arg = torch.empty((n_segments, Z.cols), dtype=torch.int32, device=Z.base.device)
+        zwin = torch.empty((n_segments, Z.cols), dtype=torch.float32, device=Z.base.device) if want_zwin else None
         check(self.lib.morig_segmax_affine_arg(Z.ptr, Z.ld, _p(rowptr), n_segments, Z.cols, _p(scale), _p(shift), out.ptr, out.ld,
-                                               _p(arg), arg.stride(0), _stream()), "morig_segmax_affine_arg")
-        return arg
+                                               _p(arg), arg.stride(0), _p(zwin), zwin.stride(0) if want_zwin else 0, _stream()),
+              "morig_segmax_affine_arg")
+        return (arg, zwin) if want_zwin else arg
 
-    def segmax_bn_backward_stats(self, dout: Mat, arg: torch.Tensor, Z: Mat, mean, rstd):
-        _need_gpu(dout.base, arg, Z.base)
+    def segmax_bn_backward_stats(self, dout: Mat, arg: torch.Tensor, Z: Optional[Mat], mean, rstd, zwin: Optional[torch.Tensor] = None):
+        """zwin ([n_seg, cols], from segmax_affine_arg): the coalesced kernel; without it the winners' rows are gathered from Z."""
+        _need_gpu(dout.base, arg, Z.base if Z is not None else zwin)
         dev = dout.base.device
         n_seg, cols = dout.rows, dout.cols
-        assert arg.shape == (n_seg, cols) and Z.cols == cols
+        assert arg.shape == (n_seg, cols) and (Z is None or Z.cols == cols) and (zwin is None or zwin.shape == (n_seg, cols))
         slabs = (n_seg + 255) // 256
         ws = torch.empty(slabs * 2 * cols, dtype=torch.float64, device=dev)
         sdz = torch.empty(cols, dtype=torch.float32, device=dev)
         sdzx = torch.empty(cols, dtype=torch.float32, device=dev)
-        check(self.lib.morig_segmax_bn_backward_stats(dout.ptr, dout.ld, _p(arg), arg.stride(0), Z.ptr, Z.ld, n_seg, cols, _p(mean), _p(rstd),
-                                                      C.c_void_p(ws.data_ptr()), ws.numel(), _p(sdz), _p(sdzx), _stream()),
-              "morig_segmax_bn_backward_stats")
+        check(self.lib.morig_segmax_bn_backward_stats(dout.ptr, dout.ld, _p(arg), arg.stride(0), Z.ptr if Z is not None else 0,
+                                                      Z.ld if Z is not None else 0, _p(zwin), zwin.stride(0) if zwin is not None else 0,
+                                                      n_seg, cols, _p(mean), _p(rstd), C.c_void_p(ws.data_ptr()), ws.numel(), _p(sdz),
+                                                      _p(sdzx), _stream()), "morig_segmax_bn_backward_stats")
         return sdz, sdzx
 
     def segmax_bn_relu_backward(self, dout: Mat, arg: torch.Tensor, Z: Mat, rowptr: torch.Tensor, seg_of_row: torch.Tensor, mean, rstd,
-                                gamma, sum_dz, sum_dzx, du: Mat, relu: bool = True):
+                                gamma, sum_dz, sum_dzx, du: Mat, relu: bool = True, want_sum: bool = False):
+        """want_sum: -> the column sums of du over the live rows (float32 [cols]), from the same pass."""
         _need_gpu(dout.base, arg, Z.base, du.base, rowptr, seg_of_row)
         assert Z.rows == du.rows and Z.cols == du.cols == dout.cols and seg_of_row.dtype == torch.int32
+        ws = sdu = None
+        if want_sum:
+            dev = du.base.device
+            ws = torch.empty(((Z.rows + 255) // 256) * 2 * Z.cols, dtype=torch.float64, device=dev)
+            sdu = torch.empty(Z.cols, dtype=torch.float32, device=dev)
         check(self.lib.morig_segmax_bn_relu_backward(dout.ptr, dout.ld, _p(arg), arg.stride(0), Z.ptr, Z.ld, _p(rowptr), dout.rows,
                                                      _p(seg_of_row), Z.rows, Z.cols, _p(mean), _p(rstd), _p(gamma), _p(sum_dz), _p(sum_dzx),
-                                                     1 if relu else 0, du.ptr, du.ld, _stream()), "morig_segmax_bn_relu_backward")
+                                                     1 if relu else 0, du.ptr, du.ld, _p(ws), ws.numel() if want_sum else 0, _p(sdu),
+                                                     _stream()), "morig_segmax_bn_relu_backward")
+        return sdu
+
+    def edge_bn_scatter_backward(self, dG: Mat, Y: Optional[Mat], csr: CSR, n_src: int, dA: Mat, dB: Mat, mean=None, rstd=None, gamma=None,
+                                 sum_dz=None, sum_dzx=None):
+        """bn_relu_backward + edge_scatter_backward in one pass pair, deterministic (no atomics, the per-edge gradient is not stored):
+        dA[v] / dB[u] = sums of d[e] = [Y > 0] gamma rstd (dG - sum_dz / n - xhat sum_dzx / n) into / out of a vertex; mean=None: d = dG."""
+        _need_gpu(dG.base, dA.base, dB.base)
+        assert dA.rows == csr.n_nodes and dB.rows == n_src and dA.cols == dB.cols == dG.cols
+        assert mean is None or (Y is not None and Y.cols == dG.cols and Y.rows == dG.rows)
+        rowptr_t, perm_t = csr.transposed(n_src)
+        check(self.lib.morig_edge_bn_scatter_backward(dG.ptr, dG.ld, Y.ptr if Y is not None else 0, Y.ld if Y is not None else 0,
+                                                      _p(csr.rowptr), _p(rowptr_t), _p(perm_t), csr.n_nodes, n_src, dG.cols, _p(mean),
+                                                      _p(rstd), _p(gamma), _p(sum_dz), _p(sum_dzx), dA.ptr, dA.ld, dB.ptr, dB.ld, _stream()),
+              "morig_edge_bn_scatter_backward")
 
     def edge_scatter_backward(self, dG: Mat, csr: CSR, n_src: int, dA: Mat, dB: Mat):
         """backward of Z[e] = A[dst_e] + B[src_e] over the live edges of ``csr``."""

@@ -266,8 +266,8 @@ class EdgeMLPTrain(torch.autograd.Function):
         mean2, var2, cnt2, share2 = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
         s2, t2, rstd2 = _bn_train(bn2, mean2, var2, cnt2, want_rstd=True)
         out = _buf(n, H, dev)
-        arg = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2)
-        ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg)
+        arg, zwin = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2, want_zwin=True)
+        ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg, zwin)
         ctx.csr = csr
         ctx.dims = (n, C, H)
         ctx.shares = (share1, share2)
@@ -277,7 +277,7 @@ class EdgeMLPTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         ops = get_ops()
-        xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg = ctx.saved_tensors
+        xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg, zwin = ctx.saved_tensors
         csr: CSR = ctx.csr
         n, C, H = ctx.dims
         dev = dout.device
@@ -286,13 +286,13 @@ class EdgeMLPTrain(torch.autograd.Function):
         do = _rows16(dout)
         DO = Mat.of(do, 0, H)
         # BatchNorm2 + ReLU behind the max: one-hot gradient per (vertex, channel)
-        sdz2, sdzx2 = ops.segmax_bn_backward_stats(DO, arg, Z2, mean2, rstd2)
+        sdz2, sdzx2 = ops.segmax_bn_backward_stats(DO, arg, None, mean2, rstd2, zwin=zwin)   # (the winners' values were kept: no gather)
         k2, kx2, _, _ = sync_backward_sums(sdz2, sdzx2, ctx.shares[1])
         du2 = _buf(z2.shape[0], H, dev)                 # (the kernel zeroes the rows past E': they feed the dX GEMM below)
         DU2 = Mat.of(du2, 0, H)
-        ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2)
         need = ctx.needs_input_grad                      # (x, W1, b1, g1, be1, W2, b2, g2, be2, ...): frozen layers skip their dW GEMMs
-        db2 = ops.bn_backward_stats(DU2, rows_dev=e_live)[0] if (need[5] or need[6]) else None
+        db2 = ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2,
+                                          want_sum=bool(need[5] or need[6]))          # db2 = column sums of du2, from the same pass
         # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
         dW2 = (ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]) if need[5] else None
         w2t = ctx.packs.get("w2T", (W2,), lambda: _pack_bwd(W2.detach().t().contiguous(), dev))
@@ -301,10 +301,11 @@ class EdgeMLPTrain(torch.autograd.Function):
         # BatchNorm1 + ReLU over the edges
         sdz1, sdzx1 = ops.bn_backward_stats(DH, Z1, mean1, rstd1, rows_dev=e_live)
         k1, kx1, _, _ = sync_backward_sums(sdz1, sdzx1, ctx.shares[0])
-        ops.bn_relu_backward(DH, Z1, mean1, rstd1, g1.detach().float().contiguous(), k1, kx1, DH, rows_dev=e_live)
-        # Z1 = relu(A[dst] + B[src])
-        dab = _buf(n, 2 * H, dev)                       # dA is written whole, dB is cleared by the operator
-        ops.edge_scatter_backward(DH, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H))
+        # Z1 = relu(A[dst] + B[src]): the BatchNorm1 + ReLU gradient of an edge is evaluated where it is summed into dA[dst] / dB[src]
+        # (never stored; both sums in a fixed order: the source side walks the transposed graph)
+        dab = _buf(n, 2 * H, dev)
+        ops.edge_bn_scatter_backward(DH, Z1, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H), mean1, rstd1, g1.detach().float().contiguous(),
+                                     k1, kx1)
         DAB = Mat.of(dab, 0, 2 * H)
         db1 = ops.bn_backward_stats(Mat.of(dab, 0, H))[0] if need[2] else None
         dW1 = None

@@ -586,9 +586,9 @@ def _emu_bn_relu_backward(self, dz: Mat, y: Mat, mean, rstd, gamma, sum_dz, sum_
     du.view()[:r] = torch.where(yv > 0, g, torch.zeros_like(g))
 
 
-def _emu_segmax_affine_arg(self, Z: Mat, rowptr, n_segments, out: Mat, scale=None, shift=None):
+def _emu_segmax_affine_arg(self, Z: Mat, rowptr, n_segments, out: Mat, scale=None, shift=None, want_zwin=False):
     p = rowptr.long().tolist()
-    z = Z.view()
+    z = z_raw = Z.view()
     if scale is not None:
         z = z * scale[: Z.cols] + shift[: Z.cols]
     res = torch.zeros((n_segments, Z.cols))
@@ -599,6 +599,10 @@ def _emu_segmax_affine_arg(self, Z: Mat, rowptr, n_segments, out: Mat, scale=Non
             res[v] = seg.max(0)[0]
             arg[v] = ((seg == res[v]).int().argmax(0) + p[v]).int()      # first maximum
     out.view().copy_(res)
+    if want_zwin:
+        cc = torch.arange(Z.cols).expand_as(arg)
+        zwin = torch.where(arg >= 0, z_raw[arg.clamp(min=0).long(), cc], torch.zeros(()))
+        return arg, zwin.contiguous()
     return arg
 
 
@@ -610,18 +614,19 @@ def _dense_dz(dout: Mat, arg, rows, cols):
     return dz
 
 
-def _emu_segmax_bn_backward_stats(self, dout: Mat, arg, Z: Mat, mean, rstd):
+def _emu_segmax_bn_backward_stats(self, dout: Mat, arg, Z, mean, rstd, zwin=None):
     # as the kernel: only the winning rows of Z are read (rows past the live edge count may hold anything)
     live = arg >= 0
-    cols = torch.arange(Z.cols).expand_as(arg)
+    cols = torch.arange(arg.shape[1]).expand_as(arg)
     g = torch.where(live, dout.view().double(), torch.zeros((), dtype=torch.float64))
-    zwin = Z.view().double()[arg.clamp(min=0).long(), cols]
+    zwin = zwin.double() if zwin is not None else Z.view().double()[arg.clamp(min=0).long(), cols]
     assert not torch.isnan(zwin[live]).any()
     xh = torch.where(live, (zwin - mean.double()) * rstd.double(), torch.zeros((), dtype=torch.float64))
     return g.sum(0).float(), (g * xh).sum(0).float()
 
 
-def _emu_segmax_bn_relu_backward(self, dout: Mat, arg, Z: Mat, rowptr, seg_of_row, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, relu=True):
+def _emu_segmax_bn_relu_backward(self, dout: Mat, arg, Z: Mat, rowptr, seg_of_row, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, relu=True,
+                                 want_sum=False):
     r = int(rowptr[-1])
     dz = _dense_dz(dout, arg, Z.rows, Z.cols)[:r].float()
     zv = Z.view()[:r]
@@ -629,6 +634,7 @@ def _emu_segmax_bn_relu_backward(self, dout: Mat, arg, Z: Mat, rowptr, seg_of_ro
     g = gamma * rstd * (dz - sum_dz / r - xh * (sum_dzx / r))
     du.view()[:r] = torch.where(zv > 0, g, torch.zeros_like(g)) if relu else g
     du.view()[r:] = 0.0                                 # the operator clears the rows past the live count
+    return du.view()[:r].double().sum(0).float() if want_sum else None
 
 
 def _emu_edge_scatter_backward(self, dG: Mat, csr: CSR, n_src, dA: Mat, dB: Mat):
@@ -636,6 +642,25 @@ def _emu_edge_scatter_backward(self, dG: Mat, csr: CSR, n_src, dA: Mat, dB: Mat)
     g = dG.view()[:E]
     a = torch.zeros((csr.n_nodes, dG.cols)).index_add_(0, csr.dst[:E].long(), g)
     b = torch.zeros((n_src, dG.cols)).index_add_(0, csr.src[:E].long(), g)
+    dA.view().copy_(a)
+    dB.view().copy_(b)
+
+
+def _emu_edge_bn_scatter_backward(self, dG: Mat, Y, csr: CSR, n_src, dA: Mat, dB: Mat, mean=None, rstd=None, gamma=None, sum_dz=None,
+                                  sum_dzx=None):
+    E = int(csr.rowptr[-1])
+    g = dG.view()[:E]
+    if mean is not None:
+        yv = Y.view()[:E]
+        xh = (yv - mean) * rstd
+        d = gamma * rstd * (g - sum_dz / E - xh * (sum_dzx / E))
+        g = torch.where(yv > 0, d, torch.zeros_like(d))
+    rowptr_t, perm_t = csr.transposed(n_src)            # (exercises the transposed graph the kernel walks)
+    assert int(rowptr_t[-1]) == E and torch.equal(torch.sort(perm_t[:E].long())[0], torch.arange(E))
+    a = torch.zeros((csr.n_nodes, dG.cols)).index_add_(0, csr.dst[:E].long(), g)
+    seg = torch.repeat_interleave(torch.arange(n_src), (rowptr_t[1:] - rowptr_t[:-1]).long())
+    assert torch.equal(csr.src[:E].long()[perm_t[:E].long()], seg)
+    b = torch.zeros((n_src, dG.cols)).index_add_(0, seg, g[perm_t[:E].long()])
     dA.view().copy_(a)
     dB.view().copy_(b)
 
@@ -661,6 +686,7 @@ EmuOps.segmax_affine_arg = _emu_segmax_affine_arg
 EmuOps.segmax_bn_backward_stats = _emu_segmax_bn_backward_stats
 EmuOps.segmax_bn_relu_backward = _emu_segmax_bn_relu_backward
 EmuOps.edge_scatter_backward = _emu_edge_scatter_backward
+EmuOps.edge_bn_scatter_backward = _emu_edge_bn_scatter_backward
 EmuOps.gemm_tn = _emu_gemm_tn
 EmuOps._flag = _emu_flag
 EmuOps.col_stats = _emu_col_stats

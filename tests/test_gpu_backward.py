@@ -196,6 +196,110 @@ def test_edge_mlp_backward(n, e, C, H):
         _check(f"edge:{k}", p.grad, q.grad, 2e-4)
 
 
+def _emu():
+    from emulate import EmuOps
+    return EmuOps()
+
+
+@pytest.mark.parametrize("n_seg,rows_per,H,ld", [(8, 4096, 128, 128), (3, 1000, 35, 37), (5, 0, 16, 16), (2, 70000, 512, 512),
+                                                 (40000, 9, 64, 64), (300, 7, 33, 36), (3000, 5, 35, 37)])
+def test_segmax_arg_short_and_long_segments(n_seg, rows_per, H, ld):
+    """few long segments (the pooling kernel: row lanes + LDS tree) and many short ones (one thread per segment and column group):
+    the value, the FIRST winning row on ties, the winner's raw value, empty segments"""
+    ops = native.get_ops()
+    g = torch.Generator().manual_seed(n_seg * 31 + H)
+    lens = torch.full((n_seg,), rows_per, dtype=torch.int64)
+    if rows_per > 4:
+        lens = lens + torch.randint(-3, 4, (n_seg,), generator=g)
+    lens[n_seg // 2] = 0                                                   # an empty segment in the middle
+    rowptr = torch.zeros(n_seg + 1, dtype=torch.int32)
+    rowptr[1:] = lens.cumsum(0).int()
+    rows = int(rowptr[-1])
+    Z = torch.randn(max(rows, 1), ld, generator=g)
+    Z[:, : H] = (Z[:, : H] * 4).round() / 4                                # many exact ties
+    scale = torch.where(torch.arange(H) % 3 == 0, -1.0, 1.5) * (torch.rand(H, generator=g) + 0.5)
+    shift = torch.randn(H, generator=g)
+    emu = _emu()
+    for sc, sh in ((scale, shift), (None, None)):
+        want = torch.zeros(n_seg, H)
+        warg, wz = emu.segmax_affine_arg(Mat.of(Z, 0, H), rowptr, n_seg, Mat.of(want, 0, H), sc, sh, want_zwin=True)
+        out = torch.full((n_seg, ld), 7.0, device=DEV)
+        arg, zwin = ops.segmax_affine_arg(Mat.of(Z.to(DEV), 0, H), rowptr.to(DEV), n_seg, Mat.of(out, 0, H),
+                                          None if sc is None else sc.to(DEV), None if sh is None else sh.to(DEV), want_zwin=True)
+        assert torch.equal(arg.cpu(), warg), (arg.cpu() != warg).nonzero()[:5]
+        assert torch.equal(zwin.cpu(), wz)
+        assert torch.allclose(out[:, :H].cpu(), want, rtol=1e-6, atol=1e-6)
+        assert bool((out[:, H:] == 7.0).all())
+        only = ops.segmax_affine_arg(Mat.of(Z.to(DEV), 0, H), rowptr.to(DEV), n_seg, Mat.of(out, 0, H),
+                                     None if sc is None else sc.to(DEV), None if sh is None else sh.to(DEV))
+        assert torch.equal(only.cpu(), warg)
+
+
+@pytest.mark.parametrize("n,e,H,ld", [(500, 6000, 64, 64), (1200, 5000, 33, 36), (64, 3000, 16, 16), (3000, 40000, 256, 256)])
+def test_edge_backward_operators(n, e, H, ld):
+    """the three row passes of the edge MLP backward against the emulation: statistics from the kept winners (no gather), du2 with
+    its column sums from one pass, BatchNorm1 + ReLU evaluated inside the two fixed-order scatter sums (bit-reproducible)"""
+    ops, emu = native.get_ops(), _emu()
+    g = torch.Generator().manual_seed(n + e)
+    ei = _graph(n, e, n + 1)
+    csr_d = ops.csr_build(ei.to(DEV), n)
+    E = int(csr_d.rowptr[-1])
+    from morig_amd.native import CSR
+    csr = CSR(csr_d.rowptr.cpu(), csr_d.src.cpu(), csr_d.dst.cpu(), n, csr_d.capacity, csr_d.status.cpu())
+    cap = csr.capacity
+    Z = torch.randn(cap, ld, generator=g)
+    Z[E:] = float("nan")                                                       # rows past the live count are never read
+    mean, rstd = Z[:E, :H].mean(0), 1.0 / Z[:E, :H].std(0)
+    gamma = torch.randn(H, generator=g)
+    dout = torch.randn(n, ld, generator=g)
+    dev = lambda t: t.to(DEV)
+    out = torch.zeros(n, H)
+    arg, zwin = emu.segmax_affine_arg(Mat.of(Z, 0, H), csr.rowptr, n, Mat.of(out, 0, H), gamma * rstd, -mean * gamma * rstd, want_zwin=True)
+    # (1) statistics: kept winners vs gathered rows vs emulation
+    want = emu.segmax_bn_backward_stats(Mat.of(dout, 0, H), arg, Mat.of(Z, 0, H), mean, rstd)
+    Zd, doutd, argd = dev(Z), dev(dout), dev(arg)
+    got_w = ops.segmax_bn_backward_stats(Mat.of(doutd, 0, H), argd, None, dev(mean), dev(rstd), zwin=dev(zwin))
+    got_g = ops.segmax_bn_backward_stats(Mat.of(doutd, 0, H), argd, Mat.of(Zd, 0, H), dev(mean), dev(rstd))
+    for a, b, w in zip(got_w, got_g, want):
+        scale = float(w.abs().max()) + 1e-6
+        assert float((a.cpu() - w).abs().max()) <= 2e-6 * scale * (n ** 0.5) and float((b.cpu() - w).abs().max()) <= 2e-6 * scale * (n ** 0.5)
+    sdz, sdzx = want
+    # (2) du2 + its column sums
+    du_w = torch.full((cap, ld), 3.0)
+    sum_w = emu.segmax_bn_relu_backward(Mat.of(dout, 0, H), arg, Mat.of(Z.nan_to_num(0.0), 0, H), csr.rowptr, csr.dst, mean, rstd, gamma, sdz,
+                                        sdzx, Mat.of(du_w, 0, H), want_sum=True)
+    du = torch.full((cap, ld), 3.0, device=DEV)
+    sum_g = ops.segmax_bn_relu_backward(Mat.of(doutd, 0, H), argd, Mat.of(Zd, 0, H), dev(csr.rowptr), dev(csr.dst), dev(mean), dev(rstd),
+                                        dev(gamma), dev(sdz), dev(sdzx), Mat.of(du, 0, H), want_sum=True)
+    assert torch.allclose(du.cpu(), du_w, rtol=1e-5, atol=1e-6 * float(du_w.abs().max()))
+    assert float((sum_g.cpu() - sum_w).abs().max()) <= 1e-5 * float(du_w[:E, :H].abs().sum(0).max())
+    assert ops.segmax_bn_relu_backward(Mat.of(doutd, 0, H), argd, Mat.of(Zd, 0, H), dev(csr.rowptr), dev(csr.dst), dev(mean), dev(rstd),
+                                       dev(gamma), dev(sdz), dev(sdzx), Mat.of(du, 0, H)) is None
+    # (3) BatchNorm + ReLU inside the scatter sums; the plain scatter; both reproducible bit for bit
+    Y = torch.relu(torch.randn(cap, ld, generator=g)); Y[E:] = float("nan")
+    G = torch.randn(cap, ld, generator=g); G[E:] = float("nan")
+    m1, r1 = Y[:E, :H].mean(0), 1.0 / (Y[:E, :H].std(0) + 0.1)
+    k0, k1 = torch.randn(H, generator=g), torch.randn(H, generator=g)
+    Yd, Gd = dev(Y), dev(G)
+    for bn in (True, False):
+        kw = dict(mean=m1, rstd=r1, gamma=gamma, sum_dz=k0, sum_dzx=k1) if bn else {}
+        wa, wb = torch.zeros(n, H), torch.zeros(n, H)
+        emu.edge_bn_scatter_backward(Mat.of(G.nan_to_num(0.0), 0, H), Mat.of(Y.nan_to_num(0.0), 0, H) if bn else None, csr, n, Mat.of(wa, 0, H),
+                                     Mat.of(wb, 0, H), **kw)
+        dab = torch.full((n, 2 * ld), 5.0, device=DEV)
+        kwd = {k: dev(v) for k, v in kw.items()}
+        ops.edge_bn_scatter_backward(Mat.of(Gd, 0, H), Mat.of(Yd, 0, H) if bn else None, csr_d, n, Mat.of(dab, 0, H), Mat.of(dab, ld, H), **kwd)
+        sa = float(wa.abs().max())
+        assert float((dab[:, :H].cpu() - wa).abs().max()) <= 2e-5 * sa and float((dab[:, ld:ld + H].cpu() - wb).abs().max()) <= 2e-5 * sa
+        again = torch.full((n, 2 * ld), 5.0, device=DEV)
+        ops.edge_bn_scatter_backward(Mat.of(Gd, 0, H), Mat.of(Yd, 0, H) if bn else None, csr_d, n, Mat.of(again, 0, H), Mat.of(again, ld, H), **kwd)
+        assert torch.equal(dab, again)
+        if not bn:                                                              # the atomic operator it replaces computes the same sums
+            old = torch.full((n, 2 * ld), 5.0, device=DEV)
+            ops.edge_scatter_backward(Mat.of(Gd, 0, H), csr_d, n, Mat.of(old, 0, H), Mat.of(old, ld, H))
+            assert torch.allclose(old, dab, rtol=1e-4, atol=1e-5 * sa)
+
+
 def _net_case(n_side=10, n_mesh=2, seed=5):
     batch = synth.make_batch(range(seed, seed + n_mesh), n_side=n_side, with_skin=False)
     return batch
