@@ -459,9 +459,9 @@ int         morig_prof_collect(int kind, int64_t* launches, double* total_ms, do
  * count (optional): receives the row count as a float. */
 int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, double* workspace,
                     int64_t workspace_doubles, float* mean, float* var, float* count, void* stream);
-/* x[r][c] <- scale[c] * x[r][c] + shift[c], in place (BatchNorm once its statistics are known) */
+/* out[r][c] = scale[c] * x[r][c] + shift[c] (BatchNorm once its statistics are known); out == NULL: in place */
 int morig_col_affine(float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, const float* scale,
-                     const float* shift, void* stream);
+                     const float* shift, float* out, int32_t ldo, void* stream);
 /* BatchNorm1d in training mode after the column statistics (torch.nn.functional.batch_norm; models/basic_modules.py:31-36): the batch
  * affine s = gamma / sqrt(var + eps), t = beta - mean * s, rstd = 1 / sqrt(var + eps) (may be NULL), and -- when running_mean /
  * running_var are given -- their update with momentum and the UNBIASED variance (count: [1] float on the device, the rows the
@@ -470,10 +470,13 @@ int morig_bn_finalize(const float* mean, const float* var, const float* count, c
                       float eps, float momentum, float* running_mean, float* running_var, int64_t* num_batches_tracked,
                       float* s, float* t, float* rstd, int32_t n, void* stream);
 /* Z[e] = relu(A[dst_e] + B[src_e]) for the E' = rowptr[n_nodes] edges of a CSR: the first edge ReLU
- * (models/basic_modules.py:193-195 after the per-vertex split of Linear1), materialised for its batch statistics */
+ * (models/basic_modules.py:193-195 after the per-vertex split of Linear1), materialised for its batch statistics. With mean != NULL
+ * the same pass also takes them: mean / var / count exactly as morig_col_stats over the E' rows of Z would (fp64, fixed order;
+ * workspace as there, sized on edge_capacity); mean == NULL: workspace / var / count are not used. */
 int morig_edge_gather_relu(const float* A, int32_t lda, const float* B, int32_t ldb, const int32_t* rowptr, int32_t n_nodes,
                            const int32_t* src_sorted, const int32_t* dst_sorted, int32_t edge_capacity, int32_t H,
-                           float* Z, int32_t ldz, void* stream);
+                           float* Z, int32_t ldz, double* workspace, int64_t workspace_doubles, float* mean, float* var, float* count,
+                           void* stream);
 /* out[v][c] = max over rows e in [rowptr[v], rowptr[v+1]) of scale[c] * Z[e][c] + shift[c] (scale == shift == NULL: plain max;
  * empty segment: 0 as torch_scatter): max aggregation behind the last BatchNorm of an edge MLP, and scatter_max over a mesh's
  * vertices (models/rignet.py:63) */

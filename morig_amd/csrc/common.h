@@ -110,8 +110,13 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 // First pass: grid (64-column groups, row slabs), 256 threads = (float4 column quads of the group) x (row lanes); every slab writes
 // its [2][cols] partial sums (zeros past the live rows). Second pass: 16 columns x 16 slab lanes per block. Every order is fixed.
 // Rows per slab: 256, more once that would give more than 1024 slabs (the second pass then adds <= 64 partials per lane).
-inline int stats_slab_rows(int rows_cap) {
-    int r = ((rows_cap > 0 ? rows_cap : 1) + 1023) / 1024;
+inline int stats_slab_rows(int rows_cap, int cols) {
+    // ~1024 workgroups over (64-column groups x row slabs): wide matrices get fewer, longer slabs -- the second pass reads
+    // slabs x 2 x cols doubles on cols / 16 workgroups, which at 1024 slabs x 256 columns was 4 MB per call and 10-17 us per launch
+    const int groups = (cols + 63) / 64;
+    int slabs = 1024 / (groups > 0 ? groups : 1);
+    if (slabs < 64) slabs = 64;
+    int r = ((rows_cap > 0 ? rows_cap : 1) + slabs - 1) / slabs;
     r = (r + 3) & ~3;
     return r < 256 ? 256 : r;
 }

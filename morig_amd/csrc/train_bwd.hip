@@ -684,7 +684,7 @@ extern "C" int morig_bn_backward_stats(const float* dz, int32_t ldz, const float
                                        float* sum_dz, float* sum_dzx, void* stream) {
     if (!dz || !workspace || !sum_dz || rows < 0 || cols <= 0 || ldz < cols) return MORIG_E_INVALID;
     if (y && (!mean || !rstd || !sum_dzx || ldy < cols)) return MORIG_E_INVALID;
-    const int slab_rows = stats_slab_rows(rows);
+    const int slab_rows = stats_slab_rows(rows, cols);
     const int slabs = cdiv(rows > 0 ? rows : 1, slab_rows);
     if (workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -749,7 +749,7 @@ extern "C" int morig_segmax_bn_backward_stats(const float* dout, int32_t ldd, co
                                               float* sum_dz, float* sum_dzx, void* stream) {
     if (!dout || !arg || (!Z && !zwin) || !mean || !rstd || !workspace || !sum_dz || !sum_dzx) return MORIG_E_INVALID;
     if (n_segments <= 0 || cols <= 0 || ldd < cols || ld_arg < cols || (zwin ? ldw < cols : ldz < cols)) return MORIG_E_INVALID;
-    const int slab_rows = stats_slab_rows(n_segments);
+    const int slab_rows = stats_slab_rows(n_segments, cols);
     const int slabs = cdiv(n_segments, slab_rows);
     if (workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -773,7 +773,7 @@ extern "C" int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, con
                                              double* workspace, int64_t workspace_doubles, float* sum_du, void* stream) {
     if (!dout || !arg || !Z || !rowptr || !seg_of_row || !mean || !rstd || !gamma || !sum_dz || !sum_dzx || !du) return MORIG_E_INVALID;
     if (n_segments <= 0 || row_capacity <= 0 || cols <= 0 || ldd < cols || ld_arg < cols || ldz < cols || ldu < cols) return MORIG_E_INVALID;
-    const int slab_rows = stats_slab_rows(row_capacity);
+    const int slab_rows = stats_slab_rows(row_capacity, cols);
     const int slabs = cdiv(row_capacity, slab_rows);
     if (sum_du && (!workspace || workspace_doubles < (int64_t)slabs * 2 * cols)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -63,39 +63,62 @@ __global__ __launch_bounds__(256) void col_stats_final_kernel(const double* __re
 }
 
 template <int V>
-__global__ void col_affine_kernel(float* __restrict__ x, int ldx, int rows_host, const int* __restrict__ rows_dev, int cols,
-                                  const float* __restrict__ scale, const float* __restrict__ shift) {
+__global__ void col_affine_kernel(const float* x, int ldx, int rows_host, const int* __restrict__ rows_dev, int cols,
+                                  const float* __restrict__ scale, const float* __restrict__ shift, float* out, int ldo) {
     const int rows = rows_dev ? *rows_dev : rows_host;
     const int qn = cols / V;
     const int64_t total = (int64_t)rows * qn;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         const int64_t r = i / qn; const int c = (int)(i - r * qn) * V;
-        float* p = x + r * ldx + c;
-        VecF<V> v = ldv<V>(p);
+        VecF<V> v = ldv<V>(x + r * ldx + c);                   // (out may be x: every thread reads its elements before it writes them)
         const VecF<V> sc = ldv<V>(scale + c), sh = ldv<V>(shift + c);
 #pragma unroll
         for (int j = 0; j < V; ++j) v.v[j] = v.v[j] * sc.v[j] + sh.v[j];
-        stv<V>(p, v);
+        stv<V>(out + r * ldo + c, v);
     }
 }
 
+// One workgroup per (64 columns, slab of rows), threads as in col_stats_partial_kernel; with `part` it also leaves the slab's fp64
+// column sums of z and z^2: the BatchNorm statistics of the first edge layer come from the pass that writes it.
 template <int V>
-__global__ void edge_gather_relu_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+__global__ __launch_bounds__(256) void edge_gather_relu_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                         const int* __restrict__ rowptr, int n_nodes, const int* __restrict__ srcS,
-                                        const int* __restrict__ dstS, int H, float* __restrict__ Z, int ldz) {
+                                        const int* __restrict__ dstS, int H, int slab_rows, float* __restrict__ Z, int ldz,
+                                        double* __restrict__ part /* NULL or [slabs][2][H] */) {
     const int E = rowptr[n_nodes];
-    const int qn = H / V;
-    const int64_t total = (int64_t)E * qn;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int64_t e = i / qn; const int c = (int)(i - e * qn) * V;
-        const VecF<V> a = ldv<V>(A + (size_t)dstS[e] * lda + c), b = ldv<V>(B + (size_t)srcS[e] * ldb + c);
-        VecF<V> z;
+    const int c0 = blockIdx.x * 64;
+    const int quads = min(16, (H - c0 + 3) >> 2);
+    const int RL = 256 / quads;
+    const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
+    const int c = c0 + q * 4;
+    const int r0 = blockIdx.y * slab_rows, r1 = min(r0 + slab_rows, E);
+    double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (rl < RL) {
+        for (int e = r0 + rl; e < r1; e += RL) {
+            const float* pa = A + (size_t)dstS[e] * lda + c;
+            const float* pb = B + (size_t)srcS[e] * ldb + c;
+            float z[4];
+            if (V == 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(pa), b4 = *reinterpret_cast<const float4*>(pb);
+                z[0] = a4.x + b4.x; z[1] = a4.y + b4.y; z[2] = a4.z + b4.z; z[3] = a4.w + b4.w;
+            } else {
 #pragma unroll
-        for (int j = 0; j < V; ++j) { const float v = a.v[j] + b.v[j]; z.v[j] = v > 0.f ? v : 0.f; }
-        stv<V>(Z + e * ldz + c, z);
+                for (int j = 0; j < 4; ++j) z[j] = c + j < H ? pa[j] + pb[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                z[j] = z[j] > 0.f ? z[j] : 0.f;
+                const double d = (double)z[j];
+                acc[0][j] += d; acc[1][j] += d * d;
+            }
+            if (V == 4) *reinterpret_cast<float4*>(Z + (size_t)e * ldz + c) = make_float4(z[0], z[1], z[2], z[3]);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < H) Z[(size_t)e * ldz + c + j] = z[j];
+        }
     }
+    if (part) stats_block_store(acc, quads, RL, q, rl, c0, H, blockIdx.y, part);
 }
 
 // one thread per (segment, V columns): the threads of a segment read consecutive columns of a row, rows walked in order
@@ -133,7 +156,7 @@ using namespace morig;
 extern "C" int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, double* workspace,
                                int64_t workspace_doubles, float* mean, float* var, float* count, void* stream) {
     if (!x || !workspace || !mean || !var || rows < 0 || cols <= 0 || ldx < cols) return MORIG_E_INVALID;
-    const int slab_rows = stats_slab_rows(rows);                    // `rows` is the capacity when rows_dev is given
+    const int slab_rows = stats_slab_rows(rows, cols);                    // `rows` is the capacity when rows_dev is given
     const int slabs = cdiv(rows > 0 ? rows : 1, slab_rows);
     if (workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -147,16 +170,17 @@ extern "C" int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const 
 }
 
 extern "C" int morig_col_affine(float* x, int32_t ldx, int32_t rows, const int32_t* rows_dev, int32_t cols, const float* scale,
-                                const float* shift, void* stream) {
-    if (!x || !scale || !shift || rows < 0 || cols <= 0 || ldx < cols) return MORIG_E_INVALID;
+                                const float* shift, float* out, int32_t ldo, void* stream) {
+    if (!x || !scale || !shift || rows < 0 || cols <= 0 || ldx < cols || (out && ldo < cols)) return MORIG_E_INVALID;
     if (rows == 0) return MORIG_OK;
+    if (!out) { out = x; ldo = ldx; }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const bool v4 = (cols & 3) == 0 && vec4_ptr(x, ldx) && vec4_ptr(scale, 0) && vec4_ptr(shift, 0);
+    const bool v4 = (cols & 3) == 0 && vec4_ptr(x, ldx) && vec4_ptr(out, ldo) && vec4_ptr(scale, 0) && vec4_ptr(shift, 0);
     int64_t blocks = ((int64_t)rows * (cols / (v4 ? 4 : 1)) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     ProfScope ps(K_MISC, s, 0.0, 8.0 * rows * (double)cols);
-    if (v4) hipLaunchKernelGGL(col_affine_kernel<4>, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, scale, shift);
-    else hipLaunchKernelGGL(col_affine_kernel<1>, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, scale, shift);
+    if (v4) hipLaunchKernelGGL(col_affine_kernel<4>, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, scale, shift, out, ldo);
+    else hipLaunchKernelGGL(col_affine_kernel<1>, dim3((int)blocks), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, scale, shift, out, ldo);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -201,19 +225,27 @@ extern "C" int morig_bn_finalize(const float* mean, const float* var, const floa
 
 extern "C" int morig_edge_gather_relu(const float* A, int32_t lda, const float* B, int32_t ldb, const int32_t* rowptr, int32_t n_nodes,
                                       const int32_t* src_sorted, const int32_t* dst_sorted, int32_t edge_capacity, int32_t H,
-                                      float* Z, int32_t ldz, void* stream) {
+                                      float* Z, int32_t ldz, double* workspace, int64_t workspace_doubles, float* mean, float* var,
+                                      float* count, void* stream) {
     if (!A || !B || !rowptr || !src_sorted || !dst_sorted || !Z || n_nodes <= 0 || edge_capacity <= 0 || H <= 0) return MORIG_E_INVALID;
     if (lda < H || ldb < H || ldz < H) return MORIG_E_INVALID;
+    const int slab_rows = stats_slab_rows(edge_capacity, H);
+    const int slabs = cdiv(edge_capacity, slab_rows);
+    if (mean && (!var || !workspace || workspace_doubles < (int64_t)slabs * 2 * H)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool v4 = (H & 3) == 0 && vec4_ptr(A, lda) && vec4_ptr(B, ldb) && vec4_ptr(Z, ldz);
-    int64_t blocks = ((int64_t)edge_capacity * (H / (v4 ? 4 : 1)) + 255) / 256;
-    if (blocks > 16384) blocks = 16384;
     ProfScope ps(K_MISC, s, 0.0, 12.0 * edge_capacity * (double)H);
-    if (v4) hipLaunchKernelGGL(edge_gather_relu_kernel<4>, dim3((int)blocks), dim3(256), 0, s, A, lda, B, ldb, rowptr, n_nodes, src_sorted,
-                               dst_sorted, H, Z, ldz);
-    else hipLaunchKernelGGL(edge_gather_relu_kernel<1>, dim3((int)blocks), dim3(256), 0, s, A, lda, B, ldb, rowptr, n_nodes, src_sorted,
-                            dst_sorted, H, Z, ldz);
+    double* part = mean ? workspace : nullptr;
+    if (v4) hipLaunchKernelGGL(edge_gather_relu_kernel<4>, dim3(cdiv(H, 64), slabs), dim3(256), 0, s, A, lda, B, ldb, rowptr, n_nodes,
+                               src_sorted, dst_sorted, H, slab_rows, Z, ldz, part);
+    else hipLaunchKernelGGL(edge_gather_relu_kernel<1>, dim3(cdiv(H, 64), slabs), dim3(256), 0, s, A, lda, B, ldb, rowptr, n_nodes,
+                            src_sorted, dst_sorted, H, slab_rows, Z, ldz, part);
     MORIG_LAUNCH_CHECK();
+    if (mean) {
+        hipLaunchKernelGGL(col_stats_final_kernel, dim3(cdiv(H, 16)), dim3(256), 0, s, workspace, slabs, edge_capacity, rowptr + n_nodes, H,
+                           mean, var, count);
+        MORIG_LAUNCH_CHECK();
+    }
     return MORIG_OK;
 }
 

@@ -124,11 +124,11 @@ _SIGNATURES = {
                                             c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_geo_ball_fill": (C.c_int, [c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_i64p, C.c_int64, C.c_void_p]),
     "morig_col_stats": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_void_p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
-    "morig_col_affine": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, C.c_void_p]),
+    "morig_col_affine": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_bn_finalize": (C.c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_float, C.c_float, c_f32p, c_f32p, c_i64p, c_f32p, c_f32p, c_f32p,
                                     C.c_int32, C.c_void_p]),
     "morig_edge_gather_relu": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32,
-                                         c_f32p, C.c_int32, C.c_void_p]),
+                                         c_f32p, C.c_int32, C.c_void_p, C.c_int64, c_f32p, c_f32p, c_f32p, C.c_void_p]),
     "morig_segmax_affine": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_bn_backward_stats": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, C.c_void_p,
                                           C.c_int64, c_f32p, c_f32p, C.c_void_p]),
@@ -724,10 +724,14 @@ class NativeOps:
                                        _p(var), _p(cnt), _stream()), "morig_col_stats")
         return mean, var, cnt
 
-    def col_affine(self, X: Mat, scale: torch.Tensor, shift: torch.Tensor, rows_dev: Optional[torch.Tensor] = None):
+    def col_affine(self, X: Mat, scale: torch.Tensor, shift: torch.Tensor, rows_dev: Optional[torch.Tensor] = None,
+                   out: Optional[Mat] = None):
+        """out = scale * X + shift per column (in place without ``out``)"""
         _need_gpu(X.base, scale, shift)
         assert scale.numel() >= X.cols and shift.numel() >= X.cols and scale.dtype == shift.dtype == torch.float32
-        check(self.lib.morig_col_affine(X.ptr, X.ld, X.rows, _p(rows_dev), X.cols, _p(scale), _p(shift), _stream()), "morig_col_affine")
+        assert out is None or (out.rows == X.rows and out.cols == X.cols)
+        check(self.lib.morig_col_affine(X.ptr, X.ld, X.rows, _p(rows_dev), X.cols, _p(scale), _p(shift), out.ptr if out is not None else 0,
+                                        out.ld if out is not None else 0, _stream()), "morig_col_affine")
 
     def bn_finalize(self, bn, mean: torch.Tensor, var: torch.Tensor, count: torch.Tensor):
         """BatchNorm1d ``bn`` in training mode after its column statistics, ONE launch: -> (s, t, rstd); the running buffers and
@@ -748,11 +752,20 @@ class NativeOps:
               "morig_bn_finalize")
         return out[0], out[1], out[2]
 
-    def edge_gather_relu(self, A: Mat, B: Mat, csr: CSR, Z: Mat):
+    def edge_gather_relu(self, A: Mat, B: Mat, csr: CSR, Z: Mat, want_stats: bool = False):
+        """want_stats: -> (mean, biased var, count [1]) of the live rows of Z, as ``col_stats(Z, rows_dev=E')``, from the same pass"""
         _need_gpu(A.base, B.base, Z.base)
         assert Z.rows == csr.capacity and A.cols == B.cols == Z.cols
+        ws = st = None
+        if want_stats:
+            dev = Z.base.device
+            ws = torch.empty(((csr.capacity + 255) // 256) * 2 * Z.cols, dtype=torch.float64, device=dev)
+            st = torch.empty(2 * Z.cols + 1, dtype=torch.float32, device=dev)
         check(self.lib.morig_edge_gather_relu(A.ptr, A.ld, B.ptr, B.ld, _p(csr.rowptr), csr.n_nodes, _p(csr.src), _p(csr.dst),
-                                              csr.capacity, Z.cols, Z.ptr, Z.ld, _stream()), "morig_edge_gather_relu")
+                                              csr.capacity, Z.cols, Z.ptr, Z.ld, _p(ws), ws.numel() if want_stats else 0,
+                                              _p(st), _p(st[Z.cols:]) if want_stats else _p(None),
+                                              _p(st[2 * Z.cols:]) if want_stats else _p(None), _stream()), "morig_edge_gather_relu")
+        return (st[:Z.cols], st[Z.cols:2 * Z.cols], st[2 * Z.cols:]) if want_stats else None
 
     def segmax_affine(self, Z: Mat, rowptr: torch.Tensor, n_segments: int, out: Mat, scale: Optional[torch.Tensor] = None,
                       shift: Optional[torch.Tensor] = None):

@@ -164,8 +164,8 @@ class DenseTrain(torch.autograd.Function):
         ops.gemm(Mat.of(xa, 0, K), pk, relu=True, Y=Mat.of(y, 0, N))
         mean, var, cnt, share = batch_moments(ops, Mat.of(y, 0, N))
         s, t, rstd = _bn_train(bn, mean, var, cnt, want_rstd=True)
-        z = y.clone()
-        ops.col_affine(Mat.of(z, 0, N), s, t)
+        z = _buf(xa.shape[0], N, dev)
+        ops.col_affine(Mat.of(y, 0, N), s, t, out=Mat.of(z, 0, N))
         ctx.save_for_backward(xa, weight, y, mean, rstd, gamma)
         ctx.dims = (K, N)
         ctx.share = share
@@ -250,8 +250,8 @@ class EdgeMLPTrain(torch.autograd.Function):
         A, B = Mat.of(ab, 0, H), Mat.of(ab, H, H)
         e_live = csr.rowptr[csr.n_nodes:csr.n_nodes + 1]
         z1 = _buf(csr.capacity, H, dev)
-        ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H))
-        mean1, var1, cnt, share1 = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live)
+        loc1 = ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H), want_stats=True)       # (its batch statistics from the same pass)
+        mean1, var1, cnt, share1 = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live, local=loc1)
         s1, t1, rstd1 = _bn_train(bn1, mean1, var1, cnt, want_rstd=True)
         Hp, Kp = max(H, 32), (H + 31) // 32 * 32
 
@@ -417,17 +417,18 @@ def temporal_attn(attn, x):
     V = x.shape[0]
     nh = attn.num_heads
     tok = torch.cat([attn.cls_token.expand(V, -1, -1), x], 1)
-
-    def heads(t):
-        L = t.shape[1]
-        return t.reshape(V, L, nh, -1).permute(0, 2, 1, 3).reshape(V * nh, L, -1)
-
-    q, k, v = heads(attn.w_qs(tok)), heads(attn.w_ks(tok)), heads(attn.w_vs(tok))
-    att = torch.softmax(torch.bmm(q, k.transpose(1, 2)) / math.sqrt(k.size(-1)), dim=-1)
-    res = torch.bmm(att, v)
-    L = res.shape[1]
-    res = res.reshape(V, nh, L, -1).permute(0, 2, 1, 3).reshape(V, L, -1)
-    h = attn.w_o(res)[:, 0, :]
+    # The projections run on the native GEMMs (forward, dX and dW): as torch matmuls they were 6 ms of a 110 ms step on hipBLASLt's
+    # float32 kernels. Only token 0 of the attention output is kept (:45) and token 0 is the CLS token of EVERY vertex, so the one
+    # query row that matters is w_qs(cls_token), shared by all vertices, and only row 0 goes through w_o; keys and values need all
+    # T + 1 tokens. The 1 x (T + 1) attention itself stays torch autograd.
+    L = tok.shape[1]
+    tok2 = tok.reshape(V * L, -1)
+    kh = linear(tok2, attn.w_ks).reshape(V, L, nh, -1)
+    vh = linear(tok2, attn.w_vs).reshape(V, L, nh, -1)
+    q0 = linear(attn.cls_token.reshape(1, -1), attn.w_qs).reshape(nh, -1)
+    att = torch.softmax(torch.einsum("hd,vlhd->vhl", q0, kh) / math.sqrt(kh.shape[-1]), dim=-1)
+    res0 = torch.einsum("vhl,vlhd->vhd", att, vh).reshape(V, -1)
+    h = linear(res0, attn.w_o)
     return mlp_layer(mlp_layer(h, attn.feedforward[0]), attn.feedforward[1])
 
 

@@ -8,8 +8,8 @@ keyframes batched as replicas, max taken inside the EdgeConv kernel) all assume 
 layer by layer instead:
 
     dense layer   morig_gemm (Linear + ReLU on MFMA) -> morig_col_stats -> running-stat update -> morig_col_affine
-    edge MLP      per-vertex GEMM ([A | B] = [(W_a - W_b) x + b | W_b x]) -> morig_edge_gather_relu -> morig_col_stats (BN1 over
-                  edges) -> morig_edge_hidden (hidden affine + Linear2 + ReLU on MFMA) -> morig_col_stats (BN2 over edges)
+    edge MLP      per-vertex GEMM ([A | B] = [(W_a - W_b) x + b | W_b x]) -> morig_edge_gather_relu (+ the BN1 statistics over
+                  edges, same pass) -> morig_edge_hidden (hidden affine + Linear2 + ReLU on MFMA) -> morig_col_stats (BN2 over edges)
                   -> morig_segmax_affine (max over incoming edges behind the BatchNorm affine)
     keyframes     one motionNet pass per keyframe, as the reference does: each pass has its own batch statistics and moves the
                   running buffers once (models/rignet.py:85-88)
@@ -45,9 +45,10 @@ def _all_reduce(buf: torch.Tensor) -> torch.Tensor:
     return buf
 
 
-def batch_moments(ops, X: Mat, rows_dev=None):
-    """-> (mean, biased var, count [1], local share n_local / n) of the rows of X over the whole (cross-rank) batch"""
-    mean, var, cnt = ops.col_stats(X, rows_dev=rows_dev)
+def batch_moments(ops, X: Mat, rows_dev=None, local=None):
+    """-> (mean, biased var, count [1], local share n_local / n) of the rows of X over the whole (cross-rank) batch; ``local``: this
+    rank's (mean, var, count) when the pass that wrote X already took them (``edge_gather_relu(want_stats=True)``)"""
+    mean, var, cnt = local if local is not None else ops.col_stats(X, rows_dev=rows_dev)
     if _SYNC["group"] is None:
         return mean, var, cnt, None
     C = mean.numel()
@@ -133,8 +134,8 @@ def edge_mlp_train(ops, X: Mat, csr: CSR, mlp, out: Mat) -> None:
     A, B = Mat.of(ab, 0, H), Mat.of(ab, H, H)
     e_live = csr.rowptr[csr.n_nodes:csr.n_nodes + 1]                       # E' on the device
     z1 = ops.empty(csr.capacity, _ld4(H), dev)
-    ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H))
-    mean1, var1, cnt, _ = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live)
+    loc1 = ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H), want_stats=True)
+    mean1, var1, cnt, _ = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live, local=loc1)
     s1, t1 = _bn_train(l1[2], mean1, var1, cnt)
     Hp, Kp = max(H, 32), (H + 31) // 32 * 32
     W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=dev)

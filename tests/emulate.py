@@ -538,16 +538,17 @@ def _emu_col_stats(self, X: Mat, rows_dev=None):
     return mean.float(), var.clamp(min=0).float(), torch.tensor([float(rows)])
 
 
-def _emu_col_affine(self, X: Mat, scale, shift, rows_dev=None):
+def _emu_col_affine(self, X: Mat, scale, shift, rows_dev=None, out=None):
     rows = int(rows_dev.item()) if rows_dev is not None else X.rows
     v = X.view()
-    v[:rows] = v[:rows] * scale[: X.cols] + shift[: X.cols]
+    (out if out is not None else X).view()[:rows] = v[:rows] * scale[: X.cols] + shift[: X.cols]
 
 
-def _emu_edge_gather_relu(self, A: Mat, B: Mat, csr: CSR, Z: Mat):
+def _emu_edge_gather_relu(self, A: Mat, B: Mat, csr: CSR, Z: Mat, want_stats=False):
     E = int(csr.rowptr[-1])
     src, dst = csr.src[:E].long(), csr.dst[:E].long()
     Z.view()[:E] = torch.relu(A.view()[dst] + B.view()[src])
+    return self.col_stats(Z, rows_dev=csr.rowptr[-1:]) if want_stats else None
 
 
 def _emu_segmax_affine(self, Z: Mat, rowptr, n_segments, out: Mat, scale=None, shift=None):

@@ -275,6 +275,16 @@ def test_edge_backward_operators(n, e, H, ld):
     assert float((sum_g.cpu() - sum_w).abs().max()) <= 1e-5 * float(du_w[:E, :H].abs().sum(0).max())
     assert ops.segmax_bn_relu_backward(Mat.of(doutd, 0, H), argd, Mat.of(Zd, 0, H), dev(csr.rowptr), dev(csr.dst), dev(mean), dev(rstd),
                                        dev(gamma), dev(sdz), dev(sdzx), Mat.of(du, 0, H)) is None
+    # (2b) the first edge layer with its statistics from the same pass == the layer, then col_stats over its live rows
+    AB = torch.randn(n, 2 * ld, generator=g).to(DEV)
+    z_a, z_b = torch.full((cap, ld), 9.0, device=DEV), torch.full((cap, ld), 9.0, device=DEV)
+    assert ops.edge_gather_relu(Mat.of(AB, 0, H), Mat.of(AB, ld, H), csr_d, Mat.of(z_a, 0, H)) is None
+    m_f, v_f, c_f = ops.edge_gather_relu(Mat.of(AB, 0, H), Mat.of(AB, ld, H), csr_d, Mat.of(z_b, 0, H), want_stats=True)
+    assert torch.equal(z_a, z_b) and bool((z_a[:, H:] == 9.0).all()) and bool((z_a[E:] == 9.0).all())
+    m_s, v_s, c_s = ops.col_stats(Mat.of(z_a, 0, H), rows_dev=csr_d.rowptr[n:n + 1])
+    want_z = torch.relu(AB[:, :H].cpu()[csr.dst[:E].long()] + AB[:, ld:ld + H].cpu()[csr.src[:E].long()])
+    assert torch.equal(z_a[:E, :H].cpu(), want_z) and float(c_f) == float(c_s) == float(E)
+    assert torch.allclose(m_f, m_s, rtol=1e-6, atol=1e-7) and torch.allclose(v_f, v_s, rtol=1e-5, atol=1e-7)
     # (3) BatchNorm + ReLU inside the scatter sums; the plain scatter; both reproducible bit for bit
     Y = torch.relu(torch.randn(cap, ld, generator=g)); Y[E:] = float("nan")
     G = torch.randn(cap, ld, generator=g); G[E:] = float("nan")
