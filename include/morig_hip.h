@@ -537,7 +537,8 @@ int morig_edge_scatter_backward(const float* dG, int32_t ldg, const int32_t* row
 /* out[N][K] = A^T B over the rows (A [rows][N], B [rows][K], fp32 MFMA): the weight gradient dW = dU^T X. The row range is split
  * over workgroups and the partial products are summed in a fixed order. workspace: morig_gemm_tn_workspace(rows, N, K) floats.
  * Arithmetic: bf16 x 3 split MFMAs by default (both operands split in the kernel: ~16 mantissa bits, float32 exponent range, 2x the
- * exact kernel's rate); the environment variable MORIG_TRAIN_BWD=f32 selects the exact-float32 MFMA kernel. */
+ * exact kernel's rate); the environment variable MORIG_TRAIN_BWD=f32 selects the exact-float32 MFMA kernel. N, K <= 32: plain
+ * float32 FMAs (exact products) on a kernel without MFMA tiles, whatever the setting. */
 int64_t morig_gemm_tn_workspace(int32_t rows, int32_t N, int32_t K);
 int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t rows, const int32_t* rows_dev, int32_t N, int32_t K,
                   float* workspace, int64_t workspace_floats, float* out, int32_t ldo, void* stream);

@@ -649,6 +649,44 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
 
 // partial tiles -> C: 32 output elements x 8 chunk lanes per block; lane j adds chunks j, j + 8, ... in order, the eight lane sums
 // are combined as a fixed tree (deterministic; the chain per lane is <= 64 additions)
+// N, K <= 32 (the 16-wide motion branches of every EdgeConvMotion: ~70 weight gradients per step over 0.26-0.56 M edge rows each):
+// a 128 x 128 MFMA tile is 1-6 % full there and the call took 50-60 us for 30-70 MB of operands. Plain FMAs instead: a workgroup
+// walks its chunk of the rows in 64-row stages through LDS, thread (i, 4 k's) keeps four outputs; products are exact float32,
+// accumulation order is fixed (rows ascending, then the chunk reduction shared with the MFMA kernels).
+__global__ __launch_bounds__(256) void gemm_tn_small_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                            int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
+                                                            float* __restrict__ part) {
+    const int rows = rows_dev ? *rows_dev : rows_host;
+    __shared__ float sA[64][33];
+    __shared__ __attribute__((aligned(16))) float sB[64][36];
+    const int tid = threadIdx.x;
+    const int ti = tid >> 3, tj = (tid & 7) * 4;                     // output row (a column of A), first of four output columns
+    const int lr = tid >> 2, lc = (tid & 3) * 8;                     // loader: stage row, first of eight columns
+    const int r0 = blockIdx.x * chunk_rows, r1 = min(r0 + chunk_rows, rows);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rb = r0; rb < r1; rb += 64) {
+        const int r = rb + lr;
+        const bool live = r < r1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sA[lr][lc + j] = (live && lc + j < N) ? A[(size_t)r * lda + lc + j] : 0.f;
+            sB[lr][lc + j] = (live && lc + j < K) ? B[(size_t)r * ldb + lc + j] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < 64; ++q) {
+            const float a = sA[q][ti];
+            const float4 b = *reinterpret_cast<const float4*>(&sB[q][tj]);
+            acc[0] = fmaf(a, b.x, acc[0]); acc[1] = fmaf(a, b.y, acc[1]); acc[2] = fmaf(a, b.z, acc[2]); acc[3] = fmaf(a, b.w, acc[3]);
+        }
+        __syncthreads();
+    }
+    if (ti < N)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (tj + j < K) part[((size_t)blockIdx.x * N + ti) * K + tj + j] = acc[j];
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, int N, int K,
                                                              float* __restrict__ out, int ldo) {
     const int64_t total = (int64_t)N * K;
@@ -841,9 +879,17 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
     // MORIG_TRAIN_BWD=f32: the exact-float32 MFMA kernel; default: the bf16 x 3 split (gemm_tn16_kernel). Read per call: the tests flip it.
     const char* e_bwd = getenv("MORIG_TRAIN_BWD");
     const bool split16 = !(e_bwd && e_bwd[0] == 'f');
+    ProfScope ps(K_MISC, s, 2.0 * rows * (double)N * K, 4.0 * rows * ((double)N + K));
+    if (N <= 32 && K <= 32 && !getenv("MORIG_TN_NO_SMALL")) {
+        const int chunk_rows = cdiv(cdiv(rows > 0 ? rows : 1, chunks), 64) * 64;
+        hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, workspace);
+        MORIG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((int)(((int64_t)N * K + 31) / 32)), dim3(256), 0, s, workspace, chunks, N, K, out, ldo);
+        MORIG_LAUNCH_CHECK();
+        return MORIG_OK;
+    }
     const int RS = split16 ? TN16_R : TN_R;
     const int chunk_rows = cdiv(cdiv(rows > 0 ? rows : 1, chunks), RS) * RS;
-    ProfScope ps(K_MISC, s, 2.0 * rows * (double)N * K, 4.0 * rows * ((double)N + K));
     const int n_tiles = cdiv(N, TN_T), k_tiles = cdiv(K, TN_T);
     const int per_xcd = cdiv((long)n_tiles * k_tiles * chunks, 8);
     if (split16)

@@ -60,9 +60,13 @@ def _buf(rows: int, cols: int, dev) -> torch.Tensor:
 
 
 def _rows16(x: torch.Tensor) -> torch.Tensor:
-    """a contiguous fp32 copy of x whose rows are 16-byte aligned (columns zero-padded to a multiple of 4)"""
+    """x as an fp32 matrix whose rows are 16-byte aligned, for ``Mat.of`` (which takes the row pitch from the stride): x itself when it
+    already is one -- also as a column window of a wider tensor, which is what the backward of ``torch.cat`` hands out: copying those
+    was 2 ms of the step -- otherwise a contiguous copy with the columns zero-padded to a multiple of 4"""
     x = x.detach().float()
     c = x.shape[1]
+    if c % 4 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.stride(0) >= c and x.data_ptr() % 16 == 0:
+        return x
     if c % 4:
         x = F.pad(x, (0, _ld4(c) - c))
     return x.contiguous()
@@ -426,8 +430,9 @@ def temporal_attn(attn, x):
     kh = linear(tok2, attn.w_ks).reshape(V, L, nh, -1)
     vh = linear(tok2, attn.w_vs).reshape(V, L, nh, -1)
     q0 = linear(attn.cls_token.reshape(1, -1), attn.w_qs).reshape(nh, -1)
-    att = torch.softmax(torch.einsum("hd,vlhd->vhl", q0, kh) / math.sqrt(kh.shape[-1]), dim=-1)
-    res0 = torch.einsum("vhl,vlhd->vhd", att, vh).reshape(V, -1)
+    # (broadcast products: as einsum / bmm these go to hipBLASLt float32 kernels that take 0.5-0.9 ms on such skinny shapes)
+    att = torch.softmax((kh * q0).sum(-1) / math.sqrt(kh.shape[-1]), dim=1)                 # [V, L, nh], over the tokens
+    res0 = (att.unsqueeze(-1) * vh).sum(1).reshape(V, -1)
     h = linear(res0, attn.w_o)
     return mlp_layer(mlp_layer(h, attn.feedforward[0]), attn.feedforward[1])
 
