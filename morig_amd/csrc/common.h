@@ -108,8 +108,8 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 
 // ---- two-pass column reductions in fp64 (train_ops.hip / train_bwd.hip) ----------------------------------------------------------
 // First pass: grid (64-column groups, row slabs), 256 threads = (float4 column quads of the group) x (row lanes); every slab writes
-// its [2][cols] partial sums (zeros past the live rows). Second pass: 16 columns x 16 slab lanes per block. Every order is fixed.
-// Rows per slab: 256, more once that would give more than 1024 slabs (the second pass then adds <= 64 partials per lane).
+// its [2][cols] partial sums (zeros past the live rows). Second pass: 4 columns x 64 slab lanes per block. Every order is fixed.
+// Rows per slab: 256, more once that would give more than ~1024 workgroups (stats_slab_rows).
 inline int stats_slab_rows(int rows_cap, int cols) {
     // ~1024 workgroups over (64-column groups x row slabs): wide matrices get fewer, longer slabs -- the second pass reads
     // slabs x 2 x cols doubles on cols / 16 workgroups, which at 1024 slabs x 256 columns was 4 MB per call and 10-17 us per launch
@@ -193,25 +193,24 @@ __device__ inline void stats_block_store(const double (&acc)[2][4], int quads, i
     }
 }
 
-// second pass of one statistic pair: returns through s / q the sums of column c (valid on lane 0 of the column: threadIdx.x < 16)
+// second pass of one statistic pair: STATS_FC columns x 64 slab lanes per workgroup (the partials of a column are few and small:
+// what a launch costs is the length of the longest lane's chain of additions -- 16 columns x 16 lanes was 64 dependent steps at 1024
+// slabs), then a fixed tree over the lanes. Returns through s / q the sums of column c, valid on threadIdx.x < STATS_FC.
+constexpr int STATS_FC = 4;
 __device__ inline void stats_final_sums(const double* __restrict__ part, int slabs, int cols, int c, double& s, double& q) {
-    const int sl = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int sl = threadIdx.x / STATS_FC, l = threadIdx.x % STATS_FC;
+    constexpr int LANES = 256 / STATS_FC;
     s = 0.0; q = 0.0;
     if (c < cols)
-        for (int b = sl; b < slabs; b += 16) { s += part[((size_t)b * 2 + 0) * cols + c]; q += part[((size_t)b * 2 + 1) * cols + c]; }
-    __shared__ double sh[2][16][16];
+        for (int b = sl; b < slabs; b += LANES) { s += part[((size_t)b * 2 + 0) * cols + c]; q += part[((size_t)b * 2 + 1) * cols + c]; }
+    __shared__ double sh[2][LANES][STATS_FC];
     sh[0][sl][l] = s; sh[1][sl][l] = q;
     __syncthreads();
-    if (sl == 0) {
-        double a[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double (&v)[16][16] = sh[k];
-            a[k] = (((v[0][l] + v[1][l]) + (v[2][l] + v[3][l])) + ((v[4][l] + v[5][l]) + (v[6][l] + v[7][l]))) +
-                   (((v[8][l] + v[9][l]) + (v[10][l] + v[11][l])) + ((v[12][l] + v[13][l]) + (v[14][l] + v[15][l])));
-        }
-        s = a[0]; q = a[1];
+    for (int h = LANES / 2; h > 0; h >>= 1) {
+        if (sl < h) { sh[0][sl][l] += sh[0][sl + h][l]; sh[1][sl][l] += sh[1][sl + h][l]; }
+        __syncthreads();
     }
+    s = sh[0][0][l]; q = sh[1][0][l];
 }
 #endif
 

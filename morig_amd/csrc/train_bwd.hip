@@ -75,13 +75,13 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     stats_block_store(acc, quads, RL, q, rl, c0, cols, blockIdx.y, part);
 }
 
-// second pass: 16 columns x 16 slab lanes per block, fixed order (common.h)
+// second pass: STATS_FC columns x 64 slab lanes per block, fixed order (common.h)
 __global__ __launch_bounds__(256) void bn_bwd_final_kernel(const double* __restrict__ part, int slabs, int cols,
                                                            float* __restrict__ sum_dz, float* __restrict__ sum_dzx) {
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int c = blockIdx.x * STATS_FC + (threadIdx.x % STATS_FC);
     double s, q;
     stats_final_sums(part, slabs, cols, c, s, q);
-    if (threadIdx.x >= 16 || c >= cols) return;
+    if (threadIdx.x >= STATS_FC || c >= cols) return;
     sum_dz[c] = (float)s;
     if (sum_dzx) sum_dzx[c] = (float)q;
 }
@@ -651,57 +651,109 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
 // are combined as a fixed tree (deterministic; the chain per lane is <= 64 additions)
 // N, K <= 32 (the 16-wide motion branches of every EdgeConvMotion: ~70 weight gradients per step over 0.26-0.56 M edge rows each):
 // a 128 x 128 MFMA tile is 1-6 % full there and the call took 50-60 us for 30-70 MB of operands. Plain FMAs instead: a workgroup
-// walks its chunk of the rows in 64-row stages through LDS, thread (i, 4 k's) keeps four outputs; products are exact float32,
-// accumulation order is fixed (rows ascending, then the chunk reduction shared with the MFMA kernels).
+// walks its chunk of the rows in 64-row stages through LDS; a thread keeps a 4 x 4 block of the output (two 16-byte LDS reads per 16
+// FMAs) and the P x P / 16 threads that cover the padded output form one of G row groups, group g taking rows g, g + G, ... of a
+// stage; the groups are added in a fixed order at the end. Products are exact float32, every order is fixed.
+template <int P /* padded output side: 16 or 32 */>
 __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                             int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
                                                             float* __restrict__ part) {
+    constexpr int TPG = (P / 4) * (P / 4);                           // threads per row group
+    constexpr int G = 256 / TPG;                                     // row groups: 16 (P = 16) or 4 (P = 32)
+    constexpr int LD = P + 4;
     const int rows = rows_dev ? *rows_dev : rows_host;
-    __shared__ float sA[64][33];
-    __shared__ __attribute__((aligned(16))) float sB[64][36];
+    __shared__ __attribute__((aligned(16))) float sA[64 * LD], sB[64 * LD];
     const int tid = threadIdx.x;
-    const int ti = tid >> 3, tj = (tid & 7) * 4;                     // output row (a column of A), first of four output columns
-    const int lr = tid >> 2, lc = (tid & 3) * 8;                     // loader: stage row, first of eight columns
+    const int g = tid / TPG, t = tid % TPG;
+    const int bi = (t / (P / 4)) * 4, bj = (t % (P / 4)) * 4;        // this thread's 4 x 4 output block
+    constexpr int CPT = 64 * P / 256;                                // loader: consecutive columns per thread (4 or 8)
+    const int lr = tid / (P / CPT), lc = (tid % (P / CPT)) * CPT;
     const int r0 = blockIdx.x * chunk_rows, r1 = min(r0 + chunk_rows, rows);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = ((N | K | lda | ldb) & 3) == 0 && ((reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(B)) & 15) == 0;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
     for (int rb = r0; rb < r1; rb += 64) {
         const int r = rb + lr;
         const bool live = r < r1;
+        if (vec) {                                                   // 16-byte pieces: each lies wholly inside or outside the live columns
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            sA[lr][lc + j] = (live && lc + j < N) ? A[(size_t)r * lda + lc + j] : 0.f;
-            sB[lr][lc + j] = (live && lc + j < K) ? B[(size_t)r * ldb + lc + j] : 0.f;
+            for (int j = 0; j < CPT; j += 4) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&sA[lr * LD + lc + j]) =
+                    (live && lc + j < N) ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + lc + j) : z;
+                *reinterpret_cast<float4*>(&sB[lr * LD + lc + j]) =
+                    (live && lc + j < K) ? *reinterpret_cast<const float4*>(B + (size_t)r * ldb + lc + j) : z;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j) {
+                sA[lr * LD + lc + j] = (live && lc + j < N) ? A[(size_t)r * lda + lc + j] : 0.f;
+                sB[lr * LD + lc + j] = (live && lc + j < K) ? B[(size_t)r * ldb + lc + j] : 0.f;
+            }
         }
         __syncthreads();
-#pragma unroll 8
-        for (int q = 0; q < 64; ++q) {
-            const float a = sA[q][ti];
-            const float4 b = *reinterpret_cast<const float4*>(&sB[q][tj]);
-            acc[0] = fmaf(a, b.x, acc[0]); acc[1] = fmaf(a, b.y, acc[1]); acc[2] = fmaf(a, b.z, acc[2]); acc[3] = fmaf(a, b.w, acc[3]);
+#pragma unroll
+        for (int q = g; q < 64; q += G) {
+            const float4 a = *reinterpret_cast<const float4*>(&sA[q * LD + bi]);
+            const float4 b = *reinterpret_cast<const float4*>(&sB[q * LD + bj]);
+            const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
         }
         __syncthreads();
     }
-    if (ti < N)
+    // the G row groups' blocks, added in group order
+    __shared__ float red[256 * 16];                                  // [G][TPG][16]
+    {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (tj + j < K) part[((size_t)blockIdx.x * N + ti) * K + tj + j] = acc[j];
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(g * TPG + t) * 16 + i * 4 + j] = acc[i][j];
+    }
+    __syncthreads();
+    for (int o = tid; o < TPG * 16; o += 256) {
+        const int tt = o >> 4, e = o & 15;
+        float sum = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) sum += red[(gg * TPG + tt) * 16 + e];
+        const int n = (tt / (P / 4)) * 4 + (e >> 2), k = (tt % (P / 4)) * 4 + (e & 3);
+        if (n < N && k < K) part[((size_t)blockIdx.x * N + n) * K + k] = sum;
+    }
 }
 
+// (256 / LN) output elements x LN chunk lanes per workgroup, then a fixed tree over the lanes. LN = 32 for many chunks (narrow
+// outputs over many rows: <= 16 additions per lane at 512 chunks), 8 for the wide outputs that have a handful of chunks.
+template <int LN>
 __global__ __launch_bounds__(256) void gemm_tn_reduce_kernel(const float* __restrict__ part, int chunks, int N, int K,
                                                              float* __restrict__ out, int ldo) {
+    constexpr int EL = 256 / LN;
     const int64_t total = (int64_t)N * K;
-    const int el = threadIdx.x & 31, ln = threadIdx.x >> 5;
-    const int64_t i = (int64_t)blockIdx.x * 32 + el;
+    const int el = threadIdx.x % EL, ln = threadIdx.x / EL;
+    const int64_t i = (int64_t)blockIdx.x * EL + el;
     float s = 0.f;
     if (i < total)
-        for (int c = ln; c < chunks; c += 8) s += part[(size_t)c * total + i];
-    __shared__ float sh[8][32];
+        for (int c = ln; c < chunks; c += LN) s += part[(size_t)c * total + i];
+    __shared__ float sh[LN][EL];
     sh[ln][el] = s;
     __syncthreads();
+    for (int h = LN / 2; h > 0; h >>= 1) {
+        if (ln < h) sh[ln][el] += sh[ln + h][el];
+        __syncthreads();
+    }
     if (ln != 0 || i >= total) return;
-    s = ((sh[0][el] + sh[1][el]) + (sh[2][el] + sh[3][el])) + ((sh[4][el] + sh[5][el]) + (sh[6][el] + sh[7][el]));
     const int64_t n = i / K; const int k = (int)(i - n * K);
-    out[n * ldo + k] = s;
+    out[n * ldo + k] = sh[0][el];
+}
+
+static void launch_tn_reduce(const float* part, int chunks, int N, int K, float* out, int ldo, hipStream_t s) {
+    const int64_t total = (int64_t)N * K;
+    if (chunks >= 64) hipLaunchKernelGGL(gemm_tn_reduce_kernel<32>, dim3((int)((total + 7) / 8)), dim3(256), 0, s, part, chunks, N, K, out, ldo);
+    else hipLaunchKernelGGL(gemm_tn_reduce_kernel<8>, dim3((int)((total + 31) / 32)), dim3(256), 0, s, part, chunks, N, K, out, ldo);
 }
 
 static int tn_chunks(int rows, int N, int K) {
@@ -730,7 +782,7 @@ extern "C" int morig_bn_backward_stats(const float* dz, int32_t ldz, const float
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols, slab_rows,
                        mean, rstd, workspace, (const int*)nullptr, 0);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, y ? sum_dzx : nullptr);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, STATS_FC)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, y ? sum_dzx : nullptr);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -799,7 +851,7 @@ extern "C" int morig_segmax_bn_backward_stats(const float* dout, int32_t ldd, co
     else hipLaunchKernelGGL(segmax_bwd_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dout, ldd, arg, ld_arg, Z, ldz, n_segments,
                        cols, slab_rows, mean, rstd, workspace);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, sum_dzx);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, STATS_FC)), dim3(256), 0, s, workspace, slabs, cols, sum_dz, sum_dzx);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -824,7 +876,7 @@ extern "C" int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, con
                             n_segments, seg_of_row, row_capacity, cols, slab_rows, mean, rstd, gamma, sum_dz, sum_dzx, relu, du, ldu, part);
     MORIG_LAUNCH_CHECK();
     if (sum_du) {
-        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, cols, sum_du, (float*)nullptr);
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, STATS_FC)), dim3(256), 0, s, workspace, slabs, cols, sum_du, (float*)nullptr);
         MORIG_LAUNCH_CHECK();
     }
     return MORIG_OK;
@@ -882,9 +934,12 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
     ProfScope ps(K_MISC, s, 2.0 * rows * (double)N * K, 4.0 * rows * ((double)N + K));
     if (N <= 32 && K <= 32 && !getenv("MORIG_TN_NO_SMALL")) {
         const int chunk_rows = cdiv(cdiv(rows > 0 ? rows : 1, chunks), 64) * 64;
-        hipLaunchKernelGGL(gemm_tn_small_kernel, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, workspace);
+        if (N <= 16 && K <= 16)
+            hipLaunchKernelGGL(gemm_tn_small_kernel<16>, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, workspace);
+        else
+            hipLaunchKernelGGL(gemm_tn_small_kernel<32>, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, workspace);
         MORIG_LAUNCH_CHECK();
-        hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((int)(((int64_t)N * K + 31) / 32)), dim3(256), 0, s, workspace, chunks, N, K, out, ldo);
+        launch_tn_reduce(workspace, chunks, N, K, out, ldo, s);
         MORIG_LAUNCH_CHECK();
         return MORIG_OK;
     }
@@ -899,7 +954,7 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles, k_tiles,
                            chunks, per_xcd, workspace);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gemm_tn_reduce_kernel, dim3((int)(((int64_t)N * K + 31) / 32)), dim3(256), 0, s, workspace, chunks, N, K, out, ldo);
+    launch_tn_reduce(workspace, chunks, N, K, out, ldo, s);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -50,11 +50,11 @@ __global__ __launch_bounds__(256) void col_stats_final_kernel(const double* __re
                                                               const int* __restrict__ rows_dev, int cols, float* __restrict__ mean,
                                                               float* __restrict__ var, float* __restrict__ count) {
     const int rows = rows_dev ? *rows_dev : rows_host;
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int c = blockIdx.x * STATS_FC + (threadIdx.x % STATS_FC);
     if (blockIdx.x == 0 && threadIdx.x == 0 && count) *count = (float)rows;
     double s, q;
     stats_final_sums(part, slabs, cols, c, s, q);
-    if (threadIdx.x >= 16 || c >= cols) return;
+    if (threadIdx.x >= STATS_FC || c >= cols) return;
     const double n = rows > 0 ? (double)rows : 1.0;
     const double m = s / n;
     double v = q / n - m * m;                          // fp64: the cancellation costs ~1e-16 relative, far below fp32
@@ -164,7 +164,7 @@ extern "C" int morig_col_stats(const float* x, int32_t ldx, int32_t rows, const 
     hipLaunchKernelGGL(col_stats_partial_kernel, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, x, ldx, rows, rows_dev, cols, slab_rows,
                        workspace);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(col_stats_final_kernel, dim3(cdiv(cols, 16)), dim3(256), 0, s, workspace, slabs, rows, rows_dev, cols, mean, var, count);
+    hipLaunchKernelGGL(col_stats_final_kernel, dim3(cdiv(cols, STATS_FC)), dim3(256), 0, s, workspace, slabs, rows, rows_dev, cols, mean, var, count);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -242,7 +242,7 @@ extern "C" int morig_edge_gather_relu(const float* A, int32_t lda, const float* 
                             src_sorted, dst_sorted, H, slab_rows, Z, ldz, part);
     MORIG_LAUNCH_CHECK();
     if (mean) {
-        hipLaunchKernelGGL(col_stats_final_kernel, dim3(cdiv(H, 16)), dim3(256), 0, s, workspace, slabs, edge_capacity, rowptr + n_nodes, H,
+        hipLaunchKernelGGL(col_stats_final_kernel, dim3(cdiv(H, STATS_FC)), dim3(256), 0, s, workspace, slabs, edge_capacity, rowptr + n_nodes, H,
                            mean, var, count);
         MORIG_LAUNCH_CHECK();
     }
