@@ -154,6 +154,41 @@ def clear_pack_cache():
     _PACKS.clear()
 
 
+class _KeyedPacks:
+    """a pack cache entry group whose validity follows given LEAF parameters: for blocks whose weight operands are built per call
+    (``torch.cat`` / ``block_diag`` of several modules' parameters -- a fresh tensor every time, whose storage address the caching
+    allocator recycles, so it must never be a cache key)"""
+
+    def __init__(self, base, prefix: str, leaves):
+        self.base, self.prefix, self.leaves = base, prefix, tuple(leaves)
+
+    def get(self, key, params, build):
+        return self.base.get(self.prefix + key, self.leaves, build)
+
+
+class _StackedBN:
+    """BatchNorm1d layers of equal width side by side (their columns concatenated); None = a padding block (gamma 1, beta 0, nothing
+    tracked). Each layer keeps its own running buffers and batch counter."""
+
+    def __init__(self, parts, width: int):
+        self.parts, self.width = list(parts), width
+
+
+def _bn_any(bn, mean, var, cnt):
+    """_bn_train(..., want_rstd=True) for a BatchNorm1d or a _StackedBN -> (s, t, rstd)"""
+    if not isinstance(bn, _StackedBN):
+        return _bn_train(bn, mean, var, cnt, want_rstd=True)
+    w, outs = bn.width, []
+    for i, part in enumerate(bn.parts):
+        m, v = mean[i * w:(i + 1) * w], var[i * w:(i + 1) * w]                 # (1-D slices: contiguous)
+        if part is None:
+            r = torch.rsqrt(v + 1e-5)
+            outs.append((r, -m * r, r))
+        else:
+            outs.append(_bn_train(part, m, v, cnt, want_rstd=True))
+    return tuple(torch.cat([o[k] for o in outs]).contiguous() for k in range(3))
+
+
 class DenseTrain(torch.autograd.Function):
     """one ``Seq(Linear, ReLU, BatchNorm1d)`` of MLP() with batch statistics (models/basic_modules.py:31-36)"""
 
@@ -256,7 +291,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         z1 = _buf(csr.capacity, H, dev)
         loc1 = ops.edge_gather_relu(A, B, csr, Mat.of(z1, 0, H), want_stats=True)       # (its batch statistics from the same pass)
         mean1, var1, cnt, share1 = batch_moments(ops, Mat.of(z1, 0, H), rows_dev=e_live, local=loc1)
-        s1, t1, rstd1 = _bn_train(bn1, mean1, var1, cnt, want_rstd=True)
+        s1, t1, rstd1 = _bn_any(bn1, mean1, var1, cnt)
         Hp, Kp = max(H, 32), (H + 31) // 32 * 32
 
         def w2_pack():
@@ -268,7 +303,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         z2 = _buf(csr.capacity, H, dev)
         ops.edge_hidden(A, B, csr, pe, Mat.of(z2, 0, H))
         mean2, var2, cnt2, share2 = batch_moments(ops, Mat.of(z2, 0, H), rows_dev=e_live)
-        s2, t2, rstd2 = _bn_train(bn2, mean2, var2, cnt2, want_rstd=True)
+        s2, t2, rstd2 = _bn_any(bn2, mean2, var2, cnt2)
         out = _buf(n, H, dev)
         arg, zwin = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2, want_zwin=True)
         ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg, zwin)
@@ -392,23 +427,68 @@ def edge_mlp(x, csr: CSR, mlp):
                               l1[2], l2[2], csr, packs_of(mlp))
 
 
-def edgeconvmotion(ec, pos, x, csr: CSR):
-    """EdgeConvMotion (models/basic_modules.py:179-202): [nn_x branch | nn_pos branch], each max-aggregated"""
-    return torch.cat([edge_mlp(x, csr, ec.nn_x), edge_mlp(pos, csr, ec.nn_pos)], 1)
+def edgeconvmotion(ec, pos, x, csr: CSR, pos_branch=None):
+    """EdgeConvMotion (models/basic_modules.py:179-202): [nn_x branch | nn_pos branch], each max-aggregated; ``pos_branch``: the
+    nn_pos result when it was computed with its siblings (``stacked_pos_branches``)"""
+    return torch.cat([edge_mlp(x, csr, ec.nn_x), pos_branch if pos_branch is not None else edge_mlp(pos, csr, ec.nn_pos)], 1)
 
 
-def gcumotion(gcu, pos, x, csr_tpl: CSR, csr_geo: CSR):
+def stacked_pos_branches(net, pos, csr: CSR, which: str):
+    """The nn_pos branches of the three EdgeConvMotions of a GCNRig on one graph take the same input (pos), the same graph and have
+    the same shape (6 -> 16 -> 16): ONE edge MLP evaluates them together -- Linear1 rows stacked, Linear2 block-diagonal, BatchNorm
+    columns side by side (statistics, running buffers and gradients stay per layer: a BatchNorm column never sees its neighbours),
+    padded with an all-zero block to the 64 columns the edge kernels come in. As three 16-wide blocks they were 36 forward and 36
+    backward blocks of ~30 launches per step, 8 ms of a 92 ms step for 1 % of its arithmetic. -> [three [n, 16] results], or None
+    when the layers do not have that common shape (the caller then evaluates them one by one)."""
+    mlps = [getattr(g, which).nn_pos for g in (net.gcu_1, net.gcu_2, net.gcu_3)]
+    try:
+        lins = [(m[0][0], m[0][2], m[1][0], m[1][2]) for m in mlps]
+    except (IndexError, TypeError):
+        return None
+    H, C2 = lins[0][0].weight.shape
+    W = 64
+    ok = H * len(lins) <= W and W % H == 0 and all(
+        l1.weight.shape == (H, C2) and l2.weight.shape == (H, H) and l1.bias is not None and l2.bias is not None and
+        b1.weight is not None and b1.bias is not None and b2.weight is not None and b2.bias is not None and
+        b1.eps == b2.eps == lins[0][1].eps for l1, b1, l2, b2 in lins)
+    if not ok or C2 != 2 * pos.shape[1]:
+        return None
+    dev = pos.device
+    pad = W - H * len(lins)
+    cache = packs_of(net)
+    z_w1, z_w2, z_v, o_v = cache.get(which + ":pos:pad", (), lambda: (
+        torch.zeros((pad, C2), device=dev), torch.zeros((pad, pad), device=dev), torch.zeros(pad, device=dev), torch.ones(pad, device=dev)))
+    if z_v.device != dev:
+        return None
+    cat = lambda ts, fill: torch.cat(list(ts) + ([fill] if pad else []))
+    W1 = cat((l[0].weight for l in lins), z_w1)
+    b1 = cat((l[0].bias for l in lins), z_v)
+    g1, be1 = cat((l[1].weight for l in lins), o_v), cat((l[1].bias for l in lins), z_v)
+    W2 = torch.block_diag(*([l[2].weight for l in lins] + ([z_w2] if pad else [])))
+    b2 = cat((l[2].bias for l in lins), z_v)
+    g2, be2 = cat((l[3].weight for l in lins), o_v), cat((l[3].bias for l in lins), z_v)
+    nopad = [None] * (pad // H)
+    bn1, bn2 = _StackedBN([l[1] for l in lins] + nopad, H), _StackedBN([l[3] for l in lins] + nopad, H)
+    leaves = [q for l in lins for q in (l[0].weight, l[0].bias, l[2].weight, l[2].bias)]
+    packs = cache if cache is _NoPacks else _KeyedPacks(cache, which + ":pos:", leaves)
+    out = EdgeMLPTrain.apply(pos, W1, b1, g1, be1, W2, b2, g2, be2, bn1, bn2, csr, packs)
+    return [out[:, i * H:(i + 1) * H] for i in range(len(lins))]
+
+
+def gcumotion(gcu, pos, x, csr_tpl: CSR, csr_geo: CSR, pos_tpl=None, pos_geo=None):
     """GCUMotion (models/basic_modules.py:205-219)"""
-    both = torch.cat([edgeconvmotion(gcu.edge_conv_tpl, pos, x, csr_tpl), edgeconvmotion(gcu.edge_conv_geo, pos, x, csr_geo)], 1)
+    both = torch.cat([edgeconvmotion(gcu.edge_conv_tpl, pos, x, csr_tpl, pos_tpl), edgeconvmotion(gcu.edge_conv_geo, pos, x, csr_geo, pos_geo)], 1)
     return mlp_layer(both, gcu.mlp[0])
 
 
 def gcnrig(net, pos, feature, csr_tpl: CSR, csr_geo: CSR, batch, mesh_ptr, n_graphs: int):
     """GCNRig.forward (models/rignet.py:59-67)"""
     tr = getattr(net, net.TRANSFORM)
-    a = gcumotion(net.gcu_1, pos, feature, csr_tpl, csr_geo)
-    b = gcumotion(net.gcu_2, pos, a, csr_tpl, csr_geo)
-    c = gcumotion(net.gcu_3, pos, b, csr_tpl, csr_geo)
+    pt = stacked_pos_branches(net, pos, csr_tpl, "edge_conv_tpl") or [None] * 3
+    pg = stacked_pos_branches(net, pos, csr_geo, "edge_conv_geo") or [None] * 3
+    a = gcumotion(net.gcu_1, pos, feature, csr_tpl, csr_geo, pt[0], pg[0])
+    b = gcumotion(net.gcu_2, pos, a, csr_tpl, csr_geo, pt[1], pg[1])
+    c = gcumotion(net.gcu_3, pos, b, csr_tpl, csr_geo, pt[2], pg[2])
     g = SegMaxPool.apply(mlp_layer(torch.cat([a, b, c], 1), net.mlp_glb[0]), mesh_ptr, n_graphs)
     x5 = torch.cat([RowGather.apply(g, batch, n_graphs), pos, feature, a, b, c], 1)                              # repeat_interleave over sorted batch ids (:64)
     h = mlp_layer(mlp_layer(x5, tr[0][0]), tr[0][1])
