@@ -534,6 +534,12 @@ int morig_edge_bn_scatter_backward(const float* dG, int32_t ldg, const float* Y,
  * edges with source u (float atomics: summation order, hence the last bits, vary run to run). dB ([n_src_nodes][ldb]) is zeroed here. */
 int morig_edge_scatter_backward(const float* dG, int32_t ldg, const int32_t* rowptr, const int32_t* src_sorted, int32_t n_nodes,
                                 int32_t n_src_nodes, int32_t H, float* dA, int32_t lda, float* dB, int32_t ldb, void* stream);
+/* the sums morig_bn_backward_stats would take over dh = dU2 W2 and Z1 (the BatchNorm of the FIRST layer of an edge MLP), from
+ * products that exist already: M = dU2^T Z1 [h_out][h_in] (morig_gemm_tn, what dW2 is made of), db2 = column sums of dU2 [h_out], W2
+ * [h_out][h_in] (Linear2, out x in): sum_dz[c] = sum_k db2[k] W2[k][c], sum_dzx[c] = rstd[c] sum_k W2[k][c] (M[k][c] - db2[k] mean[c]);
+ * fp64, no pass over the edge rows. */
+int morig_edge_bn_sums_from_products(const float* M, int32_t ldm, const float* db2, const float* W2, int32_t ldw, const float* mean,
+                                     const float* rstd, int32_t h_out, int32_t h_in, float* sum_dz, float* sum_dzx, void* stream);
 /* out[N][K] = A^T B over the rows (A [rows][N], B [rows][K], fp32 MFMA): the weight gradient dW = dU^T X. The row range is split
  * over workgroups and the partial products are summed in a fixed order. workspace: morig_gemm_tn_workspace(rows, N, K) floats.
  * Arithmetic: bf16 x 3 split MFMAs by default (both operands split in the kernel: ~16 mantissa bits, float32 exponent range, 2x the

@@ -400,6 +400,27 @@ __global__ __launch_bounds__(256) void edge_bn_scatter_bwd_kernel(const float* _
     }
 }
 
+// The two BatchNorm sums of the FIRST edge layer without a pass over the edges. The gradient that reaches its BatchNorm is
+// dh = du2 W2 (rows = edges), so   sum_e dh[e][c]            = sum_k db2[k] W2[k][c]                       (db2 = column sums of du2)
+//                                  sum_e dh[e][c] xhat[e][c] = rstd[c] sum_k W2[k][c] (M[k][c] - db2[k] mean[c])
+// with M = du2^T Z1, the product the weight gradient dW2 is made of anyway (xhat = (Z1 - mean) rstd). Both passes over dh and Z1
+// (18 GB per JointNetMotion step) become one thread per column walking H rows of two H x H matrices, in fp64.
+__global__ __launch_bounds__(64) void edge_bn_sums_from_products_kernel(const float* __restrict__ M, int ldm, const float* __restrict__ db2,
+                                                                        const float* __restrict__ W2, int ldw, const float* __restrict__ mean,
+                                                                        const float* __restrict__ rstd, int h_out, int h_in,
+                                                                        float* __restrict__ sum_dz, float* __restrict__ sum_dzx) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= h_in) return;
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < h_out; ++k) {
+        const double w = (double)W2[(size_t)k * ldw + c];
+        a += (double)db2[k] * w;
+        b += w * (double)M[(size_t)k * ldm + c];
+    }
+    sum_dz[c] = (float)a;
+    sum_dzx[c] = (float)((double)rstd[c] * (b - (double)mean[c] * a));
+}
+
 // ---- C = A^T B over the rows -----------------------------------------------------------------------------------------------
 // v_mfma_f32_32x32x2_f32: A operand lane l = A'[i = l & 31][k = l >> 5], B operand lane l = B'[k = l >> 5][j = l & 31]. With
 // A' = A^T (i = a column n of A, k = a row r) both operands are 32 consecutive floats of a row: the row-major tiles go into LDS
@@ -915,6 +936,17 @@ extern "C" int morig_edge_bn_scatter_backward(const float* dG, int32_t ldg, cons
                                n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb);
     else hipLaunchKernelGGL(edge_bn_scatter_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dG, ldg, Y, ldy, rowptr, rowptr_t, perm_t, n_nodes,
                             n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_edge_bn_sums_from_products(const float* M, int32_t ldm, const float* db2, const float* W2, int32_t ldw, const float* mean,
+                                               const float* rstd, int32_t h_out, int32_t h_in, float* sum_dz, float* sum_dzx, void* stream) {
+    if (!M || !db2 || !W2 || !mean || !rstd || !sum_dz || !sum_dzx || h_out <= 0 || h_in <= 0 || ldm < h_in || ldw < h_in) return MORIG_E_INVALID;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_MISC, s, 0.0, 0.0);
+    hipLaunchKernelGGL(edge_bn_sums_from_products_kernel, dim3(cdiv(h_in, 64)), dim3(64), 0, s, M, ldm, db2, W2, ldw, mean, rstd, h_out, h_in,
+                       sum_dz, sum_dzx);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

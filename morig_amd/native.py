@@ -146,6 +146,8 @@ _SIGNATURES = {
                                                  C.c_void_p]),
     "morig_edge_scatter_backward": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p,
                                               C.c_int32, C.c_void_p]),
+    "morig_edge_bn_sums_from_products": (C.c_int, [c_f32p, C.c_int32, c_f32p, c_f32p, C.c_int32, c_f32p, c_f32p, C.c_int32, C.c_int32,
+                                                   c_f32p, c_f32p, C.c_void_p]),
     "morig_gemm_tn_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "morig_gemm_tn": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int64, c_f32p,
                                 C.c_int32, C.c_void_p]),
@@ -859,6 +861,17 @@ class NativeOps:
         assert dA.rows == csr.n_nodes and dB.rows == n_src and dA.cols == dB.cols == dG.cols
         check(self.lib.morig_edge_scatter_backward(dG.ptr, dG.ld, _p(csr.rowptr), _p(csr.src), csr.n_nodes, n_src, dG.cols, dA.ptr, dA.ld,
                                                    dB.ptr, dB.ld, _stream()), "morig_edge_scatter_backward")
+
+    def edge_bn_sums_from_products(self, M: torch.Tensor, db2: torch.Tensor, W2: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor):
+        """-> (sum_dz, sum_dzx) of the first edge layer's BatchNorm from M = dU2^T Z1, db2 and W2 (no pass over the edges)"""
+        _need_gpu(M, db2, W2, mean, rstd)
+        h_out, h_in = W2.shape
+        assert M.shape == (h_out, h_in) and M.stride(1) == 1 and W2.stride(1) == 1 and db2.numel() >= h_out and db2.is_contiguous()
+        assert all(t.dtype == torch.float32 for t in (M, db2, W2, mean, rstd)) and mean.numel() >= h_in and rstd.numel() >= h_in
+        out = torch.empty((2, h_in), dtype=torch.float32, device=M.device)
+        check(self.lib.morig_edge_bn_sums_from_products(_p(M), M.stride(0), _p(db2), _p(W2), W2.stride(0), _p(mean), _p(rstd), h_out, h_in,
+                                                        _p(out[0]), _p(out[1]), _stream()), "morig_edge_bn_sums_from_products")
+        return out[0], out[1]
 
     def gemm_tn(self, A: Mat, B: Mat, out: Optional[Mat] = None, rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
         """A^T B over the rows: [A.cols, B.cols] (the weight gradient dU^T X)."""

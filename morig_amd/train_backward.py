@@ -83,6 +83,12 @@ def bwd_split() -> bool:
     return not os.environ.get("MORIG_TRAIN_BWD", "bf16x3").startswith("f")
 
 
+def edge_sums_by_pass() -> bool:
+    """MORIG_TRAIN_EDGE_SUMS=pass: the first edge layer's BatchNorm sums from a pass over dh and Z1 (fp64 accumulation of float32
+    products) instead of the H x H algebra on M = du2^T Z1 (whose entries carry the weight-gradient GEMM's arithmetic: bf16 x 3 by default)"""
+    return os.environ.get("MORIG_TRAIN_EDGE_SUMS", "products") == "pass"
+
+
 def _pack_bwd(weight: torch.Tensor, dev):
     """a packed Linear for a gradient GEMM dX = dU W^T-form: fp32 image always, plus the split-bf16 image unless MORIG_TRAIN_BWD=f32"""
     pk = packing.pack_linear(weight.detach().float(), None, split=False)
@@ -331,14 +337,19 @@ class EdgeMLPTrain(torch.autograd.Function):
         DU2 = Mat.of(du2, 0, H)
         need = ctx.needs_input_grad                      # (x, W1, b1, g1, be1, W2, b2, g2, be2, ...): frozen layers skip their dW GEMMs
         db2 = ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2,
-                                          want_sum=bool(need[5] or need[6]))          # db2 = column sums of du2, from the same pass
+                                          want_sum=True)                               # db2 = column sums of du2, from the same pass
         # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
-        dW2 = (ops.gemm_tn(DU2, Z1, rows_dev=e_live) * s1[None, :H] + db2[:, None] * t1[None, :H]) if need[5] else None
+        M = ops.gemm_tn(DU2, Z1, rows_dev=e_live) if need[5] else None
+        dW2 = (M * s1[None, :H] + db2[:, None] * t1[None, :H]) if need[5] else None
         w2t = ctx.packs.get("w2T", (W2,), lambda: _pack_bwd(W2.detach().t().contiguous(), dev))
         dh = _gemm_f32(ops, DU2, w2t, H)                                               # d(s1 Z1 + t1)  [capacity, H]
         DH = Mat.of(dh, 0, H)
-        # BatchNorm1 + ReLU over the edges
-        sdz1, sdzx1 = ops.bn_backward_stats(DH, Z1, mean1, rstd1, rows_dev=e_live)
+        # BatchNorm1 + ReLU over the edges. Its two sums over dh = du2 W2 follow from M = du2^T Z1, db2 and W2 (H x H algebra in fp64):
+        # no pass over the edge rows -- unless Linear2 is frozen and M was never formed
+        if M is not None and not edge_sums_by_pass():
+            sdz1, sdzx1 = ops.edge_bn_sums_from_products(M, db2, W2.detach().float().contiguous(), mean1, rstd1)
+        else:
+            sdz1, sdzx1 = ops.bn_backward_stats(DH, Z1, mean1, rstd1, rows_dev=e_live)
         k1, kx1, _, _ = sync_backward_sums(sdz1, sdzx1, ctx.shares[0])
         # Z1 = relu(A[dst] + B[src]): the BatchNorm1 + ReLU gradient of an edge is evaluated where it is summed into dA[dst] / dB[src]
         # (never stored; both sums in a fixed order: the source side walks the transposed graph)

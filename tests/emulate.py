@@ -666,6 +666,14 @@ def _emu_edge_bn_scatter_backward(self, dG: Mat, Y, csr: CSR, n_src, dA: Mat, dB
     dB.view().copy_(b)
 
 
+def _emu_edge_bn_sums_from_products(self, M, db2, W2, mean, rstd):
+    h_out, h_in = W2.shape
+    w, m = W2.double(), M.double()
+    a = db2[:h_out].double() @ w
+    b = (w * m).sum(0)
+    return a.float(), (rstd[:h_in].double() * (b - mean[:h_in].double() * a)).float()
+
+
 def _emu_gemm_tn(self, A: Mat, B: Mat, out=None, rows_dev=None):
     r = _rows(A, rows_dev)
     res = (A.view()[:r].double().t() @ B.view()[:r].double()).float()
@@ -688,6 +696,7 @@ EmuOps.segmax_bn_backward_stats = _emu_segmax_bn_backward_stats
 EmuOps.segmax_bn_relu_backward = _emu_segmax_bn_relu_backward
 EmuOps.edge_scatter_backward = _emu_edge_scatter_backward
 EmuOps.edge_bn_scatter_backward = _emu_edge_bn_scatter_backward
+EmuOps.edge_bn_sums_from_products = _emu_edge_bn_sums_from_products
 EmuOps.gemm_tn = _emu_gemm_tn
 EmuOps._flag = _emu_flag
 EmuOps.col_stats = _emu_col_stats

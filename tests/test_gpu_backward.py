@@ -285,6 +285,24 @@ def test_edge_backward_operators(n, e, H, ld):
     want_z = torch.relu(AB[:, :H].cpu()[csr.dst[:E].long()] + AB[:, ld:ld + H].cpu()[csr.src[:E].long()])
     assert torch.equal(z_a[:E, :H].cpu(), want_z) and float(c_f) == float(c_s) == float(E)
     assert torch.allclose(m_f, m_s, rtol=1e-6, atol=1e-7) and torch.allclose(v_f, v_s, rtol=1e-5, atol=1e-7)
+    # (2c) the first layer's BatchNorm sums from M = du2^T Z1, db2 and W2 == the pass over dh = du2 W2 and Z1 (float64 reference)
+    W2 = (torch.randn(H, H, generator=g) / H ** 0.5)
+    du2 = du.clone(); du2[E:] = 0.0
+    z1 = z_a.clone(); z1[E:] = 0.0
+    rd = csr_d.rowptr[n:n + 1]
+    m1, v1, _ = ops.col_stats(Mat.of(z1, 0, H), rows_dev=rd)
+    r1 = torch.rsqrt(v1 + 1e-5)
+    Mp = ops.gemm_tn(Mat.of(du2, 0, H), Mat.of(z1, 0, H), rows_dev=rd)
+    got_a, got_b = ops.edge_bn_sums_from_products(Mp, sum_g, W2.to(DEV), m1, r1)
+    dh64 = du2[:E, :H].double().cpu() @ W2.double()
+    xh64 = (z1[:E, :H].double().cpu() - m1.double().cpu()) * r1.double().cpu()
+    ref_a, ref_b = dh64.sum(0), (dh64 * xh64).sum(0)
+    bound = dh64.norm(dim=0) * xh64.norm(dim=0) + 1e-30                      # Cauchy-Schwarz scale of each column's sum
+    assert float(((got_b.cpu().double() - ref_b).abs() / bound).max()) <= 1e-4, float(((got_b.cpu().double() - ref_b).abs() / bound).max())
+    assert float(((got_a.cpu().double() - ref_a).abs() / (dh64.norm(dim=0) * E ** 0.5 + 1e-30)).max()) <= 1e-5
+    dhd = dh64.float().to(DEV)
+    by_pass = ops.bn_backward_stats(Mat.of(dhd, 0, H), Mat.of(z1[:E].contiguous(), 0, H), m1, r1)
+    assert float(((by_pass[1].cpu().double() - ref_b).abs() / bound).max()) <= 1e-5
     # (3) BatchNorm + ReLU inside the scatter sums; the plain scatter; both reproducible bit for bit
     Y = torch.relu(torch.randn(cap, ld, generator=g)); Y[E:] = float("nan")
     G = torch.randn(cap, ld, generator=g); G[E:] = float("nan")
