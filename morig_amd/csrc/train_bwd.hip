@@ -404,19 +404,31 @@ __global__ __launch_bounds__(256) void edge_bn_scatter_bwd_kernel(const float* _
 // dh = du2 W2 (rows = edges), so   sum_e dh[e][c]            = sum_k db2[k] W2[k][c]                       (db2 = column sums of du2)
 //                                  sum_e dh[e][c] xhat[e][c] = rstd[c] sum_k W2[k][c] (M[k][c] - db2[k] mean[c])
 // with M = du2^T Z1, the product the weight gradient dW2 is made of anyway (xhat = (Z1 - mean) rstd). Both passes over dh and Z1
-// (18 GB per JointNetMotion step) become one thread per column walking H rows of two H x H matrices, in fp64.
-__global__ __launch_bounds__(64) void edge_bn_sums_from_products_kernel(const float* __restrict__ M, int ldm, const float* __restrict__ db2,
-                                                                        const float* __restrict__ W2, int ldw, const float* __restrict__ mean,
-                                                                        const float* __restrict__ rstd, int h_out, int h_in,
-                                                                        float* __restrict__ sum_dz, float* __restrict__ sum_dzx) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= h_in) return;
+// (18 GB per JointNetMotion step) become a walk over two H x H matrices, in fp64.
+__global__ __launch_bounds__(256) void edge_bn_sums_from_products_kernel(const float* __restrict__ M, int ldm, const float* __restrict__ db2,
+                                                                         const float* __restrict__ W2, int ldw, const float* __restrict__ mean,
+                                                                         const float* __restrict__ rstd, int h_out, int h_in,
+                                                                         float* __restrict__ sum_dz, float* __restrict__ sum_dzx) {
+    // 16 columns x 16 row lanes per workgroup (one thread per column walked 256 rows with a dependent fp64 add each: 50 us), then the
+    // lanes in a fixed tree
+    const int cl = threadIdx.x & 15, kl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
-    for (int k = 0; k < h_out; ++k) {
-        const double w = (double)W2[(size_t)k * ldw + c];
-        a += (double)db2[k] * w;
-        b += w * (double)M[(size_t)k * ldm + c];
+    if (c < h_in)
+        for (int k = kl; k < h_out; k += 16) {
+            const double w = (double)W2[(size_t)k * ldw + c];
+            a += (double)db2[k] * w;
+            b += w * (double)M[(size_t)k * ldm + c];
+        }
+    __shared__ double sh[2][16][16];
+    sh[0][kl][cl] = a; sh[1][kl][cl] = b;
+    __syncthreads();
+    for (int h = 8; h > 0; h >>= 1) {
+        if (kl < h) { sh[0][kl][cl] += sh[0][kl + h][cl]; sh[1][kl][cl] += sh[1][kl + h][cl]; }
+        __syncthreads();
     }
+    if (kl != 0 || c >= h_in) return;
+    a = sh[0][0][cl]; b = sh[1][0][cl];
     sum_dz[c] = (float)a;
     sum_dzx[c] = (float)((double)rstd[c] * (b - (double)mean[c] * a));
 }
@@ -945,7 +957,7 @@ extern "C" int morig_edge_bn_sums_from_products(const float* M, int32_t ldm, con
     if (!M || !db2 || !W2 || !mean || !rstd || !sum_dz || !sum_dzx || h_out <= 0 || h_in <= 0 || ldm < h_in || ldw < h_in) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 0.0);
-    hipLaunchKernelGGL(edge_bn_sums_from_products_kernel, dim3(cdiv(h_in, 64)), dim3(64), 0, s, M, ldm, db2, W2, ldw, mean, rstd, h_out, h_in,
+    hipLaunchKernelGGL(edge_bn_sums_from_products_kernel, dim3(cdiv(h_in, 16)), dim3(256), 0, s, M, ldm, db2, W2, ldw, mean, rstd, h_out, h_in,
                        sum_dz, sum_dzx);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
