@@ -573,20 +573,16 @@ __device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned& hi
     lo = __builtin_bit_cast(unsigned, l);
 }
 
-__global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                        int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
-                                                        int n_tiles, int k_tiles, int chunks, int per_xcd,
-                                                        float* __restrict__ part /* [chunks][N][K] */) {
-    __shared__ __attribute__((aligned(16))) char sA[2][TN_T * TN16_P], sB[2][TN_T * TN16_P];
-    const int rows = rows_dev ? *rows_dev : rows_host;
+// One tile of one row chunk. FULL: the 128 x 128 tile lies inside N x K and both operands take 16-byte loads -- no column tests
+// anywhere, no tests per row in the stages that are whole, no branches around the MFMAs (the counters of the general form on the
+// step's large shapes: 8.7 VALU and 3 branches per MFMA, MFMA pipe 32 % busy; the guards, not the split, were most of it).
+template <bool FULL>
+__device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int N, int K, int n0, int k0,
+                                          int r_begin, int r_end, bool a_vec, bool b_vec, char (&sA)[2][TN_T * TN16_P],
+                                          char (&sB)[2][TN_T * TN16_P], float* __restrict__ o) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= n_tiles * k_tiles * chunks) return;
-    const int bx = logical % n_tiles, by = (logical / n_tiles) % k_tiles, bz = logical / (n_tiles * k_tiles);
-    const int n0 = bx * TN_T, k0 = by * TN_T;
     const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
-    const int r_begin = bz * chunk_rows, r_end = min(r_begin + chunk_rows, rows);
     tn_f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -595,11 +591,19 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int rg = tid & 7, cg = tid >> 3;                            // loader: rows 4 rg .. + 3 of the stage, columns 4 cg .. + 3 of the tile
-    const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
-    const bool b_vec = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
     const bool on_a[2] = {n0 + wn < N, n0 + wn + 32 < N}, on_b[2] = {k0 + wk < K, k0 + wk + 32 < K};
     tn_f32x4 va[4], vb[4];
+    const float* pa0 = A + (size_t)(4 * rg) * lda + n0 + 4 * cg;
+    const float* pb0 = B + (size_t)(4 * rg) * ldb + k0 + 4 * cg;
     auto fetch = [&](int r0) {                                        // global -> registers (in flight under the MFMAs of a whole stage)
+        if (FULL && r0 + TN16_R <= r_end) {                           // (block-uniform)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                va[i] = *reinterpret_cast<const tn_f32x4*>(pa0 + (size_t)(r0 + i) * lda);
+                vb[i] = *reinterpret_cast<const tn_f32x4*>(pb0 + (size_t)(r0 + i) * ldb);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = r0 + 4 * rg + i;
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    if (on_a[a] && on_b[b]) {
+                    if (FULL || (on_a[a] && on_b[b])) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
@@ -668,7 +672,6 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    float* o = part + (size_t)bz * N * K;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -676,8 +679,30 @@ __global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, k = k0 + wk + b * 32 + l31;
-                if (n < N && k < K) o[(size_t)n * K + k] = acc[a][b][r];
+                if (FULL || (n < N && k < K)) o[(size_t)n * K + k] = acc[a][b][r];
             }
+}
+
+__global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                        int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
+                                                        int n_tiles, int k_tiles, int chunks, int per_xcd,
+                                                        float* __restrict__ part /* [chunks][N][K] */) {
+    __shared__ __attribute__((aligned(16))) char sA[2][TN_T * TN16_P], sB[2][TN_T * TN16_P];
+    const int rows = rows_dev ? *rows_dev : rows_host;
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= n_tiles * k_tiles * chunks) return;
+    const int bx = logical % n_tiles, by = (logical / n_tiles) % k_tiles, bz = logical / (n_tiles * k_tiles);
+    int n0 = bx * TN_T, k0 = by * TN_T;
+    const int r_begin = bz * chunk_rows, r_end = min(r_begin + chunk_rows, rows);
+    const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+    const bool b_vec = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
+    // a last tile that would stick out is moved back inside (when the extent allows 16-byte loads there): it recomputes some columns
+    // of its neighbour -- same operands, same order, the same bits, written twice -- and takes the guard-free path like every other tile
+    if (a_vec && N >= TN_T && (N & 3) == 0) n0 = min(n0, N - TN_T);
+    if (b_vec && K >= TN_T && (K & 3) == 0) k0 = min(k0, K - TN_T);
+    float* o = part + (size_t)bz * N * K;
+    if (a_vec && b_vec && n0 + TN_T <= N && k0 + TN_T <= K) tn16_tile<true>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
+    else tn16_tile<false>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
 }
 
 // partial tiles -> C: 32 output elements x 8 chunk lanes per block; lane j adds chunks j, j + 8, ... in order, the eight lane sums

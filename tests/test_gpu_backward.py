@@ -65,7 +65,7 @@ def _graph(n, e, seed):
 
 @pytest.mark.parametrize("bwd,tol", [("f32", 2e-6), ("bf16x3", 2e-5)])
 @pytest.mark.parametrize("rows,N,K,spread", [(1000, 32, 7, 0), (5000, 130, 259, 0), (40000, 256, 64, 0), (333, 1, 1, 0), (70000, 512, 835, 0),
-                                             (30000, 128, 256, 12)])
+                                             (30000, 128, 256, 12), (3001, 200, 328, 0), (9000, 1024, 1800, 0)])
 def test_gemm_tn(rows, N, K, spread, bwd, tol, monkeypatch):
     """C = A^T B over the rows (the weight gradient): the exact-float32 MFMA kernel (MORIG_TRAIN_BWD=f32) to 2e-6, the default bf16 x 3
     split kernel to 2e-5 of the result's scale -- also on operands whose columns span 24 orders of magnitude (`spread`: column c scaled
