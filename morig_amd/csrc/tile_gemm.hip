@@ -77,7 +77,10 @@ static int debug_flags() {
 // The narrow EdgeConv tiles are latency chains (ids -> gathers -> one or two K-chunks -> scan): occupancy is what hides
 // them, so their register budget is capped for 4 (fp32, KC = 16: 6) waves per SIMD (measured -17..21 % at H = 32).
 // The dense fp32-X GEMM tile (BN = 128, KC = 32) likewise runs better at 3 waves per SIMD than at 2.
-template <int BN, int KC, int LOAD, int MODE, int PREC>
+// FAST [r04]: every row of every tile exists (M a multiple of 128), K is a multiple of KC and no debug switch is set -- decided by the
+// launcher; the row / column tests, zero fills and switch tests compile out (dense store GEMMs with fp32 X: the GCU units' MLPs of the
+// forward, dX of the training step; the counters of the general form: 7.0 VALU + 3.6 SALU instructions per MFMA, matrix pipe 39 % busy).
+template <int BN, int KC, int LOAD, int MODE, int PREC, bool FAST = false>
 __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD != LOAD_DENSE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC != PREC_F32) ? 3 :
                                (BN == 64 && LOAD == LOAD_DENSE && MODE == MODE_STORE && PREC != PREC_F32) ? 4 : 1)) void tile_kernel(const TileParams p) {
     constexpr int BM = 128;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
         const int r = lrow + i * RPP;
         const int row = row0 + r;
         if (LOAD == LOAD_DENSE) {
-            va[i] = row < Mlim;
+            va[i] = FAST || row < Mlim;
             pa[i] = p.X + (size_t)(va[i] ? row : 0) * p.ldx + 4 * lkq;
             pb[i] = nullptr;
             if (MODE == MODE_EDGEMAX) {
@@ -213,17 +216,17 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[i] = z; rb[i] = z;
+            if (!FAST) { ra[i] = z; rb[i] = z; }
             // split-fp16 X: a 16-byte piece holds halves of its whole 32-column chunk -> guard per chunk
             const int k = (PREC == PREC_F16X3 && LOAD == LOAD_DENSE && p.x16) ? ((k0 + 4 * lkq) & ~31) : (k0 + 4 * lkq);
-            if (va[i] && k < p.K && !(p.dbg & DBG_NO_GATHER)) {
+            if (FAST || (va[i] && k < p.K && !(p.dbg & DBG_NO_GATHER))) {
                 ra[i] = *reinterpret_cast<const f32x4*>(pa[i] + k0);
                 if (IS_EDGE) rb[i] = *reinterpret_cast<const f32x4*>(pb[i] + k0);
             }
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            if ((BN % RPP == 0 || lrow + i * RPP < BN) && !(p.dbg & DBG_NO_WLOAD))
+            if ((BN % RPP == 0 || lrow + i * RPP < BN) && (FAST || !(p.dbg & DBG_NO_WLOAD)))
                 rw[i] = *reinterpret_cast<const f32x4*>(pw + (size_t)i * RPP * p.ldw + k0);
         }
     };
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
 #pragma unroll
                     for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c] + rb[i][c], 0.f);      // invalid rows were fetched as 0
                 }
-            } else if (k0 + KC > p.K && !(PREC == PREC_F16X3 && p.x16)) {   // only the last chunk can cross K
+            } else if (!FAST && k0 + KC > p.K && !(PREC == PREC_F16X3 && p.x16)) {   // only the last chunk can cross K
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v[c] = (k + c < p.K) ? v[c] : 0.f;
             }
@@ -311,10 +314,10 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
     fetch(0);
     for (int c = 0; c < nchunk; ++c) {
         __syncthreads();                        // previous chunk's fragment reads are done
-        if (!(p.dbg & DBG_NO_STAGE) || c == 0) stage(c * KC);
+        if (FAST || !(p.dbg & DBG_NO_STAGE) || c == 0) stage(c * KC);
         __syncthreads();
         if (c + 1 < nchunk) fetch((c + 1) * KC);
-        if (p.dbg & DBG_NO_MFMA) continue;
+        if (!FAST && (p.dbg & DBG_NO_MFMA)) continue;
         if (PREC != PREC_F32) {
             const char* a0 = reinterpret_cast<const char*>(sA) + (wm * MT * 32 + l31) * (LDK * 4) + 16 * hi;
             const char* b0 = reinterpret_cast<const char*>(sB) + (wn * NT * 32 + l31) * (LDK * 4) + 16 * hi;
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
     }
 
     // ---- epilogue ----------------------------------------------------------------------------
-    if (p.dbg & DBG_NO_EPILOGUE) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
+    if (!FAST && (p.dbg & DBG_NO_EPILOGUE)) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }
     const int colw0 = tn * BN + wn * NT * 32;   // first global column of this wave
     if (MODE == MODE_STORE) {
         __syncthreads();                        // all waves are done with the operand tiles; sseg visible
@@ -604,6 +607,14 @@ template <int BN, int KC, int LOAD, int MODE, int PREC = PREC_F32>
 static int launch_tile(const TileParams& p0, int nblocks, hipStream_t s) {
     TileParams p = p0;
     p.dbg = debug_flags();
+    if constexpr (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE == MODE_STORE) {
+        static const bool no_fast = getenv("MORIG_TILE_NO_FAST") != nullptr;
+        if (p.dbg == 0 && !no_fast && p.M % 128 == 0 && p.K % KC == 0) {
+            hipLaunchKernelGGL((tile_kernel<BN, KC, LOAD, MODE, PREC, true>), dim3(nblocks), dim3(256), 0, s, p);
+            MORIG_LAUNCH_CHECK();
+            return MORIG_OK;
+        }
+    }
     hipLaunchKernelGGL((tile_kernel<BN, KC, LOAD, MODE, PREC>), dim3(nblocks), dim3(256), 0, s, p);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;

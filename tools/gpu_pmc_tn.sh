@@ -29,6 +29,5 @@ PY
 run sq1 SQ_WAVES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_MFMA
 run sq3 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT
-run mem FETCH_SIZE WRITE_SIZE
-run tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# (a FETCH_SIZE / TCC pass of this command did not finish inside 10 minutes on the pool: left out)
 cat $OUT
