@@ -327,3 +327,70 @@ def test_train_backward_host_wiring(emulated_ops):
     for (k, v), (_, r) in zip(mine.state_dict().items(), ref.state_dict().items()):
         if k.endswith("running_mean"):
             assert maxdiff(v, r.float()) <= 1e-4, k
+
+
+def _gcnrig_step(monkeypatch, stacked=True, sums=None):
+    """one GCNRig training step on the emulated op layer -> (output, {parameter: gradient}, {buffer: value})"""
+    import copy
+    from morig_amd import train_backward as TB
+    if not stacked:
+        monkeypatch.setattr(TB, "stacked_pos_branches", lambda *a, **k: None)
+    if sums is not None:
+        monkeypatch.setenv("MORIG_TRAIN_EDGE_SUMS", sums)
+    torch.manual_seed(11)
+    net = rn.GCNRig(chn_feature=3, chn_output=8).train()
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+    b = synth.make_batch([2, 9], n_side=6, with_skin=False)
+    feat = torch.randn(b.pos.shape[0], 3, generator=g) * 0.05
+    w = torch.randn(b.pos.shape[0], 8, generator=g)
+    with torch.enable_grad():
+        st = TB.graph_state(b)
+        out = TB.gcnrig(net, b.pos.float(), feat, st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+        (out * w).sum().backward()
+    return out.detach(), {k: p.grad.clone() for k, p in net.named_parameters()}, {k: v.clone() for k, v in net.named_buffers()}
+
+
+def test_stacked_position_branches_are_the_three_layers(emulated_ops, monkeypatch):
+    """round 4: the three 16-wide position branches of a GCNRig on one graph run as ONE edge MLP (rows of Linear1 stacked, Linear2
+    block-diagonal, BatchNorm columns side by side): same outputs, same gradients for every parameter, same running buffers and
+    batch counters as the three layers evaluated one by one"""
+    o1, g1, b1 = _gcnrig_step(monkeypatch, stacked=True)
+    o2, g2, b2 = _gcnrig_step(monkeypatch, stacked=False)
+    assert maxdiff(o1, o2) <= 2e-6 * float(o2.abs().max())
+    for k in g2:
+        assert maxdiff(g1[k], g2[k]) <= 1e-5 * max(float(g2[k].abs().max()), 1e-6), k
+    for k in b2:
+        assert maxdiff(b1[k].float(), b2[k].float()) <= 1e-6 * max(float(b2[k].float().abs().max()), 1.0), k
+    assert any(k.endswith("nn_pos.0.2.num_batches_tracked") and int(v) == 1 for k, v in b1.items())
+
+
+def test_edge_sums_from_products_equal_the_pass(emulated_ops, monkeypatch):
+    """round 4: the first edge layer's BatchNorm sums from M = du2^T Z1, db2 and W2 against the pass over dh and Z1"""
+    o1, g1, _ = _gcnrig_step(monkeypatch, sums="products")
+    o2, g2, _ = _gcnrig_step(monkeypatch, sums="pass")
+    assert torch.equal(o1, o2)
+    for k in g2:
+        assert maxdiff(g1[k], g2[k]) <= 1e-5 * max(float(g2[k].abs().max()), 1e-6), k
+
+
+def test_csr_transposed_walks_every_edge_once_by_source():
+    from morig_amd.native import CSR
+    g = torch.Generator().manual_seed(8)
+    n, E, cap = 37, 200, 260
+    dst = torch.sort(torch.randint(0, n, (E,), generator=g))[0]
+    src = torch.randint(0, n, (E,), generator=g)
+    rowptr = torch.searchsorted(dst, torch.arange(n + 1)).int()
+    junk = torch.randint(-5, 1000, (cap - E,), generator=g).int()                  # rows past the live count hold anything
+    csr = CSR(rowptr, torch.cat([src.int(), junk]), torch.cat([dst.int(), junk]), n, cap, torch.zeros(1, dtype=torch.int32))
+    rt, pt = csr.transposed()
+    assert rt.shape == (n + 1,) and int(rt[0]) == 0 and int(rt[-1]) == E and pt.shape == (cap,)
+    assert torch.equal(torch.sort(pt[:E].long())[0], torch.arange(E))
+    for u in range(n):
+        rows = pt[int(rt[u]):int(rt[u + 1])].long()
+        assert bool((src[rows] == u).all()) and bool((rows[1:] > rows[:-1]).all())   # its edges, in ascending row order
+    assert csr.transposed()[1] is pt                                                 # built once
