@@ -528,6 +528,28 @@ def temporal_attn(attn, x):
     return mlp_layer(mlp_layer(h, attn.feedforward[0]), attn.feedforward[1])
 
 
+def canonical_csr(csr: CSR) -> CSR:
+    """The CSR build claims a target's slots with an atomic cursor: the order of the edges INSIDE a segment changes from build to
+    build. Max-aggregation does not see it; the training step does -- the segment sums of the backward add in row order, and the
+    arg-max keeps the first of tied rows. Sorting every segment by source (one stable device sort of the live rows, stream-ordered,
+    no host read) makes the order a function of the graph alone: with it a training step is bit-reproducible from run to run
+    (MORIG_TRAIN_CANONICAL_CSR=0 skips the sort)."""
+    if os.environ.get("MORIG_TRAIN_CANONICAL_CSR", "1") == "0":
+        return csr
+    dev = csr.src.device
+    n = csr.n_nodes
+    live = csr.rowptr[n]
+    pos = torch.arange(csr.capacity, device=dev)
+    span = int(max(n, 1)) + 1
+    big = torch.full((), span * span, dtype=torch.int64, device=dev)
+    key = torch.where(pos < live, csr.dst.long().clamp(0, n) * span + csr.src.long().clamp(0, n), big)
+    order = torch.sort(key, stable=True).indices
+    csr.src = csr.src[order].contiguous()
+    csr.dst = csr.dst[order].contiguous()
+    csr._transposed = None
+    return csr
+
+
 def graph_state(data):
     """CSRs of the two loop-normalised graphs + mesh offsets: built once per batch, shared by every block"""
     ops = get_ops()
@@ -539,8 +561,8 @@ def graph_state(data):
     counts = torch.bincount(data.batch, minlength=ng)
     mesh_ptr = torch.zeros(ng + 1, dtype=torch.int32, device=dev)
     mesh_ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return dict(n=n, ng=int(ng), csr_tpl=ops.csr_build(data.tpl_edge_index, n), csr_geo=ops.csr_build(data.geo_edge_index, n),
-                mesh_ptr=mesh_ptr, batch=data.batch.long())
+    return dict(n=n, ng=int(ng), csr_tpl=canonical_csr(ops.csr_build(data.tpl_edge_index, n)),
+                csr_geo=canonical_csr(ops.csr_build(data.geo_edge_index, n)), mesh_ptr=mesh_ptr, batch=data.batch.long())
 
 
 def _motion_backbone(model, data, input_flow, st, aggr_method):

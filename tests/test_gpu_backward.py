@@ -529,3 +529,33 @@ def test_deformnet_training_step_gradients():
     then nothing frozen"""
     from helpers import check_deformnet_training
     check_deformnet_training(DEV)
+
+
+def test_training_step_is_bit_reproducible():
+    """round 4: no atomics are left in the backward and the CSR segments are put into a canonical order (`canonical_csr`), so two
+    training steps from the same state -- graphs rebuilt, every buffer reallocated -- give the same bits: outputs, every
+    parameter's gradient, every running buffer"""
+    from morig_amd.models import rignet as rn
+    torch.manual_seed(5)
+    net0 = _randomise(rn.GCNRig(chn_feature=3, chn_output=16), 9).train()
+    b = synth.make_batch(range(3), n_side=12, with_skin=False).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    feat = (torch.randn(b.pos.shape[0], 3, generator=g) * 0.05).to(DEV)
+    w = torch.randn(b.pos.shape[0], 16, generator=g).to(DEV)
+
+    def step(junk):
+        net = copy.deepcopy(net0).to(DEV)
+        scratch = [torch.empty(junk, device=DEV) for _ in range(3)]                # shifts the allocator's addresses between the runs
+        st = TB.graph_state(b)
+        out = TB.gcnrig(net, b.pos.float(), feat, st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
+        (out * w).sum().backward()
+        del scratch
+        return out.detach().clone(), [p.grad.clone() for p in net.parameters()], [v.clone() for v in net.buffers()]
+
+    o1, g1, b1 = step(1000)
+    o2, g2, b2 = step(777777)
+    assert torch.equal(o1, o2)
+    for (k, _), a, c in zip(net0.named_parameters(), g1, g2):
+        assert torch.equal(a, c), (k, float((a - c).abs().max()))
+    for a, c in zip(b1, b2):
+        assert torch.equal(a, c)
