@@ -559,3 +559,22 @@ def test_training_step_is_bit_reproducible():
         assert torch.equal(a, c), (k, float((a - c).abs().max()))
     for a, c in zip(b1, b2):
         assert torch.equal(a, c)
+
+
+def test_jointnet_training_step_is_bit_reproducible():
+    """the same through the module API: `model.train(); model(data, flow); loss.backward()` of jointnet_motion (keyframe loop,
+    normalisation, CLS attention, head) twice from one state"""
+    batch = synth.make_batch(range(2), n_side=10, with_skin=False).to(DEV)
+    m0 = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").train()
+    synth.load_recipe(m0, 0, mild=True)
+
+    def step():
+        m = copy.deepcopy(m0).to(DEV)
+        o = m(batch, batch.pred_flow)
+        ((o[2] ** 2).mean() + (o[1] ** 2).mean()).backward()
+        return [x.detach().clone() for x in o], [p.grad.clone() for p in m.parameters()]
+
+    (o1, g1), (o2, g2) = step(), step()
+    assert all(torch.equal(a, c) for a, c in zip(o1, o2))
+    for (k, _), a, c in zip(m0.named_parameters(), g1, g2):
+        assert torch.equal(a, c), (k, float((a - c).abs().max()))
