@@ -525,11 +525,15 @@ int morig_segmax_bn_relu_backward(const float* dout, int32_t ldd, const int32_t*
 /* morig_bn_relu_backward and morig_edge_scatter_backward in one, deterministic: with d[e] = [Y > 0] gamma rstd (dG - sum_dz / n -
  * xhat sum_dzx / n) (n = rowptr[n_nodes]; mean == NULL: d = dG), dA[v] = sum of d over the CSR segment of v and dB[u] = sum of d
  * over the edges out of u, walked through the transposed graph: rowptr_t [n_src_nodes + 1], perm_t[k] = row e of the k-th edge in
- * (source, row) order. d is evaluated where it is summed and never stored; both sums run in a fixed order (no atomics). */
+ * (source, row) order. d is evaluated where it is summed and never stored; both sums run in a fixed order (no atomics).
+ * ZA / ZB (NULL, or [n_nodes][ldza] / [n_src_nodes][ldzb] with src_sorted / dst_sorted): Y is not read, Y[e] = relu(ZA[dst e] + ZB[src e])
+ * is rebuilt where it is needed (what morig_edge_gather_relu stored, same expression, same bits): one of the two rows is fixed for a
+ * whole segment, the other comes out of the caches, and the edges x H buffer is not read from HBM again. */
 int morig_edge_bn_scatter_backward(const float* dG, int32_t ldg, const float* Y, int32_t ldy, const int32_t* rowptr,
                                    const int32_t* rowptr_t, const int32_t* perm_t, int32_t n_nodes, int32_t n_src_nodes, int32_t H,
                                    const float* mean, const float* rstd, const float* gamma, const float* sum_dz, const float* sum_dzx,
-                                   float* dA, int32_t lda, float* dB, int32_t ldb, void* stream);
+                                   float* dA, int32_t lda, float* dB, int32_t ldb, const float* ZA, int32_t ldza, const float* ZB,
+                                   int32_t ldzb, const int32_t* src_sorted, const int32_t* dst_sorted, void* stream);
 /* backward of Z[e] = A[dst_e] + B[src_e]: dA[v] = sum of dG over the CSR segment of v (fixed order), dB[u] = sum of dG over the
  * edges with source u (float atomics: summation order, hence the last bits, vary run to run). dB ([n_src_nodes][ldb]) is zeroed here. */
 int morig_edge_scatter_backward(const float* dG, int32_t ldg, const int32_t* rowptr, const int32_t* src_sorted, int32_t n_nodes,

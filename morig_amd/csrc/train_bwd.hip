@@ -353,7 +353,10 @@ __global__ __launch_bounds__(256) void edge_bn_scatter_bwd_kernel(const float* _
                                                                   const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                   const float* __restrict__ gamma, const float* __restrict__ sum_dz,
                                                                   const float* __restrict__ sum_dzx, float* __restrict__ dA, int lda,
-                                                                  float* __restrict__ dB, int ldb) {
+                                                                  float* __restrict__ dB, int ldb,
+                                                                  const float* __restrict__ ZA /* NULL, or: Y[e] = relu(ZA[dst e] + ZB[src e]) */,
+                                                                  int ldza, const float* __restrict__ ZB, int ldzb,
+                                                                  const int* __restrict__ srcS, const int* __restrict__ dstS) {
     const int qn = H / V;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nmax = max(n_nodes, n_src);
@@ -367,10 +370,20 @@ __global__ __launch_bounds__(256) void edge_bn_scatter_bwd_kernel(const float* _
         m.v[j] = mean ? mean[c + j] : 0.f; rs.v[j] = mean ? rstd[c + j] : 0.f; grs.v[j] = mean ? gamma[c + j] * rs.v[j] : 1.f;
         k0.v[j] = mean ? sum_dz[c + j] * inv_n : 0.f; k1.v[j] = mean ? sum_dzx[c + j] * inv_n : 0.f;
     }
-    auto grad = [&](int e, VecF<V>& acc) {
+    // Y given by its operands: the ReLU input is rebuilt from the two n x H matrices it was made of -- one of them is the SAME row
+    // for a whole segment (`fixed`), the other a gathered row that the caches hold (2 x 33 MB at H = 256) -- instead of a second and
+    // third read of the edges x H buffer from HBM; same expression as morig_edge_gather_relu, so the same bits
+    auto grad = [&](int e, VecF<V>& acc, const VecF<V>& fixed, const float* __restrict__ other, int ld_other, const int* __restrict__ other_row) {
         const VecF<V> g = ldv<V>(dG + (size_t)e * ldg + c);
         if (mean) {
-            const VecF<V> y = ldv<V>(Y + (size_t)e * ldy + c);
+            VecF<V> y;
+            if (ZA) {
+                const VecF<V> o = ldv<V>(other + (size_t)other_row[e] * ld_other + c);
+#pragma unroll
+                for (int j = 0; j < V; ++j) { const float s = fixed.v[j] + o.v[j]; y.v[j] = s > 0.f ? s : 0.f; }
+            } else {
+                y = ldv<V>(Y + (size_t)e * ldy + c);
+            }
 #pragma unroll
             for (int j = 0; j < V; ++j) {
                 const float xh = (y.v[j] - m.v[j]) * rs.v[j];
@@ -387,7 +400,9 @@ __global__ __launch_bounds__(256) void edge_bn_scatter_bwd_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < V; ++j) a.v[j] = 0.f;
         const int e1 = rowptr[v + 1];
-        for (int e = rowptr[v]; e < e1; ++e) grad(e, a);
+        VecF<V> fa = a;
+        if (ZA && mean) fa = ldv<V>(ZA + (size_t)v * ldza + c);               // every edge of this segment has target v
+        for (int e = rowptr[v]; e < e1; ++e) grad(e, a, fa, ZB, ldzb, srcS);
         stv<V>(dA + (size_t)v * lda + c, a);
     }
     if (v < n_src) {
@@ -395,7 +410,9 @@ __global__ __launch_bounds__(256) void edge_bn_scatter_bwd_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < V; ++j) b.v[j] = 0.f;
         const int k1e = rowptr_t[v + 1];
-        for (int k = rowptr_t[v]; k < k1e; ++k) grad(perm_t[k], b);
+        VecF<V> fb = b;
+        if (ZA && mean) fb = ldv<V>(ZB + (size_t)v * ldzb + c);               // every edge of this segment has source v
+        for (int k = rowptr_t[v]; k < k1e; ++k) grad(perm_t[k], b, fb, ZA, ldza, dstS);
         stv<V>(dB + (size_t)v * ldb + c, b);
     }
 }
@@ -960,19 +977,24 @@ extern "C" int morig_edge_scatter_backward(const float* dG, int32_t ldg, const i
 extern "C" int morig_edge_bn_scatter_backward(const float* dG, int32_t ldg, const float* Y, int32_t ldy, const int32_t* rowptr,
                                              const int32_t* rowptr_t, const int32_t* perm_t, int32_t n_nodes, int32_t n_src_nodes,
                                              int32_t H, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
-                                             const float* sum_dzx, float* dA, int32_t lda, float* dB, int32_t ldb, void* stream) {
+                                             const float* sum_dzx, float* dA, int32_t lda, float* dB, int32_t ldb, const float* ZA,
+                                             int32_t ldza, const float* ZB, int32_t ldzb, const int32_t* src_sorted,
+                                             const int32_t* dst_sorted, void* stream) {
     if (!dG || !rowptr || !rowptr_t || !perm_t || !dA || !dB || n_nodes <= 0 || n_src_nodes <= 0 || H <= 0) return MORIG_E_INVALID;
     if (ldg < H || lda < H || ldb < H) return MORIG_E_INVALID;
-    if (mean && (!Y || !rstd || !gamma || !sum_dz || !sum_dzx || ldy < H)) return MORIG_E_INVALID;
+    if (mean && (!rstd || !gamma || !sum_dz || !sum_dzx)) return MORIG_E_INVALID;
+    if (mean && !ZA && (!Y || ldy < H)) return MORIG_E_INVALID;
+    if (ZA && (!ZB || !src_sorted || !dst_sorted || ldza < H || ldzb < H)) return MORIG_E_INVALID;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_MISC, s, 0.0, 0.0);
-    const bool v4 = (H & 3) == 0 && vec4_ptr(dG, ldg) && vec4_ptr(dA, lda) && vec4_ptr(dB, ldb) && (!mean || vec4_ptr(Y, ldy));
+    const bool v4 = (H & 3) == 0 && vec4_ptr(dG, ldg) && vec4_ptr(dA, lda) && vec4_ptr(dB, ldb) &&
+                    (!mean || (ZA ? (vec4_ptr(ZA, ldza) && vec4_ptr(ZB, ldzb)) : vec4_ptr(Y, ldy)));
     const int nmax = n_nodes > n_src_nodes ? n_nodes : n_src_nodes;
     const int blocks = cdiv((long)nmax * (H / (v4 ? 4 : 1)), 256);
     if (v4) hipLaunchKernelGGL(edge_bn_scatter_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, dG, ldg, Y, ldy, rowptr, rowptr_t, perm_t, n_nodes,
-                               n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb);
+                               n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb, ZA, ldza, ZB, ldzb, src_sorted, dst_sorted);
     else hipLaunchKernelGGL(edge_bn_scatter_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, dG, ldg, Y, ldy, rowptr, rowptr_t, perm_t, n_nodes,
-                            n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb);
+                            n_src_nodes, H, mean, rstd, gamma, sum_dz, sum_dzx, dA, lda, dB, ldb, ZA, ldza, ZB, ldzb, src_sorted, dst_sorted);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -143,7 +143,7 @@ _SIGNATURES = {
                                                 C.c_void_p, C.c_int64, c_f32p, C.c_void_p]),
     "morig_edge_bn_scatter_backward": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, c_i32p, c_i32p, C.c_int32, C.c_int32,
                                                  C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, C.c_int32, c_f32p, C.c_int32,
-                                                 C.c_void_p]),
+                                                 c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, c_i32p, C.c_void_p]),
     "morig_edge_scatter_backward": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_i32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_f32p,
                                               C.c_int32, C.c_void_p]),
     "morig_edge_bn_sums_from_products": (C.c_int, [c_f32p, C.c_int32, c_f32p, c_f32p, C.c_int32, c_f32p, c_f32p, C.c_int32, C.c_int32,
@@ -843,17 +843,21 @@ class NativeOps:
         return sdu
 
     def edge_bn_scatter_backward(self, dG: Mat, Y: Optional[Mat], csr: CSR, n_src: int, dA: Mat, dB: Mat, mean=None, rstd=None, gamma=None,
-                                 sum_dz=None, sum_dzx=None):
+                                 sum_dz=None, sum_dzx=None, ZA: Optional[Mat] = None, ZB: Optional[Mat] = None):
         """bn_relu_backward + edge_scatter_backward in one pass pair, deterministic (no atomics, the per-edge gradient is not stored):
         dA[v] / dB[u] = sums of d[e] = [Y > 0] gamma rstd (dG - sum_dz / n - xhat sum_dzx / n) into / out of a vertex; mean=None: d = dG."""
         _need_gpu(dG.base, dA.base, dB.base)
         assert dA.rows == csr.n_nodes and dB.rows == n_src and dA.cols == dB.cols == dG.cols
-        assert mean is None or (Y is not None and Y.cols == dG.cols and Y.rows == dG.rows)
+        assert mean is None or ZA is not None or (Y is not None and Y.cols == dG.cols and Y.rows == dG.rows)
+        assert (ZA is None) == (ZB is None) and (ZA is None or (ZA.rows == csr.n_nodes and ZB.rows == n_src and ZA.cols == ZB.cols == dG.cols))
         rowptr_t, perm_t = csr.transposed(n_src)
         check(self.lib.morig_edge_bn_scatter_backward(dG.ptr, dG.ld, Y.ptr if Y is not None else 0, Y.ld if Y is not None else 0,
                                                       _p(csr.rowptr), _p(rowptr_t), _p(perm_t), csr.n_nodes, n_src, dG.cols, _p(mean),
-                                                      _p(rstd), _p(gamma), _p(sum_dz), _p(sum_dzx), dA.ptr, dA.ld, dB.ptr, dB.ld, _stream()),
-              "morig_edge_bn_scatter_backward")
+                                                      _p(rstd), _p(gamma), _p(sum_dz), _p(sum_dzx), dA.ptr, dA.ld, dB.ptr, dB.ld,
+                                                      ZA.ptr if ZA is not None else 0, ZA.ld if ZA is not None else 0,
+                                                      ZB.ptr if ZB is not None else 0, ZB.ld if ZB is not None else 0,
+                                                      _p(csr.src) if ZA is not None else None, _p(csr.dst) if ZA is not None else None,
+                                                      _stream()), "morig_edge_bn_scatter_backward")
 
     def edge_scatter_backward(self, dG: Mat, csr: CSR, n_src: int, dA: Mat, dB: Mat):
         """backward of Z[e] = A[dst_e] + B[src_e] over the live edges of ``csr``."""

@@ -312,7 +312,7 @@ class EdgeMLPTrain(torch.autograd.Function):
         s2, t2, rstd2 = _bn_any(bn2, mean2, var2, cnt2)
         out = _buf(n, H, dev)
         arg, zwin = ops.segmax_affine_arg(Mat.of(z2, 0, H), csr.rowptr, n, Mat.of(out, 0, H), s2, t2, want_zwin=True)
-        ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg, zwin)
+        ctx.save_for_backward(xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg, zwin, ab)
         ctx.csr = csr
         ctx.dims = (n, C, H)
         ctx.shares = (share1, share2)
@@ -322,7 +322,7 @@ class EdgeMLPTrain(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         ops = get_ops()
-        xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg, zwin = ctx.saved_tensors
+        xa, W1, W2, z1, z2, mean1, rstd1, mean2, rstd2, g1, g2, s1, t1, arg, zwin, ab = ctx.saved_tensors
         csr: CSR = ctx.csr
         n, C, H = ctx.dims
         dev = dout.device
@@ -354,8 +354,9 @@ class EdgeMLPTrain(torch.autograd.Function):
         # Z1 = relu(A[dst] + B[src]): the BatchNorm1 + ReLU gradient of an edge is evaluated where it is summed into dA[dst] / dB[src]
         # (never stored; both sums in a fixed order: the source side walks the transposed graph)
         dab = _buf(n, 2 * H, dev)
-        ops.edge_bn_scatter_backward(DH, Z1, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H), mean1, rstd1, g1.detach().float().contiguous(),
-                                     k1, kx1)
+        # (Z1 is not read again: relu(A[dst] + B[src]) is rebuilt from the n x 2H matrix [A | B] the forward kept, out of the caches)
+        ops.edge_bn_scatter_backward(DH, None, csr, n, Mat.of(dab, 0, H), Mat.of(dab, H, H), mean1, rstd1, g1.detach().float().contiguous(),
+                                     k1, kx1, ZA=Mat.of(ab, 0, H), ZB=Mat.of(ab, H, H))
         DAB = Mat.of(dab, 0, 2 * H)
         db1 = ops.bn_backward_stats(Mat.of(dab, 0, H))[0] if need[2] else None
         dW1 = None

@@ -648,11 +648,11 @@ def _emu_edge_scatter_backward(self, dG: Mat, csr: CSR, n_src, dA: Mat, dB: Mat)
 
 
 def _emu_edge_bn_scatter_backward(self, dG: Mat, Y, csr: CSR, n_src, dA: Mat, dB: Mat, mean=None, rstd=None, gamma=None, sum_dz=None,
-                                  sum_dzx=None):
+                                  sum_dzx=None, ZA=None, ZB=None):
     E = int(csr.rowptr[-1])
     g = dG.view()[:E]
     if mean is not None:
-        yv = Y.view()[:E]
+        yv = Y.view()[:E] if ZA is None else torch.relu(ZA.view()[csr.dst[:E].long()] + ZB.view()[csr.src[:E].long()])
         xh = (yv - mean) * rstd
         d = gamma * rstd * (g - sum_dz / E - xh * (sum_dzx / E))
         g = torch.where(yv > 0, d, torch.zeros_like(d))

@@ -322,6 +322,14 @@ def test_edge_backward_operators(n, e, H, ld):
         again = torch.full((n, 2 * ld), 5.0, device=DEV)
         ops.edge_bn_scatter_backward(Mat.of(Gd, 0, H), Mat.of(Yd, 0, H) if bn else None, csr_d, n, Mat.of(again, 0, H), Mat.of(again, ld, H), **kwd)
         assert torch.equal(dab, again)
+        if bn:                                  # Y rebuilt from its operands (what edge_gather_relu stored: z_a above) == Y read back, bit for bit
+            outs = []
+            for rebuilt in (False, True):
+                o = torch.full((n, 2 * ld), 5.0, device=DEV)
+                ops.edge_bn_scatter_backward(Mat.of(Gd, 0, H), None if rebuilt else Mat.of(z_a, 0, H), csr_d, n, Mat.of(o, 0, H), Mat.of(o, ld, H),
+                                             ZA=Mat.of(AB, 0, H) if rebuilt else None, ZB=Mat.of(AB, ld, H) if rebuilt else None, **kwd)
+                outs.append(o)
+            assert torch.equal(outs[0], outs[1])
         if not bn:                                                              # the atomic operator it replaces computes the same sums
             old = torch.full((n, 2 * ld), 5.0, device=DEV)
             ops.edge_scatter_backward(Mat.of(Gd, 0, H), csr_d, n, Mat.of(old, 0, H), Mat.of(old, ld, H))
