@@ -495,10 +495,12 @@ int morig_bn_backward_stats(const float* dz, int32_t ldz, const float* y, int32_
                             int32_t cols, const float* mean, const float* rstd, double* workspace, int64_t workspace_doubles,
                             float* sum_dz, float* sum_dzx, void* stream);
 /* du[r][c] = [y > 0] * gamma * rstd * (dz - sum_dz / n - xhat * sum_dzx / n): the BatchNorm and the ReLU in front of it
- * (y = ReLU output = BatchNorm input, n = rows). du may alias dz. */
+ * (y = ReLU output = BatchNorm input, n = rows). du may alias dz. sum_du (NULL or [cols]): the column sums of du (fp64 accumulation,
+ * fixed order: the bias gradient of the Linear in front) from the same pass; workspace as morig_bn_backward_stats, needed only then. */
 int morig_bn_relu_backward(const float* dz, int32_t ldz, const float* y, int32_t ldy, int32_t rows, const int32_t* rows_dev,
                            int32_t cols, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
-                           const float* sum_dzx, float* du, int32_t ldu, void* stream);
+                           const float* sum_dzx, float* du, int32_t ldu, double* workspace, int64_t workspace_doubles, float* sum_du,
+                           void* stream);
 /* morig_segmax_affine that also records which row won: arg[v][c] = row index (first on ties), -1 for an empty segment; zwin
  * (NULL or [n_segments][ldw]) receives Z[arg[v][c]][c], the winner's value in front of the affine (0 for an empty segment): the
  * backward statistics then need no gather. Few long segments (per-mesh pooling) and many short ones (edges) take different kernels. */

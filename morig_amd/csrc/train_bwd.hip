@@ -112,6 +112,57 @@ __global__ void bn_relu_bwd_kernel(const float* dz, int ldz, const float* __rest
     }
 }
 
+// the same in slab form (threads as in bn_bwd_partial_kernel), leaving the fp64 column sums of du per slab: the bias gradient of the
+// Linear in front comes out of the pass that writes du. du may alias dz (every element is read before it is written).
+template <int V>
+__global__ __launch_bounds__(256) void bn_relu_bwd_sum_kernel(const float* dz, int ldz, const float* __restrict__ y, int ldy, int rows_host,
+                                                              const int* __restrict__ rows_dev, int cols, int slab_rows,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ sum_dz,
+                                                              const float* __restrict__ sum_dzx, float* du, int ldu, double* __restrict__ part) {
+    const int rows = rows_dev ? *rows_dev : rows_host;
+    const float inv_n = rows > 0 ? 1.f / (float)rows : 0.f;
+    const int c0 = blockIdx.x * 64;
+    const int quads = min(16, (cols - c0 + 3) >> 2);
+    const int RL = 256 / quads;
+    const int q = threadIdx.x % quads, rl = threadIdx.x / quads;
+    const int c = c0 + q * 4;
+    const int r0 = blockIdx.y * slab_rows, r1 = min(r0 + slab_rows, rows);
+    double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    if (rl < RL) {
+        float m[4], rs[4], grs[4], k0[4], k1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = c + j < cols;
+            m[j] = in ? mean[c + j] : 0.f; rs[j] = in ? rstd[c + j] : 0.f; grs[j] = in ? gamma[c + j] * rs[j] : 0.f;
+            k0[j] = in ? sum_dz[c + j] * inv_n : 0.f; k1[j] = in ? sum_dzx[c + j] * inv_n : 0.f;
+        }
+        for (int r = r0 + rl; r < r1; r += RL) {
+            float yv[4], g[4], o[4];
+            if (V == 4) {
+                const float4 y4 = *reinterpret_cast<const float4*>(y + (size_t)r * ldy + c);
+                const float4 g4 = *reinterpret_cast<const float4*>(dz + (size_t)r * ldz + c);
+                yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w; g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const bool in = c + j < cols; yv[j] = in ? y[(size_t)r * ldy + c + j] : 0.f; g[j] = in ? dz[(size_t)r * ldz + c + j] : 0.f; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (yv[j] - m[j]) * rs[j];
+                const float d = grs[j] * (g[j] - k0[j] - xh * k1[j]);
+                o[j] = yv[j] > 0.f ? d : 0.f;
+                acc[0][j] += (double)o[j];
+            }
+            if (V == 4) *reinterpret_cast<float4*>(du + (size_t)r * ldu + c) = make_float4(o[0], o[1], o[2], o[3]);
+            else
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (c + j < cols) du[(size_t)r * ldu + c + j] = o[j];
+        }
+    }
+    stats_block_store(acc, quads, RL, q, rl, c0, cols, blockIdx.y, part);
+}
+
 // one thread per (segment, V columns), as segmax_affine_kernel, plus the winning row
 template <int V>
 __global__ __launch_bounds__(256) void segmax_arg_kernel(const float* __restrict__ Z, int ldz, const int* __restrict__ rowptr, int n_seg,
@@ -866,12 +917,27 @@ extern "C" int morig_bn_backward_stats(const float* dz, int32_t ldz, const float
 
 extern "C" int morig_bn_relu_backward(const float* dz, int32_t ldz, const float* y, int32_t ldy, int32_t rows, const int32_t* rows_dev,
                                       int32_t cols, const float* mean, const float* rstd, const float* gamma, const float* sum_dz,
-                                      const float* sum_dzx, float* du, int32_t ldu, void* stream) {
+                                      const float* sum_dzx, float* du, int32_t ldu, double* workspace, int64_t workspace_doubles,
+                                      float* sum_du, void* stream) {
     if (!dz || !y || !mean || !rstd || !gamma || !sum_dz || !sum_dzx || !du) return MORIG_E_INVALID;
     if (rows < 0 || cols <= 0 || ldz < cols || ldy < cols || ldu < cols) return MORIG_E_INVALID;
-    if (rows == 0) return MORIG_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const bool v4 = (cols & 3) == 0 && vec4_ptr(dz, ldz) && vec4_ptr(y, ldy) && vec4_ptr(du, ldu);
+    if (sum_du) {                                      // du and its column sums (the bias gradient) from one pass
+        const int slab_rows = stats_slab_rows(rows, cols);
+        const int slabs = cdiv(rows > 0 ? rows : 1, slab_rows);
+        if (!workspace || workspace_doubles < (int64_t)slabs * 2 * cols) return MORIG_E_INVALID;
+        ProfScope ps(K_MISC, s, 0.0, 12.0 * rows * (double)cols);
+        if (v4) hipLaunchKernelGGL(bn_relu_bwd_sum_kernel<4>, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols,
+                                   slab_rows, mean, rstd, gamma, sum_dz, sum_dzx, du, ldu, workspace);
+        else hipLaunchKernelGGL(bn_relu_bwd_sum_kernel<1>, dim3(cdiv(cols, 64), slabs), dim3(256), 0, s, dz, ldz, y, ldy, rows, rows_dev, cols,
+                                slab_rows, mean, rstd, gamma, sum_dz, sum_dzx, du, ldu, workspace);
+        MORIG_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(cdiv(cols, STATS_FC)), dim3(256), 0, s, workspace, slabs, cols, sum_du, (float*)nullptr);
+        MORIG_LAUNCH_CHECK();
+        return MORIG_OK;
+    }
+    if (rows == 0) return MORIG_OK;
     int64_t blocks = ((int64_t)rows * (cols / (v4 ? 4 : 1)) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     ProfScope ps(K_MISC, s, 0.0, 12.0 * rows * (double)cols);

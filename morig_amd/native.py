@@ -133,7 +133,7 @@ _SIGNATURES = {
     "morig_bn_backward_stats": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, C.c_void_p,
                                           C.c_int64, c_f32p, c_f32p, C.c_void_p]),
     "morig_bn_relu_backward": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, c_f32p, c_f32p, c_f32p, c_f32p,
-                                         c_f32p, c_f32p, C.c_int32, C.c_void_p]),
+                                         c_f32p, c_f32p, C.c_int32, C.c_void_p, C.c_int64, c_f32p, C.c_void_p]),
     "morig_segmax_affine_arg": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, c_i32p,
                                           C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_segmax_bn_backward_stats": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32,
@@ -792,11 +792,20 @@ class NativeOps:
                                                _p(sdz), _p(sdzx), _stream()), "morig_bn_backward_stats")
         return sdz, sdzx
 
-    def bn_relu_backward(self, dz: Mat, y: Mat, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, rows_dev: Optional[torch.Tensor] = None):
+    def bn_relu_backward(self, dz: Mat, y: Mat, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, rows_dev: Optional[torch.Tensor] = None,
+                         want_sum: bool = False):
+        """want_sum: -> the column sums of du (float32 [cols], = the bias gradient of the Linear in front), from the same pass"""
         _need_gpu(dz.base, y.base, du.base)
         assert dz.rows == y.rows == du.rows and dz.cols == y.cols == du.cols
+        ws = sdu = None
+        if want_sum:
+            dev = du.base.device
+            ws = torch.empty(((max(dz.rows, 1) + 255) // 256) * 2 * dz.cols, dtype=torch.float64, device=dev)
+            sdu = torch.empty(dz.cols, dtype=torch.float32, device=dev)
         check(self.lib.morig_bn_relu_backward(dz.ptr, dz.ld, y.ptr, y.ld, dz.rows, _p(rows_dev), dz.cols, _p(mean), _p(rstd), _p(gamma),
-                                              _p(sum_dz), _p(sum_dzx), du.ptr, du.ld, _stream()), "morig_bn_relu_backward")
+                                              _p(sum_dz), _p(sum_dzx), du.ptr, du.ld, _p(ws), ws.numel() if want_sum else 0, _p(sdu),
+                                              _stream()), "morig_bn_relu_backward")
+        return sdu
 
     def segmax_affine_arg(self, Z: Mat, rowptr: torch.Tensor, n_segments: int, out: Mat, scale=None, shift=None, want_zwin: bool = False):
         """segmax_affine + the winning row per (segment, column): int32 [n_segments, cols], -1 for empty segments. want_zwin: also the

@@ -229,9 +229,10 @@ class DenseTrain(torch.autograd.Function):
         ksdz, ksdzx, _, _ = sync_backward_sums(sdz, sdzx, ctx.share)          # dgamma / dbeta stay per-rank partial sums (as dW)
         du = torch.empty_like(y) if y.shape[1] == N else torch.zeros_like(y)
         DU = Mat.of(du, 0, N)
-        ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), ksdz, ksdzx, DU)
+        # (db = the column sums of du, from the pass that writes du)
+        db = ops.bn_relu_backward(Mat.of(dza, 0, N), Y, mean, rstd, gamma.detach().float().contiguous(), ksdz, ksdzx, DU,
+                                  want_sum=bool(ctx.needs_input_grad[2]))
         # a frozen layer (requires_grad False: e.g. train_deform_pose.py's frozen corr_extractor) pays for no weight-gradient GEMM
-        db = ops.bn_backward_stats(DU)[0] if ctx.needs_input_grad[2] else None
         dW = ops.gemm_tn(DU, Mat.of(xa, 0, K)) if ctx.needs_input_grad[1] else None
         dX = None
         if ctx.needs_input_grad[0]:

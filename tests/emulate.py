@@ -579,12 +579,13 @@ def _emu_bn_backward_stats(self, dz: Mat, y=None, mean=None, rstd=None, rows_dev
     return g.sum(0).float(), (g * xh).sum(0).float()
 
 
-def _emu_bn_relu_backward(self, dz: Mat, y: Mat, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, rows_dev=None):
+def _emu_bn_relu_backward(self, dz: Mat, y: Mat, mean, rstd, gamma, sum_dz, sum_dzx, du: Mat, rows_dev=None, want_sum=False):
     r = _rows(dz, rows_dev)
     yv = y.view()[:r]
     xh = (yv - mean) * rstd
     g = gamma * rstd * (dz.view()[:r] - sum_dz / r - xh * (sum_dzx / r))
     du.view()[:r] = torch.where(yv > 0, g, torch.zeros_like(g))
+    return du.view()[:r].double().sum(0).float() if want_sum else None
 
 
 def _emu_segmax_affine_arg(self, Z: Mat, rowptr, n_segments, out: Mat, scale=None, shift=None, want_zwin=False):

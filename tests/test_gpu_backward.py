@@ -123,6 +123,17 @@ def test_column_statistics_kernels(rows, cols, ld, c0):
         assert float((sdzx.cpu().double() - (d64 * xh).sum(0)).abs().max()) <= 1e-5 * float((d64 * xh).abs().sum(0).max())
         only, none = ops.bn_backward_stats(Mat.of(Dd, c0, cols), rows_dev=rd)
         assert none is None and torch.equal(only, sdz)
+        # BatchNorm + ReLU backward: the flat kernel, and the slab kernel that also leaves the column sums of du (the same du up to the
+        # compiler's choice of fused multiply-adds)
+        gam = torch.randn(cols, generator=g).to(DEV)
+        du_a, du_b = torch.full((rows, ld), 2.0, device=DEV), torch.full((rows, ld), 2.0, device=DEV)
+        assert ops.bn_relu_backward(Mat.of(Dd, c0, cols), Mat.of(Xd, c0, cols), mean, rstd, gam, sdz, sdzx, Mat.of(du_a, c0, cols), rows_dev=rd) is None
+        sdu = ops.bn_relu_backward(Mat.of(Dd, c0, cols), Mat.of(Xd, c0, cols), mean, rstd, gam, sdz, sdzx, Mat.of(du_b, c0, cols), rows_dev=rd,
+                                   want_sum=True)
+        assert torch.allclose(du_a, du_b, rtol=2e-6, atol=1e-6 * float(du_a.abs().max()))
+        assert torch.equal(du_a[live:], du_b[live:]) and torch.equal(du_a[:, :c0], du_b[:, :c0]) and torch.equal(du_a[:, c0 + cols:], du_b[:, c0 + cols:])
+        ref = du_b[:live, c0:c0 + cols].double().sum(0)
+        assert float((sdu.double() - ref).abs().max()) <= 1e-6 * float(du_b[:live, c0:c0 + cols].abs().double().sum(0).max())
 
 
 @pytest.mark.parametrize("n,affine,track", [(1, True, True), (130, True, True), (1024, False, True), (77, True, False)])
