@@ -95,7 +95,34 @@ __global__ __launch_bounds__(256) void edge_gather_relu_kernel(const float* __re
     const int r0 = blockIdx.y * slab_rows, r1 = min(r0 + slab_rows, E);
     double acc[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
     if (rl < RL) {
-        for (int e = r0 + rl; e < r1; e += RL) {
+        int e = r0 + rl;
+        if (V == 4) {
+            // four rows in flight: their edge ids first, then the eight gathered 16-byte pieces (one row at a time is a chain of two
+            // dependent latencies per 32 bytes: 3.6 ms per training step for 9.1 GB written, twice the HBM time)
+            for (; e + 3 * RL < r1; e += 4 * RL) {
+                int di[4], si[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { di[u] = dstS[e + u * RL]; si[u] = srcS[e + u * RL]; }
+                float4 a4[4], b4[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a4[u] = *reinterpret_cast<const float4*>(A + (size_t)di[u] * lda + c);
+                    b4[u] = *reinterpret_cast<const float4*>(B + (size_t)si[u] * ldb + c);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float z[4] = {a4[u].x + b4[u].x, a4[u].y + b4[u].y, a4[u].z + b4[u].z, a4[u].w + b4[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        z[j] = z[j] > 0.f ? z[j] : 0.f;
+                        const double d = (double)z[j];
+                        acc[0][j] += d; acc[1][j] += d * d;
+                    }
+                    *reinterpret_cast<float4*>(Z + (size_t)(e + u * RL) * ldz + c) = make_float4(z[0], z[1], z[2], z[3]);
+                }
+            }
+        }
+        for (; e < r1; e += RL) {
             const float* pa = A + (size_t)dstS[e] * lda + c;
             const float* pb = B + (size_t)srcS[e] * ldb + c;
             float z[4];
