@@ -182,12 +182,15 @@ __device__ __forceinline__ void store_tile_transposed(const P& p, ep_f32x16 (&ac
 //   acc[mt][nt][r] (before the exchange) = Y[row0 + rl_base + 32 mt + (lane & 31)][colw0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 (lane >> 5)]
 //   ps / pt: LDS panels (scale, shift) indexed by the block-local column, or nullptr; cl0 = block-local column of colw0
 //   rb_slow: the tile spans several meshes, the row bias was NOT folded into the accumulators: added here per row (rare)
-template <int MT, int NT, class P>
-__device__ __forceinline__ void store_tile_regs(const P& p, ep_f32x16 (&acc)[MT][NT], const float* ps, const float* pt,
-                                                int rl_base, int row0, int Mlim, int colw0, int cl0, int lane, bool rb_slow) {
+// CT: the launch-uniform switches (output layout, ReLU, column affine; no per-row bias left to add) as template constants -- the
+// epilogue tests them once per 8-column piece, 16-32 pieces per wave and tile: ~100-146 scalar branches per tile in the disassembly
+template <int MT, int NT, class P, bool CT, bool Y16, bool RELU, bool AFF>
+__device__ __forceinline__ void store_tile_regs_t(const P& p, ep_f32x16 (&acc)[MT][NT], const float* ps, const float* pt,
+                                                  int rl_base, int row0, int Mlim, int colw0, int cl0, int lane, bool rb_slow) {
     const int l31 = lane & 31, hi = lane >> 5;
-    const bool y16 = p.y16 != 0;
-    const bool relu = p.relu != 0, aff = ps != nullptr;
+    const bool y16 = CT ? Y16 : (p.y16 != 0);
+    const bool relu = CT ? RELU : (p.relu != 0), aff = CT ? AFF : (ps != nullptr);
+    if (CT) rb_slow = false;
     bool ovf = false;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -263,6 +266,24 @@ __device__ __forceinline__ void store_tile_regs(const P& p, ep_f32x16 (&acc)[MT]
         }
     }
     if (ovf) *p.ovf = 1;
+}
+
+template <int MT, int NT, class P>
+__device__ __forceinline__ void store_tile_regs(const P& p, ep_f32x16 (&acc)[MT][NT], const float* ps, const float* pt,
+                                                int rl_base, int row0, int Mlim, int colw0, int cl0, int lane, bool rb_slow) {
+#ifdef MORIG_EPI_GENERIC                              // measurement variant: the one body with run-time switches
+    store_tile_regs_t<MT, NT, P, false, false, false, false>(p, acc, ps, pt, rl_base, row0, Mlim, colw0, cl0, lane, rb_slow);
+#else
+    if (rb_slow) { store_tile_regs_t<MT, NT, P, false, false, false, false>(p, acc, ps, pt, rl_base, row0, Mlim, colw0, cl0, lane, rb_slow); return; }
+    const int key = (p.y16 != 0 ? 1 : 0) | (p.relu != 0 ? 2 : 0) | (ps != nullptr ? 4 : 0);          // launch-uniform
+#define MORIG_EPI_CASE(K, Y, R, A) case K: store_tile_regs_t<MT, NT, P, true, Y, R, A>(p, acc, ps, pt, rl_base, row0, Mlim, colw0, cl0, lane, false); break;
+    switch (key) {
+        MORIG_EPI_CASE(0, false, false, false) MORIG_EPI_CASE(1, true, false, false) MORIG_EPI_CASE(2, false, true, false)
+        MORIG_EPI_CASE(3, true, true, false) MORIG_EPI_CASE(4, false, false, true) MORIG_EPI_CASE(5, true, false, true)
+        MORIG_EPI_CASE(6, false, true, true) MORIG_EPI_CASE(7, true, true, true)
+    }
+#undef MORIG_EPI_CASE
+#endif
 }
 
 }  // namespace morig
