@@ -822,7 +822,8 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const float* __restr
         }
         __syncthreads();
 #pragma unroll
-        for (int q = g; q < 64; q += G) {
+        for (int qq = 0; qq < 64 / G; ++qq) {
+            const int q = g + qq * G;
             const float4 a = *reinterpret_cast<const float4*>(&sA[q * LD + bi]);
             const float4 b = *reinterpret_cast<const float4*>(&sB[q * LD + bj]);
             const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
