@@ -394,3 +394,32 @@ def test_csr_transposed_walks_every_edge_once_by_source():
         rows = pt[int(rt[u]):int(rt[u + 1])].long()
         assert bool((src[rows] == u).all()) and bool((rows[1:] > rows[:-1]).all())   # its edges, in ascending row order
     assert csr.transposed()[1] is pt                                                 # built once
+
+
+def test_canonical_csr_does_not_depend_on_the_slot_order_of_the_build():
+    """round 4: `canonical_csr` (training graphs) -- whatever order the build left a target's edges in, the segments come out sorted
+    by source, rows past the live count stay behind, and a cached transpose is dropped"""
+    from morig_amd.native import CSR
+    from morig_amd.train_backward import canonical_csr
+    g = torch.Generator().manual_seed(3)
+    n, E, cap = 29, 150, 190
+    dst = torch.sort(torch.randint(0, n, (E,), generator=g))[0]
+    src = torch.randint(0, n, (E,), generator=g)
+    rowptr = torch.searchsorted(dst, torch.arange(n + 1)).int()
+    outs = []
+    for seed in (0, 1, 2):
+        gp = torch.Generator().manual_seed(seed)
+        s2 = src.clone()
+        for v in range(n):                                                   # shuffle inside every segment: what an atomic cursor does
+            a, b = int(rowptr[v]), int(rowptr[v + 1])
+            s2[a:b] = s2[a:b][torch.randperm(b - a, generator=gp)]
+        junk = torch.randint(0, n, (cap - E,), generator=gp).int()
+        csr = CSR(rowptr, torch.cat([s2.int(), junk]), torch.cat([dst.int(), junk]), n, cap, torch.zeros(1, dtype=torch.int32))
+        csr.transposed()
+        canonical_csr(csr)
+        assert csr._transposed is None and torch.equal(csr.dst[:E].long(), dst)
+        for v in range(n):
+            seg = csr.src[int(rowptr[v]):int(rowptr[v + 1])]
+            assert bool((seg[1:] >= seg[:-1]).all())
+        outs.append(csr.src[:E].clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
