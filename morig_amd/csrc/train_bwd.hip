@@ -644,22 +644,30 @@ __device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned& hi
 // One tile of one row chunk. FULL: the 128 x 128 tile lies inside N x K and both operands take 16-byte loads -- no column tests
 // anywhere, no tests per row in the stages that are whole, no branches around the MFMAs (the counters of the general form on the
 // step's large shapes: 8.7 VALU and 3 branches per MFMA, MFMA pipe 32 % busy; the guards, not the split, were most of it).
-template <bool FULL>
+// WNT x WKT MFMA tiles per wave, WVN x WVK waves: 2 x 2 / 2 x 2 = the 128 x 128 tile on 256 threads; 4 x 2 / 2 x 4 = a 256 x 256 tile on 512
+// threads (a third less LDS traffic per MFMA: 12 fragment reads per 24 MFMAs instead of 8 per 12, half the conversion writes), for
+// outputs that have enough 256-tiles to fill the chip. The loader needs tile side = threads / 2 on both operands.
+template <bool FULL, int WNT, int WKT, int WVN, int WVK>
 __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int N, int K, int n0, int k0,
-                                          int r_begin, int r_end, bool a_vec, bool b_vec, char (&sA)[2][TN_T * TN16_P],
-                                          char (&sB)[2][TN_T * TN16_P], float* __restrict__ o) {
+                                          int r_begin, int r_end, bool a_vec, bool b_vec, char (&sA)[2][32 * WNT * WVN * TN16_P],
+                                          char (&sB)[2][32 * WKT * WVK * TN16_P], float* __restrict__ o) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wn = (wave >> 1) * 64, wk = (wave & 1) * 64;
-    tn_f32x16 acc[2][2];
+    static_assert(32 * WNT * WVN == 32 * WKT * WVK && 32 * WNT * WVN == 32 * WVN * WVK, "square tile, side = threads / 2");
+    const int wn = (wave / WVK) * (32 * WNT), wk = (wave % WVK) * (32 * WKT);
+    tn_f32x16 acc[WNT][WKT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WNT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WKT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const int rg = tid & 7, cg = tid >> 3;                            // loader: rows 4 rg .. + 3 of the stage, columns 4 cg .. + 3 of the tile
-    const bool on_a[2] = {n0 + wn < N, n0 + wn + 32 < N}, on_b[2] = {k0 + wk < K, k0 + wk + 32 < K};
+    bool on_a[WNT], on_b[WKT];
+#pragma unroll
+    for (int a = 0; a < WNT; ++a) on_a[a] = n0 + wn + 32 * a < N;
+#pragma unroll
+    for (int b = 0; b < WKT; ++b) on_b[b] = k0 + wk + 32 * b < K;
     tn_f32x4 va[4], vb[4];
     const float* pa0 = A + (size_t)(4 * rg) * lda + n0 + 4 * cg;
     const float* pb0 = B + (size_t)(4 * rg) * ldb + k0 + 4 * cg;
@@ -708,23 +716,23 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
         const bool more = r0 + TN16_R < r_end;                        // block-uniform
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {                              // the stage's two 16-row steps
-            tn_bf16x8 ah[2], al[2], bh[2], bl[2];
+            tn_bf16x8 ah[WNT], al[WNT], bh[WKT], bl[WKT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < WNT; ++a) {
                 const char* pa = sA[st] + (wn + a * 32 + l31) * TN16_P + 32 * s2 + 16 * hi;
                 ah[a] = *reinterpret_cast<const tn_bf16x8*>(pa);
                 al[a] = *reinterpret_cast<const tn_bf16x8*>(pa + 64);
             }
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
+            for (int b = 0; b < WKT; ++b) {
                 const char* pb = sB[st] + (wk + b * 32 + l31) * TN16_P + 32 * s2 + 16 * hi;
                 bh[b] = *reinterpret_cast<const tn_bf16x8*>(pb);
                 bl[b] = *reinterpret_cast<const tn_bf16x8*>(pb + 64);
             }
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < WNT; ++a)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < WKT; ++b)
                     if (FULL || (on_a[a] && on_b[b])) {
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
@@ -741,9 +749,9 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
         __builtin_amdgcn_s_barrier();
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WNT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WKT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, k = k0 + wk + b * 32 + l31;
@@ -751,26 +759,28 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
             }
 }
 
-__global__ __launch_bounds__(256) void gemm_tn16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+template <int WNT, int WKT, int WVN, int WVK>
+__global__ __launch_bounds__(64 * WVN * WVK) void gemm_tn16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
                                                         int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
                                                         int n_tiles, int k_tiles, int chunks, int per_xcd,
                                                         float* __restrict__ part /* [chunks][N][K] */) {
-    __shared__ __attribute__((aligned(16))) char sA[2][TN_T * TN16_P], sB[2][TN_T * TN16_P];
+    constexpr int TT = 32 * WNT * WVN;                                // tile side (both operands)
+    __shared__ __attribute__((aligned(16))) char sA[2][TT * TN16_P], sB[2][TT * TN16_P];
     const int rows = rows_dev ? *rows_dev : rows_host;
     const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= n_tiles * k_tiles * chunks) return;
     const int bx = logical % n_tiles, by = (logical / n_tiles) % k_tiles, bz = logical / (n_tiles * k_tiles);
-    int n0 = bx * TN_T, k0 = by * TN_T;
+    int n0 = bx * TT, k0 = by * TT;
     const int r_begin = bz * chunk_rows, r_end = min(r_begin + chunk_rows, rows);
     const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     const bool b_vec = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
     // a last tile that would stick out is moved back inside (when the extent allows 16-byte loads there): it recomputes some columns
     // of its neighbour -- same operands, same order, the same bits, written twice -- and takes the guard-free path like every other tile
-    if (a_vec && N >= TN_T && (N & 3) == 0) n0 = min(n0, N - TN_T);
-    if (b_vec && K >= TN_T && (K & 3) == 0) k0 = min(k0, K - TN_T);
+    if (a_vec && N >= TT && (N & 3) == 0) n0 = min(n0, N - TT);
+    if (b_vec && K >= TT && (K & 3) == 0) k0 = min(k0, K - TT);
     float* o = part + (size_t)bz * N * K;
-    if (a_vec && b_vec && n0 + TN_T <= N && k0 + TN_T <= K) tn16_tile<true>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
-    else tn16_tile<false>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
+    if (a_vec && b_vec && n0 + TT <= N && k0 + TT <= K) tn16_tile<true, WNT, WKT, WVN, WVK>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
+    else tn16_tile<false, WNT, WKT, WVN, WVK>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
 }
 
 // partial tiles -> C: 32 output elements x 8 chunk lanes per block; lane j adds chunks j, j + 8, ... in order, the eight lane sums
@@ -1107,8 +1117,25 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
     const int chunk_rows = cdiv(cdiv(rows > 0 ? rows : 1, chunks), RS) * RS;
     const int n_tiles = cdiv(N, TN_T), k_tiles = cdiv(K, TN_T);
     const int per_xcd = cdiv((long)n_tiles * k_tiles * chunks, 8);
-    if (split16)
-        hipLaunchKernelGGL(gemm_tn16_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles,
+    // large outputs: 256 x 256 tiles on 512 threads when they still make ~one workgroup per CU with the same chunking (the same partial
+    // buffer and reduction): a third less LDS traffic per MFMA, which is what bounds the 128 x 128 form
+    const int n_big = cdiv(N, 256), k_big = cdiv(K, 256);
+    static const bool no_big = getenv("MORIG_TN_NO_BIG") != nullptr;
+    // (one 512-thread workgroup fits a CU: the chunk count is cut to what makes ONE round of <= 256 workgroups -- 288 of them ran as a
+    // full round plus a round of 32, at twice the time of 256)
+    const int tiles_big = n_big * k_big;
+    const int chunks_big = tiles_big <= 256 ? min(chunks, max(1, 256 / tiles_big)) : chunks;
+    if (split16 && !no_big && N >= 256 && K >= 256 && (long)tiles_big * chunks_big >= 200) {
+        const int chunk_rows_b = cdiv(cdiv(rows > 0 ? rows : 1, chunks_big), RS) * RS;
+        const int per_xcd_b = cdiv((long)tiles_big * chunks_big, 8);
+        hipLaunchKernelGGL((gemm_tn16_kernel<4, 2, 2, 4>), dim3(per_xcd_b * 8), dim3(512), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows_b,
+                           n_big, k_big, chunks_big, per_xcd_b, workspace);
+        MORIG_LAUNCH_CHECK();
+        launch_tn_reduce(workspace, chunks_big, N, K, out, ldo, s);
+        MORIG_LAUNCH_CHECK();
+        return MORIG_OK;
+    } else if (split16)
+        hipLaunchKernelGGL((gemm_tn16_kernel<2, 2, 2, 2>), dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles,
                            k_tiles, chunks, per_xcd, workspace);
     else
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles, k_tiles,
