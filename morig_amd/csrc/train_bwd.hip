@@ -897,7 +897,9 @@ static int tn_chunks(int rows, int N, int K) {
     const int tiles = cdiv(N, TN_T) * cdiv(K, TN_T);
     // ~4 workgroups per CU; 2 per CU for outputs of <= 16 tiles, whose partial tiles (chunks x N x K floats, written and read back) are
     // otherwise a tenth of the operand traffic (swept on the step's shapes: 256 x 1024 over 32 768 rows 0.121 -> 0.084 ms)
-    int chunks = cdiv(tiles <= 16 ? 512 : 1024, tiles);
+    // (rounded DOWN: two 128 x 128 workgroups fit a CU, 512 slots -- 120 tiles x 9 chunks = 1 080 workgroups ran as two rounds and a third of
+    // 56; x 8 = 960 stays inside two)
+    int chunks = (tiles <= 16 ? 512 : 1024) / tiles;
     if (chunks > 512) chunks = 512;                                   // ... and at most 64 additions per lane of the reduction
     const int max_chunks = cdiv(rows > 0 ? rows : 1, 128);            // at least 128 rows per chunk
     if (chunks > max_chunks) chunks = max_chunks;
