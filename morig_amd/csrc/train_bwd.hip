@@ -899,7 +899,8 @@ static int tn_chunks(int rows, int N, int K) {
     // otherwise a tenth of the operand traffic (swept on the step's shapes: 256 x 1024 over 32 768 rows 0.121 -> 0.084 ms)
     // (rounded DOWN: two 128 x 128 workgroups fit a CU, 512 slots -- 120 tiles x 9 chunks = 1 080 workgroups ran as two rounds and a third of
     // 56; x 8 = 960 stays inside two)
-    int chunks = (tiles <= 16 ? 512 : 1024) / tiles;
+    int chunks = ((tiles <= 16 && tiles > 4) ? 512 : 1024) / tiles;   // (<= 4 tiles: 256 chunks = one round of 256 x 256 workgroups: 0.160 -> 0.150 ms
+                                                                      //  on 230 000 x 256 x 256; the same for 5-16 tiles measured slower)
     if (chunks > 512) chunks = 512;                                   // ... and at most 64 additions per lane of the reduction
     const int max_chunks = cdiv(rows > 0 ? rows : 1, 128);            // at least 128 rows per chunk
     if (chunks > max_chunks) chunks = max_chunks;
