@@ -535,6 +535,104 @@ def pct(xs, q):
     return xs[lo] + (xs[hi] - xs[lo]) * (i - lo)
 
 
+LINE_LIMIT = 4096                     # the driver keeps ~8 KB of stdout tail: the LAST line must fit well inside it
+ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_flops_per_launch", "algorithmic_bytes", "traffic",
+             "traffic_over_algorithmic", "mfma_util_counter", "mfma_issued_per_product", "frac_of_3x_split_peak", "avg_launch_ms",
+             "launches_per_step", "share_of_gpu_time", "sclk_under_load_mhz", "socket_power_w", "lib_sha256")
+
+
+def compact_roofline(roof):
+    """numbers and identifiers only (no prose): what the judge recomputes frac from"""
+    if not isinstance(roof, dict):
+        return roof
+    out = {k: roof.get(k) for k in ROOF_KEYS if k in roof}
+    out.setdefault("traffic", None)
+    return out
+
+
+def compact_cpu(cb):
+    if not isinstance(cb, dict):
+        return cb
+    out = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "cpu_model", "host_cores", "error") if k in cb}
+    if isinstance(cb.get("threads_1"), dict):
+        out["threads_1_value"] = cb["threads_1"].get("value")
+    if "sample" in cb:
+        out["sample"] = str(cb["sample"])[:160]
+    return out
+
+
+def compact_secondary(sec):
+    """ONE number per secondary workload (+ its roofline fraction / kernel and its CPU number where it has them)"""
+    if not isinstance(sec, dict):
+        return sec
+    out = {}
+    for k, v in sec.items():
+        if not isinstance(v, dict):
+            continue
+        if "error" in v:
+            out[k] = dict(error=str(v["error"])[:80])
+            continue
+        if k == "small_batch":
+            out[k] = {b: v[b].get("meshes_per_s") for b in ("B1", "B2", "B4", "B8") if isinstance(v.get(b), dict)}
+            out[k]["B8_over_B64"] = v.get("per_mesh_throughput_B8_over_B64")
+            continue
+        e = dict(value=v.get("value"), unit=v.get("unit"))
+        if "ms_per_step" in v:
+            e["ms_per_step"] = v["ms_per_step"]
+        r = v.get("roofline")
+        if isinstance(r, dict):
+            e.update(frac=r.get("frac"), bound=r.get("bound"), kernel=r.get("kernel"))
+        c = v.get("cpu_baseline")
+        if isinstance(c, dict):
+            e["cpu"] = c.get("value")
+            e["cpu_cores"] = c.get("cores")
+        out[k] = e
+    return out
+
+
+def emit(res, detail_path=None):
+    """stdout protocol. The per-workload detail (kernel tables, notes, small-batch sweep ...) goes out FIRST, one
+    '[bench-detail] <json>' line per block (none starts with '{'), and into a side file; the LAST line is the ONE compact JSON
+    object the driver parses: < LINE_LIMIT bytes, numbers and identifiers only."""
+    full = dict(res)
+    sec = full.get("secondary") or {}
+    blocks = [("headline", {k: v for k, v in full.items() if k != "secondary"})]
+    blocks += [("secondary." + k, v) for k, v in sec.items()]
+    for name, blk in blocks:
+        parts = [(name, blk)]
+        if isinstance(blk, dict) and len(json.dumps(blk)) > 3500:       # keep every detail line short too: tables go out on their own
+            rest = {k: v for k, v in blk.items() if k not in ("kernels", "roofline")}
+            parts = [(name, rest)] + [(name + "." + k, blk[k]) for k in ("roofline", "kernels") if blk.get(k) is not None]
+        for pname, part in parts:
+            print("[bench-detail] " + json.dumps({"block": pname, "detail": part}, separators=(",", ":")), flush=True)
+    path = detail_path or os.environ.get("MORIG_BENCH_DETAIL") or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+    except Exception:
+        path = None
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median",
+                                      "ms_per_step_p10", "ms_per_step_p90", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                                      "data", "config", "rccl_ranks", "backend", "per_rank_ms_per_step", "allgather_ms_per_step",
+                                      "allgather_calls_per_step", "allgather_bytes_per_rank")}
+    line["roofline"] = compact_roofline(full.get("roofline"))
+    line["whole_forward_tflops"] = full.get("whole_forward_tflops")
+    line["hbm_bound_kernels"] = {k: v.get("hbm_frac") for k, v in (full.get("hbm_bound_kernels") or {}).items()}
+    line["cpu_baseline"] = compact_cpu(full.get("cpu_baseline"))
+    line["secondary"] = compact_secondary(full.get("secondary"))
+    line["detail"] = "'[bench-detail]' stdout lines above" + (" + " + os.path.relpath(path, ROOT) if path else "")
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("hbm_bound_kernels", "per_rank_ms_per_step", "detail", "secondary"):   # never reached at the default workloads
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT, len(text)
+    print(text, flush=True)
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -920,12 +1018,15 @@ def main():
                                    "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if use_dist else ""),
                        "meshes_per_gpu": B_local, "global_batch": n_units, "vertices_per_mesh": args.n_side * args.n_side,
                        "parallelism": f"mesh-sharded dp{world}",
-                       "guard_read": ("sync: one host read at the end of every forward" if (args.workload != "jointnet" or os.environ.get("MORIG_BENCH_GUARD") == "sync")
-                                      else "deferred by one forward (forward_async): every forward's range flag / CSR status still read inside the timed region"),
-                       "geo_graph": "built on the device (morig_geo_ball_graph)" if not PLUMBING else "host recipe"},
+                       # guard_read: "sync" = one host read of the range flag / CSR status at the end of every forward; "deferred" =
+                       # read one forward later (forward_async), every forward's still inside the timed region
+                       "guard_read": "sync" if (args.workload != "jointnet" or os.environ.get("MORIG_BENCH_GUARD") == "sync") else "deferred",
+                       "geo_graph": "device" if not PLUMBING else "host"},
             "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
             "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank],
             "allgather_ms_per_step": round(allgather_ms, 4) if allgather_ms is not None else None,
+            "allgather_calls_per_step": len(gathered) if allgather_ms is not None else None,
+            "allgather_bytes_per_rank": sum(g_t.numel() * g_t.element_size() for g_t in gathered) if allgather_ms is not None else None,
             "allgather_note": ("the step's %d all_gather_into_tensor call(s) (%s bytes per rank in total) repeated 20x back to back between "
                                "fences in a separate pass, max over ranks; inside the timed steps the same calls are part of ms_per_step"
                                % (len(gathered), sum(g_t.numel() * g_t.element_size() for g_t in gathered))) if allgather_ms is not None else None,
@@ -952,7 +1053,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline_other(args.workload, args.cpu_seconds, args.n_side, args.n_pts, 1000)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+        emit(res)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
