@@ -80,11 +80,20 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
         int xr = r; if (row0 + xr >= p.M) xr = p.M - 1 - row0;
         return ((unsigned)xr * (unsigned)p.ldx + 4u * (pslot ^ ((r >> 1) & 7))) * 4u;   // rule 21: swizzle the SOURCE
     };
+    // Measurement builds (tools/gpu_gemm_ablate.sh; results wrong by construction): DMAP_ABL_HOT = every LDS-DMA re-reads chunk 0 of
+    // tile 0 (cache-hot: what the instructions cost without the memory behind them), DMAP_ABL_NODMA = none issued in the steady
+    // state, DMAP_ABL_NOWAIT = nobody waits for them to land, DMAP_ABL_NOFRAG = no fragment reads in the steady state
     auto dma_x = [&](const char* xb, unsigned o, int c, int stage, int j) __attribute__((always_inline)) {
+#ifdef DMAP_ABL_HOT
+        xb = reinterpret_cast<const char*>(p.X); c = 0;
+#endif
         asm volatile("" : "+v"(o));              // keep (scalar base + lane offset) addressing
         __builtin_amdgcn_global_load_lds((glb_void_t*)(xb + c * 128 + o), (lds_void_t*)(smem + stage * STAGE + (wave * XJ + j) * 1024), 16, 0, 0);
     };
     auto dma_w = [&](const char* wb, int c, int stage, int j) __attribute__((always_inline)) {
+#ifdef DMAP_ABL_HOT
+        wb = reinterpret_cast<const char*>(p.W); c = 0;
+#endif
         unsigned o = ow[j];
         asm volatile("" : "+v"(o));
         __builtin_amdgcn_global_load_lds((glb_void_t*)(wb + c * 128 + o), (lds_void_t*)(smem + stage * STAGE + BM * 128 + (wave * WJ + j) * 1024), 16, 0, 0);
@@ -164,14 +173,30 @@ __global__ __launch_bounds__(512) void gemm16_dmap_kernel(const GemmDmaParams) {
     Frag f0, f1;
     auto chunk_iter = [&](int st, auto morec, auto goc, const char* xb, const char* wb, int cc, bool reclamp, int nrow0)
                           __attribute__((always_inline)) {
+#ifdef DMAP_ABL_NODMA
+        constexpr bool more = decltype(morec)::value != 0, go = false;
+#else
         constexpr bool more = decltype(morec)::value != 0, go = decltype(goc)::value != 0;
+#endif
+#ifdef DMAP_ABL_NOFRAG
+        asm volatile("" : "+v"(f1.ah[0]), "+v"(f1.al[0]), "+v"(f1.ah[1]), "+v"(f1.al[1]));
+        asm volatile("" : "+v"(f1.bh[0]), "+v"(f1.bl[0]), "+v"(f1.bh[1]), "+v"(f1.bl[1]), "+v"(f1.bh[2]), "+v"(f1.bl[2]), "+v"(f1.bh[3]), "+v"(f1.bl[3]));
+#else
         load_frag(f1, st, 1);
+#endif
         mma(f0);
         if constexpr (more) {
+#ifndef DMAP_ABL_NOWAIT
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // chunk c+1 landed for this wave (the only DMA in flight)
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my own reads of chunk c have returned ...
             __builtin_amdgcn_s_barrier();                          // ... and everyone's: stage `st` is free
+#ifdef DMAP_ABL_NOFRAG
+            asm volatile("" : "+v"(f0.ah[0]), "+v"(f0.al[0]), "+v"(f0.ah[1]), "+v"(f0.al[1]));
+            asm volatile("" : "+v"(f0.bh[0]), "+v"(f0.bl[0]), "+v"(f0.bh[1]), "+v"(f0.bl[1]), "+v"(f0.bh[2]), "+v"(f0.bl[2]), "+v"(f0.bh[3]), "+v"(f0.bl[3]));
+#else
             load_frag(f0, st ^ 1, 0);
+#endif
         }
         unsigned o0 = ox[0], o1 = ox[1], o2 = ox[2], o3 = ox[3];
         if (go && reclamp) { o0 = x_offset(0, nrow0); o1 = x_offset(1, nrow0); o2 = x_offset(2, nrow0); o3 = x_offset(3, nrow0); }

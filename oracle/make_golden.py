@@ -223,6 +223,34 @@ def joints_fixtures():
               modes_unweighted=plain, joints_nms=joints_nms, joints=joints, side=side)
 
 
+def joints_larger_fixture():
+    """the larger joint-extraction case of tests/test_joints_host.py (6144 mirrored points, k = 245, 29 mean-shift steps, NMS) from the
+    reference's own utils/cluster_utils.py functions and sklearn's estimate_bandwidth: the GPU test used to re-run a float64 CPU
+    restatement of them on every run (52 s of the suite's host time); the point recipe is the test's, seeded"""
+    print("joint-extraction fixture, larger set")
+    import types
+    from sklearn.cluster import estimate_bandwidth
+    sys.path.insert(0, shim.REFERENCE_ROOT)
+    for name in ("open3d", "cv2"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    if not hasattr(np, "bool"):
+        np.bool = bool
+    if not hasattr(np, "int"):
+        np.int = int
+    cu = __import__("utils.cluster_utils", fromlist=["meanshift_cluster"])
+    rng = np.random.default_rng(3)
+    centres = rng.uniform(-0.4, 0.4, (12, 3)); centres[:, 0] = -np.abs(centres[:, 0])
+    half = centres[rng.integers(0, 12, 3072)] + rng.normal(0, 0.03, (3072, 3))
+    pts = np.concatenate([half, half * np.array([[-1, 1, 1]])])
+    attn = np.tile((rng.random((3072, 1)) ** 2).astype(np.float32), (2, 1))
+    bandwidth = estimate_bandwidth(pts, quantile=0.04)
+    modes = cu.meanshift_cluster(pts, bandwidth, attn, max_iter=30)
+    kept = cu.nms_meanshift(modes, attn=attn, bandwidth=bandwidth, thrd_density=0.02)
+    quick = cu.meanshift_cluster(pts, 10.0, None, max_iter=200)
+    _save("joints_larger", dict(seed=3, n_half=3072, quantile=0.04, threshold2=0.02, max_iter=30, quick_bandwidth=10.0, quick_max_iter=200),
+          pts=pts, attn=attn, bandwidth=np.array([bandwidth]), modes=modes, kept=kept, quick=quick)
+
+
 def geo_edges_fixture():
     """data_proc/common_ops.py:214-226 run as is on a precomputed distance matrix: `calc_surface_geodesic` (open3d remeshing +
     Dijkstra, :162-211) is replaced by a function that hands back the matrix, the mesh object is a stand-in with `.vertices`.
@@ -380,6 +408,8 @@ def main():
         return radius_cpu_fixture(ref)
     if len(sys.argv) > 1 and sys.argv[1] == "joints":
         return joints_fixtures()
+    if len(sys.argv) > 1 and sys.argv[1] == "joints_larger":
+        return joints_larger_fixture()
     if len(sys.argv) > 1 and sys.argv[1] == "geo_edges":
         return geo_edges_fixture()
     if len(sys.argv) > 1 and sys.argv[1] == "dataset":
@@ -508,6 +538,7 @@ def main():
     train_mode_fixture(ref)
     deformnet_fixtures(ref)
     joints_fixtures()
+    joints_larger_fixture()
     dataset_fixtures()
 
     # ---- writers (utils/io_utils.py:41-55, training/train_rig.py:253-258) ---------------

@@ -595,11 +595,27 @@ def _emu_segmax_affine_arg(self, Z: Mat, rowptr, n_segments, out: Mat, scale=Non
         z = z * scale[: Z.cols] + shift[: Z.cols]
     res = torch.zeros((n_segments, Z.cols))
     arg = torch.full((n_segments, Z.cols), -1, dtype=torch.int32)
-    for v in range(n_segments):
-        if p[v + 1] > p[v]:
-            seg = z[p[v]:p[v + 1]]
-            res[v] = seg.max(0)[0]
-            arg[v] = ((seg == res[v]).int().argmax(0) + p[v]).int()      # first maximum
+    pt = rowptr.long()[: n_segments + 1]
+    lens = pt[1:] - pt[:-1]
+    lmax = int(lens.max()) if n_segments else 0
+    if n_segments > 64 and 0 < lmax and n_segments * lmax * Z.cols <= 2 ** 28:
+        # many short segments: one padded [segments, longest, columns] gather instead of a Python loop over the segments (the
+        # 40 000-segment case took 33 s of the GPU suite's host time this way); same first-maximum rule
+        k = torch.arange(lmax)
+        valid = k[None, :] < lens[:, None]
+        zz = z[(pt[:-1, None] + k[None, :]).clamp(max=z.shape[0] - 1)]
+        zz = torch.where(valid[:, :, None], zz, torch.full((), float("-inf")))
+        top = zz.max(1)[0]
+        first = (zz == top[:, None, :]).int().argmax(1)
+        live = (lens > 0)[:, None]
+        res = torch.where(live, top, torch.zeros(()))
+        arg = torch.where(live, first + pt[:-1, None], torch.full((), -1, dtype=torch.long)).int()
+    else:
+        for v in range(n_segments):
+            if p[v + 1] > p[v]:
+                seg = z[p[v]:p[v + 1]]
+                res[v] = seg.max(0)[0]
+                arg[v] = ((seg == res[v]).int().argmax(0) + p[v]).int()      # first maximum
     out.view().copy_(res)
     if want_zwin:
         cc = torch.arange(Z.cols).expand_as(arg)

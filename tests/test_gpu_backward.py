@@ -376,6 +376,16 @@ def _grad_report(tag, mine, ref64, ref32, cos_floor, med_factor=5.0):
     return med, med32, worst_cos, worst_cos32
 
 
+_ORACLE_RUNS = {}
+
+
+def _oracle_once(key, run):
+    """memo of a CPU-oracle run (networks with their gradients filled, outputs, initial state) shared by the parametrisations of a test"""
+    if key not in _ORACLE_RUNS:
+        _ORACLE_RUNS[key] = run()
+    return _ORACLE_RUNS[key]
+
+
 @pytest.fixture(params=["f32", "f16x3"])
 def precision(request, monkeypatch):
     """network-level runs on both arithmetic paths of the train-mode forward: the default exact-fp32 MFMA contractions and the
@@ -388,20 +398,25 @@ def precision(request, monkeypatch):
 def test_gcnrig_backward(precision):
     """one GCNRig (3 GCUMotion units = 12 edge MLPs, pooling, the transform MLP) end to end"""
     kw = dict(chn_feature=3, chn_output=32)
-    ref64 = _randomise(nets.RigGCN(**kw), 3).train().double()
-    ref32 = copy.deepcopy(ref64).float()
-    mine = models.rignet.GCNRig(**kw).train()
-    mine.load_state_dict(copy.deepcopy(ref32.state_dict()))
-    mine.to(DEV)
     b = _net_case()
     g = torch.Generator().manual_seed(1)
     feat = torch.randn(b.pos.shape[0], 3, generator=g) * 0.05
     w = torch.randn(b.pos.shape[0], 32, generator=g)
-    outs = {}
-    for name, net, dt in (("r64", ref64, torch.float64), ("r32", ref32, torch.float32)):
-        o = net(b.pos.to(dt), feat.to(dt), b.tpl_edge_index, b.geo_edge_index, b.batch)
-        (o * w.to(dt)).sum().backward()
-        outs[name] = o.detach()
+
+    def oracle_run():
+        ref64 = _randomise(nets.RigGCN(**kw), 3).train().double()
+        ref32 = copy.deepcopy(ref64).float()
+        sd0 = copy.deepcopy(ref32.state_dict())                 # before the train-mode forwards move the BatchNorm buffers
+        outs = {}
+        for name, net, dt in (("r64", ref64, torch.float64), ("r32", ref32, torch.float32)):
+            o = net(b.pos.to(dt), feat.to(dt), b.tpl_edge_index, b.geo_edge_index, b.batch)
+            (o * w.to(dt)).sum().backward()
+            outs[name] = o.detach()
+        return ref64, ref32, sd0, outs
+    ref64, ref32, sd0, outs = _oracle_once("gcnrig", oracle_run)
+    mine = models.rignet.GCNRig(**kw).train()
+    mine.load_state_dict(copy.deepcopy(sd0))
+    mine.to(DEV)
     bd = b.to(DEV)
     st = TB.graph_state(bd)
     o = TB.gcnrig(mine, bd.pos.float(), feat.to(DEV), st["csr_tpl"], st["csr_geo"], st["batch"], st["mesh_ptr"], st["ng"])
@@ -417,11 +432,6 @@ def test_jointnet_training_step_gradients(aggr, precision):
     """JointNetMotion in training mode: forward, a scalar loss over all three outputs, backward -- every parameter gradient
     against torch.autograd on the oracle (models/rignet.py:70-133, training/train_rig.py:136-195)."""
     kw = dict(num_keyframes=5, chn_output=3, aggr_method=aggr)
-    ref64 = _randomise(nets.jointnet_motion(**kw), 7).train().double()
-    ref32 = copy.deepcopy(ref64).float()
-    mine = models.jointnet_motion(**kw).train()
-    mine.load_state_dict(copy.deepcopy(ref32.state_dict()))
-    mine.to(DEV)
     b = _net_case(n_side=9, n_mesh=2, seed=11)
     g = torch.Generator().manual_seed(2)
     n = b.pos.shape[0]
@@ -430,13 +440,24 @@ def test_jointnet_training_step_gradients(aggr, precision):
     def loss(o, dt, dev="cpu"):
         return (o[0] * w_all.to(dev, dt)).sum() + (o[1] * w_aggr.to(dev, dt)).sum() + (o[2] * w_out.to(dev, dt)).sum()
 
-    outs = {}
-    for name, net, dt in (("r64", ref64, torch.float64), ("r32", ref32, torch.float32)):
-        bb = copy.copy(b)
-        bb.pos = b.pos.to(dt)
-        o = net(bb, b.pred_flow.to(dt))
-        loss(o, dt).backward()
-        outs[name] = [t.detach() for t in o]
+    def oracle_run():
+        ref64 = _randomise(nets.jointnet_motion(**kw), 7).train().double()
+        ref32 = copy.deepcopy(ref64).float()
+        sd0 = copy.deepcopy(ref32.state_dict())                 # before the train-mode forwards move the BatchNorm buffers
+        outs = {}
+        for name, net, dt in (("r64", ref64, torch.float64), ("r32", ref32, torch.float32)):
+            bb = copy.copy(b)
+            bb.pos = b.pos.to(dt)
+            o = net(bb, b.pred_flow.to(dt))
+            loss(o, dt).backward()
+            outs[name] = [t.detach() for t in o]
+        return ref64, ref32, sd0, outs
+    # the float64 / float32 autograd runs of the CPU oracle do not depend on the HIP path's arithmetic: once per `aggr`, shared by
+    # both `precision` cases (they were half of this test's host time)
+    ref64, ref32, sd0, outs = _oracle_once(("jointnet", aggr), oracle_run)
+    mine = models.jointnet_motion(**kw).train()
+    mine.load_state_dict(copy.deepcopy(sd0))
+    mine.to(DEV)
     bd = b.to(DEV)
     o = TB.motion_head_step(mine, bd, bd.pred_flow)
     loss(o, torch.float32, DEV).backward()
