@@ -15,7 +15,7 @@ enum Kind : int {
     K_GEMM16_BN128, K_GEMM16_BN64, K_GEMM16_BN32, K_GEMM16_POOL,
     K_EDGE16_H32, K_EDGE16_H64, K_EDGE16_H128, K_EDGE16_H256, K_POINTCONV16, K_GEMM16_DMA,
     K_COSINE_KNN, K_FLOW_VOTE, K_JOINTS,
-    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH, K_EDGE16_X3, K_EDGE_X3, K_EDGE16_X3P,
+    K_GEMM16_DMAP, K_GEMM16_DMA128, K_EDGE16_H256_PP, K_EDGE16_H128_WS, K_EDGE16_PC, K_GEOGRAPH, K_EDGE16_X3, K_EDGE_X3, K_EDGE16_X3P, K_EDGE16_H128_RL,
     K_COUNT
 };
 static_assert(K_COUNT <= MORIG_PROF_KINDS, "raise MORIG_PROF_KINDS");
@@ -71,6 +71,7 @@ void set_reserved_cus(int n);
 int reserved_cus();
 int launch_edge_pp(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_pp.hip (persistent)
 int launch_edge_ws(const EdgePcParams& p, int nblocks, hipStream_t s);        // edge_ws.hip (persistent, W2 resident in registers; 4-aligned CSR)
+int launch_edge_rl(const EdgePcParams& p, int ntiles64, hipStream_t s);       // edge_rl.hip (persistent, H = 128, W2 resident in LDS, waves independent; 4-aligned CSR)
 int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); // gemm_dma.hip
 struct EdgeX3Params {
     const float* X; int ldx;                       // [rows][ldx >= 4]: 3 input channels per vertex

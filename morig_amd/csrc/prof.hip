@@ -67,7 +67,7 @@ static const char* kNames[K_COUNT] = {
     "gemm_f16x3_bn128", "gemm_f16x3_bn64", "gemm_f16x3_bn32", "gemm_f16x3_pool",
     "edgeconv_f16x3_h32", "edgeconv_f16x3_h64", "edgeconv_f16x3_h128", "edgeconv_f16x3_h256", "pointconv_f16x3", "gemm_f16x3_dma",
     "cosine_knn", "flow_vote", "joint_extraction",
-    "gemm_f16x3_dmap", "gemm_f16x3_dma128", "edgeconv_f16x3_h256_pp", "edgeconv_f16x3_h128_ws", "edgeconv_f16x3_pc", "geo_graph", "edgeconv_f16x3_x3", "edgeconv_x3", "edgeconv_f16x3_x3_persistent",
+    "gemm_f16x3_dmap", "gemm_f16x3_dma128", "edgeconv_f16x3_h256_pp", "edgeconv_f16x3_h128_ws", "edgeconv_f16x3_pc", "geo_graph", "edgeconv_f16x3_x3", "edgeconv_x3", "edgeconv_f16x3_x3_persistent", "edgeconv_f16x3_h128_rl",
 };
 // kinds whose launches all run ONE kernel: the symbol as rocprofv3 prints it (prefix up to the template arguments that matter: the tile
 // engine's sixth argument -- the guard-free FAST form of a dense store GEMM -- is chosen per launch from the shape)
@@ -79,7 +79,7 @@ static const char* kSymbols[K_COUNT] = {
     "tile_kernel<128, 32, 0, 0, 1,", "tile_kernel<64, 32, 0, 0, 1,", "tile_kernel<32, 32, 0, 0, 1,", "gemm16_dmap_kernel<true>",
     "tile_kernel<32, 32, 1, 2, 1,", "tile_kernel<64, 32, 1, 2, 1,", "edge_pp_kernel<128", "edge_ws_kernel<256", nullptr, "gemm16_dma_kernel<256, 256, 4, 2",
     nullptr, nullptr, nullptr,
-    "gemm16_dmap_kernel<false>", "gemm16_dma_kernel<128, 128, 2, 2", "edge_pp_kernel<256", "edge_ws_kernel<128", "edge_pc_kernel", "geo_ball_graph_kernel", "tile_kernel<32, 32, 2, 2, 1,", "tile_kernel<32, 32, 2, 2, 0,", "edge_x3_kernel",
+    "gemm16_dmap_kernel<false>", "gemm16_dma_kernel<128, 128, 2, 2", "edge_pp_kernel<256", "edge_ws_kernel<128", "edge_pc_kernel", "geo_ball_graph_kernel", "tile_kernel<32, 32, 2, 2, 1,", "tile_kernel<32, 32, 2, 2, 0,", "edge_x3_kernel", "edge_rl128_kernel",
 };
 
 }  // namespace morig

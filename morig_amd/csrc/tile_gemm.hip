@@ -848,9 +848,13 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     // H = 128 has half the MFMA work per gathered byte: measured on par with / behind the producer-consumer kernel, which stays
     // the default there (MORIG_WS128=1 selects edge_ws.hip for it too)
     static const bool ws128 = [] { const char* e = getenv("MORIG_WS128"); return e && e[0] == '1'; }();
-    const bool use_ws = wide && !one_shot && !want_pp && pp_ok && a->quad_aligned && (a->lda & 3) == 0 && (a->ldb & 3) == 0 &&
-                        (a->H == 256 || ws128);
-    const int tile_rows = (use_ws && a->H == 256) ? 64 : 128;   // edge_ws.hip: 64-row tiles at H = 256
+    // H = 128 with a 4-aligned CSR: the row-local kernel (edge_rl.hip: W2 resident in LDS, eight independent waves, no barrier in the
+    // main loop; 64-row tiles). MORIG_RL128=0 keeps the producer-consumer kernel (A/B runs)
+    static const bool rl128 = [] { const char* e = getenv("MORIG_RL128"); return !(e && e[0] == '0'); }();
+    const bool quad_ok = wide && !one_shot && !want_pp && pp_ok && a->quad_aligned && (a->lda & 3) == 0 && (a->ldb & 3) == 0;
+    const bool use_rl = quad_ok && a->H == 128 && rl128 && !ws128;
+    const bool use_ws = quad_ok && !use_rl && (a->H == 256 || ws128);
+    const int tile_rows = ((use_ws && a->H == 256) || use_rl) ? 64 : 128;   // edge_ws.hip at H = 256, edge_rl.hip: 64-row tiles
 
     // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
     {
@@ -872,6 +876,10 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
+        if (use_rl) {
+            prof_retag(K_EDGE16_H128_RL);
+            return launch_edge_rl(q, cdiv(a->edge_capacity, 64) * a->replicas, s);
+        }
         if (use_ws) {
             if (a->H == 128) prof_retag(K_EDGE16_H128_WS);
             return launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
