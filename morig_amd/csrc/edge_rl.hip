@@ -39,9 +39,8 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
     constexpr int HSLOT = 2048 + 512;                    // one half-slot: 64 B rows x 32 B, then 16 A quads x 32 B
     constexpr int RAWW = 4 * HSLOT;                      // per wave
     constexpr int NDMA = 3, NIDX = 4;                    // wave-instructions per half-slot / per index fetch
-    __shared__ __attribute__((aligned(1024))) char smem[WB + 8 * RAWW + 3 * H * 4];
+    __shared__ __attribute__((aligned(1024))) char smem[WB + 8 * RAWW];
     char* wlds = smem;
-    float* sbias = reinterpret_cast<float*>(smem + WB + 8 * RAWW);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (uniform for the compiler: scalar bases, s_cbranch)
@@ -54,10 +53,22 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
         const int n = 32 * nt + (ln & 31), h2 = ln >> 5;
         const char* src = reinterpret_cast<const char*>(p.W + (size_t)n * p.ldw) + (s >> 1) * 128 + hl * 64 + ((s & 1) * 16 + 4 * h2) * 2;
         const f32x2 a = *reinterpret_cast<const f32x2*>(src), b = *reinterpret_cast<const f32x2*>(src + 16);
-        *reinterpret_cast<f32x4*>(wlds + i * 16) = f32x4{a[0], a[1], b[0], b[1]};
+        // rows of W2 whose output column has a NEGATIVE BatchNorm scale are stored negated (sign bits of the four halves of a word pair:
+        // exact), so that y = relu(acc + b) * sc + sh is RISING in the accumulator of every column: the epilogue needs max only
+        const unsigned flip = p.scale[n] < 0.f ? 0x80008000u : 0u;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4*>(wlds + i * 16) = u32x4{__float_as_uint(a[0]) ^ flip, __float_as_uint(a[1]) ^ flip,
+                                                        __float_as_uint(b[0]) ^ flip, __float_as_uint(b[1]) ^ flip};
     }
-    if (tid < H) { sbias[tid] = p.bias[tid]; sbias[H + tid] = p.scale[tid]; sbias[2 * H + tid] = p.shift[tid]; }
     __syncthreads();                                     // the only workgroup barrier of the kernel
+    // the four column constants of this lane's two output columns (epilogue): col = 32 (pr + 2 hi) + l31
+    float eb[2], eg[2], es[2], et[2];
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const int col = 32 * (pr + 2 * hi) + l31;
+        es[pr] = p.scale[col]; et[pr] = p.shift[col]; eb[pr] = p.bias[col];
+        eg[pr] = es[pr] < 0.f ? -1.f : 1.f;
+    }
 
     // ---- this WAVE's tile list: XCD x owns a contiguous range of 64-row tiles; the waves of a workgroup take adjacent tiles ----
     const int Etot = p.rowptr[p.n_nodes];
@@ -182,31 +193,13 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
     auto epilogue = [&]() __attribute__((always_inline)) {
         // the min / max below read the accumulators from inline assembly: ordered behind the MFMAs and given their wait states by hand
         // (edge_pp.hip write_z_quad; DESIGN section 5, lesson 11)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) asm volatile("s_nop 15" : "+v"(acc[mt][nt]));
-        if (p.dbg & 1) return;
-        float y[MT][NT][4];                               // quad 2 q + hi of row tile mt, column 32 nt + l31
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int col = 32 * nt + l31;
-            const float b = sbias[col], sc = sbias[H + col], sh = sbias[2 * H + col];
-            const bool rising = sc >= 0.f;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float a0 = acc[mt][nt][4 * q], a1 = acc[mt][nt][4 * q + 1], a2 = acc[mt][nt][4 * q + 2], a3 = acc[mt][nt][4 * q + 3];
-                    float hi4, lo4, t3;
-                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
-                    asm("v_max_f32 %0, %1, %2" : "=v"(hi4) : "v"(t3), "v"(a3));
-                    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
-                    asm("v_min_f32 %0, %1, %2" : "=v"(lo4) : "v"(t3), "v"(a3));
-                    const float x = rising ? hi4 : lo4;
-                    y[mt][nt][q] = fmaxf(x + b, 0.f) * sc + sh;
-                }
+        {
+            f32x16 &c00 = acc[0][0], &c01 = acc[0][1], &c02 = acc[0][2], &c03 = acc[0][3];
+            f32x16 &c10 = acc[1][0], &c11 = acc[1][1], &c12 = acc[1][2], &c13 = acc[1][3];
+            asm volatile("s_nop 15" : "+v"(c00), "+v"(c01), "+v"(c02), "+v"(c03), "+v"(c10), "+v"(c11), "+v"(c12), "+v"(c13));
         }
+        if (p.dbg & 1) return;
+        // quad 2 q + hi of row tile mt, column 32 nt + l31: max of the quad's four accumulators (every column is rising, see the W2 image);
         // half-wave exchange: afterwards lanes 0..31 hold column 32 pr + l31, lanes 32..63 column 32 (pr + 2) + l31, and seq[pr][i] is
         // quad i = 8 mt + 2 q + {0, 1} of the tile, i = 0..15 in row order
         float seq[2][16];
@@ -216,7 +209,17 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float fa = y[mt][pr][q], fb = y[mt][pr + 2][q];
+                    float fa, fb, t3;
+                    {
+                        const float a0 = acc[mt][pr][4 * q], a1 = acc[mt][pr][4 * q + 1], a2 = acc[mt][pr][4 * q + 2], a3 = acc[mt][pr][4 * q + 3];
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
+                        asm("v_max_f32 %0, %1, %2" : "=v"(fa) : "v"(t3), "v"(a3));
+                    }
+                    {
+                        const float a0 = acc[mt][pr + 2][4 * q], a1 = acc[mt][pr + 2][4 * q + 1], a2 = acc[mt][pr + 2][4 * q + 2], a3 = acc[mt][pr + 2][4 * q + 3];
+                        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
+                        asm("v_max_f32 %0, %1, %2" : "=v"(fb) : "v"(t3), "v"(a3));
+                    }
                     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(fa), __float_as_uint(fb), false, false);
                     const unsigned ua = sw[0], ub = sw[1];
                     seq[pr][mt * 8 + 2 * q] = __uint_as_float(ua);
@@ -228,7 +231,10 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
         const int first = __builtin_amdgcn_readlane(cq, 0);
         const bool first_cont = crow0 > 0 && prev == first;
         float* obase = p.Y + (size_t)crep * p.rep_out * p.ldy + 32 * (2 * hi) + l31;
-        auto flush = [&](int id, float m0, float m1, bool partial) __attribute__((always_inline)) {
+        // the affine once per SEGMENT: y = relu(sg x + b) * sc + sh is rising in the stored accumulator x = sg acc, so max commutes with it
+        auto flush = [&](int id, float x0, float x1, bool partial) __attribute__((always_inline)) {
+            const float m0 = fmaxf(x0 * eg[0] + eb[0], 0.f) * es[0] + et[0];
+            const float m1 = fmaxf(x1 * eg[1] + eb[1], 0.f) * es[1] + et[1];
             float* o = obase + (size_t)id * p.ldy;
             if (partial) { atomic_max_f32(o, m0); atomic_max_f32(o + 32, m1); }
             else { o[0] = m0; o[32] = m1; }
@@ -253,39 +259,56 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
     // ---- one unit = the 6 MFMAs of (step s, column tile nt) and its share of the side work: the conversions of step s + 1 ----
     //   unit 0: (mt 0, h 0)   unit 1: (mt 1, h 0) -> half-slot (s + 1, 0) is free: D(s + 3, 0)
     //   unit 2: (mt 0, h 1)   unit 3: (mt 1, h 1) -> half-slot (s + 1, 1) is free: D(s + 3, 1)
-    // A unit issues its raw reads and the next unit's W2 fragments, then its MFMAs, then converts (the reads return under the MFMAs).
-    // vmcnt: the reads of unit 0 need D(s + 1, 0) (issued in unit 1 of step s - 2), those of unit 2 need D(s + 1, 1) (unit 3 of step
-    // s - 2): three half-slot fetches are younger at either point, plus the index fetch of step 0, unit 0 while it is younger
-    f32x4 ra, rb;
+    // The raw reads of a conversion are issued ONE UNIT AHEAD (two register pairs, unit parity), the W2 fragments of a unit likewise: a
+    // unit never waits for an LDS round trip it has just started (measured: with the reads in the same unit every unit exposed one).
+    // vmcnt: the reads issued in unit 1 need D(s + 1, 1) (unit 3 of step s - 2), those issued in unit 3 need D(s + 2, 0) (unit 1 of step
+    // s - 1): two half-slot fetches are younger at either point, plus the index fetch of step 0, unit 0 while it is younger
+#if defined(RL_NO_DMA) || defined(RL_NO_WAIT)
+#define RL_VMWAIT(n) do { } while (0)
+#else
+#define RL_VMWAIT(n) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n) : "memory")
+#endif
+    f32x4 ra[2], rb[2];
     auto unit = [&](auto sc, auto ntc, int j) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value, nt = decltype(ntc)::value;
         constexpr int par = s & 1, npar = par ^ 1;
-        constexpr int s1 = s + 1;                                            // the step whose operands are converted now
-        constexpr int mt = nt & 1, h = nt >> 1;
-        load_w(RC<s + (nt + 1) / 4>{}, RC<(nt + 1) & 3>{});
+        constexpr int mt = nt & 1, h = nt >> 1;                              // this unit converts (mt, h) of step s + 1 from pair nt & 1
+        constexpr int n1 = (nt + 1) & 3, sn = s + 1 + (nt + 1) / 4;          // the next unit converts (n1 & 1, n1 >> 1) of step sn
+        // (measurement builds, tools/gpu_rl_ablate.sh, results wrong by construction: RL_NO_RAW / RL_NO_CONV / RL_NO_DMA / RL_NO_W / RL_NO_WAIT)
+#ifdef RL_NO_W
+        asm volatile("" : "+v"(wh[(nt + 1) & 1]), "+v"(wl[(nt + 1) & 1]));
+#else
+        load_w(RC<s + (nt + 1) / 4>{}, RC<n1>{});
+#endif
         if constexpr (nt == 0) {
-            constexpr int cnt = 3 * NDMA + (s == 1 ? NIDX : 0);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(cnt) : "memory");
             if constexpr (s == 0) load_indices(j + 1);
-            if constexpr (s == 5) { tie(); switch_gather(); }                // (the index fetch completed behind the wait of step 2, unit 0)
+            if constexpr (s == 5) { tie(); switch_gather(); }                // (the index fetch completed behind the wait of step 1, unit 3)
         }
-        if constexpr (nt == 2) {
-            constexpr int cnt = 3 * NDMA + (s <= 1 ? NIDX : 0);
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(cnt) : "memory");
-        }
-        raw_load((2 * s1 + h) & 3, RC<mt>{}, ra, rb);
+        if constexpr (nt == 1) { constexpr int cnt = 2 * NDMA + (s <= 1 ? NIDX : 0); RL_VMWAIT(cnt); }
+        if constexpr (nt == 3) { constexpr int cnt = 2 * NDMA + (s == 0 ? NIDX : 0); RL_VMWAIT(cnt); }
+#ifdef RL_NO_RAW
+        asm volatile("" : "+v"(ra[(nt + 1) & 1]), "+v"(rb[(nt + 1) & 1]));
+#else
+        raw_load((2 * sn + (n1 >> 1)) & 3, RC<(n1 & 1)>{}, ra[(nt + 1) & 1], rb[(nt + 1) & 1]);
+#endif
+#ifdef RL_NO_CONV
+        asm volatile("" :: "v"(ra[nt & 1]), "v"(rb[nt & 1]));
+#else
+        convert(RC<npar>{}, RC<mt>{}, RC<h>{}, ra[nt & 1], rb[nt & 1]);
+#endif
         mma(RC<par>{}, ntc, RC<(s == 0 ? 1 : 0)>{});
-        convert(RC<npar>{}, RC<mt>{}, RC<h>{}, ra, rb);
         __builtin_amdgcn_sched_barrier(0);
+#ifndef RL_NO_DMA
         // D() last in the unit: the MFMAs are queued (an LDS-DMA costs the issuing wave ~60-180 cycles of issue)
         if constexpr (nt == 1) { dma(RC<(s + 3) & (NS - 1)>{}, RC<0>{}); __builtin_amdgcn_sched_barrier(0); }
         if constexpr (nt == 3) { dma(RC<(s + 3) & (NS - 1)>{}, RC<1>{}); __builtin_amdgcn_sched_barrier(0); }
+#endif
     };
     auto step = [&](auto sc, int j) __attribute__((always_inline)) {
         unit(sc, RC<0>{}, j); unit(sc, RC<1>{}, j); unit(sc, RC<2>{}, j); unit(sc, RC<3>{}, j);
     };
 
-    // ---- prologue: tile 0's steps 0..2 in flight, step 0 converted ----
+    // ---- prologue: tile 0's steps 0..2 in flight, step 0 converted, the first raw pair of step 1 read ----
     load_indices(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     tie();
@@ -294,13 +317,15 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
     dma(RC<0>{}, RC<0>{}); dma(RC<0>{}, RC<1>{}); dma(RC<1>{}, RC<0>{}); dma(RC<1>{}, RC<1>{});
     load_w(RC<0>{}, RC<0>{});
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NDMA) : "memory");
-    raw_load(0, RC<0>{}, ra, rb);   convert(RC<0>{}, RC<0>{}, RC<0>{}, ra, rb);
-    raw_load(0, RC<1>{}, ra, rb);   convert(RC<0>{}, RC<1>{}, RC<0>{}, ra, rb);
-    raw_load(1, RC<0>{}, ra, rb);   convert(RC<0>{}, RC<0>{}, RC<1>{}, ra, rb);
-    raw_load(1, RC<1>{}, ra, rb);   convert(RC<0>{}, RC<1>{}, RC<1>{}, ra, rb);
+    raw_load(0, RC<0>{}, ra[0], rb[0]);   convert(RC<0>{}, RC<0>{}, RC<0>{}, ra[0], rb[0]);
+    raw_load(0, RC<1>{}, ra[0], rb[0]);   convert(RC<0>{}, RC<1>{}, RC<0>{}, ra[0], rb[0]);
+    raw_load(1, RC<0>{}, ra[0], rb[0]);   convert(RC<0>{}, RC<0>{}, RC<1>{}, ra[0], rb[0]);
+    raw_load(1, RC<1>{}, ra[0], rb[0]);   convert(RC<0>{}, RC<1>{}, RC<1>{}, ra[0], rb[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     dma(RC<2>{}, RC<0>{}); dma(RC<2>{}, RC<1>{});
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * NDMA) : "memory");        // D(1, 0) landed
+    raw_load(2, RC<0>{}, ra[0], rb[0]);
 
 #pragma unroll 1
     for (int j = 0; j < n_my; ++j) {
