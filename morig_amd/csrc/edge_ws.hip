@@ -114,6 +114,13 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
             wh[S] = f16x8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
             wl[S] = f16x8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
         }
+        // [r05] a column whose BatchNorm scale is negative keeps its W2 row NEGATED (exact): y = relu(acc + b) * sc + sh is then rising
+        // in the stored accumulator x = sg * acc of EVERY column, so the epilogue takes max only (no min, no select) and applies the
+        // affine once per segment, after the segmented max (edge_rl.hip does the same)
+        if (p.scale[32 * wn + l31] < 0.f) {
+#pragma unroll
+            for (int S = 0; S < NS; ++S) { wh[S] = -wh[S]; wl[S] = -wl[S]; }
+        }
     }
 
     // ---- gather state: this lane's slice of D().
@@ -264,27 +271,23 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[1], wh[S], c1, 0, 0, 0);
         acc[0] = c0; acc[1] = c1;
     };
-    // y = relu(acc + b) * sc + sh is monotone in acc: the max over a quad's four rows is f(max acc) or f(min acc)
+    // y = relu(sg x + b) * sc + sh is rising in the stored accumulator x (see the W2 slice above): the scan region receives the max of
+    // a quad's four accumulators, the affine waits for the end of the segmented max
     auto write_z = [&]() __attribute__((always_inline)) {
-        // the min/max below read the accumulators from inline assembly: ordered behind the MFMAs and given their wait states by
+        // the max below reads the accumulators from inline assembly: ordered behind the MFMAs and given their wait states by
         // hand (see edge_pp.hip write_z_quad; DESIGN section 5, lesson 11)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) asm volatile("s_nop 15" : "+v"(acc[mt]));
         const int col = 32 * wn + l31;
-        const float b = sbias[col], sc = sbias[H + col], sh = sbias[2 * H + col];
-        const bool rising = sc >= 0.f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float a0 = acc[mt][4 * q], a1 = acc[mt][4 * q + 1], a2 = acc[mt][4 * q + 2], a3 = acc[mt][4 * q + 3];
-                float hi4, lo4, t3;
+                float hi4, t3;
                 asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
                 asm("v_max_f32 %0, %1, %2" : "=v"(hi4) : "v"(t3), "v"(a3));
-                asm("v_min3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
-                asm("v_min_f32 %0, %1, %2" : "=v"(lo4) : "v"(t3), "v"(a3));
-                const float x = rising ? hi4 : lo4;
-                Z[((wm * MT + mt) * 8 + 2 * q + hi) * ZQ + col] = fmaxf(x + b, 0.f) * sc + sh;
+                Z[((wm * MT + mt) * 8 + 2 * q + hi) * ZQ + col] = hi4;
             }
     };
     // ([r04] measured and not adopted here, profiles/r04r_*: segments dealt round-robin to the waves instead of by quad-row ownership,
@@ -319,6 +322,20 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
                 const fvec z1 = *reinterpret_cast<const fvec*>(zl + min(q + 1, e - 1) * ZQ);
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], fmaxf(z0[v], z1[v]));
+            }
+            {   // this lane's VEC columns: bias, scale, shift from the LDS panel, fetched one after the other behind the reduction (the
+                // kernel sits at its register limit: three more live vectors spilled a lane constant into the main loop)
+                __builtin_amdgcn_sched_barrier(0);
+                const float* sbl = sbias + VEC * lane;
+                asm volatile("" : "+v"(sbl));             // ONE address register + immediate offsets (three hoisted ones were what spilled)
+                const fvec cb = *reinterpret_cast<const fvec*>(sbl);
+                const fvec cs = *reinterpret_cast<const fvec*>(sbl + H);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf((cs[v] < 0.f ? -m[v] : m[v]) + cb[v], 0.f);
+                __builtin_amdgcn_sched_barrier(0);
+                const fvec ct = *reinterpret_cast<const fvec*>(sbl + 2 * H);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = m[v] * cs[v] + ct[v];
             }
             float* o = obase + (size_t)sg * p.ldy;
             const bool partial = (b == 0 && first_cont) || (e == NQ && last_cont);
