@@ -316,6 +316,35 @@ def roofline_of(prof, psteps, clocks=None):
     return roof, breakdown, total_ms
 
 
+def mfma_power_probe(seconds=1.5, index=0):
+    """The matrix pipes' rate under the socket POWER CAP (morig_ubench_mfma: every wave issues v_mfma_f32_32x32x16_f16 from registers,
+    random fp16 operands): the data sheet's 2.5 PFLOP/s assumes 2.4 GHz, which the cap does not grant once operands toggle. Returns the
+    dense f16 TFLOP/s this GPU sustains, with the clock and power sampled during the probe (peaks "verify on the box")."""
+    import ctypes
+    import torch
+    from morig_amd import native
+    lib = native.load_library()
+    scratch = torch.zeros(16, device="cuda")
+    fl = ctypes.c_double(0.0)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    iters = 4000
+    native.check(lib.morig_ubench_mfma(0, iters, 2, scratch.data_ptr(), ctypes.byref(fl), st), "morig_ubench_mfma")
+    torch.cuda.synchronize()
+    cs = ClockSampler(index=index, period=0.02).start()
+    t0 = time.perf_counter()
+    total = 0.0
+    while time.perf_counter() - t0 < seconds:
+        native.check(lib.morig_ubench_mfma(0, iters, 8, scratch.data_ptr(), ctypes.byref(fl), st), "morig_ubench_mfma")
+        torch.cuda.synchronize()
+        total += fl.value
+    dt = time.perf_counter() - t0
+    cs.stop()
+    sm = cs.summary()
+    return dict(tflops=round(total / dt / 1e12, 1), sclk_mhz=sm.get("sclk_under_load_mhz"), socket_power_w=sm.get("socket_power_w"),
+                seconds=round(dt, 2), operands="random fp16", kernel="ubench_mfma_kernel<0>",
+                note="every wave issues v_mfma_f32_32x32x16_f16 back to back from registers: what the socket power cap leaves of the 2.5 PFLOP/s")
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -538,7 +567,8 @@ def pct(xs, q):
 LINE_LIMIT = 4096                     # the driver keeps ~8 KB of stdout tail: the LAST line must fit well inside it
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_flops_per_launch", "algorithmic_bytes", "traffic",
              "traffic_over_algorithmic", "mfma_util_counter", "mfma_issued_per_product", "frac_of_3x_split_peak", "avg_launch_ms",
-             "launches_per_step", "share_of_gpu_time", "sclk_under_load_mhz", "socket_power_w", "lib_sha256")
+             "launches_per_step", "share_of_gpu_time", "sclk_under_load_mhz", "socket_power_w", "mfma_power_capped_tflops",
+             "frac_of_power_capped_peak", "lib_sha256")
 
 
 def compact_roofline(roof):
@@ -646,6 +676,8 @@ def main():
                          "corrnet = configs[3] (8192-point clouds, 32 pairs per GPU); deformnet = the producer of pred_flow "
                          "(SURVEY 8 f-1), same pairs as corrnet")
     ap.add_argument("--n-pts", type=int, default=8192)
+    ap.add_argument("--power-probe-seconds", type=float, default=1.5,
+                    help="length of the matrix-pipe power-cap probe behind roofline.mfma_power_capped_tflops (0 = skip)")
     ap.add_argument("--cpu-seconds", type=float, default=30.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--secondary-cpu-seconds", type=float, default=10.0,
                     help="budget of the cpu_baseline leg of each of the mask_skin / corrnet secondary entries (0 = skip)")
@@ -994,6 +1026,15 @@ def main():
         psteps = max(args.prof_steps, 1)
         if prof:
             roof, breakdown, total_ms = roofline_of(prof, psteps, clocks)
+            if roof.get("bound") == "mfma" and args.power_probe_seconds > 0:
+                try:
+                    pp = mfma_power_probe(args.power_probe_seconds, local)
+                    roof["mfma_power_capped"] = pp
+                    roof["mfma_power_capped_tflops"] = pp["tflops"]
+                    k = roof.get("mfma_issued_per_product") or 1
+                    roof["frac_of_power_capped_peak"] = round(k * roof["achieved"] / pp["tflops"], 4) if pp["tflops"] else None
+                except Exception as e:
+                    roof["mfma_power_capped"] = dict(error=repr(e)[:200])
             # the index / copy kernels are the HBM-bound ones: bytes the launcher declares / event time, against 8 TB/s
             for k in ("csr_build", "copy", "rownorm"):
                 v = prof.get(k)

@@ -450,6 +450,11 @@ const char* morig_prof_symbol(int kind);
 /* synchronises the recorded events; per kind: launches, total ms, algorithmic flops, algorithmic bytes */
 int         morig_prof_collect(int kind, int64_t* launches, double* total_ms, double* flops, double* bytes);
 
+/* Probe of the matrix pipes' POWER-CAPPED rate (bench.py `roofline.mfma_power_capped_tflops`; SURVEY 8(d) "verify on the box"): enqueues
+ * `launches` persistent kernels in which every wave of the chip issues `iters` x 24 v_mfma_f32_32x32x16_f16 from registers
+ * (mode 0: random fp16 operands, mode 1: zeros). scratch: >= 1 float of device memory; *flops (optional): dense f16 flops enqueued. */
+int morig_ubench_mfma(int mode, int iters, int launches, float* scratch, double* flops, void* stream);
+
 /* ---- train-mode forward support (forward half; training/train_rig.py:136-195) -------------------------------
  * In model.train() every BatchNorm1d normalises with the statistics of the current batch -- over vertices in the dense
  * MLPs, over EDGES inside the per-edge MLPs (models/basic_modules.py:31-36, 153-155, 192-195) -- so the layers run unfused:

@@ -198,6 +198,7 @@ _SIGNATURES = {
     "morig_prof_reset": (C.c_int, []),
     "morig_prof_name": (C.c_char_p, [C.c_int]),
     "morig_prof_symbol": (C.c_char_p, [C.c_int]),
+    "morig_ubench_mfma": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "morig_prof_collect": (C.c_int, [C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
