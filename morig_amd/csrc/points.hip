@@ -192,6 +192,195 @@ __global__ __launch_bounds__(FPS_T) void fps_lds_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------
+// [r05] Bucketed variant: the SAME sample sequence with most of the distance updates skipped. A sample changes dist[p] only where
+// |p - c|^2 < dist[p]; after the first few dozen samples that is a small neighbourhood of c, yet the kernel above still updates all
+// 8192 points per sample (VALU-bound: ~0.9 us per sample on the one CU a cloud owns, 3.6 ms for SA1's 4096 samples). Here the points
+// are first counting-sorted by the Morton code of an 8 x 8 x 8 grid over the cloud's bounding box (LDS, once), so that the 128 points
+// a wave holds in one register PAIR (2 x 64 lanes) are neighbours: a bucket. Every bucket keeps its bounding box and its current
+// max min-distance (lanes 0..H-1 of the wave); per sample, lanes 0..H-1 evaluate the lower bound of |p - c|^2 over their box -- with
+// the per-point operation order, so by monotonicity of rounding it is <= every point's computed value -- and only buckets with
+// bound < max are updated (exactly: a skipped bucket provably changes nothing). A wave without updates re-submits its cached
+// candidate. Arg-max ties go to the lowest ORIGINAL index, as before: key = (value, ~orig index, sorted position).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned morton3(unsigned x, unsigned y, unsigned z) {       // 3 bits each -> 9 bits
+    auto spread = [](unsigned v) { return (v & 1u) | ((v & 2u) << 2) | ((v & 4u) << 4); };
+    return spread(x) | (spread(y) << 1) | (spread(z) << 2);
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int PPT>                                        // even, <= 8
+__global__ __launch_bounds__(FPS_T) void fps_bkt_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
+                                                        const int* __restrict__ out_ptr, const int* __restrict__ start,
+                                                        int* __restrict__ idx_out) {
+    constexpr int NP = PPT * FPS_T, H = PPT / 2, NCELL = 512;
+    __shared__ float sx[NP], sy[NP], sz[NP];              // coordinates in SORTED order
+    __shared__ unsigned short sorig[NP];                  // original index of a sorted position
+    __shared__ int s_hist[NCELL + 1];
+    __shared__ float s_box[6 * (FPS_T / 64)];
+    __shared__ unsigned long long s_key[3];
+    __shared__ int s_start;
+    const int b = blockIdx.x;
+    const int p0 = ptr[b], n = ptr[b + 1] - p0;
+    const int o0 = out_ptr[b], m = out_ptr[b + 1] - o0;
+    if (n <= 0 || m <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int cur0 = start ? start[b] : 0;
+    if (cur0 < 0 || cur0 >= n) cur0 = 0;
+
+    // ---- cloud bounding box ----
+    float lx = INFINITY, ly = INFINITY, lz = INFINITY, hx = -INFINITY, hy = -INFINITY, hz = -INFINITY;
+    float qx[PPT], qy[PPT], qz[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = tid + i * FPS_T;
+        qx[i] = qy[i] = qz[i] = 0.f;
+        if (j < n) {
+            const float* q = pos + (size_t)(p0 + j) * ldp;
+            qx[i] = q[0]; qy[i] = q[1]; qz[i] = q[2];
+            lx = fminf(lx, qx[i]); ly = fminf(ly, qy[i]); lz = fminf(lz, qz[i]);
+            hx = fmaxf(hx, qx[i]); hy = fmaxf(hy, qy[i]); hz = fmaxf(hz, qz[i]);
+        }
+    }
+    lx = wave_min_f(lx); ly = wave_min_f(ly); lz = wave_min_f(lz); hx = wave_max_f(hx); hy = wave_max_f(hy); hz = wave_max_f(hz);
+    if (lane == 0) { s_box[w * 6] = lx; s_box[w * 6 + 1] = ly; s_box[w * 6 + 2] = lz; s_box[w * 6 + 3] = hx; s_box[w * 6 + 4] = hy; s_box[w * 6 + 5] = hz; }
+    for (int i = tid; i <= NCELL; i += FPS_T) s_hist[i] = 0;
+    if (tid < 3) s_key[tid] = 0ull;
+    __syncthreads();
+    for (int k = 0; k < FPS_T / 64; ++k) {
+        lx = fminf(lx, s_box[k * 6]); ly = fminf(ly, s_box[k * 6 + 1]); lz = fminf(lz, s_box[k * 6 + 2]);
+        hx = fmaxf(hx, s_box[k * 6 + 3]); hy = fmaxf(hy, s_box[k * 6 + 4]); hz = fmaxf(hz, s_box[k * 6 + 5]);
+    }
+    // cell of a point: any monotone map works (the grid only decides the ORDER of the points, never a result); non-finite
+    // coordinates land in cell 0
+    const float gx = 8.f / fmaxf(hx - lx, 1e-30f), gy = 8.f / fmaxf(hy - ly, 1e-30f), gz = 8.f / fmaxf(hz - lz, 1e-30f);
+    auto cell_of = [&](float x, float y, float z) {
+        const int cx = min(max((int)((x - lx) * gx), 0), 7), cy = min(max((int)((y - ly) * gy), 0), 7), cz = min(max((int)((z - lz) * gz), 0), 7);
+        return (int)morton3((unsigned)cx, (unsigned)cy, (unsigned)cz);
+    };
+    // ---- counting sort by cell: histogram, exclusive scan (wave 0), scatter ----
+    int cell[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = tid + i * FPS_T;
+        cell[i] = j < n ? cell_of(qx[i], qy[i], qz[i]) : -1;
+        if (j < n) atomicAdd(&s_hist[cell[i]], 1);
+    }
+    __syncthreads();
+    if (w == 0) {                                          // 512 counters: 8 per lane, then a wave scan of the lane sums
+        int c[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { c[k] = s_hist[lane * 8 + k]; sum += c[k]; }
+        int incl = sum;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        int run = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { s_hist[lane * 8 + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int j = tid + i * FPS_T;
+        if (j < n) {
+            const int d = atomicAdd(&s_hist[cell[i]], 1);
+            sx[d] = qx[i]; sy[d] = qy[i]; sz[d] = qz[i]; sorig[d] = (unsigned short)j;
+            if (j == cur0) s_start = d;
+        }
+    }
+    __syncthreads();
+    // ---- this thread's points: sorted positions w * 64 * PPT + i * 64 + lane (register pair h = positions of i = 2h, 2h + 1) ----
+    fps_f2 px[H], py[H], pz[H], dist[H];
+    unsigned short org[PPT];
+    float bx0 = INFINITY, bx1 = -INFINITY, by0 = INFINITY, by1 = -INFINITY, bz0 = INFINITY, bz1 = -INFINITY, pmax = -1.f;   // lane h: bucket h
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+        float l0 = INFINITY, l1 = INFINITY, l2 = INFINITY, h0 = -INFINITY, h1 = -INFINITY, h2 = -INFINITY;
+        bool any = false;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int d = w * 64 * PPT + (2 * h + e) * 64 + lane;
+            float x = 0.f, y = 0.f, z = 0.f, dd = -1.f;                 // dd = -1: never selected
+            unsigned short og = 0xffff;
+            if (d < n) {
+                x = sx[d]; y = sy[d]; z = sz[d]; og = sorig[d]; dd = INFINITY; any = true;
+                l0 = fminf(l0, x); l1 = fminf(l1, y); l2 = fminf(l2, z); h0 = fmaxf(h0, x); h1 = fmaxf(h1, y); h2 = fmaxf(h2, z);
+            }
+            px[h][e] = x; py[h][e] = y; pz[h][e] = z; dist[h][e] = dd; org[2 * h + e] = og;
+        }
+        l0 = wave_min_f(l0); l1 = wave_min_f(l1); l2 = wave_min_f(l2); h0 = wave_max_f(h0); h1 = wave_max_f(h1); h2 = wave_max_f(h2);
+        const bool live = __ballot(any) != 0ull;
+        if (lane == h) { bx0 = l0; by0 = l1; bz0 = l2; bx1 = h0; by1 = h1; bz1 = h2; pmax = live ? INFINITY : -1.f; }
+    }
+    // per lane: the low key word of the best point THIS LANE holds among the wave's maxima (0: none), and the wave's max value; both
+    // survive the samples in which the wave updates nothing (the lanes that hold the maximum re-submit it)
+    unsigned mykey = 0u;
+    float wv = -1.f;
+    int cur = s_start;
+    for (int s = 0; s < m; ++s) {
+        if (tid == 0) { idx_out[o0 + s] = p0 + (int)sorig[cur]; s_key[(s + 1) % 3] = 0ull; }
+        if (s + 1 == m) break;
+        const float cx = sx[cur], cy = sy[cur], cz = sz[cur];
+        // lower bound of |p - c|^2 over bucket `lane`'s box, in the per-point operation order
+        unsigned long long need;
+        {
+#pragma clang fp contract(off)
+            const float ex = fmaxf(fmaxf(bx0 - cx, cx - bx1), 0.f), ey = fmaxf(fmaxf(by0 - cy, cy - by1), 0.f), ez = fmaxf(fmaxf(bz0 - cz, cz - bz1), 0.f);
+            const float lb = (ex * ex + ey * ey) + ez * ez;
+            need = __ballot(lane < H && lb < pmax);
+        }
+        if (need != 0ull) {                                // wave-uniform
+            const fps_f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+            int bmi[H];                                    // max of this lane's pair, as int bits (>= 0 or the -1.0 pattern)
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                if (need & (1ull << h)) {
+#pragma clang fp contract(off)
+                    const fps_f2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
+                    const fps_f2 d = (dx * dx + dy * dy) + dz * dz;
+                    dist[h][0] = fminf(dist[h][0], d[0]); dist[h][1] = fminf(dist[h][1], d[1]);
+                }
+                bmi[h] = __float_as_int(fmaxf(fmaxf(dist[h][0], dist[h][1]), 0.f));
+            }
+            // H wave maxima side by side (independent DPP chains: the latency of one); buckets without points stay at -1
+#pragma unroll
+            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0xB1, 0xF, 0xF, false));
+#pragma unroll
+            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0x4E, 0xF, 0xF, false));
+#pragma unroll
+            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0x141, 0xF, 0xF, false));
+#pragma unroll
+            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0x140, 0xF, 0xF, false));
+            int wvi = -1;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const int m4 = max(max(__builtin_amdgcn_readlane(bmi[h], 0), __builtin_amdgcn_readlane(bmi[h], 16)),
+                                   max(__builtin_amdgcn_readlane(bmi[h], 32), __builtin_amdgcn_readlane(bmi[h], 48)));
+                const bool live_h = __builtin_amdgcn_readlane(__float_as_int(pmax), h) >= 0;        // pmax >= 0 (incl. +inf): the bucket has points
+                if (lane == h && live_h) pmax = __int_as_float(m4);
+                if (live_h) wvi = max(wvi, m4);
+            }
+            wv = wvi >= 0 ? __int_as_float(wvi) : -1.f;
+            mykey = 0u;                                    // valid bit | (~orig & 0x1fff) << 13 | sorted position: larger = lower original index
+            if (wvi >= 0) {
+#pragma unroll
+                for (int i = 0; i < PPT; ++i)
+                    if (dist[i >> 1][i & 1] == wv)
+                        mykey = max(mykey, (1u << 26) | ((0x1fffu - (unsigned)org[i]) << 13) | (unsigned)(w * 64 * PPT + i * 64 + lane));
+            }
+        }
+        if (mykey != 0u) atomicMax(&s_key[s % 3], ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)mykey);
+        __syncthreads();
+        cur = (int)((unsigned)(s_key[s % 3] & 0xffffffffull) & 0x1fffu);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Ball query (torch_cluster.radius CUDA semantics): one wave per centre scans its cloud in index order,
 // 64 points per step; ballot + popcount keeps the first `max_nbrs` hits with d^2 < r^2 in order.
 // Writes an int64 COO (row 0 = source point, row 1 = centre), unused slots = -1, ready for morig_csr_build.
@@ -400,7 +589,14 @@ extern "C" int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, cons
 #define MORIG_FPS_CASE(P) hipLaunchKernelGGL((fps_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
 #define MORIG_FPS_LDS_CASE(P) hipLaunchKernelGGL((fps_lds_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
     static const bool old_fps = getenv("MORIG_FPS_OLD") != nullptr;
-    if (ppt <= 8 && !old_fps) {
+    static const bool bkt = [] { const char* e = getenv("MORIG_FPS_BKT"); return !(e && e[0] == '0'); }();
+#define MORIG_FPS_BKT_CASE(P) hipLaunchKernelGGL((fps_bkt_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
+    if (ppt <= 8 && !old_fps && bkt) {
+        if (ppt <= 2) MORIG_FPS_BKT_CASE(2);
+        else if (ppt <= 4) MORIG_FPS_BKT_CASE(4);
+        else MORIG_FPS_BKT_CASE(8);
+    }
+    else if (ppt <= 8 && !old_fps) {
         if (ppt <= 2) MORIG_FPS_LDS_CASE(2);
         else if (ppt <= 4) MORIG_FPS_LDS_CASE(4);
         else MORIG_FPS_LDS_CASE(8);
