@@ -92,6 +92,8 @@ int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_
  *                                                                   models/corrnet.py:43-45
  * (the broadcast is never materialised: the pooled vector enters the next layer as `rowbias`).
  */
+#define MORIG_SPLIT_F16 0
+#define MORIG_SPLIT_BF16 1
 typedef struct morig_gemm_args {
     int32_t M, N, K;          /* logical sizes: Y is M x N, X is M x K                            */
     const float* X; int32_t ldx;
@@ -108,17 +110,19 @@ typedef struct morig_gemm_args {
                                                    * receives 0 (torch_scatter's fill) */
     /* optional fast path (see "split-fp16" below): W_split has the shape/stride of W; overflow is an int32
      * on the device that the kernel sets to 1 if an operand left the fp16 range (result then invalid).
-     * W_split WITHOUT an overflow word (overflow = NULL) selects the bf16 split instead: W_split then holds
-     * bf16 halves (hi = bf16(w), lo = bf16(w - hi), same layout), X is split the same way in the kernel and the
-     * three products run on v_mfma_f32_32x32x16_bf16 -- bf16 keeps float32's exponent range, so there is no range
-     * condition to report; ~16 mantissa bits per operand. Plain stores only (no pool, no split activations):
-     * the gradient contractions of the training path (dX = dU W). */
+     * w_split_format = MORIG_SPLIT_BF16 selects the bf16 split instead: W_split then holds bf16 halves
+     * (hi = bf16(w), lo = bf16(w - hi), same layout), X is split the same way in the kernel and the three products
+     * run on v_mfma_f32_32x32x16_bf16 -- bf16 keeps float32's exponent range, so there is no range condition to
+     * report (overflow may be NULL); ~16 mantissa bits per operand. Plain stores only (no pool, no split
+     * activations): the gradient contractions of the training path (dX = dU W). With MORIG_SPLIT_F16 (= 0) a
+     * missing overflow word is MORIG_E_INVALID: the format is never inferred from a NULL pointer. */
     const void* W_split; int32_t* overflow;
     /* split-fp16 ACTIVATIONS (only with W_split): a matrix window whose first column and row stride are
      * multiples of 32 floats and whose every aligned 32-column chunk holds [32 halves hi | 32 halves lo].
      * x_split: X is in that layout (loader becomes a plain copy: the hi/lo split was done once by the
      * producer instead of once per column tile); y_split: write Y in that layout. */
     int32_t x_split, y_split;
+    int32_t w_split_format;   /* MORIG_SPLIT_F16 (0) or MORIG_SPLIT_BF16 (1): what W_split holds */
 } morig_gemm_args;
 int morig_gemm(const morig_gemm_args* a, void* stream);
 

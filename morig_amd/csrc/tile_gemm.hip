@@ -665,9 +665,12 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
     const double bytes = 4.0 * ((double)a->M * a->K + (double)a->N * a->K + (pool ? 0.0 : (double)a->M * a->N));
 
     const bool f16 = a->W_split != nullptr;
-    // [r04] W_split WITHOUT an overflow word = the bf16 split (W_split then holds bf16 halves; bf16 has float32's exponent range, so
-    // there is no range guard to report through): fp32 X, fp32 Y, plain stores -- the backward contractions
-    const bool bf16 = f16 && a->overflow == nullptr;
+    // the bf16 split (W_split holds bf16 halves; bf16 has float32's exponent range, so there is no range guard to report through):
+    // fp32 X, fp32 Y, plain stores -- the backward contractions. Selected by w_split_format, never inferred from a missing overflow
+    // word: a caller that forgets the word on an fp16 image gets MORIG_E_INVALID, not silently unguarded results
+    if (f16 && a->w_split_format != MORIG_SPLIT_F16 && a->w_split_format != MORIG_SPLIT_BF16) return MORIG_E_INVALID;
+    const bool bf16 = f16 && a->w_split_format == MORIG_SPLIT_BF16;
+    if (f16 && !bf16 && a->overflow == nullptr) return MORIG_E_INVALID;
     if (f16) {
         if (!aligned16(a->W_split)) return MORIG_E_INVALID;
         if (bf16 && (pool || a->x_split || a->y_split)) return MORIG_E_UNSUPPORTED;

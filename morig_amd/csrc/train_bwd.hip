@@ -972,7 +972,10 @@ extern "C" int morig_segmax_affine_arg(const float* Z, int32_t ldz, const int32_
     ProfScope ps(K_MISC, s, 0.0, 0.0);
     const bool v4 = (H & 3) == 0 && vec4_ptr(Z, ldz) && vec4_ptr(out, ldo) && vec4_ptr(arg, ld_arg) && (!zwin || vec4_ptr(zwin, ldw));
     const long threads = (long)n_segments * (H / (v4 ? 4 : 1));
-    if (threads < 32768 && n_segments <= 65535) {        // too few (segment, column group) pairs to fill the chip: the segments are what is long
+    // too few (segment, column group) pairs to fill the chip AND few segments: the segments are what is long (mesh pooling: one
+    // segment per mesh and replica, <= 64 x 5 on the path). A small GRAPH (hundreds of vertices, ~10 rows each) has as few pairs
+    // but short segments: one 256-thread tree per (segment, 16 columns) would be slower there than the per-thread kernel
+    if (threads < 32768 && n_segments <= 400) {
         const dim3 grid(cdiv(H, 16), n_segments);
         if (v4) hipLaunchKernelGGL(segmax_arg_long_kernel<4>, grid, dim3(256), 0, s, Z, ldz, rowptr, H, scale, shift, out, ldo, arg, ld_arg,
                                    zwin, ldw);

@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
         ("Y", c_f32p), ("ldy", C.c_int32),
         ("pool", c_f32p), ("ld_pool", C.c_int32), ("n_seg", C.c_int32),
         ("W_split", C.c_void_p), ("overflow", c_i32p),
-        ("x_split", C.c_int32), ("y_split", C.c_int32),
+        ("x_split", C.c_int32), ("y_split", C.c_int32), ("w_split_format", C.c_int32),
     ]
 
 
@@ -587,7 +587,7 @@ class NativeOps:
         if getattr(lin, "Wsplit_bf16", None) is not None:
             # the bf16 split (no range guard: W_split without an overflow word, include/morig_hip.h): whatever self.precision says
             assert pool is None and not x_split and not y_split
-            a.W_split, a.overflow = lin.Wsplit_bf16.data_ptr(), 0
+            a.W_split, a.overflow, a.w_split_format = lin.Wsplit_bf16.data_ptr(), 0, 1     # MORIG_SPLIT_BF16
         elif self.fast and lin.Wsplit is not None:
             a.W_split, a.overflow = lin.Wsplit.data_ptr(), self._flag(X.base.device).data_ptr()
         a.x_split, a.y_split = int(x_split), int(y_split)

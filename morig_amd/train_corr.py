@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from .native import Mat
 from .runtime import get_ops
-from .train_backward import RowGather, SegMaxPool, _guarded_step, canonical_csr, edge_mlp, gcnrig, linear, mlp_layer
+from .train_backward import RowGather, SegMaxPool, _canonical_csr_of, _guarded_step, edge_mlp, gcnrig, linear, mlp_layer
 
 
 def _mlp(x, layers):
@@ -130,7 +130,7 @@ def _state(net, data, random_start):
     plan = _HostPlan(vcounts, pcounts, [m.ratio for m in (net.pts_sa1_module, net.pts_sa2_module, net.pts_sa3_module)], random_start, dev)
     n = data.vtx.shape[0]
     return dict(B=B, n=n, plan=plan, ptr_v=plan.ptr_v, vtx_batch=vb.long(), vcounts=vcounts,
-                csr_tpl=canonical_csr(ops.csr_build(data.tpl_edge_index, n)), csr_geo=canonical_csr(ops.csr_build(data.geo_edge_index, n)))
+                csr_tpl=_canonical_csr_of(data.tpl_edge_index, n), csr_geo=_canonical_csr_of(data.geo_edge_index, n))
 
 
 def _guarded(data, net, random_start, body):

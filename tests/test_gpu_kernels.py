@@ -128,6 +128,30 @@ def test_gemm_store(ops, M, N, K, relu, bn):
     assert float(yb[:, :2].abs().sum()) == 0 and float(yb[:, 2 + N:].abs().sum()) == 0     # window respected
 
 
+def test_gemm_refuses_a_split_image_without_its_range_guard():
+    """the weight format of morig_gemm is explicit (w_split_format): an fp16-split image handed over WITHOUT the overflow word is
+    MORIG_E_INVALID, not silently taken for the bf16 split; an unknown format value is refused as well"""
+    import ctypes as C
+    o = native.get_ops()
+    lin = packing.to_device(_lin(64, 64, 5, False), DEV)
+    assert lin.Wsplit is not None
+    x = torch.randn(128, 64, device=DEV)
+    y = torch.zeros(128, 64, device=DEV)
+
+    def call(overflow, fmt):
+        a = native.GemmArgs()
+        a.M, a.N, a.K = 128, 64, 64
+        a.X, a.ldx = x.data_ptr(), 64
+        a.W, a.ldw = lin.W.data_ptr(), lin.W.stride(0)
+        a.Y, a.ldy = y.data_ptr(), 64
+        a.W_split, a.overflow, a.w_split_format = lin.Wsplit.data_ptr(), overflow, fmt
+        return o.lib.morig_gemm(C.byref(a), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    assert call(flag.data_ptr(), 0) == 0
+    assert call(0, 0) == -1 and call(flag.data_ptr(), 7) == -1          # MORIG_E_INVALID
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,N,K,nseg", [(1000, 1024, 832, 7), (130, 512, 256, 130), (4096, 1024, 64, 1), (300, 200, 100, 3)])
 def test_gemm_pool_and_rowbias(ops, M, N, K, nseg):
     g = torch.Generator().manual_seed(M + nseg)

@@ -398,7 +398,7 @@ def test_csr_transposed_walks_every_edge_once_by_source():
 
 def test_canonical_csr_does_not_depend_on_the_slot_order_of_the_build():
     """round 4: `canonical_csr` (training graphs) -- whatever order the build left a target's edges in, the segments come out sorted
-    by source, rows past the live count stay behind, and a cached transpose is dropped"""
+    by source, rows past the live count stay behind; the result is a NEW CSR (no cached transpose), the argument is left as built"""
     from morig_amd.native import CSR
     from morig_amd.train_backward import canonical_csr
     g = torch.Generator().manual_seed(3)
@@ -415,8 +415,10 @@ def test_canonical_csr_does_not_depend_on_the_slot_order_of_the_build():
             s2[a:b] = s2[a:b][torch.randperm(b - a, generator=gp)]
         junk = torch.randint(0, n, (cap - E,), generator=gp).int()
         csr = CSR(rowptr, torch.cat([s2.int(), junk]), torch.cat([dst.int(), junk]), n, cap, torch.zeros(1, dtype=torch.int32))
+        built = csr.src.clone()
         csr.transposed()
-        canonical_csr(csr)
+        raw, csr = csr, canonical_csr(csr)
+        assert csr is not raw and torch.equal(raw.src, built) and raw._transposed is not None
         assert csr._transposed is None and torch.equal(csr.dst[:E].long(), dst)
         for v in range(n):
             seg = csr.src[int(rowptr[v]):int(rowptr[v + 1])]
