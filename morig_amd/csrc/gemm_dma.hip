@@ -347,6 +347,20 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
         static const bool want_tr = [] { const char* e = getenv("MORIG_GEMM_TR"); return !(e && e[0] == '0'); }();
         const bool tr = want_tr && !p.pool && (reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0 &&
                         (!p.rowbias || ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0 && (p.ld_rowbias & 3) == 0));
+        // [r05] measured and NOT adopted (profiles/r05j_shortk_128_tile_ab.txt): the short-K store launches (the [A | B] producers,
+        // K = 64 -> 512, 256 -> 1024) on 128 x 128 tiles, two workgroups per CU, so that one's stores run under the other's MFMAs:
+        // 0.698 vs 0.615 ms (K = 256) and 0.233 vs 0.177 ms (K = 64), sustained. The 256 CUs are not in phase, so the chip's HBM writes
+        // are already smooth (K = 64: 3.8 TB/s written), and the small tile doubles the LDS-DMA pieces per MFMA. MORIG_DMA_SHORTK=<K>
+        // selects it for K <= <K> (A/B switch; default 0 = never)
+        static const int shortk = [] { const char* e = getenv("MORIG_DMA_SHORTK"); return e ? atoi(e) : 0; }();
+        if (tr && shortk > 0 && p.K <= shortk && p.N % 128 == 0) {
+            p.tiles_n = p.N / 128;
+            const int nb128 = cdiv(p.M, 128) * p.tiles_n;
+            prof_retag(K_GEMM16_DMA128);
+            hipLaunchKernelGGL((gemm16_dma_kernel<128, 128, 2, 2, true>), dim3(nb128), dim3(256), 0, s, p);
+            MORIG_LAUNCH_CHECK();
+            return MORIG_OK;
+        }
         if (tr) hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, true>), dim3(nb), dim3(512), 0, s, p);
         else    hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, false>), dim3(nb), dim3(512), 0, s, p);
 #ifdef MORIG_DMA_TRACE
