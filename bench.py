@@ -955,7 +955,7 @@ def main():
                 sdt, _, _ = timed_run(train_step, n_secondary, 1)
             secondary["train_step"] = dict(metric="meshes/sec jointnet_motion TRAINING step (train-mode forward + backward, no optimizer), 4 k-vert synthetic",
                                            value=round(nb * n_secondary / sdt, 2), unit="meshes/s", ms_per_step=round(sdt / n_secondary * 1e3, 3),
-                                           steps=n_secondary, warmup=1, batch=nb, config="SURVEY 8(f-4); exact-fp32 MFMA contractions")
+                                           steps=n_secondary, warmup=1, batch=nb, config="SURVEY 8(f-4); forward contractions on exact-fp32 MFMA (MORIG_TRAIN_PRECISION), gradient contractions on the bf16 x 3 split (MORIG_TRAIN_BWD)")
             del tm, d2
             torch.cuda.empty_cache()
         except Exception as e:                                   # the secondary lines never take the headline line down
@@ -981,7 +981,7 @@ def main():
                 sdt, _, _ = timed_run(corr_train_step, n_secondary, 1)
             secondary["corrnet_train_step"] = dict(metric="pairs/sec corrnet TRAINING step (train-mode forward + backward, no optimizer), 4 k-vert mesh + 8 k-point cloud per pair",
                                                    value=round(nbc * n_secondary / sdt, 2), unit="pairs/s", ms_per_step=round(sdt / n_secondary * 1e3, 3),
-                                                   steps=n_secondary, warmup=1, batch=nbc, config="SURVEY 8(f-4); exact-fp32 MFMA contractions")
+                                                   steps=n_secondary, warmup=1, batch=nbc, config="SURVEY 8(f-4); forward contractions on exact-fp32 MFMA (MORIG_TRAIN_PRECISION), gradient contractions on the bf16 x 3 split (MORIG_TRAIN_BWD)")
             del cm, dc
             torch.cuda.empty_cache()
         except Exception as e:
