@@ -138,6 +138,12 @@ class GCNRig(NativeModule):
             glb=packing.pack_mlp_layer(self.mlp_glb[0]),
             g=packing.pack_linear(Wg),                                   # x_global @ Wg^T  -> per-mesh row bias
             t1=packing.pack_linear(Wrest, l1[0].bias, l1[2], in_cols=in_cols, k_total=self.FEAT + F),
+            # [r05] merged layout (3-channel feature next to the positions in ONE 32-column chunk: K = POS + 7 -> POS + 32 instead of
+            # POS + 35 -> POS + 64, one K chunk of 28 less in the largest GEMM of the motion pass); used when gcu_1 runs on the raw
+            # 3-channel rows (morig_edgeconv_x3) and therefore never reads the feature window of the wide buffer (`run`)
+            t1m=(packing.pack_linear(Wrest, l1[0].bias, l1[2],
+                                     in_cols=[self.POS + i for i in range(3)] + [self.POS + 4 + i for i in range(F)] + list(range(self.POS)),
+                                     k_total=self.POS + 4 + F) if F == 3 else None),
             t2=packing.pack_mlp_layer(tr[0][1]),
             t3=packing.pack_linear(tr[1].weight, tr[1].bias),
         )
@@ -154,11 +160,23 @@ class GCNRig(NativeModule):
         n, R, F = pos4.shape[0], replicas, self.chn_feature
         M = n * R
         sp = ops.split_activations                    # GEMM -> GEMM activations in the split-fp16 layout
-        wide = ops.empty(M, self.wide_ld, dev)
-        ops.copy2d_rep(Mat.of(pos4), Mat.of(wide, self.POS, 32, 0, n), R, n, split=sp)       # the same positions in every replica
-        write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
+        import os
+        merged = (F == 3 and feat3 is not None and pk.get("t1m") is not None and hasattr(ops, "edgeconv_x3")
+                  and os.environ.get("MORIG_EDGE_X3", "1") != "0" and os.environ.get("MORIG_MERGED_POS_FEAT", "1") != "0"
+                  and "x3t" in self.gcu_1.packed(dev))
+        if merged:
+            # [pos xyz 0 | feature 0 | zeros] in the ONE chunk at POS: rows of pos4 repeated per replica beside the plain feature rows
+            feat_col, k_t1, t1 = self.POS + 4, self.POS + 4 + F, pk["t1m"]
+            wide = ops.empty(M, self.POS + 32, dev)
+            pf8 = torch.cat([pos4.repeat(R, 1), feat3.view()[:, :4]], 1).contiguous()
+            ops.copy2d_pad(Mat.of(pf8), Mat.of(wide, self.POS, 32), split=sp)
+        else:
+            feat_col, k_t1, t1 = self.FEAT, self.FEAT + F, pk["t1"]
+            wide = ops.empty(M, self.wide_ld, dev)
+            ops.copy2d_rep(Mat.of(pos4), Mat.of(wide, self.POS, 32, 0, n), R, n, split=sp)       # the same positions in every replica
+            write_feature(Mat.of(wide, self.FEAT, self.feat_slot), sp)
         posm = Mat.of(pos4, 0, 3)
-        self.gcu_1.run(ops, posm, Mat.of(wide, self.FEAT, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp,
+        self.gcu_1.run(ops, posm, Mat.of(wide, feat_col, F), csr_tpl, csr_geo, Mat.of(wide, self.X1, self.WIDTHS[0]), R, split=sp,
                        pos_feat=pf[0], x3=feat3 if F == 3 else None)
         # the 128- and 256-wide layers take both graphs with 4-aligned segments (quad-reduced, single-pass epilogue of the
         # wave-specialised kernel: +12..18 % on the geo graph; on the tpl graph, in-degree 7 -> 8 rows, still -4 % since the
@@ -174,7 +192,7 @@ class GCNRig(NativeModule):
         gb = ops.empty(R * n_graphs, 1024, dev)
         ops.gemm(Mat.of(pooled), pk["g"], relu=False, Y=Mat.of(gb))
         h1 = ops.empty(M, 1024, dev)
-        ops.gemm(Mat.of(wide, 0, self.FEAT + F), pk["t1"], relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg,
+        ops.gemm(Mat.of(wide, 0, k_t1), t1, relu=True, Y=Mat.of(h1), rowbias=Mat.of(gb), seg=seg,
                  x_split=sp, y_split=sp)
         h2 = ops.empty(M, 256, dev)
         ops.gemm(Mat.of(h1), pk["t2"], relu=True, Y=Mat.of(h2), x_split=sp, y_split=sp)
