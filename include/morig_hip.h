@@ -563,6 +563,11 @@ int morig_edge_bn_sums_from_products(const float* M, int32_t ldm, const float* d
 int64_t morig_gemm_tn_workspace(int32_t rows, int32_t N, int32_t K);
 int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t rows, const int32_t* rows_dev, int32_t N, int32_t K,
                   float* workspace, int64_t workspace_floats, float* out, int32_t ldo, void* stream);
+/* the same with every row of B centred on b_shift [K] first: C = A^T (B - 1 b_shift^T); b_shift = NULL: plain A^T B. For products that are
+ * used as  M - colsum(A) (x) mean  afterwards (the BatchNorm sums of the first edge layer, morig_edge_bn_sums_from_products): with the rows
+ * centred on that mean the split contraction itself carries no cancellation */
+int morig_gemm_tn_shift(const float* A, int32_t lda, const float* B, int32_t ldb, const float* b_shift, int32_t rows, const int32_t* rows_dev,
+                        int32_t N, int32_t K, float* workspace, int64_t workspace_floats, float* out, int32_t ldo, void* stream);
 
 #ifdef __cplusplus
 }

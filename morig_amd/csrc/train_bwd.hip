@@ -514,6 +514,7 @@ typedef float tn_f32x16 __attribute__((ext_vector_type(16)));
 typedef float tn_f32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                                      const float* __restrict__ bshift,
                                                       int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
                                                       int n_tiles, int k_tiles, int chunks, int per_xcd,
                                                       float* __restrict__ part /* [chunks][N][K] */) {
@@ -543,6 +544,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     // 32-column sub-tiles that lie wholly past N / K (narrow layers: H = 16, 32; K = 3 position inputs) are skipped (wave-uniform)
     const bool on_a[2] = {n0 + wn < N, n0 + wn + 32 < N}, on_b[2] = {k0 + wk < K, k0 + wk + 32 < K};
     tn_f32x4 va[TN_R / 8], vb[TN_R / 8];
+    tn_f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};                            // B - 1 shift^T: this thread's four columns (0 past K, 0 without a shift)
+    if (bshift) { for (int q = 0; q < 4; ++q) if (k0 + lc + q < K) sh4[q] = bshift[k0 + lc + q]; }
     auto fetch = [&](int r0) {                                      // global -> registers (in flight under the MFMAs of a whole stage)
 #pragma unroll
         for (int p = 0; p < TN_R / 8; ++p) {
@@ -555,6 +558,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
                 else { for (int q = 0; q < 4; ++q) if (n0 + lc + q < N) va[p][q] = pa[q]; }
                 if (b_vec && k0 + lc + 4 <= K) vb[p] = *reinterpret_cast<const tn_f32x4*>(pb);
                 else { for (int q = 0; q < 4; ++q) if (k0 + lc + q < K) vb[p][q] = pb[q]; }
+                vb[p] -= sh4;
             }
         }
     };
@@ -648,7 +652,8 @@ __device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned& hi
 // threads (a third less LDS traffic per MFMA: 12 fragment reads per 24 MFMAs instead of 8 per 12, half the conversion writes), for
 // outputs that have enough 256-tiles to fill the chip. The loader needs tile side = threads / 2 on both operands.
 template <bool FULL, int WNT, int WKT, int WVN, int WVK>
-__device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, int N, int K, int n0, int k0,
+__device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
+                                          const float* __restrict__ bshift, int N, int K, int n0, int k0,
                                           int r_begin, int r_end, bool a_vec, bool b_vec, char (&sA)[2][32 * WNT * WVN * TN16_P],
                                           char (&sB)[2][32 * WKT * WVK * TN16_P], float* __restrict__ o) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -669,6 +674,8 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
 #pragma unroll
     for (int b = 0; b < WKT; ++b) on_b[b] = k0 + wk + 32 * b < K;
     tn_f32x4 va[4], vb[4];
+    tn_f32x4 sh4 = {0.f, 0.f, 0.f, 0.f};                              // B - 1 shift^T: this thread's four columns (0 past K, 0 without a shift)
+    if (bshift) { for (int q = 0; q < 4; ++q) if (k0 + 4 * cg + q < K) sh4[q] = bshift[k0 + 4 * cg + q]; }
     const float* pa0 = A + (size_t)(4 * rg) * lda + n0 + 4 * cg;
     const float* pb0 = B + (size_t)(4 * rg) * ldb + k0 + 4 * cg;
     auto fetch = [&](int r0) {                                        // global -> registers (in flight under the MFMAs of a whole stage)
@@ -676,7 +683,7 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 va[i] = *reinterpret_cast<const tn_f32x4*>(pa0 + (size_t)(r0 + i) * lda);
-                vb[i] = *reinterpret_cast<const tn_f32x4*>(pb0 + (size_t)(r0 + i) * ldb);
+                vb[i] = *reinterpret_cast<const tn_f32x4*>(pb0 + (size_t)(r0 + i) * ldb) - sh4;
             }
             return;
         }
@@ -691,6 +698,7 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
                 else { for (int q = 0; q < 4; ++q) if (n0 + 4 * cg + q < N) va[i][q] = pa[q]; }
                 if (b_vec && k0 + 4 * cg + 4 <= K) vb[i] = *reinterpret_cast<const tn_f32x4*>(pb);
                 else { for (int q = 0; q < 4; ++q) if (k0 + 4 * cg + q < K) vb[i][q] = pb[q]; }
+                vb[i] -= sh4;
             }
         }
     };
@@ -761,7 +769,7 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
 
 template <int WNT, int WKT, int WVN, int WVK>
 __global__ __launch_bounds__(64 * WVN * WVK) void gemm_tn16_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                        int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
+                                                        const float* __restrict__ bshift, int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
                                                         int n_tiles, int k_tiles, int chunks, int per_xcd,
                                                         float* __restrict__ part /* [chunks][N][K] */) {
     constexpr int TT = 32 * WNT * WVN;                                // tile side (both operands)
@@ -779,8 +787,8 @@ __global__ __launch_bounds__(64 * WVN * WVK) void gemm_tn16_kernel(const float* 
     if (a_vec && N >= TT && (N & 3) == 0) n0 = min(n0, N - TT);
     if (b_vec && K >= TT && (K & 3) == 0) k0 = min(k0, K - TT);
     float* o = part + (size_t)bz * N * K;
-    if (a_vec && b_vec && n0 + TT <= N && k0 + TT <= K) tn16_tile<true, WNT, WKT, WVN, WVK>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
-    else tn16_tile<false, WNT, WKT, WVN, WVK>(A, lda, B, ldb, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
+    if (a_vec && b_vec && n0 + TT <= N && k0 + TT <= K) tn16_tile<true, WNT, WKT, WVN, WVK>(A, lda, B, ldb, bshift, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
+    else tn16_tile<false, WNT, WKT, WVN, WVK>(A, lda, B, ldb, bshift, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
 }
 
 // partial tiles -> C: 32 output elements x 8 chunk lanes per block; lane j adds chunks j, j + 8, ... in order, the eight lane sums
@@ -792,7 +800,7 @@ __global__ __launch_bounds__(64 * WVN * WVK) void gemm_tn16_kernel(const float* 
 // stage; the groups are added in a fixed order at the end. Products are exact float32, every order is fixed.
 template <int P /* padded output side: 16 or 32 */>
 __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                                            int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
+                                                            const float* __restrict__ bshift, int rows_host, const int* __restrict__ rows_dev, int N, int K, int chunk_rows,
                                                             float* __restrict__ part) {
     constexpr int TPG = (P / 4) * (P / 4);                           // threads per row group
     constexpr int G = 256 / TPG;                                     // row groups: 16 (P = 16) or 4 (P = 32)
@@ -811,6 +819,9 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const float* __restr
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    float shv[CPT];                                                  // B - 1 shift^T: this thread's loader columns
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) shv[j] = (bshift && lc + j < K) ? bshift[lc + j] : 0.f;
     for (int rb = r0; rb < r1; rb += 64) {
         const int r = rb + lr;
         const bool live = r < r1;
@@ -820,14 +831,18 @@ __global__ __launch_bounds__(256) void gemm_tn_small_kernel(const float* __restr
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 *reinterpret_cast<float4*>(&sA[lr * LD + lc + j]) =
                     (live && lc + j < N) ? *reinterpret_cast<const float4*>(A + (size_t)r * lda + lc + j) : z;
-                *reinterpret_cast<float4*>(&sB[lr * LD + lc + j]) =
-                    (live && lc + j < K) ? *reinterpret_cast<const float4*>(B + (size_t)r * ldb + lc + j) : z;
+                float4 bq = z;
+                if (live && lc + j < K) {
+                    bq = *reinterpret_cast<const float4*>(B + (size_t)r * ldb + lc + j);
+                    bq.x -= shv[j]; bq.y -= shv[j + 1]; bq.z -= shv[j + 2]; bq.w -= shv[j + 3];
+                }
+                *reinterpret_cast<float4*>(&sB[lr * LD + lc + j]) = bq;
             }
         } else {
 #pragma unroll
             for (int j = 0; j < CPT; ++j) {
                 sA[lr * LD + lc + j] = (live && lc + j < N) ? A[(size_t)r * lda + lc + j] : 0.f;
-                sB[lr * LD + lc + j] = (live && lc + j < K) ? B[(size_t)r * ldb + lc + j] : 0.f;
+                sB[lr * LD + lc + j] = (live && lc + j < K) ? B[(size_t)r * ldb + lc + j] - shv[j] : 0.f;
             }
         }
         __syncthreads();
@@ -1098,8 +1113,20 @@ extern "C" int64_t morig_gemm_tn_workspace(int32_t rows, int32_t N, int32_t K) {
     return (int64_t)tn_chunks(rows, N, K) * N * K;
 }
 
+extern "C" int morig_gemm_tn_shift(const float* A, int32_t lda, const float* B, int32_t ldb, const float* b_shift, int32_t rows,
+                                   const int32_t* rows_dev, int32_t N, int32_t K, float* workspace, int64_t workspace_floats, float* out,
+                                   int32_t ldo, void* stream);
 extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_t ldb, int32_t rows, const int32_t* rows_dev, int32_t N,
                              int32_t K, float* workspace, int64_t workspace_floats, float* out, int32_t ldo, void* stream) {
+    return morig_gemm_tn_shift(A, lda, B, ldb, nullptr, rows, rows_dev, N, K, workspace, workspace_floats, out, ldo, stream);
+}
+
+// C = A^T (B - 1 b_shift^T): every row of B is centred on the vector b_shift [K] before it is split / multiplied (b_shift = NULL:
+// plain A^T B). For products that are used as  M - colsum(A) (x) mean  afterwards (the BatchNorm sums of the first edge layer):
+// with the rows centred on that mean the contraction itself carries no cancellation
+extern "C" int morig_gemm_tn_shift(const float* A, int32_t lda, const float* B, int32_t ldb, const float* b_shift, int32_t rows,
+                                   const int32_t* rows_dev, int32_t N, int32_t K, float* workspace, int64_t workspace_floats, float* out,
+                                   int32_t ldo, void* stream) {
     if (!A || !B || !workspace || !out || rows < 0 || N <= 0 || K <= 0 || lda < N || ldb < K || ldo < K) return MORIG_E_INVALID;
     const int chunks = tn_chunks(rows, N, K);
     if (workspace_floats < (int64_t)chunks * N * K) return MORIG_E_INVALID;
@@ -1111,9 +1138,9 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
     if (N <= 32 && K <= 32 && !getenv("MORIG_TN_NO_SMALL")) {
         const int chunk_rows = cdiv(cdiv(rows > 0 ? rows : 1, chunks), 64) * 64;
         if (N <= 16 && K <= 16)
-            hipLaunchKernelGGL(gemm_tn_small_kernel<16>, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, workspace);
+            hipLaunchKernelGGL(gemm_tn_small_kernel<16>, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, b_shift, rows, rows_dev, N, K, chunk_rows, workspace);
         else
-            hipLaunchKernelGGL(gemm_tn_small_kernel<32>, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, workspace);
+            hipLaunchKernelGGL(gemm_tn_small_kernel<32>, dim3(chunks), dim3(256), 0, s, A, lda, B, ldb, b_shift, rows, rows_dev, N, K, chunk_rows, workspace);
         MORIG_LAUNCH_CHECK();
         launch_tn_reduce(workspace, chunks, N, K, out, ldo, s);
         MORIG_LAUNCH_CHECK();
@@ -1134,17 +1161,17 @@ extern "C" int morig_gemm_tn(const float* A, int32_t lda, const float* B, int32_
     if (split16 && !no_big && N >= 256 && K >= 256 && (long)tiles_big * chunks_big >= 200) {
         const int chunk_rows_b = cdiv(cdiv(rows > 0 ? rows : 1, chunks_big), RS) * RS;
         const int per_xcd_b = cdiv((long)tiles_big * chunks_big, 8);
-        hipLaunchKernelGGL((gemm_tn16_kernel<4, 2, 2, 4>), dim3(per_xcd_b * 8), dim3(512), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows_b,
+        hipLaunchKernelGGL((gemm_tn16_kernel<4, 2, 2, 4>), dim3(per_xcd_b * 8), dim3(512), 0, s, A, lda, B, ldb, b_shift, rows, rows_dev, N, K, chunk_rows_b,
                            n_big, k_big, chunks_big, per_xcd_b, workspace);
         MORIG_LAUNCH_CHECK();
         launch_tn_reduce(workspace, chunks_big, N, K, out, ldo, s);
         MORIG_LAUNCH_CHECK();
         return MORIG_OK;
     } else if (split16)
-        hipLaunchKernelGGL((gemm_tn16_kernel<2, 2, 2, 2>), dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles,
+        hipLaunchKernelGGL((gemm_tn16_kernel<2, 2, 2, 2>), dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, b_shift, rows, rows_dev, N, K, chunk_rows, n_tiles,
                            k_tiles, chunks, per_xcd, workspace);
     else
-        hipLaunchKernelGGL(gemm_tn_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, rows, rows_dev, N, K, chunk_rows, n_tiles, k_tiles,
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(per_xcd * 8), dim3(256), 0, s, A, lda, B, ldb, b_shift, rows, rows_dev, N, K, chunk_rows, n_tiles, k_tiles,
                            chunks, per_xcd, workspace);
     MORIG_LAUNCH_CHECK();
     launch_tn_reduce(workspace, chunks, N, K, out, ldo, s);

@@ -151,6 +151,8 @@ _SIGNATURES = {
     "morig_gemm_tn_workspace": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "morig_gemm_tn": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int64, c_f32p,
                                 C.c_int32, C.c_void_p]),
+    "morig_gemm_tn_shift": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int64,
+                                      c_f32p, C.c_int32, C.c_void_p]),
     "morig_knn_interpolate": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p,
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_i32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
     "morig_knn_search": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
@@ -887,17 +889,21 @@ class NativeOps:
                                                         _p(out[0]), _p(out[1]), _stream()), "morig_edge_bn_sums_from_products")
         return out[0], out[1]
 
-    def gemm_tn(self, A: Mat, B: Mat, out: Optional[Mat] = None, rows_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """A^T B over the rows: [A.cols, B.cols] (the weight gradient dU^T X)."""
+    def gemm_tn(self, A: Mat, B: Mat, out: Optional[Mat] = None, rows_dev: Optional[torch.Tensor] = None,
+                b_shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """A^T B over the rows: [A.cols, B.cols] (the weight gradient dU^T X). b_shift [B.cols]: every row of B is centred on it first,
+        A^T (B - 1 b_shift^T)."""
         _need_gpu(A.base, B.base)
+        if b_shift is not None:
+            assert b_shift.dtype == torch.float32 and b_shift.is_contiguous() and b_shift.numel() >= B.cols
         assert A.rows == B.rows
         dev = A.base.device
         if out is None:
             out = Mat.of(torch.empty((A.cols, B.cols), dtype=torch.float32, device=dev))
         n_ws = int(self.lib.morig_gemm_tn_workspace(A.rows, A.cols, B.cols))
         ws = torch.empty(max(n_ws, 1), dtype=torch.float32, device=dev)
-        check(self.lib.morig_gemm_tn(A.ptr, A.ld, B.ptr, B.ld, A.rows, _p(rows_dev), A.cols, B.cols, _p(ws), ws.numel(), out.ptr, out.ld,
-                                     _stream()), "morig_gemm_tn")
+        check(self.lib.morig_gemm_tn_shift(A.ptr, A.ld, B.ptr, B.ld, _p(b_shift), A.rows, _p(rows_dev), A.cols, B.cols, _p(ws), ws.numel(),
+                                           out.ptr, out.ld, _stream()), "morig_gemm_tn_shift")
         return out.base
 
     def radius_sample(self, x: Mat, y: Mat, radius: float, max_nbrs: int, seed: int):

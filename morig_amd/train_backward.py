@@ -339,16 +339,19 @@ class EdgeMLPTrain(torch.autograd.Function):
         need = ctx.needs_input_grad                      # (x, W1, b1, g1, be1, W2, b2, g2, be2, ...): frozen layers skip their dW GEMMs
         db2 = ops.segmax_bn_relu_backward(DO, arg, Z2, csr.rowptr, csr.dst, mean2, rstd2, g2.detach().float().contiguous(), k2, kx2, DU2,
                                           want_sum=True)                               # db2 = column sums of du2, from the same pass
-        # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1
-        M = ops.gemm_tn(DU2, Z1, rows_dev=e_live) if need[5] else None
-        dW2 = (M * s1[None, :H] + db2[:, None] * t1[None, :H]) if need[5] else None
+        # Linear2 on h = s1 Z1 + t1:  dW2 = du2^T h = (du2^T Z1) diag(s1) + db2 (x) t1. The product is taken on rows CENTRED on the layer's
+        # batch mean, Mc = du2^T (Z1 - 1 mean1^T) = M - db2 (x) mean1: Z1 is post-ReLU (mean > 0, often >> std), and the BatchNorm sums
+        # below need exactly M - db2 (x) mean1 -- formed after a bf16 x 3 contraction of the uncentred rows it cancelled heavily
+        m1c = mean1.detach().float().contiguous()
+        Mc = ops.gemm_tn(DU2, Z1, rows_dev=e_live, b_shift=m1c) if need[5] else None
+        dW2 = ((Mc + db2[:, None] * m1c[None, :H]) * s1[None, :H] + db2[:, None] * t1[None, :H]) if need[5] else None
         w2t = ctx.packs.get("w2T", (W2,), lambda: _pack_bwd(W2.detach().t().contiguous(), dev))
         dh = _gemm_f32(ops, DU2, w2t, H)                                               # d(s1 Z1 + t1)  [capacity, H]
         DH = Mat.of(dh, 0, H)
         # BatchNorm1 + ReLU over the edges. Its two sums over dh = du2 W2 follow from M = du2^T Z1, db2 and W2 (H x H algebra in fp64):
         # no pass over the edge rows -- unless Linear2 is frozen and M was never formed
-        if M is not None and not edge_sums_by_pass():
-            sdz1, sdzx1 = ops.edge_bn_sums_from_products(M, db2, W2.detach().float().contiguous(), mean1, rstd1)
+        if Mc is not None and not edge_sums_by_pass():
+            sdz1, sdzx1 = ops.edge_bn_sums_from_products(Mc, db2, W2.detach().float().contiguous(), torch.zeros_like(m1c), rstd1)
         else:
             sdz1, sdzx1 = ops.bn_backward_stats(DH, Z1, mean1, rstd1, rows_dev=e_live)
         k1, kx1, _, _ = sync_backward_sums(sdz1, sdzx1, ctx.shares[0])

@@ -691,9 +691,12 @@ def _emu_edge_bn_sums_from_products(self, M, db2, W2, mean, rstd):
     return a.float(), (rstd[:h_in].double() * (b - mean[:h_in].double() * a)).float()
 
 
-def _emu_gemm_tn(self, A: Mat, B: Mat, out=None, rows_dev=None):
+def _emu_gemm_tn(self, A: Mat, B: Mat, out=None, rows_dev=None, b_shift=None):
     r = _rows(A, rows_dev)
-    res = (A.view()[:r].double().t() @ B.view()[:r].double()).float()
+    b = B.view()[:r].double()
+    if b_shift is not None:                                  # rows of B centred on b_shift first (morig_gemm_tn_shift)
+        b = b - b_shift[:B.cols].double()[None, :]
+    res = (A.view()[:r].double().t() @ b).float()
     if out is not None:
         out.view().copy_(res)
         return out.base

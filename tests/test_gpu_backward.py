@@ -314,6 +314,30 @@ def test_edge_backward_operators(n, e, H, ld):
     dhd = dh64.float().to(DEV)
     by_pass = ops.bn_backward_stats(Mat.of(dhd, 0, H), Mat.of(z1[:E].contiguous(), 0, H), m1, r1)
     assert float(((by_pass[1].cpu().double() - ref_b).abs() / bound).max()) <= 1e-5
+    # (2d) the same sums with the contraction taken on rows CENTRED on the batch mean (morig_gemm_tn_shift; what edge_mlp's backward does):
+    # Mc = du2^T (Z1 - 1 mean^T) needs no  - db2 (x) mean  afterwards, so nothing cancels -- also when mean >> std, the post-ReLU case
+    # the uncentred product was weakest in: here every column of Z1 is lifted by 40 standard deviations
+    for lift in (0.0, 40.0):
+        z1l = z1.clone()
+        z1l[:E, :H] += lift * z1[:E, :H].std(0)[None, :]
+        ml, vl, _ = ops.col_stats(Mat.of(z1l, 0, H), rows_dev=rd)
+        rl = torch.rsqrt(vl + 1e-5)
+        xh = (z1l[:E, :H].double().cpu() - ml.double().cpu()) * rl.double().cpu()
+        want_b = (dh64 * xh).sum(0)
+        bnd = dh64.norm(dim=0) * xh.norm(dim=0) + 1e-30
+        Mc = ops.gemm_tn(Mat.of(du2, 0, H), Mat.of(z1l, 0, H), rows_dev=rd, b_shift=ml.contiguous())
+        _, cb = ops.edge_bn_sums_from_products(Mc, sum_g, W2.to(DEV), torch.zeros_like(ml), rl)
+        err_c = float(((cb.cpu().double() - want_b).abs() / bnd).max())
+        Mu = ops.gemm_tn(Mat.of(du2, 0, H), Mat.of(z1l, 0, H), rows_dev=rd)
+        _, ub = ops.edge_bn_sums_from_products(Mu, sum_g, W2.to(DEV), ml, rl)
+        err_u = float(((ub.cpu().double() - want_b).abs() / bnd).max())
+        assert err_c <= 2e-5, (lift, err_c, err_u)                      # centred: float32-class whatever the mean
+        if lift:
+            assert err_u > 4 * err_c, (err_c, err_u)                    # (what the centring buys; the uncentred form degrades with the lift)
+        back = (Mc + sum_g[:, None] * ml[None, :]).cpu().double()       # M = Mc + db2 (x) mean: the weight gradient's product
+        m64 = du2[:E, :H].double().cpu().t() @ z1l[:E, :H].double().cpu()
+        sc64 = float((du2[:E, :H].double().cpu().abs().t() @ z1l[:E, :H].double().cpu().abs()).max())
+        assert float((back - m64).abs().max()) <= 1e-5 * sc64 and float((Mu.cpu().double() - m64).abs().max()) <= 1e-5 * sc64
     # (3) BatchNorm + ReLU inside the scatter sums; the plain scatter; both reproducible bit for bit
     Y = torch.relu(torch.randn(cap, ld, generator=g)); Y[E:] = float("nan")
     G = torch.randn(cap, ld, generator=g); G[E:] = float("nan")
