@@ -653,7 +653,7 @@ __device__ __forceinline__ void split_pair_bf16(float x0, float x1, unsigned& hi
 // outputs that have enough 256-tiles to fill the chip. The loader needs tile side = threads / 2 on both operands.
 template <bool FULL, int WNT, int WKT, int WVN, int WVK>
 __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb,
-                                          const float* __restrict__ bshift, int N, int K, int n0, int k0,
+                                          const float* __restrict__ bshift, int N, int K, int n0, int k0, int n_own, int k_own,
                                           int r_begin, int r_end, bool a_vec, bool b_vec, char (&sA)[2][32 * WNT * WVN * TN16_P],
                                           char (&sB)[2][32 * WKT * WVK * TN16_P], float* __restrict__ o) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -763,7 +763,9 @@ __device__ __forceinline__ void tn16_tile(const float* __restrict__ A, int lda, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + wn + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, k = k0 + wk + b * 32 + l31;
-                if (FULL || (n < N && k < K)) o[(size_t)n * K + k] = acc[a][b][r];
+                // a tile that was moved back inside the matrix recomputes part of its neighbour's block: it stores only what it owns
+                // (n >= n_own, k >= k_own), so no element of `part` has two writers
+                if ((FULL || (n < N && k < K)) && n >= n_own && k >= k_own) o[(size_t)n * K + k] = acc[a][b][r];
             }
 }
 
@@ -779,6 +781,7 @@ __global__ __launch_bounds__(64 * WVN * WVK) void gemm_tn16_kernel(const float* 
     if ((int)(blockIdx.x >> 3) >= per_xcd || logical >= n_tiles * k_tiles * chunks) return;
     const int bx = logical % n_tiles, by = (logical / n_tiles) % k_tiles, bz = logical / (n_tiles * k_tiles);
     int n0 = bx * TT, k0 = by * TT;
+    const int n_own = n0, k_own = k0;                                 // first row / column of the block this workgroup owns
     const int r_begin = bz * chunk_rows, r_end = min(r_begin + chunk_rows, rows);
     const bool a_vec = (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
     const bool b_vec = (ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0;
@@ -787,8 +790,8 @@ __global__ __launch_bounds__(64 * WVN * WVK) void gemm_tn16_kernel(const float* 
     if (a_vec && N >= TT && (N & 3) == 0) n0 = min(n0, N - TT);
     if (b_vec && K >= TT && (K & 3) == 0) k0 = min(k0, K - TT);
     float* o = part + (size_t)bz * N * K;
-    if (a_vec && b_vec && n0 + TT <= N && k0 + TT <= K) tn16_tile<true, WNT, WKT, WVN, WVK>(A, lda, B, ldb, bshift, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
-    else tn16_tile<false, WNT, WKT, WVN, WVK>(A, lda, B, ldb, bshift, N, K, n0, k0, r_begin, r_end, a_vec, b_vec, sA, sB, o);
+    if (a_vec && b_vec && n0 + TT <= N && k0 + TT <= K) tn16_tile<true, WNT, WKT, WVN, WVK>(A, lda, B, ldb, bshift, N, K, n0, k0, n_own, k_own, r_begin, r_end, a_vec, b_vec, sA, sB, o);
+    else tn16_tile<false, WNT, WKT, WVN, WVK>(A, lda, B, ldb, bshift, N, K, n0, k0, n_own, k_own, r_begin, r_end, a_vec, b_vec, sA, sB, o);
 }
 
 // partial tiles -> C: 32 output elements x 8 chunk lanes per block; lane j adds chunks j, j + 8, ... in order, the eight lane sums
