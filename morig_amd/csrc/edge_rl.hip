@@ -156,8 +156,10 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
             float hb, lb;
             split_pair_f16(v[i], v[i + 1], hb, lb);
             zh[par][mt][2 * h + (i >> 1)] = hb; zl[par][mt][2 * h + (i >> 1)] = lb;
+#ifndef RL_NO_AMAX                                             // (measurement build: no range guard)
             { float am = amax; const float u0 = v[i], u1 = v[i + 1]; asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(am) : "v"(u0), "v"(u1)); amax = am; }   // (in place: left to the scheduler, the
                                                                                                  // four values were kept alive and spilled)
+#endif
         }
     };
 
