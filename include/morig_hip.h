@@ -156,8 +156,17 @@ typedef struct morig_edgeconv_args {
     float* out; int32_t ldo;           /* out[row][0..H)                                  */
     const void* W2_split; int32_t* overflow;   /* optional split-fp16 fast path (H >= 32), as in morig_gemm_args */
     int32_t quad_aligned;              /* the CSR was built with MORIG_CSR_PAD4: segments are 4-aligned */
+    int32_t out_split;                 /* store `out` in the split-fp16 activation layout (morig_gemm_args.x_split: per 32-column chunk
+                                          32 hi halves, then 32 lo halves) so that the unit's MLP (models/basic_modules.py:216-217,
+                                          `self.mlp(torch.cat(...))`) reads it through the LDS-DMA GEMM without an fp32 -> fp16 pass.
+                                          Needs W2_split + overflow, `out` 128-byte aligned, ldo % 32 == 0 and the launch on one of the
+                                          4-aligned-CSR kernels (H = 128 / 256): ask morig_edgeconv_can_split_out first;
+                                          MORIG_E_UNSUPPORTED otherwise. *overflow is raised when a result leaves the fp16 range. */
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
+/* 1 when morig_edgeconv would honour out_split for these arguments (pointers, widths, CSR form and the library's environment
+ * switches are looked at; out_split itself is ignored), 0 otherwise. Launches nothing. */
+int morig_edgeconv_can_split_out(const morig_edgeconv_args* a);
 
 /* The same EdgeConv for a vertex input of 3 channels (the position branches, models/basic_modules.py:193-195 `nn_pos([pos_i, pos_j - pos_i])`,
  * and motionNet's first unit, whose feature is the 3-channel keyframe flow, models/rignet.py:86): the first Linear is evaluated inside the

@@ -48,6 +48,8 @@ struct EdgePcParams {
     const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int rep_in; int rep_out; int tiles_per_rep;
     int replicas;
     float* Y; int ldy;
+    int y16;                                     // edge_rl.hip / edge_ws.hip: results leave in the split-fp16 activation layout
+    int run;                                     // edge_rl.hip / edge_ws.hip: consecutive tiles per wave / workgroup (open segments are carried)
     int* ovf;
     int quad;                                    // CSR segments are 4-aligned (MORIG_CSR_PAD4)
     unsigned long long* trace;                   // -DMORIG_PP_TRACE builds only

@@ -33,6 +33,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 template <int C> using RC = std::integral_constant<int, C>;
 
+// Y16: whole segments leave as split-fp16 halves (per 32-column chunk 32 hi, then 32 lo: the layout the unit's MLP GEMM DMAs into LDS);
+// tile-straddling segments stay fp32 atomics and are rewritten by split_boundary_rows (tile_gemm.hip)
+template <bool Y16>
 __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p) {
     constexpr int H = 128, BM = 64, MT = 2, NT = 4, NS = H / 16;
     constexpr int WB = NS * NT * 2 * 1024;               // W2 image: [step][column tile][hi | lo][lane] x 16 B = 64 KB
@@ -70,16 +73,27 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
         eg[pr] = es[pr] < 0.f ? -1.f : 1.f;
     }
 
-    // ---- this WAVE's tile list: XCD x owns a contiguous range of 64-row tiles; the waves of a workgroup take adjacent tiles ----
+    // ---- this WAVE's tile list: the 64-row tiles (numbered over the replicas) are cut into RUNS of R = 2^lg consecutive tiles; XCD x owns
+    // a contiguous range of runs, the waves of a workgroup take adjacent runs. Inside a run the wave carries a segment that is still
+    // open at the end of a tile into the next one (cm0 / cm1 below): only rows that straddle a RUN boundary are shared through atomics
+    // (R = 1: every boundary, the [r04] form -- 19 % of the geo graph's rows went through init + atomics then) ----
     const int Etot = p.rowptr[p.n_nodes];
     const int tpr = (Etot + BM - 1) / BM;
     const int T = tpr * p.replicas;
+    const int lg = 31 - __builtin_clz(p.run > 0 ? p.run : 1), R = 1 << lg;
+    const int NR = (T + R - 1) >> lg;
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-    const int t_lo = (int)((long long)T * xcd / 8), t_hi = (int)((long long)T * (xcd + 1) / 8);
+    const int r_lo = (int)((long long)NR * xcd / 8), r_hi = (int)((long long)NR * (xcd + 1) / 8);
     const int wi = bi * 8 + wave, nw = nbx * 8;
-    const int n_my = (t_hi - t_lo - wi + nw - 1) / nw;
-    if (n_my <= 0) return;                               // wave-uniform
-    auto tile_of = [&](int j) __attribute__((always_inline)) { return t_lo + wi + (j < n_my ? j : n_my - 1) * nw; };
+    const int nruns = (r_hi - r_lo - wi + nw - 1) / nw;
+    if (nruns <= 0) return;                              // wave-uniform
+    const int n_my = ((nruns - 1) << lg) + min(R, T - ((r_lo + wi + (nruns - 1) * nw) << lg));
+    auto tile_of = [&](int j) __attribute__((always_inline)) {
+        const int jj = j < n_my ? j : n_my - 1;
+        return ((r_lo + wi + (jj >> lg) * nw) << lg) + (jj & (R - 1));
+    };
+    float cm0 = 0.f, cm1 = 0.f;                          // the open segment carried into the next tile of the run (this lane's 2 columns)
+    bool cpart = false;                                  // ... and whether it came in over the run's first boundary (shared row)
 
     // ---- gather state ----
     // B instruction i covers rows 32 i + (lane >> 1), 16-byte piece lane & 1 of the row's 32 bytes; the A instruction (lanes 0..31)
@@ -192,7 +206,8 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
     };
 
     // ---- epilogue of the computed tile: everything in registers ----
-    auto epilogue = [&]() __attribute__((always_inline)) {
+    auto epilogue = [&](int j) __attribute__((always_inline)) {
+        const bool run_first = (j & (R - 1)) == 0, run_last = (j & (R - 1)) == R - 1 || j == n_my - 1;   // wave-uniform
         // the min / max below read the accumulators from inline assembly: ordered behind the MFMAs and given their wait states by hand
         // (edge_pp.hip write_z_quad; DESIGN section 5, lesson 11)
         {
@@ -239,11 +254,22 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
             const float m1 = fmaxf(x1 * eg[1] + eb[1], 0.f) * es[1] + et[1];
             float* o = obase + (size_t)id * p.ldy;
             if (partial) { atomic_max_f32(o, m0); atomic_max_f32(o + 32, m1); }
+            else if constexpr (Y16) {
+                // my two columns sit in chunks 2 hi and 2 hi + 1 at position l31: [hi half | +64 B lo half] in each 128-byte chunk
+                float hp, lp;
+                split_pair_f16(m0, m1, hp, lp);
+                const unsigned hu = __float_as_uint(hp), lu = __float_as_uint(lp);
+                unsigned short* oh = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(o - l31) + 2 * l31);
+                oh[0] = (unsigned short)hu;        oh[32] = (unsigned short)lu;
+                oh[64] = (unsigned short)(hu >> 16); oh[96] = (unsigned short)(lu >> 16);
+                float am = amax; asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(am) : "v"(m0), "v"(m1)); amax = am;
+            }
             else { o[0] = m0; o[32] = m1; }
         };
         float m0 = seq[0][0], m1 = seq[1][0];
         int id = first;
         bool part = first_cont;
+        if (first_cont && !run_first) { m0 = fmaxf(m0, cm0); m1 = fmaxf(m1, cm1); part = cpart; }     // continued inside the run: mine
 #pragma unroll
         for (int i = 1; i < 16; ++i) {
             const int di = __builtin_amdgcn_readlane(cq, 2 * i);
@@ -255,7 +281,8 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
             }
         }
         const bool last_cont = crow0 + BM < Etot && id == after;
-        flush(id, m0, m1, part || last_cont);
+        if (last_cont && !run_last) { cm0 = m0; cm1 = m1; cpart = part; }                            // goes on in my next tile
+        else flush(id, m0, m1, part || last_cont);
     };
 
     // ---- one unit = the 6 MFMAs of (step s, column tile nt) and its share of the side work: the conversions of step s + 1 ----
@@ -333,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void edge_rl128_kernel(const EdgePcParams p
     for (int j = 0; j < n_my; ++j) {
         step(RC<0>{}, j); step(RC<1>{}, j); step(RC<2>{}, j); step(RC<3>{}, j);
         step(RC<4>{}, j); step(RC<5>{}, j); step(RC<6>{}, j); step(RC<7>{}, j);
-        epilogue();
+        epilogue(j);
         switch_compute();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup
@@ -364,7 +391,8 @@ int launch_edge_rl(const EdgePcParams& p0, int ntiles, hipStream_t s) {
     if (avail < 8) avail = 8;
     const int nwg = (ntiles + 7) / 8;
     const int grid = nwg < avail ? ((nwg + 7) / 8) * 8 : avail;
-    hipLaunchKernelGGL(edge_rl128_kernel, dim3(grid), dim3(512), 0, s, p);
+    if (p.y16) hipLaunchKernelGGL(edge_rl128_kernel<true>, dim3(grid), dim3(512), 0, s, p);
+    else       hipLaunchKernelGGL(edge_rl128_kernel<false>, dim3(grid), dim3(512), 0, s, p);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

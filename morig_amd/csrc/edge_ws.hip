@@ -50,7 +50,9 @@ template <int C> using WC = std::integral_constant<int, C>;
 // gathered B rows + 4 KB of A quads per workgroup.
 template <int H> struct WsGeom { static constexpr int BM = H == 256 ? 64 : 128, KC = H == 256 ? 64 : 32; };
 
-template <int H>
+// Y16: whole segments leave as split-fp16 halves (per 32-column chunk 32 hi, then 32 lo: the layout the unit's MLP GEMM DMAs into LDS);
+// tile-straddling segments stay fp32 atomics and are rewritten by split_boundary_rows (tile_gemm.hip)
+template <int H, bool Y16 = false>
 __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     constexpr int BM = WsGeom<H>::BM, KC = WsGeom<H>::KC;
     constexpr int LDB = 4 * KC + 16;                     // bytes per Z row = [KC hi | KC lo | 16 pad]
@@ -73,13 +75,15 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     constexpr int SWITCHC = NC >= 3 ? NC - 3 : (NC + NC - 3) % NC;   // chunk whose D() is the first of the NEXT tile
     static_assert(NC == 4, "index prefetch schedule");
 
-    __shared__ __attribute__((aligned(128))) char smem[3 * RAWS + 2 * ZSTAGE + NQ * ZQ * 4 + 3 * 32 * 4 + 64 + 3 * H * 4];
+    __shared__ __attribute__((aligned(128))) char smem[3 * RAWS + 2 * ZSTAGE + NQ * ZQ * 4 + 3 * 32 * 4 + 64 + 3 * H * 4 + 2 * H * 4 + 16];
     char* raw = smem;
     char* zring = smem + 3 * RAWS;
     float* Z = reinterpret_cast<float*>(zring + 2 * ZSTAGE);
     int* sq_all = reinterpret_cast<int*>(zring + 2 * ZSTAGE + NQ * ZQ * 4);   // [3][32] destination id per quad row
     int* sflag = sq_all + 3 * 32;                                              // [3][2] first / last segment continues
     float* sbias = reinterpret_cast<float*>(sflag + 16);                       // [3][H] bias, BN scale, BN shift
+    float* carry = sbias + 3 * H;                                              // [2][H] open segment handed to the next tile of the run (tile parity)
+    int* cshared = reinterpret_cast<int*>(carry + 2 * H);                      // [2] ... and whether it entered over the run's first boundary
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -90,11 +94,20 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     const int Etot = p.rowptr[p.n_nodes];
     const int tpr = (Etot + BM - 1) / BM;
     const int T = tpr * p.replicas;
+    // [r05] the tiles (numbered over the replicas) are cut into RUNS of R = 2^lg consecutive tiles and a workgroup works through whole
+    // runs: a segment that is still open at the end of a tile is handed to the next tile through `carry` instead of going through
+    // atomics -- only rows that straddle a RUN boundary are shared between workgroups (R = 1: every boundary, the [r04] form)
+    const int lg = 31 - __builtin_clz(p.run > 0 ? p.run : 1), R = 1 << lg;
+    const int NR = (T + R - 1) >> lg;
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-    const int t_lo = (int)((long long)T * xcd / 8), t_hi = (int)((long long)T * (xcd + 1) / 8);
-    const int n_my = (t_hi - t_lo - bi + nbx - 1) / nbx;
-    if (n_my <= 0) return;                                                     // block-uniform
-    auto tile_of = [&](int j) __attribute__((always_inline)) { return t_lo + bi + (j < n_my ? j : n_my - 1) * nbx; };
+    const int r_lo = (int)((long long)NR * xcd / 8), r_hi = (int)((long long)NR * (xcd + 1) / 8);
+    const int nruns = (r_hi - r_lo - bi + nbx - 1) / nbx;
+    if (nruns <= 0) return;                                                    // block-uniform
+    const int n_my = ((nruns - 1) << lg) + min(R, T - ((r_lo + bi + (nruns - 1) * nbx) << lg));
+    auto tile_of = [&](int j) __attribute__((always_inline)) {
+        const int jj = j < n_my ? j : n_my - 1;
+        return ((r_lo + bi + (jj >> lg) * nbx) << lg) + (jj & (R - 1));
+    };
     if (tid < H) { sbias[tid] = p.bias[tid]; sbias[H + tid] = p.scale[tid]; sbias[2 * H + tid] = p.shift[tid]; }
 
     // ---- resident W2 slice. Z slot s2 = 2 * step + hi of a chunk holds the chunk's k = 4 s2 + {0..3} and KC/2 + 4 s2 + {0..3}
@@ -295,9 +308,11 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     // partner wave on the SIMD the epilogue's latency chains are already covered, the extra bit walking is not)
     // segmented max over the NQ quad rows of a finished tile: a wave owns NQ/8 quad rows and every segment that STARTS
     // there; a lane holds VEC adjacent columns; two ballots list the segment starts (same scheme as edge_pp.hip)
-    auto scan = [&](int t, int slot) __attribute__((always_inline)) {
+    auto scan = [&](int js, int slot) __attribute__((always_inline)) {
         typedef float fvec __attribute__((ext_vector_type(VEC)));
         if (p.dbg & 1) return;
+        const int t = tile_of(js);
+        const bool run_first = (js & (R - 1)) == 0, run_last = (js & (R - 1)) == R - 1 || js == n_my - 1;
         const int rep = t / tpr;
         const int* sq = sq_all + slot * 32;
         const bool first_cont = sflag[slot * 2] != 0, last_cont = sflag[slot * 2 + 1] != 0;
@@ -323,11 +338,26 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], fmaxf(z0[v], z1[v]));
             }
+            // the run's bookkeeping (block-uniform branches): a first segment that began in my previous tile takes what that tile left
+            // in `carry`; a last segment that goes on into my next tile is left there (max domain, before the affine) and not stored
+            __builtin_amdgcn_sched_barrier(0);
+            const float* sbl = sbias + VEC * lane;        // ONE address register + immediate offsets for the panels AND the carry rows behind
+            asm volatile("" : "+v"(sbl));                 // them (hoisted per-panel addresses were what spilled into the main loop)
+            bool shared = b == 0 && first_cont && run_first;
+            if (b == 0 && first_cont && !run_first) {
+                const fvec cv = *reinterpret_cast<const fvec*>(sbl + 3 * H + ((js & 1) ^ 1) * H);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], cv[v]);
+                shared = cshared[(js & 1) ^ 1] != 0;
+            }
+            if (e == NQ && last_cont && !run_last) {
+                *reinterpret_cast<fvec*>(const_cast<float*>(sbl) + 3 * H + (js & 1) * H) = m;
+                if (lane == 0) cshared[js & 1] = shared ? 1 : 0;
+                continue;
+            }
+            shared = shared || (e == NQ && last_cont);
             {   // this lane's VEC columns: bias, scale, shift from the LDS panel, fetched one after the other behind the reduction (the
                 // kernel sits at its register limit: three more live vectors spilled a lane constant into the main loop)
-                __builtin_amdgcn_sched_barrier(0);
-                const float* sbl = sbias + VEC * lane;
-                asm volatile("" : "+v"(sbl));             // ONE address register + immediate offsets (three hoisted ones were what spilled)
                 const fvec cb = *reinterpret_cast<const fvec*>(sbl);
                 const fvec cs = *reinterpret_cast<const fvec*>(sbl + H);
 #pragma unroll
@@ -338,10 +368,23 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
                 for (int v = 0; v < VEC; ++v) m[v] = m[v] * cs[v] + ct[v];
             }
             float* o = obase + (size_t)sg * p.ldy;
-            const bool partial = (b == 0 && first_cont) || (e == NQ && last_cont);
-            if (partial && !(p.dbg & 32)) {               // (dbg 32: timing experiment -- plain stores, wrong results on shared rows)
+            if (shared && !(p.dbg & 32)) {                // (dbg 32: timing experiment -- plain stores, wrong results on shared rows)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
+            } else if constexpr (Y16) {
+                // my VEC adjacent columns never straddle a chunk: hi halves at (column % 32) * 2 inside the 128-byte chunk, lo halves 64 B on
+                char* oc = reinterpret_cast<char*>(o - VEC * lane) + ((VEC * lane) >> 5) * 128 + ((VEC * lane) & 31) * 2;
+                typedef float hvec __attribute__((ext_vector_type(VEC / 2)));
+                hvec hv, lv;
+#pragma unroll
+                for (int v = 0; v < VEC; v += 2) {
+                    float hb, lb;
+                    split_pair_f16(m[v], m[v + 1], hb, lb);
+                    if constexpr (VEC == 2) { hv = hb; lv = lb; } else { hv[v >> 1] = hb; lv[v >> 1] = lb; }
+                    amax = fmaxf(amax, fmaxf(fabsf(m[v]), fabsf(m[v + 1])));
+                }
+                *reinterpret_cast<hvec*>(oc) = hv;
+                *reinterpret_cast<hvec*>(oc + 64) = lv;
             } else {
                 *reinterpret_cast<fvec*>(o) = m;
             }
@@ -415,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
 #endif
         if constexpr (c == 3) load_indices(j + 2);
         rs = rs_v;
-        if constexpr (c == 1) { if (j > 0) { WS_TS(4); scan(tile_of(j - 1), (j - 1) % 3); WS_TS(5); } }
+        if constexpr (c == 1) { if (j > 0) { WS_TS(4); scan(j - 1, (j - 1) % 3); WS_TS(5); } }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef WS_NO_BARRIER
         __builtin_amdgcn_s_barrier();
@@ -437,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     if (!(p.dbg & 1)) write_z();
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             // no LDS-DMA may outlive the workgroup
     __builtin_amdgcn_s_barrier();
-    scan(tile_of(n_my - 1), (n_my - 1) % 3);
+    scan(n_my - 1, (n_my - 1) % 3);
     if (!(amax < 65000.f)) *p.ovf = 1;
 }
 
@@ -474,7 +517,9 @@ int launch_edge_ws(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     int avail = ncu - ((reserved_cus() + 7) / 8) * 8;
     if (avail < 8) avail = 8;
     const int grid = nblocks < avail ? ((nblocks + 7) / 8) * 8 : avail;      // one persistent workgroup per CU, multiple of 8 (XCDs)
-    if (p.H == 256) hipLaunchKernelGGL((edge_ws_kernel<256>), dim3(grid), dim3(512), 0, s, p);
+    if (p.H == 256 && p.y16) hipLaunchKernelGGL((edge_ws_kernel<256, true>), dim3(grid), dim3(512), 0, s, p);
+    else if (p.H == 256) hipLaunchKernelGGL((edge_ws_kernel<256>), dim3(grid), dim3(512), 0, s, p);
+    else if (p.H == 128 && p.y16) hipLaunchKernelGGL((edge_ws_kernel<128, true>), dim3(grid), dim3(512), 0, s, p);
     else if (p.H == 128) hipLaunchKernelGGL((edge_ws_kernel<128>), dim3(grid), dim3(512), 0, s, p);
     else return MORIG_E_UNSUPPORTED;
     MORIG_LAUNCH_CHECK();

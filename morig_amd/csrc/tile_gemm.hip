@@ -568,36 +568,116 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
     static_assert(NPASS <= 4, "column passes");
 }
 
-// Rows of `out` whose segment straddles a 128-edge tile boundary are combined with integer-atomic float max
+// Rows of `out` whose segment straddles a tile boundary are combined with integer-atomic float max
 // by the two (or more) tiles involved: only THOSE rows need the identity pattern 0xFFFFFFFF beforehand.
-// [r04] one WAVE per boundary, four boundaries per 256-thread workgroup, 16-byte stores where the row allows them: the H = 256
-// launches used to start 410 k workgroups of 64 threads that stored 4 bytes per thread and pass (0.41 ms per step in total).
+// [r05] a LANE per boundary for the index chain (rowptr[n] -> dstS[e] -> rowptr[d]: three dependent loads, which one wave per
+// boundary paid 330 k times per launch on the geo graph), then the wave walks the rows its lanes found and stores them 16 bytes per
+// lane ([r04] had one wave per boundary: 17 us per launch on average, 0.3 ms per step).
+// Tiles are numbered over the replicas, t = replica * tpr + tile (tpr = ceil(E' / tile_rows), E' read on the device); a persistent
+// kernel that carries an open segment from tile to tile inside RUNS of `run` consecutive tiles (edge_rl.hip / edge_ws.hip) shares rows
+// only where a run ends: candidate g = 1, 2, ... is the boundary in front of tile t = g * run (run = 1: every tile boundary).
+// -> the output row (replica * rep_out + destination) whose segment straddles that boundary, or -1.
+__device__ __forceinline__ int straddled_row(const int* __restrict__ rowptr, const int* __restrict__ dstS, int n_nodes, int tile_rows,
+                                             int run, int replicas, int rep_out, int g, int n_cand, bool last_only) {
+    if (g > n_cand) return -1;
+    const int Etot = rowptr[n_nodes];
+    const int tpr = (Etot + tile_rows - 1) / tile_rows;
+    if (tpr <= 0) return -1;
+    const long long t = (long long)g * run;
+    const int rep = (int)(t / tpr), tile = (int)(t - (long long)rep * tpr);
+    if (rep >= replicas || tile == 0) return -1;                      // a replica starts here: nothing above it
+    const int e = tile * tile_rows;                                   // < Etot
+    const int d = dstS[e];
+    if (rowptr[d] >= e) return -1;                                    // a segment starts exactly on the boundary: no sharing
+    // several shared boundaries inside one long segment: the LAST one stands for the row (the next one of this replica is run tiles on)
+    if (last_only && (long long)e + (long long)run * tile_rows < rowptr[d + 1]) return -1;
+    return rep * rep_out + d;
+}
+
 __global__ __launch_bounds__(256) void init_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
                                                                  int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out,
-                                                                 int tile_rows, int n_bound) {
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (b >= n_bound) return;
-    const int e = (b + 1) * tile_rows;
-    if (e >= rowptr[n_nodes]) return;
-    const int d = dstS[e];
-    if (rowptr[d] >= e) return;                       // a segment starts exactly on the boundary: no sharing
-    float* orow = out + ((size_t)blockIdx.y * rep_out + d) * ldo;
-    if (((reinterpret_cast<uintptr_t>(orow) | (uintptr_t)(H * 4)) & 15) == 0) {
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-        u32x4* o4 = reinterpret_cast<u32x4*>(orow);
-        for (int c = lane; c < H / 4; c += 64) o4[c] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    } else {
-        unsigned* o = reinterpret_cast<unsigned*>(orow);
-        for (int c = lane; c < H; c += 64) o[c] = 0xFFFFFFFFu;
+                                                                 int tile_rows, int run, int replicas, int n_cand) {
+    const int lane = threadIdx.x & 63;
+    const int d = straddled_row(rowptr, dstS, n_nodes, tile_rows, run, replicas, rep_out, blockIdx.x * 256 + threadIdx.x + 1, n_cand, false);
+    const bool vec = ((reinterpret_cast<uintptr_t>(out) | (uintptr_t)(ldo * 4) | (uintptr_t)(H * 4)) & 15) == 0;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned long long todo = __ballot(d >= 0);
+    while (todo) {                                                    // wave-uniform
+        const int l = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        float* orow = out + (size_t)__builtin_amdgcn_readlane(d, l) * ldo;
+        if (vec) {
+            u32x4* o4 = reinterpret_cast<u32x4*>(orow);
+            for (int c = lane; c < H / 4; c += 64) o4[c] = u32x4{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        } else {
+            unsigned* o = reinterpret_cast<unsigned*>(orow);
+            for (int c = lane; c < H; c += 64) o[c] = 0xFFFFFFFFu;
+        }
     }
 }
 
 static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
-                              int rep_out, int slots, hipStream_t s, int tile_rows = 128) {
-    const int nb = cdiv(edge_capacity, tile_rows) - 1;
-    if (nb <= 0) return MORIG_OK;
-    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(cdiv(nb, 4), slots), dim3(256), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out,
-                       tile_rows, nb);
+                              int rep_out, int slots, hipStream_t s, int tile_rows = 128, int run = 1) {
+    const int n_cand = cdiv((long)cdiv(edge_capacity, tile_rows) * slots, run) - 1;      // upper bound (capacity >= E')
+    if (n_cand <= 0) return MORIG_OK;
+    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(cdiv(n_cand, 256)), dim3(256), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out,
+                       tile_rows, run, slots, n_cand);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+// out_split launches (edge_rl.hip / edge_ws.hip): whole segments leave the kernel as split-fp16 halves, the shared rows above as fp32
+// atomics -- the only rows still in fp32 afterwards. This pass rewrites exactly those rows in place (a 32-column chunk occupies the
+// same 128 bytes in both layouts: a lane reads 4 adjacent columns, then stores their 4 hi and 4 lo halves over the chunk; a wave
+// instruction covers whole chunks, so every read of a chunk precedes every write to it). A segment that straddles several shared
+// boundaries is converted at the LAST one (once). Same lane-per-candidate index phase as the pass above; the rows are taken four at a
+// time so that four loads are in flight.
+__global__ __launch_bounds__(256) void split_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
+                                                                  int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out,
+                                                                  int tile_rows, int run, int replicas, int n_cand, int* __restrict__ ovf) {
+    // 16 candidates per wave (lanes 0..15 run the index chain): a wave converts its rows one group of four after the other, a load
+    // round trip each -- with 64 candidates per wave the launch was one long latency chain (24 us on average for 5 k rows)
+    const int lane = threadIdx.x & 63;
+    const int g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + lane + 1;
+    const int d = lane < 16 ? straddled_row(rowptr, dstS, n_nodes, tile_rows, run, replicas, rep_out, g, n_cand, true) : -1;
+    unsigned long long todo = __ballot(d >= 0);
+    float am = 0.f;
+    while (todo) {                                                    // wave-uniform
+        int dr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int l = todo ? __builtin_ctzll(todo) : -1;
+            todo &= todo - 1;                                         // (0 stays 0)
+            dr[i] = l >= 0 ? __builtin_amdgcn_readlane(d, l) : -1;
+        }
+        for (int c0 = 0; c0 < H; c0 += 256) {
+            const int c = c0 + 4 * lane;
+            float4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (dr[i] >= 0 && c < H) v[i] = *reinterpret_cast<const float4*>(out + (size_t)dr[i] * ldo + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (dr[i] >= 0 && c < H) {
+                    float h0, l0, h1, l1;
+                    split_pair_f16(v[i].x, v[i].y, h0, l0);
+                    split_pair_f16(v[i].z, v[i].w, h1, l1);
+                    am = fmaxf(am, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+                    char* oc = reinterpret_cast<char*>(out + (size_t)dr[i] * ldo) + (c >> 5) * 128 + (c & 31) * 2;
+                    *reinterpret_cast<float2*>(oc) = make_float2(h0, h1);
+                    *reinterpret_cast<float2*>(oc + 64) = make_float2(l0, l1);
+                }
+        }
+    }
+    if (!(am < 65000.f)) *ovf = 1;                    // also NaN (the identity pattern would be one: every such row was written)
+}
+
+static int split_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
+                               int rep_out, int slots, hipStream_t s, int tile_rows, int run, int* ovf) {
+    const int n_cand = cdiv((long)cdiv(edge_capacity, tile_rows) * slots, run) - 1;
+    if (n_cand <= 0) return MORIG_OK;
+    hipLaunchKernelGGL(split_boundary_rows_kernel, dim3(cdiv(n_cand, 64)), dim3(256), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out,
+                       tile_rows, run, slots, n_cand, ovf);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -830,6 +910,55 @@ extern "C" int morig_segmax_gemm(const morig_segmax_args* a, void* stream) {
     return MORIG_E_UNSUPPORTED;
 }
 
+// which kernel a morig_edgeconv launch takes: H = 256 / 128 on the split-fp16 path go to the specialised kernels; with a 4-aligned CSR
+// the W2-stationary one (edge_ws.hip), whose H = 256 tiles are 64 rows. MORIG_EDGE_KERNEL=pp|pc keeps the older kernels (A/B runs).
+struct EdgePlan { bool wide, one_shot, pp_ok, use_rl, use_ws, split_ok; int tile_rows, run; };
+static EdgePlan edge_plan(const morig_edgeconv_args* a) {
+    EdgePlan pl = {};
+    const bool f16 = a->W2_split != nullptr;
+    static const char* ek = getenv("MORIG_EDGE_KERNEL");
+    static const bool one_shot = ek && ek[0] == 'p' && ek[1] == 'c';
+    static const bool want_pp = ek && ek[0] == 'p' && ek[1] == 'p';
+    pl.one_shot = one_shot;
+    pl.wide = f16 && (a->H == 256 || a->H == 128) && a->s1 == nullptr && !getenv("MORIG_NO_EDGE_PC");
+    // the persistent kernels store 16-byte result vectors and address gathered rows with 32-bit byte offsets
+    pl.pp_ok = (reinterpret_cast<uintptr_t>(a->out) & 15) == 0 && (a->ldo & 3) == 0 &&
+               (double)a->n_nodes * a->lda * 4.0 < 4.0e9 && (double)a->n_nodes * a->ldb * 4.0 < 4.0e9;
+    // H = 128 has half the MFMA work per gathered byte: measured on par with / behind the producer-consumer kernel, which stays
+    // the default there (MORIG_WS128=1 selects edge_ws.hip for it too)
+    static const bool ws128 = [] { const char* e = getenv("MORIG_WS128"); return e && e[0] == '1'; }();
+    // H = 128 with a 4-aligned CSR: the row-local kernel (edge_rl.hip: W2 resident in LDS, eight independent waves, no barrier in the
+    // main loop; 64-row tiles). MORIG_RL128=0 keeps the producer-consumer kernel (A/B runs)
+    static const bool rl128 = [] { const char* e = getenv("MORIG_RL128"); return !(e && e[0] == '0'); }();
+    const bool quad_ok = pl.wide && !one_shot && !want_pp && pl.pp_ok && a->quad_aligned && (a->lda & 3) == 0 && (a->ldb & 3) == 0;
+    pl.use_rl = quad_ok && a->H == 128 && rl128 && !ws128;
+    pl.use_ws = quad_ok && !pl.use_rl && (a->H == 256 || ws128);
+    pl.tile_rows = ((pl.use_ws && a->H == 256) || pl.use_rl) ? 64 : 128;   // edge_ws.hip at H = 256, edge_rl.hip: 64-row tiles
+    // the two kernels above carry a segment that is still open at the end of a tile into the next tile of the same RUN of consecutive
+    // tiles (one wave / one workgroup works through a run): only rows that straddle a run boundary are shared through atomics.
+    // MORIG_EDGE_RUN=<tiles> (1 = every tile boundary is shared, the [r04] behaviour)
+    // Measured (profiles/r05n_*): runs of 4 .. 8 tiles gain 0.5 % of the step over 1, 16 and more lose to the coarser work split --
+    // so at most 8, and short enough that every wave (edge_rl.hip, 8 per CU) / workgroup (edge_ws.hip) still gets >= 16 runs
+    static const int run_env = [] { const char* e = getenv("MORIG_EDGE_RUN"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 4096 ? 4096 : v); }();
+    pl.run = 1;
+    if (pl.use_rl || pl.use_ws) {
+        const long tiles = (long)cdiv(a->edge_capacity, pl.tile_rows) * a->replicas;
+        const long units = pl.use_rl ? 2048 : 256;
+        while (pl.run * 2 <= run_env && tiles / (units * 16) >= pl.run * 2) pl.run *= 2;
+    }
+    // split-fp16 results: the two kernels above, chunk-aligned output window (MORIG_EDGE_SPLIT_OUT=0: never, A/B runs)
+    static const bool no_split = [] { const char* e = getenv("MORIG_EDGE_SPLIT_OUT"); return e && e[0] == '0'; }();
+    pl.split_ok = (pl.use_rl || pl.use_ws) && !no_split && a->overflow != nullptr && (a->ldo & 31) == 0 &&
+                  (reinterpret_cast<uintptr_t>(a->out) & 127) == 0;
+    return pl;
+}
+
+extern "C" int morig_edgeconv_can_split_out(const morig_edgeconv_args* a) {
+    TileParams p = {};
+    if (edge_common(a, p) != MORIG_OK) return 0;
+    return edge_plan(a).split_ok ? 1 : 0;
+}
+
 extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     TileParams p = {};
     const int st = edge_common(a, p);
@@ -838,32 +967,16 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nblocks = p.tiles_per_rep * a->replicas;
     const bool f16 = a->W2_split != nullptr;
-
-    // which kernel: H = 256 / 128 on the split-fp16 path go to the specialised kernels; with a 4-aligned CSR the W2-stationary
-    // one (edge_ws.hip), whose H = 256 tiles are 64 rows. MORIG_EDGE_KERNEL=pp|pc keeps the older kernels (A/B runs).
-    static const char* ek = getenv("MORIG_EDGE_KERNEL");
-    static const bool one_shot = ek && ek[0] == 'p' && ek[1] == 'c';
-    static const bool want_pp = ek && ek[0] == 'p' && ek[1] == 'p';
-    const bool wide = f16 && (a->H == 256 || a->H == 128) && a->s1 == nullptr && !getenv("MORIG_NO_EDGE_PC");
-    // the persistent kernels store 16-byte result vectors and address gathered rows with 32-bit byte offsets
-    const bool pp_ok = (reinterpret_cast<uintptr_t>(a->out) & 15) == 0 && (a->ldo & 3) == 0 &&
-                       (double)a->n_nodes * a->lda * 4.0 < 4.0e9 && (double)a->n_nodes * a->ldb * 4.0 < 4.0e9;
-    // H = 128 has half the MFMA work per gathered byte: measured on par with / behind the producer-consumer kernel, which stays
-    // the default there (MORIG_WS128=1 selects edge_ws.hip for it too)
-    static const bool ws128 = [] { const char* e = getenv("MORIG_WS128"); return e && e[0] == '1'; }();
-    // H = 128 with a 4-aligned CSR: the row-local kernel (edge_rl.hip: W2 resident in LDS, eight independent waves, no barrier in the
-    // main loop; 64-row tiles). MORIG_RL128=0 keeps the producer-consumer kernel (A/B runs)
-    static const bool rl128 = [] { const char* e = getenv("MORIG_RL128"); return !(e && e[0] == '0'); }();
-    const bool quad_ok = wide && !one_shot && !want_pp && pp_ok && a->quad_aligned && (a->lda & 3) == 0 && (a->ldb & 3) == 0;
-    const bool use_rl = quad_ok && a->H == 128 && rl128 && !ws128;
-    const bool use_ws = quad_ok && !use_rl && (a->H == 256 || ws128);
-    const int tile_rows = ((use_ws && a->H == 256) || use_rl) ? 64 : 128;   // edge_ws.hip at H = 256, edge_rl.hip: 64-row tiles
+    const EdgePlan pl = edge_plan(a);
+    const bool wide = pl.wide, one_shot = pl.one_shot, pp_ok = pl.pp_ok, use_rl = pl.use_rl, use_ws = pl.use_ws;
+    const int tile_rows = pl.tile_rows;
+    if (a->out_split && !pl.split_ok) return MORIG_E_UNSUPPORTED;
 
     // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
     {
         const int slots = a->replicas;
         const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
-                                           a->out_rep_stride, slots, s, tile_rows);
+                                           a->out_rep_stride, slots, s, tile_rows, pl.run);
         if (st2 != MORIG_OK) return st2;
     }
 
@@ -878,14 +991,21 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
         q.rowptr = p.rowptr; q.srcS = p.srcS; q.dstS = p.dstS; q.n_nodes = p.n_nodes;
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
         q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
+        q.y16 = a->out_split ? 1 : 0; q.run = pl.run;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
-        if (use_rl) {
-            prof_retag(K_EDGE16_H128_RL);
-            return launch_edge_rl(q, cdiv(a->edge_capacity, 64) * a->replicas, s);
-        }
-        if (use_ws) {
-            if (a->H == 128) prof_retag(K_EDGE16_H128_WS);
-            return launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
+        if (use_rl || use_ws) {
+            int st3;
+            if (use_rl) {
+                prof_retag(K_EDGE16_H128_RL);
+                st3 = launch_edge_rl(q, cdiv(a->edge_capacity, 64) * a->replicas, s);
+            } else {
+                if (a->H == 128) prof_retag(K_EDGE16_H128_WS);
+                st3 = launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
+            }
+            if (st3 != MORIG_OK || !a->out_split) return st3;
+            // the rows two tiles share were combined as fp32 atomics: into the split layout now
+            return split_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo, a->out_rep_stride,
+                                       a->replicas, s, tile_rows, pl.run, a->overflow);
         }
         if (one_shot || !pp_ok) { prof_retag(K_EDGE16_PC); return launch_edge_pc(q, nblocks, s); }
         if (a->H == 256) prof_retag(K_EDGE16_H256_PP);

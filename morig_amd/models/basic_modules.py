@@ -330,6 +330,13 @@ class GCUMotion(NativeModule):
         vx, (xt, xg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_x, self.edge_conv_geo.nn_x])
         vp, (pt, pg) = packing.pack_edge_pair([self.edge_conv_tpl.nn_pos, self.edge_conv_geo.nn_pos])
         pk = dict(vx=vx, xt=xt, xg=xg, vp=vp, pt=pt, pg=pg, mlp=packing.pack_mlp_layer(self.mlp[0]))
+        # [r05] the same layer for the unit's row laid out [x_tpl(H) | x_geo(H) | pos_tpl(D) | pos_geo(D)]: every block then starts on
+        # a 32-column chunk, so the wide EdgeConv kernels can store split-fp16 rows (morig_edgeconv out_split) and this GEMM reads them
+        # through the LDS-DMA kernel (reference order, :216: [x_tpl | pos_tpl | x_geo | pos_geo])
+        H, D = xt.H, pt.H
+        if H % 32 == 0 and (2 * D) % 32 == 0:
+            cols = (list(range(H)) + [2 * H + i for i in range(D)] + [H + i for i in range(H)] + [2 * H + D + i for i in range(D)])
+            pk["mlp_s"] = packing.pack_mlp_layer(self.mlp[0], in_cols=cols, k_total=2 * H + 2 * D)
         # a 3-channel feature with a 32-wide hidden layer (motionNet's first unit: the keyframe flow): the first Linear in the form
         # morig_edgeconv_x3 evaluates in its loader
         if xt.H == 32 and self.edge_conv_tpl.nn_x[0][0].weight.shape[1] == 6:
@@ -365,6 +372,24 @@ class GCUMotion(NativeModule):
             pab = ops.empty(n, 4 * D, dev)
             ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
+        if not use_x3 and "mlp_s" in pk and self._split_rows(ops, pk, ab, ec, csr_tpl, csr_geo, H, replicas, n):
+            # split-fp16 rows [x_tpl | x_geo | pos_tpl | pos_geo] straight from the EdgeConv kernels into the LDS-DMA GEMM
+            ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
+                         replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
+            ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H, H),
+                         replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
+            p2 = ops.empty(n, 2 * D, dev)               # [pos_tpl | pos_geo] side by side: ONE chunk-aligned split copy into every replica
+            if pos_feat is not None:
+                # (library copies, not torch.cat: with strided inputs torch's cat did not replay from a captured HIP graph --
+                # tests/test_gpu_networks.py::test_captured_forward_replays_bit_identically)
+                ops.copy2d(pos_feat[0], Mat.of(p2, 0, D))
+                ops.copy2d(pos_feat[1], Mat.of(p2, D, D))
+            else:
+                ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(p2, 0, D))
+                ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(p2, D, D))
+            ops.copy2d_rep(Mat.of(p2), Mat.of(ec, 2 * H, 2 * D, 0, n), replicas, n, split=True)
+            ops.gemm(Mat.of(ec), pk["mlp_s"], relu=True, Y=out, x_split=True, y_split=split_out)
+            return
         if use_x3:
             ops.edgeconv_x3(x3, pk["x3t"], csr_tpl, pk["xt"], Mat.of(ec, 0, H), replicas=replicas, in_rep_stride=n, out_rep_stride=n)
             ops.edgeconv_x3(x3, pk["x3g"], csr_geo, pk["xg"], Mat.of(ec, H + D, H), replicas=replicas, in_rep_stride=n, out_rep_stride=n)
@@ -384,6 +409,16 @@ class GCUMotion(NativeModule):
                 ops.copy2d_rep(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, n, n), replicas - 1, n)
                 ops.copy2d_rep(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, n, n), replicas - 1, n)
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split_out)
+
+    @staticmethod
+    def _split_rows(ops, pk, ab, ec, csr_tpl, csr_geo, H, replicas, n) -> bool:
+        """May both feature EdgeConvs of this unit store split-fp16 rows? The library decides (kernel choice, alignment, its
+        environment switches); MORIG_EC_SPLIT=0 keeps the fp32 rows (A/B runs)."""
+        if not ops.split_activations or not hasattr(ops, "edgeconv_can_split_out") or os.environ.get("MORIG_EC_SPLIT", "1") == "0":
+            return False
+        kw = dict(replicas=replicas, in_rep_stride=n, out_rep_stride=n)
+        return (ops.edgeconv_can_split_out(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H), **kw) and
+                ops.edgeconv_can_split_out(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H, H), **kw))
 
     def _forward(self, pos, x, tpl_edge_index, geo_edge_index):
         ops = get_ops()

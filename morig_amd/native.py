@@ -56,6 +56,7 @@ class EdgeConvArgs(C.Structure):
         ("out", c_f32p), ("ldo", C.c_int32),
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
         ("quad_aligned", C.c_int32),
+        ("out_split", C.c_int32),
     ]
 
 
@@ -181,6 +182,7 @@ _SIGNATURES = {
     "morig_nms_greedy": (C.c_int, [c_f64p, c_f32p, C.c_int32, c_f64p, c_i32p, C.c_double, C.c_float, c_u8p, C.c_void_p]),
     "morig_gather_rows": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_void_p]),
     "morig_edgeconv": (C.c_int, [C.POINTER(EdgeConvArgs), C.c_void_p]),
+    "morig_edgeconv_can_split_out": (C.c_int, [C.POINTER(EdgeConvArgs)]),
     "morig_copy2d": (C.c_int, [c_f32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "morig_copy2d_pad": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_copy2d_pad_rep": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
@@ -597,10 +599,20 @@ class NativeOps:
 
     # -- fused edge conv ----------------------------------------------------------------------------
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
-                 in_rep_stride: int = 0, out_rep_stride: int = 0):
+                 in_rep_stride: int = 0, out_rep_stride: int = 0, out_split: bool = False):
+        """out_split: `out` (a chunk-aligned window, H % 32 == 0) is written in the split-fp16 activation layout; only where
+        ``edgeconv_can_split_out`` says so for the same arguments (MORIG_E_UNSUPPORTED otherwise)."""
         _need_gpu(A.base, B.base, out.base)
         a = self._edge_args(A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride)
+        a.out_split = 1 if out_split else 0
         check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
+
+    def edgeconv_can_split_out(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
+                               in_rep_stride: int = 0, out_rep_stride: int = 0) -> bool:
+        """Would ``edgeconv(..., out_split=True)`` run for these arguments? (kernel choice, alignment, environment switches: the library
+        decides, morig_edgeconv_can_split_out; nothing is launched)"""
+        a = self._edge_args(A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride)
+        return bool(self.lib.morig_edgeconv_can_split_out(C.byref(a)))
 
     def _edge_args(self, A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride):
         a = EdgeConvArgs()

@@ -114,8 +114,14 @@ class EmuOps:
             Y.view().copy_(acc)
 
     # -- fused edge conv ---------------------------------------------------------------------------
-    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0):
+    def edgeconv_can_split_out(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0):
+        # the library's rule (tile_gemm.hip edge_plan): the 4-aligned-CSR kernels at H = 128 / 256, chunk-aligned output window
+        return bool(self.emulate_split and csr.quad and ec.H in (128, 256) and ec.s1 is None and out.col0 % 32 == 0 and out.ld % 32 == 0)
+
+    def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0, out_split=False):
         assert A.ld % 4 == 0 and A.col0 % 4 == 0 and B.ld % 4 == 0 and B.col0 % 4 == 0
+        if out_split:
+            assert self.edgeconv_can_split_out(A, B, csr, ec, out), "out_split where the library would refuse it"
         H = ec.H
         E = int(csr.rowptr[-1])
         src, dst = csr.src[:E].long(), csr.dst[:E].long()

@@ -281,6 +281,56 @@ def test_edgeconv_persistent_many_tiles(ops, H, pad4):
     assert torch.equal(out[:n], out[n:])                      # replicas of one input: identical bits
 
 
+@pytest.mark.parametrize("H", [128, 256])
+@pytest.mark.parametrize("n,e,hub,reps", [(700, 5000, 3, 2), (20000, 300000, 777, 2), (64, 200, None, 1)])
+def test_edgeconv_split_fp16_rows(H, n, e, hub, reps):
+    """morig_edgeconv out_split: the 4-aligned-CSR kernels store split-fp16 rows (chunk = [32 hi | 32 lo]) into a chunk-aligned column
+    window -- whole segments from the kernel, tile-straddling ones (atomics in fp32) through the boundary pass, a hub longer than several
+    tiles converted exactly once. Decoded, every element is the fp32 launch's result to the split's resolution (lo is fp16(v - hi):
+    2^-22 relative, 2^-25 absolute where lo is an fp16 subnormal); the columns beside the window stay untouched; a result beyond the
+    fp16 range raises the guard."""
+    from morig_amd import native
+    o = native.get_ops()
+    o.precision = "f16x3"
+    g = torch.Generator().manual_seed(H + n)
+    ei = _rand_graph(n, e, 13, hub)
+    if hub is not None and n >= 20000:
+        ei = torch.cat([ei, torch.stack([torch.randint(0, n, (700,), generator=g), torch.full((700,), 1234)])], dim=1)
+    ab = torch.randn(n * reps, 2 * H, generator=g).to(DEV)
+    ec = packing.to_device(_edge_pack(H, 5, folded=True), DEV)
+    ec.s2 = ec.s2 * torch.where(torch.arange(ec.s2.numel(), device=DEV) % 3 == 0, -1.0, 1.0)       # both signs of the BN scale
+    csr = o.csr_build(ei.to(DEV), n, pad4=True)
+    ld = 2 * H + 64
+    kw = dict(replicas=reps, in_rep_stride=n, out_rep_stride=n)
+    plain = torch.zeros(n * reps, ld, device=DEV)
+    o.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(plain, H, H), **kw)
+    rows = torch.full((n * reps, ld), 7.0, device=DEV)
+    assert o.edgeconv_can_split_out(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(rows, H, H), **kw)
+    o._flag(ab.device).zero_()
+    o.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(rows, H, H), out_split=True, **kw)
+    torch.cuda.synchronize()
+    assert int(o._flag(ab.device).item()) == 0
+    got = packing.unsplit_f16(rows[:, H:2 * H].contiguous().cpu(), H)
+    want = plain[:, H:2 * H].cpu()
+    assert not torch.isnan(got).any()
+    assert ((got - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** -24).all(), maxdiff(got, want)
+    assert float((rows[:, :H] - 7.0).abs().sum()) == 0 and float((rows[:, 2 * H:] - 7.0).abs().sum()) == 0
+    # twice the same bits (no order dependence through the atomics + the boundary pass)
+    again = torch.full((n * reps, ld), 7.0, device=DEV)
+    o.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(again, H, H), out_split=True, **kw)
+    assert torch.equal(rows, again)
+    # refused where the launch would not take one of the two kernels (plain CSR), and the guard: a result of 1e5
+    csr1 = o.csr_build(ei.to(DEV), n)
+    assert not o.edgeconv_can_split_out(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr1, ec, Mat.of(rows, H, H), **kw)
+    with pytest.raises(native.MorigNativeError):
+        o.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr1, ec, Mat.of(rows, H, H), out_split=True, **kw)
+    ec.t2 = ec.t2 + 1.0e5
+    o.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(rows, H, H), out_split=True, **kw)
+    torch.cuda.synchronize()
+    assert int(o._flag(ab.device).item()) == 1
+    o._flag(ab.device).zero_()
+
+
 def test_edgeconv_sign_cases(ops):
     """negative BN scales (max of a decreasing function) and all-negative outputs (the integer-atomic
     max identity must not leak)."""

@@ -36,13 +36,17 @@ def main():
                                                                                  replicas=R, in_rep_stride=n, out_rep_stride=n),
                                    2.0 * csr.edge_count * R * H * H)
     M = R * n
-    for (K, N) in ((1862, 1024), (256, 1024), (64, 512)):
+    for (K, N) in ((1862, 1024), (256, 1024), (64, 512), (544, 512), (288, 256)):
         g = torch.Generator().manual_seed(K)
         lin = packing.to_device(packing.pack_linear(torch.randn(N, K, generator=g) / K ** 0.5, torch.zeros(N)), DEV)
         x = torch.randn(M, (K + 31) // 32 * 32, device=DEV).half().float()      # (any finite bit pattern: timing and power only)
         y = torch.empty(M, N, device=DEV)
         cases[f"gemm_K{K}_N{N}"] = (lambda x=x, lin=lin, y=y, K=K: ops.gemm(Mat.of(x, 0, K), lin, True, Y=Mat.of(y), x_split=True, y_split=True),
                                     2.0 * M * K * N)
+        if K in (544, 288):       # the unit MLP behind the EdgeConvs: fp32 rows in (tile kernel, in-kernel split) vs split rows in (LDS-DMA kernel)
+            xf = torch.randn(M, K, device=DEV)
+            cases[f"gemm_f32x_K{K}_N{N}"] = (lambda xf=xf, lin=lin, y=y, K=K: ops.gemm(Mat.of(xf, 0, K), lin, True, Y=Mat.of(y), y_split=True),
+                                             2.0 * M * K * N)
     only = os.environ.get('OP_ONLY')
     for name, (fn, fl) in cases.items():
         if only and only not in name:
