@@ -101,6 +101,13 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     const int NR = (T + R - 1) >> lg;
     const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3, nbx = gridDim.x >> 3;
     const int r_lo = (int)((long long)NR * xcd / 8), r_hi = (int)((long long)NR * (xcd + 1) / 8);
+#ifdef WS_OLD_MAP                                       // (measurement build, valid with MORIG_EDGE_RUN=1 only: the [r04] list)
+    const int t_lo = (int)((long long)T * xcd / 8), t_hi = (int)((long long)T * (xcd + 1) / 8);
+    const int n_my = (t_hi - t_lo - bi + nbx - 1) / nbx;
+    if (n_my <= 0) return;
+    auto tile_of = [&](int j) __attribute__((always_inline)) { return t_lo + bi + (j < n_my ? j : n_my - 1) * nbx; };
+    (void)r_lo; (void)r_hi;
+#else
     const int nruns = (r_hi - r_lo - bi + nbx - 1) / nbx;
     if (nruns <= 0) return;                                                    // block-uniform
     const int n_my = ((nruns - 1) << lg) + min(R, T - ((r_lo + bi + (nruns - 1) * nbx) << lg));
@@ -108,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         const int jj = j < n_my ? j : n_my - 1;
         return ((r_lo + bi + (jj >> lg) * nbx) << lg) + (jj & (R - 1));
     };
+#endif
     if (tid < H) { sbias[tid] = p.bias[tid]; sbias[H + tid] = p.scale[tid]; sbias[2 * H + tid] = p.shift[tid]; }
 
     // ---- resident W2 slice. Z slot s2 = 2 * step + hi of a chunk holds the chunk's k = 4 s2 + {0..3} and KC/2 + 4 s2 + {0..3}
@@ -315,7 +323,9 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         const bool run_first = (js & (R - 1)) == 0, run_last = (js & (R - 1)) == R - 1 || js == n_my - 1;
         const int rep = t / tpr;
         const int* sq = sq_all + slot * 32;
-        const bool first_cont = sflag[slot * 2] != 0, last_cont = sflag[slot * 2 + 1] != 0;
+        // (scalars: the branches on them below are s_cbranch, not exec-mask regions -- as VGPR values the run bookkeeping cost 3 %)
+        const bool first_cont = __builtin_amdgcn_readfirstlane(sflag[slot * 2]) != 0,
+                   last_cont = __builtin_amdgcn_readfirstlane(sflag[slot * 2 + 1]) != 0;
         const int q0 = __builtin_amdgcn_readfirstlane(wave * (NQ / 8));
         const float* zl = Z + VEC * lane;
         float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + VEC * lane;
@@ -325,9 +335,12 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         const unsigned START = (unsigned)__ballot(lane < NQ && (ql == 0 || sv != sp));
         const unsigned VALID = (unsigned)__ballot(lane < NQ && sv >= 0);
         unsigned mine = START & VALID & (((1u << (NQ / 8)) - 1u) << q0);
-        while (mine) {                                                       // wave-uniform: SALU bit walking
-            const int b = __builtin_ctz(mine);
-            mine &= mine - 1u;
+        // One segment [b, e) of quad rows. SPECIAL = the tile's first segment if it began above the tile, and its last one if it goes on
+        // below: the only ones the run bookkeeping (carry in / carry out / shared row) concerns. They are taken OUT of the bit walk
+        // below and handled after it by their owner wave, so the hot loop is the plain form: reduce, affine, store -- with the
+        // bookkeeping's branches inside the loop the kernel lost 3 % (profiles/r05p_*), although none of them is taken there.
+        auto segment = [&](int b, auto special_c) __attribute__((always_inline)) {
+            constexpr bool SPECIAL = decltype(special_c)::value;
             const unsigned later = b < 31 ? (START & ~((2u << b) - 1u)) : 0u;
             const int e = later ? __builtin_ctz(later) : NQ;                 // the segment covers quad rows [b, e)
             const int sg = __builtin_amdgcn_readlane(sv, b);
@@ -338,24 +351,27 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], fmaxf(z0[v], z1[v]));
             }
-            // the run's bookkeeping (block-uniform branches): a first segment that began in my previous tile takes what that tile left
-            // in `carry`; a last segment that goes on into my next tile is left there (max domain, before the affine) and not stored
             __builtin_amdgcn_sched_barrier(0);
             const float* sbl = sbias + VEC * lane;        // ONE address register + immediate offsets for the panels AND the carry rows behind
             asm volatile("" : "+v"(sbl));                 // them (hoisted per-panel addresses were what spilled into the main loop)
-            bool shared = b == 0 && first_cont && run_first;
-            if (b == 0 && first_cont && !run_first) {
-                const fvec cv = *reinterpret_cast<const fvec*>(sbl + 3 * H + ((js & 1) ^ 1) * H);
+            bool shared = false;
+            if constexpr (SPECIAL) {
+                // a first segment that began in my previous tile takes what that tile left in `carry`; a last segment that goes on into my
+                // next tile is left there (max domain, before the affine) and not stored; rows over a RUN boundary are shared (atomics)
+                shared = b == 0 && first_cont && run_first;
+                if (b == 0 && first_cont && !run_first) {
+                    const fvec cv = *reinterpret_cast<const fvec*>(sbl + 3 * H + ((js & 1) ^ 1) * H);
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], cv[v]);
-                shared = cshared[(js & 1) ^ 1] != 0;
+                    for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], cv[v]);
+                    shared = __builtin_amdgcn_readfirstlane(cshared[(js & 1) ^ 1]) != 0;
+                }
+                if (e == NQ && last_cont && !run_last) {
+                    *reinterpret_cast<fvec*>(const_cast<float*>(sbl) + 3 * H + (js & 1) * H) = m;
+                    if (lane == 0) cshared[js & 1] = shared ? 1 : 0;
+                    return;
+                }
+                shared = shared || (e == NQ && last_cont);
             }
-            if (e == NQ && last_cont && !run_last) {
-                *reinterpret_cast<fvec*>(const_cast<float*>(sbl) + 3 * H + (js & 1) * H) = m;
-                if (lane == 0) cshared[js & 1] = shared ? 1 : 0;
-                continue;
-            }
-            shared = shared || (e == NQ && last_cont);
             {   // this lane's VEC columns: bias, scale, shift from the LDS panel, fetched one after the other behind the reduction (the
                 // kernel sits at its register limit: three more live vectors spilled a lane constant into the main loop)
                 const fvec cb = *reinterpret_cast<const fvec*>(sbl);
@@ -368,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
                 for (int v = 0; v < VEC; ++v) m[v] = m[v] * cs[v] + ct[v];
             }
             float* o = obase + (size_t)sg * p.ldy;
-            if (shared && !(p.dbg & 32)) {                // (dbg 32: timing experiment -- plain stores, wrong results on shared rows)
+            if (SPECIAL && shared && !(p.dbg & 32)) {     // (dbg 32: timing experiment -- plain stores, wrong results on shared rows)
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
             } else if constexpr (Y16) {
@@ -388,7 +404,20 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
             } else {
                 *reinterpret_cast<fvec*>(o) = m;
             }
+        };
+        const unsigned sv_all = START & VALID;
+        const int lastb = sv_all ? 31 - __builtin_clz(sv_all) : 0;            // where the tile's last segment starts
+        const bool own_first = first_cont && (mine & 1u) != 0;
+        const bool own_last = last_cont && sv_all != 0 && ((mine >> lastb) & 1u) != 0 && !(own_first && lastb == 0);
+        if (own_first) mine &= ~1u;
+        if (own_last) mine &= ~(1u << lastb);
+        while (mine) {                                                       // wave-uniform: SALU bit walking
+            const int b = __builtin_ctz(mine);
+            mine &= mine - 1u;
+            segment(b, std::false_type{});
         }
+        if (own_first) segment(0, std::true_type{});
+        if (own_last) segment(lastb, std::true_type{});
     };
 
     // ---- prologue: tile 0's chunks 0..2 in flight, chunk 0 converted ----

@@ -278,6 +278,17 @@ class EdgeConvMotion(NativeModule):
         return out
 
 
+def _edge_rows_can_split(ops, ab, ec, csr_tpl, csr_geo, et, eg, H, replicas, n) -> bool:
+    """May the two feature EdgeConvs of a unit -- operands [A_tpl | B_tpl | A_geo | B_geo] in `ab`, results into columns [0, H) and
+    [H, 2H) of `ec` -- store split-fp16 rows? The library decides (kernel choice, alignment, its environment switches:
+    morig_edgeconv_can_split_out); MORIG_EC_SPLIT=0 keeps the fp32 rows (A/B runs)."""
+    if not ops.split_activations or not hasattr(ops, "edgeconv_can_split_out") or os.environ.get("MORIG_EC_SPLIT", "1") == "0":
+        return False
+    kw = dict(replicas=replicas, in_rep_stride=n if replicas > 1 else 0, out_rep_stride=n if replicas > 1 else 0)
+    return (ops.edgeconv_can_split_out(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, et, Mat.of(ec, 0, H), **kw) and
+            ops.edgeconv_can_split_out(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, eg, Mat.of(ec, H, H), **kw))
+
+
 class GCU(NativeModule):
     """models/basic_modules.py:165-177."""
 
@@ -300,9 +311,12 @@ class GCU(NativeModule):
         ab = ops.empty(n, 4 * H, dev)
         ops.gemm(x, pk["vertex"], relu=False, Y=Mat.of(ab), x_split=split_in)
         ec = ops.empty(n, 2 * H, dev)
-        ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["et"], Mat.of(ec, 0, H))
-        ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["eg"], Mat.of(ec, H, H))
-        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split_out)
+        # [r05] where the library takes it (wide layers on 4-aligned CSRs), the two EdgeConvs store split-fp16 rows and the unit MLP reads
+        # them through the LDS-DMA GEMM (morig_edgeconv out_split); [x_tpl | x_geo] is the reference's order (:176), both chunk-aligned
+        sp = H % 32 == 0 and _edge_rows_can_split(ops, ab, ec, csr_tpl, csr_geo, pk["et"], pk["eg"], H, 1, 0)
+        ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["et"], Mat.of(ec, 0, H), out_split=sp)
+        ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["eg"], Mat.of(ec, H, H), out_split=sp)
+        ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, x_split=sp, y_split=split_out)
 
     def _forward(self, pos, tpl_edge_index, geo_edge_index):
         ops = get_ops()
@@ -372,7 +386,7 @@ class GCUMotion(NativeModule):
             pab = ops.empty(n, 4 * D, dev)
             ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
-        if not use_x3 and "mlp_s" in pk and self._split_rows(ops, pk, ab, ec, csr_tpl, csr_geo, H, replicas, n):
+        if not use_x3 and "mlp_s" in pk and _edge_rows_can_split(ops, ab, ec, csr_tpl, csr_geo, pk["xt"], pk["xg"], H, replicas, n):
             # split-fp16 rows [x_tpl | x_geo | pos_tpl | pos_geo] straight from the EdgeConv kernels into the LDS-DMA GEMM
             ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
                          replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
@@ -409,16 +423,6 @@ class GCUMotion(NativeModule):
                 ops.copy2d_rep(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, n, n), replicas - 1, n)
                 ops.copy2d_rep(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, n, n), replicas - 1, n)
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, y_split=split_out)
-
-    @staticmethod
-    def _split_rows(ops, pk, ab, ec, csr_tpl, csr_geo, H, replicas, n) -> bool:
-        """May both feature EdgeConvs of this unit store split-fp16 rows? The library decides (kernel choice, alignment, its
-        environment switches); MORIG_EC_SPLIT=0 keeps the fp32 rows (A/B runs)."""
-        if not ops.split_activations or not hasattr(ops, "edgeconv_can_split_out") or os.environ.get("MORIG_EC_SPLIT", "1") == "0":
-            return False
-        kw = dict(replicas=replicas, in_rep_stride=n, out_rep_stride=n)
-        return (ops.edgeconv_can_split_out(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H), **kw) and
-                ops.edgeconv_can_split_out(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H, H), **kw))
 
     def _forward(self, pos, x, tpl_edge_index, geo_edge_index):
         ops = get_ops()

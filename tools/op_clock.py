@@ -32,8 +32,9 @@ def main():
         ec = packing.to_device(packing.PackedEdge(H, None, None, W, torch.zeros(H), torch.ones(H), torch.zeros(H), packing.split_f16(W)), DEV)
         ab = torch.randn(R * n, 4 * H, device=DEV)
         o = torch.empty(R * n, 2 * H + 32, device=DEV)
+        osp = os.environ.get("OP_SPLIT") == "1"            # results in the split-fp16 layout (the form the networks' wide units use)
         cases[f"edge_geo_H{H}"] = (lambda ab=ab, o=o, ec=ec, H=H: ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(o, 0, H),
-                                                                                 replicas=R, in_rep_stride=n, out_rep_stride=n),
+                                                                                 replicas=R, in_rep_stride=n, out_rep_stride=n, out_split=osp),
                                    2.0 * csr.edge_count * R * H * H)
     M = R * n
     for (K, N) in ((1862, 1024), (256, 1024), (64, 512), (544, 512), (288, 256)):
