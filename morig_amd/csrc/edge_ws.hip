@@ -354,8 +354,11 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
             __builtin_amdgcn_sched_barrier(0);
             const float* sbl = sbias + VEC * lane;        // ONE address register + immediate offsets for the panels AND the carry rows behind
             asm volatile("" : "+v"(sbl));                 // them (hoisted per-panel addresses were what spilled into the main loop)
-            bool shared = false;
-            if constexpr (SPECIAL) {
+            // (the fp32-rows form of the kernel -- a fallback since the units take split rows -- keeps the [r04] shape: ONE copy of this
+            // code inside the bit walk, every tile boundary shared, launched with run = 1; three copies + the carry code spilled 11
+            // registers into its main loop)
+            bool shared = SPECIAL && ((b == 0 && first_cont) || (e == NQ && last_cont));
+            if constexpr (SPECIAL && Y16) {
                 // a first segment that began in my previous tile takes what that tile left in `carry`; a last segment that goes on into my
                 // next tile is left there (max domain, before the affine) and not stored; rows over a RUN boundary are shared (atomics)
                 shared = b == 0 && first_cont && run_first;
@@ -399,25 +402,36 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
                     if constexpr (VEC == 2) { hv = hb; lv = lb; } else { hv[v >> 1] = hb; lv[v >> 1] = lb; }
                     amax = fmaxf(amax, fmaxf(fabsf(m[v]), fabsf(m[v + 1])));
                 }
+                // (measured and not kept, profiles/r05r_*: lane pairs trading halves for ONE 16-byte store per lane, as edge_rl.hip does --
+                // no change; at 252 of 256 registers this kernel's time moves by +-4 % with ANY edit of the epilogue: dropping the range
+                // guard above made it 4 % slower)
                 *reinterpret_cast<hvec*>(oc) = hv;
                 *reinterpret_cast<hvec*>(oc + 64) = lv;
             } else {
                 *reinterpret_cast<fvec*>(o) = m;
             }
         };
-        const unsigned sv_all = START & VALID;
-        const int lastb = sv_all ? 31 - __builtin_clz(sv_all) : 0;            // where the tile's last segment starts
-        const bool own_first = first_cont && (mine & 1u) != 0;
-        const bool own_last = last_cont && sv_all != 0 && ((mine >> lastb) & 1u) != 0 && !(own_first && lastb == 0);
-        if (own_first) mine &= ~1u;
-        if (own_last) mine &= ~(1u << lastb);
-        while (mine) {                                                       // wave-uniform: SALU bit walking
-            const int b = __builtin_ctz(mine);
-            mine &= mine - 1u;
-            segment(b, std::false_type{});
+        if constexpr (!Y16) {
+            while (mine) {                                                   // wave-uniform: SALU bit walking
+                const int b = __builtin_ctz(mine);
+                mine &= mine - 1u;
+                segment(b, std::true_type{});
+            }
+        } else {
+            const unsigned sv_all = START & VALID;
+            const int lastb = sv_all ? 31 - __builtin_clz(sv_all) : 0;        // where the tile's last segment starts
+            const bool own_first = first_cont && (mine & 1u) != 0;
+            const bool own_last = last_cont && sv_all != 0 && ((mine >> lastb) & 1u) != 0 && !(own_first && lastb == 0);
+            if (own_first) mine &= ~1u;
+            if (own_last) mine &= ~(1u << lastb);
+            while (mine) {                                                   // wave-uniform: SALU bit walking
+                const int b = __builtin_ctz(mine);
+                mine &= mine - 1u;
+                segment(b, std::false_type{});
+            }
+            if (own_first) segment(0, std::true_type{});
+            if (own_last) segment(lastb, std::true_type{});
         }
-        if (own_first) segment(0, std::true_type{});
-        if (own_last) segment(lastb, std::true_type{});
     };
 
     // ---- prologue: tile 0's chunks 0..2 in flight, chunk 0 converted ----

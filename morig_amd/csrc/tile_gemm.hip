@@ -855,7 +855,7 @@ extern "C" int morig_edge_hidden(const morig_edgeconv_args* a, void* stream) {
     TileParams p = {};
     const int st = edge_common(a, p);
     if (st != MORIG_OK) return st;
-    if (a->replicas != 1) return MORIG_E_UNSUPPORTED;
+    if (a->replicas != 1 || a->out_split) return MORIG_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity);
     const double flops = 2.0 * E * a->H * (double)a->H;
@@ -941,7 +941,7 @@ static EdgePlan edge_plan(const morig_edgeconv_args* a) {
     // so at most 8, and short enough that every wave (edge_rl.hip, 8 per CU) / workgroup (edge_ws.hip) still gets >= 16 runs
     static const int run_env = [] { const char* e = getenv("MORIG_EDGE_RUN"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : (v > 4096 ? 4096 : v); }();
     pl.run = 1;
-    if (pl.use_rl || pl.use_ws) {
+    if (pl.use_rl || (pl.use_ws && a->out_split)) {              // (edge_ws.hip carries segments in its split-rows form only)
         const long tiles = (long)cdiv(a->edge_capacity, pl.tile_rows) * a->replicas;
         const long units = pl.use_rl ? 2048 : 256;
         while (pl.run * 2 <= run_env && tiles / (units * 16) >= pl.run * 2) pl.run *= 2;

@@ -13,6 +13,7 @@ for round in 1 2; do
       run8f) export MORIG_EDGE_RUN=8; unset OP_SPLIT ;;        # fp32 rows out (no conversion pass, the <.., false> kernels)
       run1f) unset OP_SPLIT ;;
       prev) d=_old; unset OP_SPLIT; [ -d _old ] || continue ;;
+      r8_*) export MORIG_EDGE_RUN=8 MORIG_HIP_LIB=$PWD/morig_amd/lib/variants/lib_ws_${v#r8_}.so ;;      # a variant library at run 8
       *) export MORIG_HIP_LIB=$PWD/morig_amd/lib/variants/lib_ws_$v.so ;;
     esac
     ( cd $d && OP_ONLY=${OPK:-edge_geo_H256} timeout 200 python tools/op_clock.py 2 2>&1 | grep edge_geo | sed "s/^/$v /" ) | tee -a $OUT
