@@ -569,7 +569,8 @@ def test_captured_forward_replays_bit_identically(sides):
     assert cf.check() is True
     for a, b in zip(want2, out):
         assert torch.equal(a, b)
-    # an overflowing input is reported by the replay's own snapshot
+    # an overflowing input is reported by the replay's own snapshot (MORIG_PRECISION=f32 has no range guard: nothing to report)
+    from morig_amd import native
     d.pred_flow.mul_(1.0e7)
     cf.replay()
-    assert cf.check() is False
+    assert cf.check() is (native.get_ops().precision == "f32")
