@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define MORIG_ABI_VERSION 1
+/* 2 (round 5): morig_gemm_args.w_split_format and morig_edgeconv_args.out_split appended to their structs; morig_gemm_tn_shift,
+ * morig_edgeconv_can_split_out, morig_ubench_mfma added. A caller built against version 1 passes shorter structs: check the version. */
+#define MORIG_ABI_VERSION 2
 
 /* status codes */
 #define MORIG_OK              0

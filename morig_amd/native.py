@@ -227,7 +227,7 @@ def load_library(path: str = LIB_PATH):
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the header and the build disagree
         fn.restype, fn.argtypes = res, args
-    if lib.morig_abi_version() != 1:
+    if lib.morig_abi_version() != 2:
         raise MorigNativeError("libmorig_hip.so ABI version mismatch")
     _lib = lib
     return lib
