@@ -21,14 +21,29 @@
 #define MORIG_HIP_H
 
 #include <stdint.h>
+#include <string.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 /* 2 (round 5): morig_gemm_args.w_split_format and morig_edgeconv_args.out_split appended to their structs; morig_gemm_tn_shift,
- * morig_edgeconv_can_split_out, morig_ubench_mfma added. A caller built against version 1 passes shorter structs: check the version. */
-#define MORIG_ABI_VERSION 2
+ * morig_edgeconv_can_split_out, morig_ubench_mfma added.
+ * 3 (round 6): every argument struct STARTS with `uint32_t struct_size` (see below): appending a member no longer lets the library read
+ * past the end of an older caller's struct. morig_gemm_args gained X_tail / ld_tail / tail_rows / tail_cols; morig_pack_tails added. */
+#define MORIG_ABI_VERSION 3
+
+/* Argument structs (morig_gemm_args, morig_edgeconv_args, morig_edgeconv_x3_args, morig_segmax_args, morig_pointconv_args):
+ * the first member, struct_size, is sizeof() of the struct AS THE CALLER WAS COMPILED (MORIG_INIT_ARGS sets it and zeroes the rest).
+ * Members are only ever appended. The library copies min(struct_size, its own sizeof) bytes into a zeroed struct of its own, so members
+ * the caller does not know read as 0 / NULL; a struct_size below the ABI-3 size of the struct (MORIG_*_ARGS_V3_SIZE: what a version-1 / -2
+ * caller's memory would spell there, or garbage) is MORIG_E_INVALID. */
+#define MORIG_INIT_ARGS(type, var) type var; memset(&(var), 0, sizeof(var)); (var).struct_size = (uint32_t)sizeof(var)
+#define MORIG_GEMM_ARGS_V3_SIZE        192u
+#define MORIG_EDGECONV_ARGS_V3_SIZE    184u
+#define MORIG_EDGECONV_X3_ARGS_V3_SIZE 168u
+#define MORIG_SEGMAX_ARGS_V3_SIZE      144u
+#define MORIG_POINTCONV_ARGS_V3_SIZE   176u
 
 /* status codes */
 #define MORIG_OK              0
@@ -97,6 +112,7 @@ int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_
 #define MORIG_SPLIT_F16 0
 #define MORIG_SPLIT_BF16 1
 typedef struct morig_gemm_args {
+    uint32_t struct_size;     /* sizeof(morig_gemm_args) of the caller's build (ABI 3)                */
     int32_t M, N, K;          /* logical sizes: Y is M x N, X is M x K                            */
     const float* X; int32_t ldx;
     const float* W; int32_t ldw;     /* packed weights [Npad][ldw]: row n = output channel n, ldw >= roundup(K,32),
@@ -125,6 +141,14 @@ typedef struct morig_gemm_args {
      * producer instead of once per column tile); y_split: write Y in that layout. */
     int32_t x_split, y_split;
     int32_t w_split_format;   /* MORIG_SPLIT_F16 (0) or MORIG_SPLIT_BF16 (1): what W_split holds */
+    /* [ABI 3] optional K TAIL (x_split launches only): the last tail_cols columns of X -- columns [K - tail_cols, K); tail_cols % 32 == 0,
+     * K % 32 == 0, K > tail_cols -- are read from X_tail[row % tail_rows] instead of X[row]: 128-byte aligned rows of ld_tail floats
+     * (ld_tail % 32 == 0, >= tail_cols) in the split-fp16 chunk layout. This is how a replica-invariant block of a concatenated input
+     * enters without being copied into every replica's row: the position-branch features [pos_tpl | pos_geo] of a GCUMotion unit under
+     * the keyframe loop (models/basic_modules.py:216-217 inside models/rignet.py:85-86; rows r * n + v of the 5 replicas all read tail
+     * row v). X then needs only ldx >= K - tail_cols. MORIG_E_UNSUPPORTED where the launch would not take the LDS-DMA store kernel
+     * (N % 256 != 0, pool, misaligned Y): the caller copies the block into X instead (morig_copy2d_pad_rep). */
+    const float* X_tail; int32_t ld_tail, tail_rows, tail_cols;
 } morig_gemm_args;
 int morig_gemm(const morig_gemm_args* a, void* stream);
 
@@ -142,6 +166,7 @@ int morig_gemm(const morig_gemm_args* a, void* stream);
  * H = hidden = output width; supported H: 16, 32, 64, 128, 256.
  */
 typedef struct morig_edgeconv_args {
+    uint32_t struct_size;              /* sizeof(morig_edgeconv_args) of the caller's build (ABI 3) */
     int32_t H;
     int32_t n_nodes, replicas;
     int32_t in_rep_stride;             /* row offset of replica r in A/B: r*in_rep_stride (0 = shared by all replicas) */
@@ -178,6 +203,7 @@ int morig_edgeconv_can_split_out(const morig_edgeconv_args* a);
  *   X [rows][ldx] (ldx >= 4, 16-byte aligned rows; columns 0..2 used), replica r reads rows r * in_rep_stride + vertex;
  *   W1a, W1b [32][4] (column 3 ignored), b1 [32]; everything else as morig_edgeconv_args. */
 typedef struct morig_edgeconv_x3_args {
+    uint32_t struct_size;              /* sizeof(morig_edgeconv_x3_args) of the caller's build (ABI 3) */
     int32_t H;
     int32_t n_nodes, replicas;
     int32_t in_rep_stride, out_rep_stride;
@@ -200,6 +226,7 @@ int morig_edgeconv_x3(const morig_edgeconv_x3_args* a, void* stream);
  * Linear splits per vertex exactly like EdgeConv's: B_j = W1 [x_j ‖ pos_j] + b1, A_i = -W1p pos_i.        */
 int morig_edge_hidden(const morig_edgeconv_args* a, void* stream);
 typedef struct morig_segmax_args {
+    uint32_t struct_size;                /* sizeof(morig_segmax_args) of the caller's build (ABI 3) */
     int32_t N, K;
     const float* X; int32_t ldx;         /* per-edge rows [edge_capacity][ldx]                       */
     const float* W; int32_t ldw;         /* packed like morig_gemm_args.W (rows padded to 32/64/128/256) */
@@ -221,6 +248,7 @@ int morig_segmax_gemm(const morig_segmax_args* a, void* stream);
  * *status is set to 1 when a slot names a source >= n_src (out is unspecified then); *overflow as in morig_gemm.
  * MORIG_E_UNSUPPORTED for other widths: the caller falls back to morig_edge_hidden + morig_segmax_gemm. */
 typedef struct morig_pointconv_args {
+    uint32_t struct_size;                /* sizeof(morig_pointconv_args) of the caller's build (ABI 3) */
     const float* A; int32_t lda;
     const float* B; int32_t ldb;
     const int64_t* slots; int32_t max_nbrs;
@@ -249,6 +277,14 @@ int morig_copy2d_pad(const float* src, int32_t lds, int32_t rows, int32_t cols, 
 int morig_copy2d_pad_rep(const float* src, int32_t lds, int32_t rows, int32_t cols, int32_t src_col_step, float* dst,
                          int32_t ldd, int32_t slot_cols, int32_t replicas, int64_t dst_row_step, int32_t split,
                          int32_t* overflow, void* stream);
+/* K tails (morig_gemm_args.X_tail) of up to MORIG_MAX_TAILS concatenations in ONE launch: tail t, row v =
+ * [src[v][col_a[t] .. + wa) | src[v][col_b[t] .. + wb) | zeros up to 32] as one split-fp16 chunk at dst + t * tail_stride + v * 32 floats
+ * (wa + wb <= 32; dst 128-byte aligned, tail_stride % 32 == 0). Builds [pos_tpl | pos_geo] (models/basic_modules.py:216-217) of every
+ * GCUMotion unit of a forward from the buffer the paired position branches wrote (morig_edgeconv_x3). *overflow as in morig_gemm. */
+#define MORIG_MAX_TAILS 8
+int morig_pack_tails(const float* src, int32_t lds, int32_t rows, const int32_t* col_a /* host [n_tails] */,
+                     const int32_t* col_b /* host [n_tails] */, int32_t wa, int32_t wb, int32_t n_tails, float* dst,
+                     int64_t tail_stride, int32_t* overflow, void* stream);
 
 /* gather columns: dst[r*ldd + c] = src[r*lds + cols[c]]  (skin_input column selection,
  * models/rignet.py:158-171). cols: int32 [n_cols] on device. */

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include "../../include/morig_hip.h"
 
 namespace morig {
@@ -58,6 +59,7 @@ struct EdgePcParams {
 struct GemmDmaParams {
     int M, N, K;
     const float* X; int ldx;                     // split-fp16 layout
+    const float* Xt; int ldt; int tail_rows; int tail_chunks;   // morig_gemm_args.X_tail: the last tail_chunks chunks of X from Xt[row % tail_rows]
     const float* W; int ldw;                     // split-fp16 layout, rows padded to the column tile
     const float* bias; const float* scale; const float* shift; int relu;
     const float* rowbias; int ld_rowbias; const int* seg;
@@ -88,6 +90,21 @@ struct EdgeX3Params {
 
 int launch_edge_x3(const EdgeX3Params& p, int n_tiles_cap, hipStream_t s);      // edge_x3.hip (persistent 32-wide EdgeConv on 3-channel inputs)
 int launch_gemm16_dmap(const GemmDmaParams& p, hipStream_t s);                // gemm_dmap.hip (persistent, 256 x 256 tiles)
+
+// [ABI 3] every argument struct starts with struct_size: the caller's struct is copied into a zeroed struct of THIS build (members the
+// caller does not know read as 0); a size below the struct's ABI-3 size -- a version-1 / -2 caller, or garbage -- is refused.
+static_assert(sizeof(morig_gemm_args) >= MORIG_GEMM_ARGS_V3_SIZE && sizeof(morig_edgeconv_args) >= MORIG_EDGECONV_ARGS_V3_SIZE &&
+              sizeof(morig_edgeconv_x3_args) >= MORIG_EDGECONV_X3_ARGS_V3_SIZE && sizeof(morig_segmax_args) >= MORIG_SEGMAX_ARGS_V3_SIZE &&
+              sizeof(morig_pointconv_args) >= MORIG_POINTCONV_ARGS_V3_SIZE, "argument structs only grow");
+template <class T> static inline bool take_args(const T* a, T& mine, uint32_t v3_size) {
+    if (!a) return false;
+    const uint32_t n = a->struct_size;
+    if (n < v3_size || n > 1024u || (n & 7u)) return false;      // (an old-layout struct spells M / H / N here: almost always refused too)
+    memset(&mine, 0, sizeof(T));
+    memcpy(&mine, a, n < sizeof(T) ? n : sizeof(T));
+    mine.struct_size = (uint32_t)sizeof(T);
+    return true;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

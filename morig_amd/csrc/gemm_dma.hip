@@ -26,7 +26,10 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 // TR (store launches of the 256 x 256 tile): the MFMAs run with the operands swapped (A = W fragment, B = X fragment), the result
 // tile is D^T and leaves through the register epilogue (epilogue_store.h: store_tile_regs) -- no LDS transposition; the bias and,
 // when the tile lies in one mesh, the row bias are the accumulators' initial value (panel in LDS, filled under the prologue DMA).
-template <int BM, int BN, int NT, int DMA_NS, bool TR = false>
+// TAIL [r06]: the last `tail_chunks` 32-column chunks of X come from p.Xt[row % tail_rows] (morig_gemm_args.X_tail: a replica-invariant
+// block of a concatenated input, e.g. a unit's position-branch features under the keyframe loop, read from ONE copy instead of being
+// copied into every replica's row first). A separate instantiation: the four extra lane offsets stay out of the other launches.
+template <int BM, int BN, int NT, int DMA_NS, bool TR = false, bool TAIL = false>
 __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_kernel(const GemmDmaParams p) {
     constexpr int MT = 2;
     constexpr int WNW = BN / (32 * NT);          // waves along N
@@ -91,14 +94,32 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
         const int r = (wave * WJ + j) * 8 + rsub;
         ow[j] = ((unsigned)r * (unsigned)p.ldw + 4u * (pslot ^ ((r >> 1) & 7))) * 4u;
     }
+    const int nchunk = (p.K + 31) / 32;
+    // TAIL: chunk c >= c_tail is chunk c - c_tail of tail row (global row % tail_rows); offsets relative to the tail's base
+    unsigned ot[TAIL ? XJ : 1];
+    const int c_tail = TAIL ? nchunk - p.tail_chunks : nchunk;
+    const char* tbase = reinterpret_cast<const char*>(p.Xt);
+    if constexpr (TAIL) {
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int r = (wave * XJ + j) * 8 + rsub;
+            int gr = row0 + r; if (gr >= p.M) gr = p.M - 1;
+            ot[j] = ((unsigned)(gr % p.tail_rows) * (unsigned)p.ldt + 4u * (unsigned)(pslot ^ ((r >> 1) & 7))) * 4u;
+        }
+    }
+    // the source of X piece j of chunk c: (block-uniform base, lane offset)
+    auto x_src = [&](int c, int j) __attribute__((always_inline)) -> const char* {
+        unsigned o = ox[j];
+        const char* b = xbase + c * 128;
+        if constexpr (TAIL) { if (c >= c_tail) { o = ot[j]; b = tbase + (c - c_tail) * 128; } }
+        asm volatile("" : "+v"(o));                  // keep (scalar base + lane offset) addressing
+        return b + o;
+    };
     auto issue_x = [&](int c) {
         char* st = smem + (c % DMA_NS) * DMA_STAGE;
 #pragma unroll
-        for (int j = 0; j < XJ; ++j) {
-            unsigned o = ox[j];
-            asm volatile("" : "+v"(o));              // keep (scalar base + lane offset) addressing
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(xbase + c * 128 + o), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < XJ; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)x_src(c, j), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
     };
     auto issue_w = [&](int c) {
         char* st = smem + (c % DMA_NS) * DMA_STAGE;
@@ -119,7 +140,6 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    const int nchunk = (p.K + 31) / 32;
     // prologue: NS-1 chunks in flight (PER_CHUNK DMA instructions per chunk per wave)
 #pragma unroll
     for (int c = 0; c < DMA_NS - 1; ++c) if (c < nchunk) issue(c);
@@ -184,9 +204,7 @@ __global__ __launch_bounds__((BM / 64) * (BN / (32 * NT)) * 64) void gemm16_dma_
     auto issue_one = [&](int c, int j) __attribute__((always_inline)) {       // DMA instruction j of chunk c (X pieces, then W pieces)
         char* st = smem + (c % DMA_NS) * DMA_STAGE;
         if (j < XJ) {
-            unsigned o = ox[j];
-            asm volatile("" : "+v"(o));
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(xbase + c * 128 + o), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)x_src(c, j), (lds_void_t*)(st + (wave * XJ + j) * 1024), 16, 0, 0);
         } else {
             unsigned o = ow[j - XJ];
             asm volatile("" : "+v"(o));
@@ -329,7 +347,8 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
     const bool vec_ok = p.pool != nullptr ||
                         ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0 &&
                          (!p.rowbias || ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0 && (p.ld_rowbias & 3) == 0)));
-    if (mode == 256 && p.N % 256 == 0 && p.K > 32 && vec_ok && (persist == 2 || (persist == 1 && deep_wide))) {
+    if (p.Xt && !(mode == 256 && p.N % 256 == 0 && !p.pool)) return MORIG_E_UNSUPPORTED;      // K tails: the 256 x 256 store kernel only
+    if (!p.Xt && mode == 256 && p.N % 256 == 0 && p.K > 32 && vec_ok && (persist == 2 || (persist == 1 && deep_wide))) {
         // (a ping-pong schedule for these launches -- the two waves of a SIMD alternating 48-MFMA slots and load slots, gemm_pp.hip in
         // commit a267b6e -- was built, bit-identical, and measured 3-11 % slower: profiles/r04b..r04d, DESIGN section 5 [r04])
         if (!p.pool) prof_retag(K_GEMM16_DMAP);       // the pooled kind already names this kernel
@@ -353,7 +372,7 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
         // are already smooth (K = 64: 3.8 TB/s written), and the small tile doubles the LDS-DMA pieces per MFMA. MORIG_DMA_SHORTK=<K>
         // selects it for K <= <K> (A/B switch; default 0 = never)
         static const int shortk = [] { const char* e = getenv("MORIG_DMA_SHORTK"); return e ? atoi(e) : 0; }();
-        if (tr && shortk > 0 && p.K <= shortk && p.N % 128 == 0) {
+        if (tr && !p.Xt && shortk > 0 && p.K <= shortk && p.N % 128 == 0) {
             p.tiles_n = p.N / 128;
             const int nb128 = cdiv(p.M, 128) * p.tiles_n;
             prof_retag(K_GEMM16_DMA128);
@@ -361,8 +380,10 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
             MORIG_LAUNCH_CHECK();
             return MORIG_OK;
         }
-        if (tr) hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, true>), dim3(nb), dim3(512), 0, s, p);
-        else    hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, false>), dim3(nb), dim3(512), 0, s, p);
+        if (p.Xt && !tr) return MORIG_E_UNSUPPORTED;
+        if (p.Xt)    hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, true, true>), dim3(nb), dim3(512), 0, s, p);
+        else if (tr) hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, true>), dim3(nb), dim3(512), 0, s, p);
+        else         hipLaunchKernelGGL((gemm16_dma_kernel<256, 256, 4, 2, false>), dim3(nb), dim3(512), 0, s, p);
 #ifdef MORIG_DMA_TRACE
         {
             unsigned long long h[64];

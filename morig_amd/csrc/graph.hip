@@ -284,6 +284,34 @@ __global__ void copy2d_pad_rep4_kernel(const float* __restrict__ src, int lds, i
     }
 }
 
+// K tails of several concatenations in one launch (morig_pack_tails): a thread = (tail t, row v, 4 adjacent columns) -> two 8-byte stores
+// (hi pairs, lo pairs) of the row's ONE split chunk; columns [0, wa) from src[v][col_a[t] ..], [wa, wa + wb) from src[v][col_b[t] ..], zeros behind
+struct TailCols { int a[MORIG_MAX_TAILS], b[MORIG_MAX_TAILS]; };
+__global__ void pack_tails_kernel(const float* __restrict__ src, int lds, int rows, TailCols tc, int wa, int wb, int n_tails,
+                                  float* __restrict__ dst, int64_t tail_stride, int* ovf) {
+    const int64_t n = (int64_t)rows * n_tails * 8;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i & 7) * 4;
+        const int64_t rv = i >> 3;
+        const int t = (int)(rv / rows); const int64_t r = rv - (int64_t)t * rows;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = c + j;
+            v[j] = cc < wa ? src[r * lds + tc.a[t] + cc] : (cc < wa + wb ? src[r * lds + tc.b[t] + (cc - wa)] : 0.f);
+        }
+        float h0, h1, l0, l1;
+        split_pair_f16(v[0], v[1], h0, l0);
+        split_pair_f16(v[2], v[3], h1, l1);
+        const float am = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        if (!(am < 65000.f)) *ovf = 1;                     // (NaN too)
+        char* yh = reinterpret_cast<char*>(dst + t * tail_stride + r * 32) + 2 * c;
+        *reinterpret_cast<float2*>(yh) = make_float2(h0, h1);
+        *reinterpret_cast<float2*>(yh + 64) = make_float2(l0, l1);
+    }
+}
+
 __global__ void gather_cols_kernel(const float* __restrict__ src, int lds, const int* __restrict__ cols, int ncols,
                                    float* __restrict__ dst, int ldd, int rows) {
     const int64_t n = (int64_t)rows * ncols;
@@ -694,6 +722,24 @@ extern "C" int morig_copy2d_pad_rep(const float* src, int32_t lds, int32_t rows,
     else
         hipLaunchKernelGGL(copy2d_pad_rep_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, src_col_step,
                            dst, ldd, slot_cols, replicas, dst_row_step, split, overflow);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
+extern "C" int morig_pack_tails(const float* src, int32_t lds, int32_t rows, const int32_t* col_a, const int32_t* col_b, int32_t wa, int32_t wb,
+                                int32_t n_tails, float* dst, int64_t tail_stride, int32_t* overflow, void* stream) {
+    if (!src || !dst || !col_a || !col_b || !overflow || rows < 0 || n_tails < 1 || n_tails > MORIG_MAX_TAILS || wa < 0 || wb < 0 || wa + wb > 32 ||
+        wa + wb == 0 || (tail_stride & 31) || tail_stride < (int64_t)rows * 32 || (reinterpret_cast<uintptr_t>(dst) & 127)) return MORIG_E_INVALID;
+    TailCols tc = {};
+    for (int t = 0; t < n_tails; ++t) {
+        if (col_a[t] < 0 || col_b[t] < 0 || col_a[t] + wa > lds || col_b[t] + wb > lds) return MORIG_E_INVALID;
+        tc.a[t] = col_a[t]; tc.b[t] = col_b[t];
+    }
+    if (rows == 0) return MORIG_OK;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ProfScope ps(K_COPY, s, 0.0, 4.0 * rows * n_tails * (double)(wa + wb + 32));
+    hipLaunchKernelGGL(pack_tails_kernel, dim3(grid_for((int64_t)rows * n_tails * 8)), dim3(256), 0, s, src, lds, rows, tc, wa, wb, n_tails,
+                       dst, tail_stride, overflow);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

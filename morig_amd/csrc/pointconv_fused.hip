@@ -320,8 +320,11 @@ static int launch_pcf(const PcfParams& p, hipStream_t s) {
 
 using namespace morig;
 
-extern "C" int morig_pointconv_fused(const morig_pointconv_args* a, void* stream) {
-    if (!a || !a->A || !a->B || !a->slots || !a->W2_split || !a->b2 || !a->W3_split || !a->out || !a->overflow || !a->status)
+extern "C" int morig_pointconv_fused(const morig_pointconv_args* a_in, void* stream) {
+    morig_pointconv_args mine;
+    if (!take_args(a_in, mine, MORIG_POINTCONV_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+    const morig_pointconv_args* a = &mine;
+    if (!a->A || !a->B || !a->slots || !a->W2_split || !a->b2 || !a->W3_split || !a->out || !a->overflow || !a->status)
         return MORIG_E_INVALID;
     if (a->n_centres <= 0 || a->n_src < a->n_centres || a->max_nbrs != 64) return MORIG_E_INVALID;
     if (a->lda < a->H || a->ldb < a->H || (a->lda & 3) || (a->ldb & 3) || a->ldw2 < a->H || a->ldw3 < a->H || (a->ldw2 & 3) || (a->ldw3 & 3) ||

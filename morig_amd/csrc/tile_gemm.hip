@@ -722,13 +722,24 @@ static int pool_finalize(float* pool, int n_seg, int ld_pool, hipStream_t s) {
 
 using namespace morig;
 
-extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
-    if (!a || !a->X || !a->W) return MORIG_E_INVALID;
+extern "C" int morig_gemm(const morig_gemm_args* a_in, void* stream) {
+    morig_gemm_args mine;
+    if (!take_args(a_in, mine, MORIG_GEMM_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+    const morig_gemm_args* a = &mine;
+    if (!a->X || !a->W) return MORIG_E_INVALID;
     if (a->M < 0 || a->N <= 0 || a->K <= 0) return MORIG_E_INVALID;
     if (a->M == 0) return MORIG_OK;
     if ((a->ldx & 3) || (a->ldw & 3) || !aligned16(a->X) || !aligned16(a->W)) return MORIG_E_INVALID;
-    if (a->ldx < ((a->K + 3) & ~3) || a->ldw < ((a->K + 31) & ~31)) return MORIG_E_INVALID;
+    const bool tail = a->X_tail != nullptr;
+    if (tail) {
+        // K tail: split chunks from X_tail[row % tail_rows] (include/morig_hip.h); everything about it is checked here, the kernel choice below
+        if (!a->x_split || !a->W_split || a->tail_cols <= 0 || (a->tail_cols & 31) || (a->K & 31) || a->K <= a->tail_cols || a->tail_rows <= 0 ||
+            (a->ld_tail & 31) || a->ld_tail < a->tail_cols || (reinterpret_cast<uintptr_t>(a->X_tail) & 127) ||
+            (double)a->tail_rows * a->ld_tail * 4.0 >= 4.0e9) return MORIG_E_INVALID;
+    }
+    if (a->ldx < (((a->K - (tail ? a->tail_cols : 0)) + 3) & ~3) || a->ldw < ((a->K + 31) & ~31)) return MORIG_E_INVALID;
     const bool pool = a->pool != nullptr;
+    if (tail && pool) return MORIG_E_UNSUPPORTED;
     if (!pool && !a->Y) return MORIG_E_INVALID;
     if (pool && a->Y) return MORIG_E_UNSUPPORTED;           // one consumer per launch
     if ((pool || a->rowbias) && !a->seg) return MORIG_E_INVALID;
@@ -760,7 +771,7 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
     const bool kc64 = f16 && a->K >= 64 && (a->ldw & 63) == 0 && a->ldw >= ((a->K + 63) & ~63) && !getenv("MORIG_KC32");
     if (a->x_split || a->y_split) {
         if (!f16) return MORIG_E_INVALID;                        // split activations only exist on the split-fp16 path
-        if (a->x_split && ((a->ldx & 31) || a->ldx < ((a->K + 31) & ~31) || (reinterpret_cast<uintptr_t>(a->X) & 127))) return MORIG_E_INVALID;
+        if (a->x_split && ((a->ldx & 31) || a->ldx < (((a->K - (tail ? a->tail_cols : 0)) + 31) & ~31) || (reinterpret_cast<uintptr_t>(a->X) & 127))) return MORIG_E_INVALID;
         if (a->y_split && (pool || (a->ldy & 31) || (reinterpret_cast<uintptr_t>(a->Y) & 127))) return MORIG_E_INVALID;
         p.x16 = a->x_split ? 1 : 0; p.y16 = a->y_split ? 1 : 0;
     }
@@ -795,9 +806,11 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
         q.bias = a->bias; q.scale = a->scale; q.shift = a->shift; q.relu = a->relu;
         q.rowbias = a->rowbias; q.ld_rowbias = a->ld_rowbias; q.seg = a->seg;
         q.Y = a->Y; q.ldy = a->ldy; q.y16 = a->y_split ? 1 : 0; q.tiles_n = cdiv(a->N, 128); q.ovf = a->overflow;
+        if (tail) { q.Xt = a->X_tail; q.ldt = a->ld_tail; q.tail_rows = a->tail_rows; q.tail_chunks = a->tail_cols / 32; }
         ProfScope ps(K_GEMM16_DMA, s, flops, bytes);
         return launch_gemm16_dma(q, tiles_m, s);
     }
+    if (tail) return MORIG_E_UNSUPPORTED;
     if (bf16) {
         ProfScope ps(K_MISC, s, flops, bytes);
         if (a->N > 64) { p.tiles_n = cdiv(a->N, 128); return launch_tile<128, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X3>(p, tiles_m * p.tiles_n, s); }
@@ -828,7 +841,7 @@ extern "C" int morig_gemm(const morig_gemm_args* a, void* stream) {
 }
 
 static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
-    if (!a || !a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
+    if (!a->A || !a->B || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
     if ((a->s1 == nullptr) != (a->t1 == nullptr) || !a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
     if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
     if ((a->lda & 3) || (a->ldb & 3) || (a->ldw & 3) || !aligned16(a->A) || !aligned16(a->B) || !aligned16(a->W2) ||
@@ -851,7 +864,10 @@ static int edge_common(const morig_edgeconv_args* a, TileParams& p) {
     return MORIG_OK;
 }
 
-extern "C" int morig_edge_hidden(const morig_edgeconv_args* a, void* stream) {
+extern "C" int morig_edge_hidden(const morig_edgeconv_args* a_in, void* stream) {
+    morig_edgeconv_args mine;
+    if (!take_args(a_in, mine, MORIG_EDGECONV_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+    const morig_edgeconv_args* a = &mine;
     TileParams p = {};
     const int st = edge_common(a, p);
     if (st != MORIG_OK) return st;
@@ -875,8 +891,11 @@ extern "C" int morig_edge_hidden(const morig_edgeconv_args* a, void* stream) {
     }
 }
 
-extern "C" int morig_segmax_gemm(const morig_segmax_args* a, void* stream) {
-    if (!a || !a->X || !a->W || !a->rowptr || !a->dst_sorted || !a->out) return MORIG_E_INVALID;
+extern "C" int morig_segmax_gemm(const morig_segmax_args* a_in, void* stream) {
+    morig_segmax_args mine;
+    if (!take_args(a_in, mine, MORIG_SEGMAX_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+    const morig_segmax_args* a = &mine;
+    if (!a->X || !a->W || !a->rowptr || !a->dst_sorted || !a->out) return MORIG_E_INVALID;
     if (a->N <= 0 || a->K <= 0 || a->n_nodes <= 0 || a->edge_capacity <= 0) return MORIG_E_INVALID;
     if ((a->ldx & 3) || (a->ldw & 3) || !aligned16(a->X) || !aligned16(a->W)) return MORIG_E_INVALID;
     if (a->ldx < ((a->K + 3) & ~3) || a->ldw < ((a->K + 31) & ~31) || a->ldo < a->N) return MORIG_E_INVALID;
@@ -953,13 +972,19 @@ static EdgePlan edge_plan(const morig_edgeconv_args* a) {
     return pl;
 }
 
-extern "C" int morig_edgeconv_can_split_out(const morig_edgeconv_args* a) {
+extern "C" int morig_edgeconv_can_split_out(const morig_edgeconv_args* a_in) {
+    morig_edgeconv_args mine;
+    if (!take_args(a_in, mine, MORIG_EDGECONV_ARGS_V3_SIZE)) return 0;
+    const morig_edgeconv_args* a = &mine;
     TileParams p = {};
     if (edge_common(a, p) != MORIG_OK) return 0;
     return edge_plan(a).split_ok ? 1 : 0;
 }
 
-extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
+extern "C" int morig_edgeconv(const morig_edgeconv_args* a_in, void* stream) {
+    morig_edgeconv_args mine;
+    if (!take_args(a_in, mine, MORIG_EDGECONV_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+    const morig_edgeconv_args* a = &mine;
     TileParams p = {};
     const int st = edge_common(a, p);
     if (st != MORIG_OK) return st;
@@ -1033,8 +1058,11 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a, void* stream) {
 // EdgeConv whose vertex input has 3 channels: first Linear evaluated in the loader from the gathered endpoints (LOAD_EDGE3), then the
 // 32-wide second layer + max exactly as morig_edgeconv. Replaces `morig_gemm` (K = 3 -> [A | B]) + `morig_edgeconv` for the position
 // branches (models/basic_modules.py:193-195: nn_pos([pos_i, pos_j - pos_i])) and for motionNet's first unit (nn_x on the 3-channel flow).
-extern "C" int morig_edgeconv_x3(const morig_edgeconv_x3_args* a, void* stream) {
-    if (!a || !a->X || !a->W1a || !a->W1b || !a->b1 || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
+extern "C" int morig_edgeconv_x3(const morig_edgeconv_x3_args* a_in, void* stream) {
+    morig_edgeconv_x3_args mine;
+    if (!take_args(a_in, mine, MORIG_EDGECONV_X3_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+    const morig_edgeconv_x3_args* a = &mine;
+    if (!a->X || !a->W1a || !a->W1b || !a->b1 || !a->rowptr || !a->src_sorted || !a->dst_sorted || !a->W2 || !a->out) return MORIG_E_INVALID;
     if (!a->b2 || !a->s2 || !a->t2) return MORIG_E_INVALID;
     if (a->H != 32) return MORIG_E_UNSUPPORTED;
     if (a->n_nodes <= 0 || a->replicas <= 0 || a->edge_capacity <= 0 || a->ldx < 4 || (a->ldx & 3) || !aligned16(a->X)) return MORIG_E_INVALID;

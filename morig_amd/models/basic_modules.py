@@ -366,8 +366,11 @@ class GCUMotion(NativeModule):
         """pos: [n, P] window; x: [R*n, C] window (replica-major); out: [R*n, O] window.
         split: x and out are windows in the split-fp16 activation layout (GEMM -> GEMM hand-off);
         split_in / split_out override it for one side.
-        pos_feat: (Mat [n, D], Mat [n, D]) = this unit's position-branch results on the tpl / geo graph, already computed by
-        ``run_pos_groups`` (paired with another unit's): copied into every replica instead of being computed here.
+        pos_feat: (Mat [n, D], Mat [n, D][, Mat [n, 32] or None]) = this unit's position-branch results on the tpl / geo graph, already
+        computed by ``run_pos_groups`` (paired with another unit's): copied into every replica instead of being computed here. The third
+        entry, when given, is the same pair once more as ONE split-fp16 chunk per vertex [pos_tpl | pos_geo] (ops.pack_tails): where the
+        unit's MLP runs on the LDS-DMA store kernel it reads that block as the K TAIL of its input (row v of the tail for the rows
+        r n + v of all replicas: morig_gemm_args.X_tail) and nothing is copied at all.
         x3: the 3-channel feature as plain fp32 rows [R*n, 4] (first unit of motionNet): its two EdgeConvs then evaluate the first
         Linear in-kernel from the gathered endpoints (morig_edgeconv_x3) and the [A | B] GEMM is not run."""
         split_in = split if split_in is None else split_in
@@ -385,6 +388,9 @@ class GCUMotion(NativeModule):
         if pos_feat is None:
             pab = ops.empty(n, 4 * D, dev)
             ops.gemm(pos, pk["vp"], relu=False, Y=Mat.of(pab))
+        tail = pos_feat[2] if (pos_feat is not None and len(pos_feat) > 2) else None
+        use_tail = (tail is not None and not use_x3 and "mlp_s" in pk and hasattr(ops, "gemm_takes_tail")
+                    and ops.gemm_takes_tail(pk["mlp_s"], out, 2 * D))
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
         if not use_x3 and "mlp_s" in pk and _edge_rows_can_split(ops, ab, ec, csr_tpl, csr_geo, pk["xt"], pk["xg"], H, replicas, n):
             # split-fp16 rows [x_tpl | x_geo | pos_tpl | pos_geo] straight from the EdgeConv kernels into the LDS-DMA GEMM
@@ -392,6 +398,11 @@ class GCUMotion(NativeModule):
                          replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
             ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H, H),
                          replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
+            if use_tail:
+                # [r06] the replica-invariant block is not copied into the replicas' rows: the GEMM reads it from the one tail row per vertex
+                # (the pos columns of `ec` stay unwritten and unread)
+                ops.gemm(Mat.of(ec, 0, 2 * H), pk["mlp_s"], relu=True, Y=out, x_split=True, y_split=split_out, x_tail=tail)
+                return
             p2 = ops.empty(n, 2 * D, dev)               # [pos_tpl | pos_geo] side by side: ONE chunk-aligned split copy into every replica
             if pos_feat is not None:
                 # (library copies, not torch.cat: with strided inputs torch's cat did not replay from a captured HIP graph --
@@ -441,7 +452,9 @@ def run_pos_groups(ops, packed_groups, pos: Mat, csr_tpl, csr_geo):
     With 3-channel positions the first Linear is evaluated inside the EdgeConv kernel from the gathered endpoints
     (morig_edgeconv_x3: no per-vertex [A | B] table, 32 instead of 256 gathered bytes per edge row); wider position inputs (SkinNet's
     33 channels are not paired: D = 64) would take one vertex GEMM for all pairs.
-    -> per covered unit (Mat tpl [n, D], Mat geo [n, D]), windows of one side buffer."""
+    -> per covered unit (Mat tpl [n, D], Mat geo [n, D], tail): the first two are windows of one side buffer; tail = the pair once more
+    as one split-fp16 chunk per vertex, [n, 32] = [pos_tpl | pos_geo | 0] (ops.pack_tails: ONE launch for all units; None off the
+    split-fp16 path or for D > 16), which the units' MLPs read as the K tail of their input (GCUMotion.run)."""
     vertex, edges, n_pairs = packed_groups
     if n_pairs == 0:
         return []
@@ -466,6 +479,11 @@ def run_pos_groups(ops, packed_groups, pos: Mat, csr_tpl, csr_geo):
             ops.edgeconv(Mat.of(pab, c0 + 2 * H, H), Mat.of(pab, c0 + 3 * H, H), csr_geo, eg, Mat.of(side, 2 * H * g + H, H))
         for j in range(2):
             out.append((Mat.of(side, 2 * H * g + j * D, D), Mat.of(side, 2 * H * g + H + j * D, D)))
+    if ops.split_activations and 2 * D <= 32 and len(out) <= 8 and hasattr(ops, "pack_tails") and os.environ.get("MORIG_GEMM_TAIL", "1") != "0":
+        tails = ops.pack_tails(side, [t.col0 for t, _ in out], [g_.col0 for _, g_ in out], D, D)
+        out = [(t, g_, Mat.of(tails[u])) for u, (t, g_) in enumerate(out)]
+    else:
+        out = [(t, g_, None) for t, g_ in out]
     return out
 
 

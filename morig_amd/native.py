@@ -27,6 +27,7 @@ c_u8p = C.c_void_p
 
 class GemmArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("X", c_f32p), ("ldx", C.c_int32),
         ("W", c_f32p), ("ldw", C.c_int32),
@@ -38,11 +39,13 @@ class GemmArgs(C.Structure):
         ("pool", c_f32p), ("ld_pool", C.c_int32), ("n_seg", C.c_int32),
         ("W_split", C.c_void_p), ("overflow", c_i32p),
         ("x_split", C.c_int32), ("y_split", C.c_int32), ("w_split_format", C.c_int32),
+        ("X_tail", c_f32p), ("ld_tail", C.c_int32), ("tail_rows", C.c_int32), ("tail_cols", C.c_int32),
     ]
 
 
 class EdgeConvArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("H", C.c_int32),
         ("n_nodes", C.c_int32), ("replicas", C.c_int32),
         ("in_rep_stride", C.c_int32), ("out_rep_stride", C.c_int32),
@@ -62,6 +65,7 @@ class EdgeConvArgs(C.Structure):
 
 class EdgeConvX3Args(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("H", C.c_int32),
         ("n_nodes", C.c_int32), ("replicas", C.c_int32),
         ("in_rep_stride", C.c_int32), ("out_rep_stride", C.c_int32),
@@ -78,6 +82,7 @@ class EdgeConvX3Args(C.Structure):
 
 class PointConvArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("A", c_f32p), ("lda", C.c_int32), ("B", c_f32p), ("ldb", C.c_int32),
         ("slots", C.c_void_p), ("max_nbrs", C.c_int32), ("n_centres", C.c_int32), ("n_src", C.c_int32),
         ("H", C.c_int32), ("H3", C.c_int32),
@@ -89,6 +94,7 @@ class PointConvArgs(C.Structure):
 
 class SegmaxArgs(C.Structure):
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("N", C.c_int32), ("K", C.c_int32),
         ("X", c_f32p), ("ldx", C.c_int32),
         ("W", c_f32p), ("ldw", C.c_int32),
@@ -98,6 +104,14 @@ class SegmaxArgs(C.Structure):
         ("out", c_f32p), ("ldo", C.c_int32),
         ("W_split", C.c_void_p), ("overflow", c_i32p),
     ]
+
+
+def _args(cls):
+    """a zeroed argument struct with its struct_size set (ABI 3: the library refuses a struct shorter than its version-3 layout and reads
+    members past struct_size as zero, include/morig_hip.h)"""
+    a = cls()
+    a.struct_size = C.sizeof(cls)
+    return a
 
 
 _SIGNATURES = {
@@ -188,6 +202,8 @@ _SIGNATURES = {
     "morig_copy2d_pad_rep": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int64,
                                         C.c_int32, c_i32p, C.c_void_p]),
     "morig_gather_cols": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
+    "morig_pack_tails": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32,
+                                   c_f32p, C.c_int64, c_i32p, C.c_void_p]),
     "morig_make_seg": (C.c_int, [c_i64p, C.c_int32, C.c_int32, C.c_int32, c_i32p, C.c_void_p]),
     "morig_rownorm": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_void_p]),
     "morig_cls_attention": (C.c_int, [c_f32p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_f32p, c_f32p, c_f32p, C.c_int32, C.c_void_p]),
@@ -207,6 +223,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+ABI_VERSION = 3                # include/morig_hip.h MORIG_ABI_VERSION
 _lib = None
 
 
@@ -227,8 +244,9 @@ def load_library(path: str = LIB_PATH):
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the header and the build disagree
         fn.restype, fn.argtypes = res, args
-    if lib.morig_abi_version() != 2:
-        raise MorigNativeError("libmorig_hip.so ABI version mismatch")
+    if lib.morig_abi_version() != ABI_VERSION:
+        raise MorigNativeError(f"libmorig_hip.so ABI version {lib.morig_abi_version()}, this binding is written against {ABI_VERSION} "
+                               "(argument structs start with struct_size since 3): rebuild with `make -C morig_amd/csrc`")
     _lib = lib
     return lib
 
@@ -560,9 +578,12 @@ class NativeOps:
     # -- dense ----------------------------------------------------------------------------------
     def gemm(self, X: Mat, lin, relu: bool, Y: Optional[Mat] = None, rowbias: Optional[Mat] = None,
              seg: Optional[torch.Tensor] = None, pool: Optional[torch.Tensor] = None, affine: bool = True,
-             x_split: bool = False, y_split: bool = False):
+             x_split: bool = False, y_split: bool = False, x_tail: Optional[Mat] = None):
         """x_split / y_split: the X window is / the Y window shall be in the split-fp16 activation layout
-        (include/morig_hip.h); only meaningful while ``self.fast``."""
+        (include/morig_hip.h); only meaningful while ``self.fast``.
+        x_tail: the last ``x_tail.cols`` columns of the input come from row (row % x_tail.rows) of this split-layout matrix instead of X
+        (morig_gemm_args.X_tail: a replica-invariant block read from ONE copy); X then holds the first K - x_tail.cols columns.
+        Only where ``gemm_takes_tail`` says so."""
         _need_gpu(X.base, lin.W)
         if x_split or y_split:
             if not self.fast:
@@ -570,9 +591,13 @@ class NativeOps:
             if lin.Wsplit is None:                    # weights outside the fp16 range: force the fp32 redo
                 self._flag(X.base.device).fill_(1)
                 return
-        a = GemmArgs()
+        a = _args(GemmArgs)
         a.M, a.N, a.K = X.rows, lin.N, lin.K
-        assert X.cols == lin.K, (X.cols, lin.K)
+        if x_tail is not None:
+            assert x_split and X.cols + x_tail.cols == lin.K and x_tail.cols % 32 == 0, (X.cols, x_tail.cols, lin.K)
+            a.X_tail, a.ld_tail, a.tail_rows, a.tail_cols = x_tail.ptr, x_tail.ld, x_tail.rows, x_tail.cols
+        else:
+            assert X.cols == lin.K, (X.cols, lin.K)
         a.X, a.ldx = X.ptr, X.ld
         a.W, a.ldw = lin.W.data_ptr(), lin.W.stride(0)
         a.bias = lin.bias.data_ptr() if lin.bias is not None else 0
@@ -597,6 +622,27 @@ class NativeOps:
         a.x_split, a.y_split = int(x_split), int(y_split)
         check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")
 
+    def gemm_takes_tail(self, lin, Y: Mat, n_tail_cols: int) -> bool:
+        """May ``gemm(..., x_split=True, x_tail=...)`` be used for this layer and output window? Mirrors the library's kernel choice
+        (csrc/gemm_dma.hip: K tails exist on the 256 x 256 LDS-DMA store kernel only); MORIG_GEMM_TAIL=0 switches the tails off (A/B runs:
+        the block is then copied into every replica's row, the round-5 plan)."""
+        return (self.fast and os.environ.get("MORIG_GEMM_TAIL", "1") != "0" and os.environ.get("MORIG_NO_DMA") is None and
+                lin.Wsplit is not None and lin.N % 256 == 0 and lin.K % 32 == 0 and n_tail_cols % 32 == 0 and lin.K > n_tail_cols and
+                Y.ptr % 16 == 0 and Y.ld % 4 == 0 and os.environ.get("MORIG_GEMM_TR", "1") != "0" and
+                os.environ.get("MORIG_DMA_TILE", "256") == "256")
+
+    def pack_tails(self, src: torch.Tensor, col_a, col_b, wa: int, wb: int) -> torch.Tensor:
+        """-> [n_tails, rows, 32] split-fp16 chunks: tail t, row v = [src[v, col_a[t]:+wa] | src[v, col_b[t]:+wb] | 0] (morig_pack_tails),
+        ONE launch for every tail of a forward."""
+        _need_gpu(src)
+        assert src.dim() == 2 and src.dtype == torch.float32 and src.stride(1) == 1 and len(col_a) == len(col_b) <= 8
+        n, rows = len(col_a), src.shape[0]
+        out = torch.empty((n, rows, 32), dtype=torch.float32, device=src.device)
+        ca, cb = (C.c_int32 * n)(*col_a), (C.c_int32 * n)(*col_b)
+        check(self.lib.morig_pack_tails(_p(src), src.stride(0), rows, ca, cb, wa, wb, n, _p(out), rows * 32,
+                                        self._flag(src.device).data_ptr(), _stream()), "morig_pack_tails")
+        return out
+
     # -- fused edge conv ----------------------------------------------------------------------------
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
                  in_rep_stride: int = 0, out_rep_stride: int = 0, out_split: bool = False):
@@ -615,7 +661,7 @@ class NativeOps:
         return bool(self.lib.morig_edgeconv_can_split_out(C.byref(a)))
 
     def _edge_args(self, A, B, csr, ec, out, replicas, in_rep_stride, out_rep_stride):
-        a = EdgeConvArgs()
+        a = _args(EdgeConvArgs)
         a.H = ec.H
         a.n_nodes, a.replicas = csr.n_nodes, replicas
         a.in_rep_stride, a.out_rep_stride = in_rep_stride, out_rep_stride
@@ -638,7 +684,7 @@ class NativeOps:
         window starting at column 0 of 16-byte aligned rows; first = (W1a [32, 4], W1b [32, 4], b1 [32]) from packing.pack_first_x3."""
         _need_gpu(X.base, out.base)
         assert ec.H == 32 and ec.s1 is None and X.col0 % 4 == 0 and X.ld % 4 == 0
-        a = EdgeConvX3Args()
+        a = _args(EdgeConvX3Args)
         a.H = 32
         a.n_nodes, a.replicas = csr.n_nodes, replicas
         a.in_rep_stride, a.out_rep_stride = in_rep_stride, out_rep_stride
@@ -663,7 +709,7 @@ class NativeOps:
     def segmax_gemm(self, X: Mat, lin, relu: bool, csr: CSR, out: Mat):
         _need_gpu(X.base, out.base)
         assert X.rows == csr.capacity and X.cols == lin.K and out.rows == csr.n_nodes and out.cols == lin.N
-        a = SegmaxArgs()
+        a = _args(SegmaxArgs)
         a.N, a.K = lin.N, lin.K
         a.X, a.ldx = X.ptr, X.ld
         a.W, a.ldw = lin.W.data_ptr(), lin.W.stride(0)
@@ -693,7 +739,7 @@ class NativeOps:
         assert A.cols == B.cols == ec.H and out.rows == A.rows and out.cols == l3.N and B.rows >= A.rows
         dev = A.base.device
         status = torch.zeros(1, dtype=torch.int32, device=dev)
-        a = PointConvArgs()
+        a = _args(PointConvArgs)
         a.A, a.lda, a.B, a.ldb = A.ptr, A.ld, B.ptr, B.ld
         a.slots, a.max_nbrs, a.n_centres, a.n_src = coo.data_ptr(), max_nbrs, A.rows, B.rows
         a.H, a.H3 = ec.H, l3.N

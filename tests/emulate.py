@@ -85,7 +85,28 @@ class EmuOps:
             self.copy2d_pad(Mat.of(src.base, src.col0 + r * src_col_step, src.cols, src.row0, src.rows),
                             Mat.of(dst.base, dst.col0, dst.cols, dst.row0 + r * dst_row_step, dst.rows), split=split)
 
-    def gemm(self, X: Mat, lin, relu, Y=None, rowbias=None, seg=None, pool=None, affine=True, x_split=False, y_split=False):
+    def gemm_takes_tail(self, lin, Y: Mat, n_tail_cols):
+        # the library's rule (csrc/gemm_dma.hip): K tails on the 256 x 256 LDS-DMA store kernel only
+        return bool(self.emulate_split and lin.N % 256 == 0 and lin.K % 32 == 0 and n_tail_cols % 32 == 0 and lin.K > n_tail_cols
+                    and Y.col0 % 4 == 0 and Y.ld % 4 == 0)
+
+    def pack_tails(self, src, col_a, col_b, wa, wb):
+        assert wa + wb <= 32 and len(col_a) == len(col_b) <= 8
+        out = torch.zeros((len(col_a), src.shape[0], 32), dtype=torch.float32)
+        for t, (a, b) in enumerate(zip(col_a, col_b)):
+            out[t, :, :wa] = src[:, a:a + wa]
+            out[t, :, wa:wa + wb] = src[:, b:b + wb]
+        assert not torch.isnan(out).any(), "pack_tails reads uninitialised memory"
+        return out
+
+    def gemm(self, X: Mat, lin, relu, Y=None, rowbias=None, seg=None, pool=None, affine=True, x_split=False, y_split=False, x_tail=None):
+        if x_tail is not None:
+            # morig_gemm_args.X_tail: the last x_tail.cols input columns from row (row % x_tail.rows) of the tail matrix
+            assert x_split and pool is None and self.gemm_takes_tail(lin, Y, x_tail.cols), "x_tail where the library would refuse it"
+            assert x_tail.col0 % 32 == 0 and x_tail.ld % 32 == 0 and X.cols + x_tail.cols == lin.K
+            full = torch.cat([X.view(), x_tail.view()[torch.arange(X.rows) % x_tail.rows]], dim=1).contiguous()
+            assert X.col0 % 32 == 0 and X.ld % 32 == 0 and not torch.isnan(full).any()
+            return self.gemm(Mat.of(full), lin, relu, Y=Y, rowbias=rowbias, seg=seg, pool=pool, affine=affine, y_split=y_split)
         if x_split:
             assert X.col0 % 32 == 0 and X.ld % 32 == 0, "split-fp16 X window must be chunk aligned"
             # logical K may end inside a chunk: the remaining columns of that chunk must hold finite data

@@ -24,6 +24,16 @@ def ops(request):
     o.precision = prev
 
 
+@pytest.fixture(autouse=True)
+def _restore_precision():
+    """several tests below pin the process-wide op layer to one arithmetic path: whatever a test sets is undone behind it, so the tests that
+    follow run on the path their own fixture selected (order-dependent results otherwise)"""
+    o = native.get_ops()
+    prev = o.precision
+    yield
+    o.precision = prev
+
+
 def _rand_graph(n, e, seed, hub=None):
     g = torch.Generator().manual_seed(seed)
     src = torch.randint(0, n, (e,), generator=g)
@@ -139,7 +149,7 @@ def test_gemm_refuses_a_split_image_without_its_range_guard():
     y = torch.zeros(128, 64, device=DEV)
 
     def call(overflow, fmt):
-        a = native.GemmArgs()
+        a = native._args(native.GemmArgs)
         a.M, a.N, a.K = 128, 64, 64
         a.X, a.ldx = x.data_ptr(), 64
         a.W, a.ldw = lin.W.data_ptr(), lin.W.stride(0)
@@ -856,6 +866,82 @@ def test_gemm_dma_register_epilogue(M, N, K, segs, y_split, relu):
             got = full[:M, 4:4 + N]
             assert float((full[M:] - 5.0).abs().sum()) == 0 and float((full[:M, :4] - 5.0).abs().sum()) == 0 and float((full[:M, 4 + N:] - 5.0).abs().sum()) == 0
         assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item()), (use_rb,)
+
+
+@pytest.mark.parametrize("n,R,N,K,tc", [(517, 5, 512, 544, 32), (300, 1, 256, 288, 32), (250, 4, 256, 96, 32), (200, 3, 256, 320, 64),
+                                        (4096, 5, 512, 544, 32)])
+@pytest.mark.parametrize("y_split", [False, True])
+def test_gemm_k_tail_reads_the_replica_invariant_block_from_one_copy(n, R, N, K, tc, y_split):
+    """morig_gemm_args.X_tail [ABI 3]: the last tail_cols input columns of row m come from row (m % tail_rows) of a separate split-layout
+    matrix -- the [pos_tpl | pos_geo] block of a GCUMotion unit under the keyframe loop (models/basic_modules.py:216-217 inside
+    models/rignet.py:85-86) enters the unit's MLP without being copied into the 5 replicas' rows. Against the same GEMM on the
+    materialised concatenation (torch, CPU); tiles that straddle a replica boundary (n % 256 != 0) included."""
+    o = native.get_ops()
+    o.precision = "f16x3"
+    g = torch.Generator().manual_seed(n + K)
+    M, Km = n * R, K - tc
+    xm = torch.randn(M, Km, generator=g)
+    xt = torch.randn(n, tc, generator=g)
+    lin = _lin(N, K, 8, bn=True)
+    full = torch.cat([xm, xt.repeat(R, 1)], dim=1).contiguous()
+    want = torch.zeros(M, N)
+    EmuOps().gemm(Mat.of(full), lin, True, Y=Mat.of(want))
+    ling = packing.to_device(lin, DEV)
+    xs = packing.split_f16(xm.contiguous()).to(DEV)
+    ts = packing.split_f16(xt.contiguous()).to(DEV)
+    Np = N
+    if y_split:
+        ys = torch.full((M + 3, Np + 32), 5.0, device=DEV)
+        Y = Mat.of(ys, 32, N, 0, M)
+    else:
+        ys = torch.full((M + 3, N + 8), 5.0, device=DEV)
+        Y = Mat.of(ys, 4, N, 0, M)
+    assert o.gemm_takes_tail(ling, Y, tc)
+    o.gemm(Mat.of(xs), ling, True, Y=Y, x_split=True, y_split=y_split, x_tail=Mat.of(ts))
+    torch.cuda.synchronize()
+    fullg = ys.cpu()
+    if y_split:
+        got = packing.unsplit_f16(fullg[:M].contiguous(), Np + 32)[:, 32:32 + N]
+        assert float((fullg[M:] - 5.0).abs().sum()) == 0 and float((fullg[:M, :32] - 5.0).abs().sum()) == 0
+    else:
+        got = fullg[:M, 4:4 + N]
+        assert float((fullg[M:] - 5.0).abs().sum()) == 0 and float((fullg[:M, :4] - 5.0).abs().sum()) == 0
+    assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_gemm_k_tail_is_refused_where_the_kernel_has_none():
+    """narrow outputs / pooled launches have no K tail: MORIG_E_UNSUPPORTED (the plans ask ``gemm_takes_tail`` first), bad tail
+    geometry is MORIG_E_INVALID"""
+    o = native.get_ops()
+    o.precision = "f16x3"
+    lin = packing.to_device(_lin(64, 96, 3, True), DEV)
+    xs = packing.split_f16(torch.randn(256, 64)).to(DEV)
+    ts = packing.split_f16(torch.randn(64, 32)).to(DEV)
+    y = torch.zeros(256, 64, device=DEV)
+    assert not o.gemm_takes_tail(lin, Mat.of(y), 32)
+    with pytest.raises(native.MorigNativeError, match="unsupported"):
+        o.gemm(Mat.of(xs), lin, True, Y=Mat.of(y), x_split=True, x_tail=Mat.of(ts))
+    lin2 = packing.to_device(_lin(256, 96, 3, True), DEV)
+    y2 = torch.zeros(256, 256, device=DEV)
+    with pytest.raises(native.MorigNativeError, match="invalid"):
+        o.gemm(Mat.of(xs), lin2, True, Y=Mat.of(y2), x_split=True, x_tail=Mat.of(torch.zeros(64, 64, device=DEV), 8, 32))   # chunk not 128-byte aligned
+    torch.cuda.synchronize()
+
+
+def test_pack_tails_builds_every_units_chunk_in_one_launch():
+    """morig_pack_tails: tail t, row v = [src[v, a_t : a_t + 16] | src[v, b_t : b_t + 16]] as one split-fp16 chunk"""
+    o = native.get_ops()
+    o.precision = "f16x3"
+    g = torch.Generator().manual_seed(5)
+    src = torch.randn(1000, 192, generator=g)
+    ca, cb = [0, 16, 64, 80, 128, 144], [32, 48, 96, 112, 160, 176]
+    got = o.pack_tails(src.to(DEV), ca, cb, 16, 16)
+    torch.cuda.synchronize()
+    assert got.shape == (6, 1000, 32)
+    for t in range(6):
+        want = torch.cat([src[:, ca[t]:ca[t] + 16], src[:, cb[t]:cb[t] + 16]], 1)
+        back = packing.unsplit_f16(got[t].cpu().contiguous(), 32)
+        assert (back - want).abs().max().item() <= 1e-6 * max(1.0, want.abs().max().item())
 
 
 def test_copy2d_pad_plain_and_split():

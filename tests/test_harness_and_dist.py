@@ -52,8 +52,45 @@ def test_c_abi_exports_every_declared_symbol():
     lib = native.load_library()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.morig_abi_version() == 2
+    assert lib.morig_abi_version() == 3 == native.ABI_VERSION
     assert lib.morig_strerror(-2).decode().startswith("unsupported")
+
+
+def test_c_abi_argument_structs_carry_their_size():
+    """ABI 3 (include/morig_hip.h): every argument struct starts with struct_size. The ctypes mirrors have the header's sizes; a struct
+    whose struct_size is missing (0), shorter than the version-3 layout, or a version-2 struct (no struct_size member: its first word
+    is M / H) is refused with MORIG_E_INVALID before anything is read or launched -- so this runs without a GPU."""
+    import ctypes as C
+    from morig_amd import native
+    hdr = open(os.path.join(ROOT, "include", "morig_hip.h")).read()
+    sizes = {k: int(v) for k, v in re.findall(r"#define MORIG_([A-Z0-9_]+)_ARGS_V3_SIZE\s+(\d+)u", hdr)}
+    mirrors = dict(GEMM=native.GemmArgs, EDGECONV=native.EdgeConvArgs, EDGECONV_X3=native.EdgeConvX3Args, SEGMAX=native.SegmaxArgs,
+                   POINTCONV=native.PointConvArgs)
+    assert set(sizes) == set(mirrors)
+    for k, cls in mirrors.items():
+        assert C.sizeof(cls) == sizes[k], (k, C.sizeof(cls), sizes[k])          # nothing appended since version 3
+        assert cls._fields_[0] == ("struct_size", C.c_uint32)
+        assert native._args(cls).struct_size == C.sizeof(cls)
+    lib = native.load_library()
+    calls = dict(GEMM=lib.morig_gemm, EDGECONV=lib.morig_edgeconv, EDGECONV_X3=lib.morig_edgeconv_x3, SEGMAX=lib.morig_segmax_gemm,
+                 POINTCONV=lib.morig_pointconv_fused)
+    for k, cls in mirrors.items():
+        for bad in (0, 8, sizes[k] - 8, sizes[k] + 4, 4096):
+            a = cls()
+            a.struct_size = bad
+            assert calls[k](C.byref(a), None) == -1, (k, bad)                    # MORIG_E_INVALID
+    assert lib.morig_edgeconv_can_split_out(C.byref(native.EdgeConvArgs())) == 0
+
+    class GemmArgsV2(C.Structure):             # the round-5 layout: M first, no struct_size, no K tail
+        _fields_ = [f for f in native.GemmArgs._fields_ if f[0] not in ("struct_size", "X_tail", "ld_tail", "tail_rows", "tail_cols")]
+    old = GemmArgsV2()
+    old.M, old.N, old.K = 1310720, 512, 544
+    buf = (C.c_char * 256)()                   # (room behind it: the call must not depend on what follows a short struct)
+    C.memmove(buf, C.byref(old), C.sizeof(old))
+    assert lib.morig_gemm(C.cast(buf, C.POINTER(native.GemmArgs)), None) == -1
+    # a LONGER struct from a newer caller is fine: the members this build knows are read, the rest ignored (here: all pointers NULL -> invalid)
+    a = native._args(native.GemmArgs)
+    assert lib.morig_gemm(C.byref(a), None) == -1
 
 
 def test_product_refuses_to_run_without_gpu():
