@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void split_boundary_rows_kernel(const int* __r
     const int d = lane < 16 ? straddled_row(rowptr, dstS, n_nodes, tile_rows, run, replicas, rep_out, g, n_cand, true) : -1;
     unsigned long long todo = __ballot(d >= 0);
     float am = 0.f;
+    bool bad = false;                                                 // a NaN: fmaxf drops NaN operands, so the amax below never sees one
     while (todo) {                                                    // wave-uniform
         int dr[4];
 #pragma unroll
@@ -663,13 +664,16 @@ __global__ __launch_bounds__(256) void split_boundary_rows_kernel(const int* __r
                     split_pair_f16(v[i].x, v[i].y, h0, l0);
                     split_pair_f16(v[i].z, v[i].w, h1, l1);
                     am = fmaxf(am, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
+                    bad |= !(v[i].x == v[i].x && v[i].y == v[i].y && v[i].z == v[i].z && v[i].w == v[i].w);
                     char* oc = reinterpret_cast<char*>(out + (size_t)dr[i] * ldo) + (c >> 5) * 128 + (c & 31) * 2;
                     *reinterpret_cast<float2*>(oc) = make_float2(h0, h1);
                     *reinterpret_cast<float2*>(oc + 64) = make_float2(l0, l1);
                 }
         }
     }
-    if (!(am < 65000.f)) *ovf = 1;                    // also NaN (the identity pattern would be one: every such row was written)
+    // range guard on the converted rows; a NaN -- a result, or a shared row still at the identity pattern 0xFFFFFFFF because no atomic
+    // reached it (would be a bug: both tiles of a boundary write the row) -- is raised by its own test (fmaxf hides it)
+    if (bad || !(am < 65000.f)) *ovf = 1;
 }
 
 static int split_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,

@@ -14,7 +14,7 @@ Data-flow restructurings (all exact up to fp32 rounding):
 from __future__ import annotations
 
 import math
-
+import os
 from typing import Optional
 
 import numpy as np
@@ -149,18 +149,20 @@ class GCNRig(NativeModule):
         )
 
     def run(self, ops, pos4: torch.Tensor, write_feature, csr_tpl, csr_geo, seg: torch.Tensor, n_graphs: int,
-            replicas: int, out: Mat, csr_geo_wide=None, csr_tpl_wide=None, pos_feats=None, feat3: Optional[Mat] = None):
+            replicas: int, out: Mat, csr_geo_wide=None, csr_tpl_wide=None, pos_feats=None, feat3: Optional[Mat] = None,
+            posfeat8: Optional[Mat] = None):
         """pos4: [n, 4] (pos, 0); write_feature(window Mat [R*n, feat_slot], split) fills the feature slot
         (zero padded); seg: int32 [R*n] = r*n_graphs + batch[v]; out: [R*n, chn_output] window.
         pos_feats: per unit the position-branch results computed ahead by run_pos_groups (or None entries).
-        feat3: a 3-channel feature once more as plain fp32 rows [R*n, 4] (gcu_1 then runs morig_edgeconv_x3 on it)."""
+        feat3: a 3-channel feature once more as plain fp32 rows [R*n, 4] (gcu_1 then runs morig_edgeconv_x3 on it).
+        posfeat8: [R*n, 8] plain fp32 rows [pos xyz 0 | feature xyz 0] (the caller built them with library copies; feat3 is its
+        columns 4..7): the merged 32-column chunk at POS is ONE split copy of it."""
         pf = list(pos_feats) if pos_feats is not None else [None, None, None]
         dev = pos4.device
         pk = self.packed(dev)
         n, R, F = pos4.shape[0], replicas, self.chn_feature
         M = n * R
         sp = ops.split_activations                    # GEMM -> GEMM activations in the split-fp16 layout
-        import os
         merged = (F == 3 and feat3 is not None and pk.get("t1m") is not None and hasattr(ops, "edgeconv_x3")
                   and os.environ.get("MORIG_EDGE_X3", "1") != "0" and os.environ.get("MORIG_MERGED_POS_FEAT", "1") != "0"
                   and "x3t" in self.gcu_1.packed(dev))
@@ -168,8 +170,14 @@ class GCNRig(NativeModule):
             # [pos xyz 0 | feature 0 | zeros] in the ONE chunk at POS: rows of pos4 repeated per replica beside the plain feature rows
             feat_col, k_t1, t1 = self.POS + 4, self.POS + 4 + F, pk["t1m"]
             wide = ops.empty(M, self.POS + 32, dev)
-            pf8 = torch.cat([pos4.repeat(R, 1), feat3.view()[:, :4]], 1).contiguous()
-            ops.copy2d_pad(Mat.of(pf8), Mat.of(wide, self.POS, 32), split=sp)
+            if posfeat8 is None:
+                # (library copies, no torch.cat / repeat: three ATen launches less, and strided cat inputs did not replay from a captured
+                # HIP graph -- ADVICE r5)
+                pf8 = ops.empty(M, 8, dev)
+                ops.copy2d_rep(Mat.of(pos4, 0, 4), Mat.of(pf8, 0, 4, 0, n), R, n)
+                ops.copy2d(Mat.of(feat3.base, feat3.col0, 4, feat3.row0, feat3.rows), Mat.of(pf8, 4, 4))
+                posfeat8 = Mat.of(pf8)
+            ops.copy2d_pad(posfeat8, Mat.of(wide, self.POS, 32), split=sp)
         else:
             feat_col, k_t1, t1 = self.FEAT, self.FEAT + F, pk["t1"]
             wide = ops.empty(M, self.wide_ld, dev)
@@ -252,10 +260,12 @@ class _MotionBackbone(NativeModule):
         pos_feats = pos_feats + [None] * (6 - len(pos_feats))
         # the 3-channel keyframe flows once more as plain fp32 rows [T n, 4]: motionNet's first unit evaluates its first edge Linear from
         # the gathered endpoints (morig_edgeconv_x3) instead of gathering per-vertex [A | B] rows
-        flow4 = ops.empty(T * n, 4, dev)
-        ops.copy2d_rep(Mat.of(flow, 0, 3), Mat.of(flow4, 0, 4, 0, n), T, n, src_col_step=3)
+        # ... as columns 4..7 of rows [pos xyz 0 | flow_t xyz 0]: the same rows are the merged position / feature chunk of mlp_transform's input
+        pf8 = ops.empty(T * n, 8, dev)
+        ops.copy2d_rep(Mat.of(pos4, 0, 4), Mat.of(pf8, 0, 4, 0, n), T, n)
+        ops.copy2d_rep(Mat.of(flow, 0, 3), Mat.of(pf8, 4, 4, 0, n), T, n, src_col_step=3)
         self.motionNet.run(ops, pos4, write_flow, csr_tpl, csr_geo, seg_T, ng, T, Mat.of(raw), csr_geo_wide=csr_geo4,
-                           csr_tpl_wide=csr_tpl4, pos_feats=pos_feats[:3], feat3=Mat.of(flow4))
+                           csr_tpl_wide=csr_tpl4, pos_feats=pos_feats[:3], feat3=Mat.of(pf8, 4, 4), posfeat8=Mat.of(pf8))
         motion_all = torch.empty((n, T, C), dtype=torch.float32, device=dev)
         ops.rownorm(Mat.of(raw), n, T, motion_all, T * C, C)          # F.normalize + torch.stack(dim=1)
 

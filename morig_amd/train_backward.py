@@ -557,7 +557,17 @@ def canonical_csr(csr: CSR) -> CSR:
 # an epoch loop that feeds the SAME edge tensors again (a dataset cached on the device) then pays the four device sorts of a step
 # once. Opt-in (MORIG_TRAIN_CSR_CACHE=1): bench.py's training step re-feeds one batch, and its time is meant to include the graph
 # preparation a fresh batch costs. Entries die with their edge tensor (weak reference) or when it is written to (_version).
+# REQUIREMENT while the switch is on: an edge tensor is IMMUTABLE once fed. A hit is validated by (data_ptr, shape, n, object identity,
+# autograd version counter) only -- writes that bypass the counter (`edge_index.data[...] = ...`, a kernel writing through data_ptr(), an
+# alias of the same storage edited in place) are NOT seen and the stale CSR and its transpose would be reused silently; a cached CSR's
+# index-range status word is checked by the forward that built it, not again on a hit. After such an edit call ``invalidate_csr_cache()``.
 _CSR_CACHE: dict = {}
+
+
+def invalidate_csr_cache() -> None:
+    """drop every cached canonical CSR (MORIG_TRAIN_CSR_CACHE=1): needed only after an edge tensor was edited in a way the autograd
+    version counter does not see (see above)"""
+    _CSR_CACHE.clear()
 
 
 def _canonical_csr_of(edge_index: torch.Tensor, n: int) -> CSR:

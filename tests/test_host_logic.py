@@ -115,6 +115,37 @@ def test_full_networks(name, outs):
             assert rel_excess(r, a[key], TOL) <= 0, key     # skin logits reach |30|: normalise by output scale
 
 
+def test_position_blocks_enter_the_unit_mlps_as_k_tails(emulated_ops):
+    """[r06] under the split-activation plan the replica-invariant [pos_tpl | pos_geo] block of the wide units (gcu_2, gcu_3 of motionNet
+    and of the head) is NOT copied into the 5 replicas' rows: ONE pack_tails launch per forward, the units' MLPs read it as the K tail
+    (morig_gemm_args.X_tail). The fp32 plan keeps the copies. Results equal the golden either way (test_full_networks)."""
+    ops = runtime._test_ops
+    calls = dict(tail_gemms=0, pack=0, rep_split=0)
+    gemm, pack, rep = ops.gemm, ops.pack_tails, ops.copy2d_rep
+
+    def gemm_(*a, **k):
+        calls["tail_gemms"] += k.get("x_tail") is not None
+        return gemm(*a, **k)
+
+    def pack_(*a, **k):
+        calls["pack"] += 1
+        return pack(*a, **k)
+
+    def rep_(src, dst, replicas, step, src_col_step=0, split=False):
+        calls["rep_split"] += bool(split and dst.cols == 32 and dst.ld in (288, 544))      # a [pos_tpl | pos_geo] chunk behind [x_tpl | x_geo]
+        return rep(src, dst, replicas, step, src_col_step=src_col_step, split=split)
+    ops.gemm, ops.pack_tails, ops.copy2d_rep = gemm_, pack_, rep_
+    meta, a = load_golden("jointnet_ragged")
+    m = synth.load_recipe(models.__dict__[meta["arch"]](**meta["kwargs"]).eval(), meta["recipe_seed"])
+    d = data_from(a)
+    res = m(d, d.pred_flow)
+    assert rel_excess(res[2], a["pred_shift"], TOL) <= 0
+    if ops.emulate_split:
+        assert calls == dict(tail_gemms=4, pack=1, rep_split=0), calls
+    else:
+        assert calls["tail_gemms"] == 0 and calls["pack"] == 0, calls
+
+
 def test_packed_cache_invalidation():
     meta, a = load_golden("gcu_3_32")
     m = bm.GCU(3, 32).eval()
