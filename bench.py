@@ -96,6 +96,22 @@ def measured_mfma_util(symbol):
     return (round(busy / (4.0 * cu), 4), None) if cu else (None, f"{symbol} not in profiles/mfma_pmc_latest.json")
 
 
+def measured_mfma_issued(symbol):
+    """v_mfma instructions one launch of a kernel symbol ISSUES (SQ_INSTS_MFMA of the committed counter pass, per-dispatch average over the
+    symbol's launches) -> (count or None, reason or None). Against 3 x the algorithmic products it prices what the launch spends on CSR
+    padding and tile quantisation (VERDICT r5 #1c)."""
+    prof, why = _profile_json("mfma_pmc_latest.json")
+    if prof is None or symbol is None:
+        return None, why or "no single kernel symbol"
+    n = d_all = 0.0
+    for name, v in _kernels_of(prof, symbol):
+        if v.get("SQ_INSTS_MFMA"):
+            d = v.get("dispatches", 1)
+            n += v["SQ_INSTS_MFMA"] * d
+            d_all += d
+    return (n / d_all, None) if d_all else (None, f"{symbol} not in profiles/mfma_pmc_latest.json")
+
+
 class ClockSampler:
     """Samples the GPU's shader clock and socket power in a background thread while a timed loop runs (VERDICT r3 #1c: the
     clock in the line is the clock of THIS run). Sources, first one that answers: the amdsmi Python binding, the amdgpu sysfs
@@ -243,6 +259,16 @@ class ClockSampler:
                          if ss else "no clock source answered on this host (amdsmi / sysfs / rocm-smi)")
 
 
+def _issued_fields(dom, per_product):
+    """mfma_issued_over_algorithmic = v_mfma_f32_32x32x16 instructions the dominant kernel issues per launch (counter pass) / (per_product x
+    algorithmic FLOPs per launch / 32 768 FLOPs per instruction): 1.0 = no padded rows, no tile quantisation"""
+    issued, why = measured_mfma_issued(dom["symbol"])
+    if not issued or not dom["launches"] or dom["flops"] <= 0:
+        return dict(mfma_issued_per_launch=None, mfma_issued_over_algorithmic=None, mfma_issued_unavailable=why)
+    alg = per_product * dom["flops"] / dom["launches"] / 32768.0
+    return dict(mfma_issued_per_launch=round(issued), mfma_issued_over_algorithmic=round(issued / alg, 4))
+
+
 def roofline_of(prof, psteps, clocks=None):
     """-> (roofline dict of the dominant kernel symbol, per-kind breakdown, total GPU ms) from one morig_prof_* pass.
     Launch kinds are grouped by the ONE kernel symbol they run (morig_prof_symbol), so the dominant entry is the object
@@ -282,7 +308,8 @@ def roofline_of(prof, psteps, clocks=None):
     alg_bytes = round(dom["bytes"] / dom["launches"]) if dom["launches"] else None
     traffic, traffic_why = measured_traffic(dom["symbol"])
     tr = dict(algorithmic_bytes=alg_bytes,
-              algorithmic_bytes_unit="operand + result bytes per launch as the launcher declares them (fp32 elements, each once)",
+              algorithmic_bytes_unit="compulsory bytes per launch as the launcher declares them: every operand-table row and every result row ONCE "
+                                     "(fp32 elements; the per-edge re-reads of gathered rows are L2 hits and are not counted)",
               traffic=traffic, traffic_unavailable=traffic_why,
               traffic_over_algorithmic=round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
               traffic_unit="HBM bytes per launch ((2 x FETCH_SIZE + WRITE_SIZE) KiB, rocprofv3 --pmc, profiles/traffic_latest.json)")
@@ -296,6 +323,7 @@ def roofline_of(prof, psteps, clocks=None):
         roof = dict(bound="mfma", achieved=round(achieved, 2), peak=peak, unit="TFLOP/s", frac=round(achieved / peak, 4),
                     algorithmic_flops_per_launch=round(dom["flops"] / dom["launches"]) if dom["launches"] else None,
                     mfma_issued_per_product=3 if split else 1,
+                    **_issued_fields(dom, 3 if split else 1),
                     frac_of_3x_split_peak=round(3 * achieved / peak, 4) if split else None,
                     frac_of_3x_split_peak_at_sclk=round(3 * achieved / peak * PEAK_SCLK_MHZ / sclk, 4) if (split and sclk) else None,
                     mfma_util_counter=util, mfma_util_counter_unavailable=util_why,
@@ -380,6 +408,32 @@ def build_batch(seeds, n_side, with_skin=False, n_pts=0, dev=None):
         b = synth.make_batch(seeds, n_side=n_side, n_pts=n_pts, with_skin=with_skin)
     else:
         b = synth.make_batch_device(seeds, dev, n_side=n_side, n_pts=n_pts, with_skin=with_skin, geo_seed=seeds[0])
+    b.num_graphs = len(seeds)
+    return b
+
+
+RAGGED_SIDES = (32, 80)               # grid sides of the ragged batch: 1 024 ... 6 400 vertices per mesh
+GEO_RADIUS = 0.06                     # data_proc/common_ops.py:214 get_geo_edges(radius=0.06): ONE radius for every mesh size
+
+
+def ragged_sides(seeds, lo=RAGGED_SIDES[0], hi=RAGGED_SIDES[1]):
+    """grid side of every mesh of the ragged batch: a pure function of its seed (uniform over [lo, hi])"""
+    import numpy as np
+    return [int(np.random.default_rng([0x52414747, int(sd)]).integers(lo, hi + 1)) for sd in seeds]
+
+
+def build_batch_ragged(seeds, sides, dev=None):
+    """The config-5 stand-in (BASELINE.json configs[4] is blocked offline): meshes of DIFFERENT sizes in one batch, as the rig datasets
+    hold them (datasets/dataset_rig.py:85-138: ~1-5 k vertices per character), same recipe as build_batch per mesh, the reference's
+    fixed ball radius 0.06 for all of them (small meshes get fewer than 15 ball members, large ones the random subset of 15)."""
+    from morig_amd import synth
+    if dev is None or dev.type != "cuda":
+        b = synth.collate([synth.make_mesh(sd, n_side=ns, geo_radius=GEO_RADIUS, with_skin=False) for sd, ns in zip(seeds, sides)])
+    else:
+        from morig_amd import graph_build
+        b = synth.collate([synth.make_mesh(sd, n_side=ns, geo="none", with_skin=False) for sd, ns in zip(seeds, sides)]).to(dev)
+        b.geo_edge_index = graph_build.get_geo_edges(b.pos, b.batch, GEO_RADIUS, 15, seed=int(seeds[0]), self_loops=True,
+                                                     num_graphs=len(seeds))
     b.num_graphs = len(seeds)
     return b
 
@@ -478,20 +532,21 @@ def cpu_baseline_other(workload, seconds, n_side, n_pts, seed):
 
 NAMES = {"jointnet": ("meshes/sec jointnet_motion forward, 4 k-vert synthetic",
                       "jointnet_motion(num_keyframes=5, attn) eval forward", "BASELINE.json configs[1]"),
+         "jointnet_ragged": ("meshes/sec jointnet_motion forward, ragged synthetic batch (1 024 ... 6 400 vertices per mesh)",
+                             "jointnet_motion(num_keyframes=5, attn) eval forward", "configs[4] stand-in"),
          "mask_skin": ("meshes/sec masknet_motion + skinnet_motion forward, 4 k-vert synthetic",
-                       "masknet_motion + skinnet_motion(nearest_bone=5) eval forwards", "BASELINE.json configs[2]"),
+                       "masknet_motion + skinnet_motion(5 bones) eval fwds", "configs[2]"),
          "corrnet": ("pairs/sec corrnet forward, 4 k-vert mesh + 8 k-point cloud",
-                     "corrnet(train_vismask=True, random_start=False) eval forward", "BASELINE.json configs[3]"),
+                     "corrnet(vismask, fixed FPS start) eval forward", "configs[3]"),
          "deformnet": ("pairs/sec deformnet forward, 4 k-vert mesh + 8 k-point cloud",
-                       "deformnet(tau_nce=0.07, num_interp=5) eval forward (CorrNet + votes + GCNDeform)",
-                       "SURVEY 8(f-1), pairs of BASELINE.json configs[3]")}
+                       "deformnet(tau 0.07, 5 interp) eval fwd", "SURVEY 8(f-1), configs[3] pairs")}
 
 
 def make_step(workload, data, dev, gather, model_only=False):
     """-> step() running ONE forward of `workload` over the resident batch (+ the all-gather of its outputs);
     model_only (jointnet): -> step(data) for any batch"""
     from morig_amd import models, synth
-    if workload == "jointnet":
+    if workload in ("jointnet", "jointnet_ragged"):
         model = models.jointnet_motion(num_keyframes=5, chn_output=3, aggr_method="attn").eval()
         synth.load_recipe(model, 0, mild=True).to(dev)
         if model_only:
@@ -566,7 +621,7 @@ def pct(xs, q):
 
 LINE_LIMIT = 4096                     # the driver keeps ~8 KB of stdout tail: the LAST line must fit well inside it
 ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "algorithmic_flops_per_launch", "algorithmic_bytes", "traffic",
-             "traffic_over_algorithmic", "mfma_util_counter", "mfma_issued_per_product", "frac_of_3x_split_peak", "avg_launch_ms",
+             "traffic_over_algorithmic", "mfma_util_counter", "mfma_issued_per_product", "mfma_issued_over_algorithmic", "frac_of_3x_split_peak", "avg_launch_ms",
              "launches_per_step", "share_of_gpu_time", "sclk_under_load_mhz", "socket_power_w", "mfma_power_capped_tflops",
              "frac_of_power_capped_peak", "lib_sha256")
 
@@ -609,6 +664,8 @@ def compact_secondary(sec):
         e = dict(value=v.get("value"), unit=v.get("unit"))
         if "ms_per_step" in v:
             e["ms_per_step"] = v["ms_per_step"]
+        if "vertices_per_s" in v:                      # the ragged batch: vertices/s beside the uniform batch's
+            e.update(vertices_per_s=v["vertices_per_s"], over_uniform=v.get("vertices_per_s_over_uniform"))
         r = v.get("roofline")
         if isinstance(r, dict):
             e.update(frac=r.get("frac"), bound=r.get("bound"), kernel=r.get("kernel"))
@@ -644,7 +701,7 @@ def emit(res, detail_path=None):
         path = None
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_median",
                                       "ms_per_step_p10", "ms_per_step_p90", "higher_is_better", "scaling", "vs_baseline", "dtype",
-                                      "data", "config", "rccl_ranks", "backend", "per_rank_ms_per_step", "allgather_ms_per_step",
+                                      "data", "config", "vertices_per_s", "rccl_ranks", "backend", "per_rank_ms_per_step", "allgather_ms_per_step",
                                       "allgather_calls_per_step", "allgather_bytes_per_rank")}
     line["roofline"] = compact_roofline(full.get("roofline"))
     line["whole_forward_tflops"] = full.get("whole_forward_tflops")
@@ -671,7 +728,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="meshes per GPU (weak) / in total (strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--n-side", type=int, default=64, help="mesh grid side (64 -> 4096 vertices)")
-    ap.add_argument("--workload", default="jointnet", choices=["jointnet", "mask_skin", "corrnet", "deformnet"],
+    ap.add_argument("--workload", default="jointnet", choices=["jointnet", "jointnet_ragged", "mask_skin", "corrnet", "deformnet"],
                     help="jointnet = BASELINE.json configs[1] (the headline metric); mask_skin = configs[2]; "
                          "corrnet = configs[3] (8192-point clouds, 32 pairs per GPU); deformnet = the producer of pred_flow "
                          "(SURVEY 8 f-1), same pairs as corrnet")
@@ -740,8 +797,18 @@ def main():
 
     from morig_amd import dist as mdist, native
 
-    data = build_batch(seeds, args.n_side, with_skin=with_skin, n_pts=args.n_pts if pairs else 0, dev=dev).to(dev)
+    ragged = args.workload == "jointnet_ragged"
+    if ragged:
+        sides = ragged_sides(seeds, *((4, 8) if PLUMBING else RAGGED_SIDES))
+        data = build_batch_ragged(seeds, sides, dev=dev).to(dev)
+    else:
+        data = build_batch(seeds, args.n_side, with_skin=with_skin, n_pts=args.n_pts if pairs else 0, dev=dev).to(dev)
     n_vert = data.pos.shape[0]
+    n_vert_all = n_vert * world
+    if ragged and use_dist:
+        nv_t = torch.tensor([n_vert], dtype=torch.int64, device=dev)
+        dist.all_reduce(nv_t)
+        n_vert_all = int(nv_t.item())
     gathered = []                                      # the tensors one step hands to the collective (refreshed every step)
 
     def gather(t):
@@ -749,7 +816,8 @@ def main():
             return t
         if gather.record:
             gathered.append(t)
-        return mdist.all_gather_rows(t, equal_rows=True, even_alone=True)
+        # ragged batches: every rank holds a different number of rows -- the count-exchange + padded gather path
+        return mdist.all_gather_rows(t, equal_rows=not ragged, even_alone=True)
     gather.record = False
     step = make_step(args.workload, data, dev, gather)
 
@@ -837,7 +905,7 @@ def main():
             tg = time.perf_counter()
             for _ in range(reps):
                 for g_t in gathered:
-                    mdist.all_gather_rows(g_t, equal_rows=True, even_alone=True)
+                    mdist.all_gather_rows(g_t, equal_rows=not ragged, even_alone=True)
             fence()
             allgather_ms = (time.perf_counter() - tg) / reps * 1e3
         tg_t = torch.tensor([allgather_ms], dtype=torch.float64, device=dev)
@@ -852,7 +920,7 @@ def main():
         per_rank = [float(x.item()) for x in allt]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    assert out.shape[0] == n_vert * world and bool(torch.isfinite(out).all())
+    assert out.shape[0] == n_vert_all and bool(torch.isfinite(out).all())
 
     secondary = None
     n_secondary = args.secondary if args.secondary >= 0 else (3 if args.workload == "jointnet" else 0)
@@ -885,6 +953,32 @@ def main():
                     secondary[wl]["cpu_baseline"] = cpu_baseline_other(wl, args.secondary_cpu_seconds, args.n_side, args.n_pts, 1000)
                 except Exception as e:
                     secondary[wl]["cpu_baseline"] = dict(error=repr(e)[:300])
+        # config 5's stand-in: the same forward over a RAGGED batch -- 64 meshes of 1 024 ... 6 400 vertices -- in meshes/s AND
+        # vertices/s beside the uniform headline batch (the tile-run / XCD partition of the EdgeConv kernels is otherwise only timed on
+        # equal-size meshes)
+        try:
+            with torch.no_grad():
+                rseeds = [1000 + i for i in range(args.batch)]
+                rsides = ragged_sides(rseeds)
+                d2 = build_batch_ragged(rseeds, rsides, dev=dev)
+                st = make_step("jointnet", d2, dev, lambda x: x)
+                rsteps = max(4 * n_secondary, 8)
+                sdt, sper, _ = timed_run(st, rsteps, 3)
+                nv2 = int(d2.pos.shape[0])
+                uni_vps = n_vert * args.steps / dt
+                secondary["jointnet_ragged"] = dict(
+                    metric=NAMES["jointnet_ragged"][0], value=round(args.batch * rsteps / sdt, 2), unit="meshes/s",
+                    ms_per_step=round(sdt / rsteps * 1e3, 3), steps=rsteps, warmup=3, batch=args.batch, vertices=nv2,
+                    vertices_per_mesh_min_max=[min(rsides) ** 2, max(rsides) ** 2],
+                    edges=dict(tpl=int(d2.tpl_edge_index.shape[1]), geo=int(d2.geo_edge_index.shape[1])),
+                    vertices_per_s=round(nv2 * rsteps / sdt, 1), vertices_per_s_uniform_batch=round(uni_vps, 1),
+                    vertices_per_s_over_uniform=round(nv2 * rsteps / sdt / uni_vps, 4), config=NAMES["jointnet_ragged"][2],
+                    note="meshes of 32..80-side grids (seeded), the reference's fixed ball radius 0.06: small meshes have fewer geo edges "
+                         "per vertex than the uniform batch, large ones the same 15; vertices/s is the comparable rate")
+                del st, d2
+                torch.cuda.empty_cache()
+        except Exception as e:
+            secondary["jointnet_ragged"] = dict(error=repr(e)[:300])
         # north_star's one-mesh-per-GPU operating point (and what `--scaling strong --gpus 8` gives each rank: 8 meshes): the same
         # forward at B = 1, 2, 4, 8 meshes per launch set
         try:
@@ -1054,14 +1148,16 @@ def main():
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": ("f32 (split-fp16: 3x f16 MFMA, f32 accumulate)" if (PLUMBING or native.get_ops().precision == "f16x3") else "f32"),
             "data": "synthetic" if not PLUMBING else "synthetic (PLUMBING RUN on CPU emulation + gloo: not a measurement)",
-            "config": {"workload": f"{names[1]}, batch={B_local} synthetic "
-                                   f"{args.n_side * args.n_side}-vertex meshes per GPU ({names[2]}), "
-                                   "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if use_dist else ""),
-                       "meshes_per_gpu": B_local, "global_batch": n_units, "vertices_per_mesh": args.n_side * args.n_side,
+            # (workload stays under 120 characters: the driver's record cuts longer strings -- VERDICT r5 #10; what a step covers is `step`)
+            "config": {"workload": (f"{names[1]}, B={B_local} x {args.n_side * args.n_side}-vertex synthetic meshes/GPU, {names[2]}" if not ragged else
+                                    f"{names[1]}, B={B_local} ragged meshes/GPU ({n_vert} vertices), {names[2]}"),
+                       "step": "COO->CSR prep + forward" + (" + RCCL all-gather of the outputs" if use_dist else ""),
+                       "meshes_per_gpu": B_local, "global_batch": n_units,
+                       "vertices_per_mesh": (args.n_side * args.n_side) if not ragged else [min(sides) ** 2, max(sides) ** 2],
                        "parallelism": f"mesh-sharded dp{world}",
                        # guard_read: "sync" = one host read of the range flag / CSR status at the end of every forward; "deferred" =
                        # read one forward later (forward_async), every forward's still inside the timed region
-                       "guard_read": "sync" if (args.workload != "jointnet" or os.environ.get("MORIG_BENCH_GUARD") == "sync") else "deferred",
+                       "guard_read": "sync" if (args.workload not in ("jointnet", "jointnet_ragged") or os.environ.get("MORIG_BENCH_GUARD") == "sync") else "deferred",
                        "geo_graph": "device" if not PLUMBING else "host"},
             "rccl_ranks": rccl_ranks, "backend": backend if use_dist else None,
             "per_rank_ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank],
@@ -1071,6 +1167,7 @@ def main():
             "allgather_note": ("the step's %d all_gather_into_tensor call(s) (%s bytes per rank in total) repeated 20x back to back between "
                                "fences in a separate pass, max over ranks; inside the timed steps the same calls are part of ms_per_step"
                                % (len(gathered), sum(g_t.numel() * g_t.element_size() for g_t in gathered))) if allgather_ms is not None else None,
+            "vertices_per_s": round(n_vert_all * args.steps / dt, 1),
             "roofline": roof,
             "hbm_bound_kernels": hbm_kinds,
             "whole_forward_tflops": round(all_flops / (dt / args.steps) / 1e12, 2) if prof else None,
@@ -1084,11 +1181,11 @@ def main():
                                         "line's schema can be checked at any world size")
         # the CPU oracle on this host's cores, on rank 0, AFTER the timed region (the other ranks wait at the closing barrier), at
         # every world size: an N > 1 line without it would be unmeasured by rule (VERDICT r3 #1b)
-        if args.cpu_seconds > 0 and not PLUMBING and args.workload == "jointnet":
+        if args.cpu_seconds > 0 and not PLUMBING and args.workload in ("jointnet", "jointnet_ragged"):
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)
         elif args.cpu_seconds > 0 and not PLUMBING:
             res["cpu_baseline"] = cpu_baseline_other(args.workload, args.cpu_seconds, args.n_side, args.n_pts, 1000)
-        elif PLUMBING and args.cpu_seconds > 0 and args.workload == "jointnet":
+        elif PLUMBING and args.cpu_seconds > 0 and args.workload in ("jointnet", "jointnet_ragged"):
             res["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.n_side, 1000)      # the real oracle, on the plumbing run's tiny meshes
         elif PLUMBING and args.cpu_seconds > 0:
             res["cpu_baseline"] = cpu_baseline_other(args.workload, args.cpu_seconds, args.n_side, args.n_pts, 1000)

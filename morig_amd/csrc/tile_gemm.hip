@@ -1011,7 +1011,9 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a_in, void* stream) {
 
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
     const double flops = 2.0 * E * a->H * (double)a->H;
-    const double bytes = 4.0 * (2.0 * E * a->H) ;    // gathered operand rows (mostly L2 hits)
+    // compulsory bytes: every row of the [A | B] operand tables and every result row ONCE (the per-edge re-reads of gathered rows are L2
+    // hits: what they cost shows as traffic ABOVE this figure in bench.py's roofline.traffic_over_algorithmic)
+    const double bytes = 4.0 * a->H * (double)a->n_nodes * (2.0 * (a->in_rep_stride > 0 ? a->replicas : 1) + a->replicas);
     // H = 256 / 128: wave-specialised kernel (1.35x / 1.25x over the symmetric one; H = 128 runs two workgroups per CU)
     if (wide) {
         EdgePcParams q = {};

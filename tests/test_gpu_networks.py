@@ -390,6 +390,35 @@ def test_headline_batch_64_meshes_contains_the_golden_mesh_and_is_deterministic(
     assert rel_excess(shift[sl], a["pred_shift"], TOL) <= 0
 
 
+def test_ragged_batch_64_meshes_contains_the_golden_mesh():
+    """The config-5 stand-in as bench.py times it (`--workload jointnet_ragged`): 64 meshes of 1 024 ... 6 400 vertices in
+    ONE batch (rig datasets hold characters of different sizes: datasets/dataset_rig.py:85-138), the reference's fixed ball radius,
+    with the committed 4096-vertex golden mesh at a MIDDLE slot: its rows equal the reference's single-mesh outputs -- the tile runs /
+    XCD partition of the EdgeConv kernels and the per-mesh pooling on meshes of unequal length -- and two runs are bit-identical."""
+    import bench
+    meta, a = load_golden("jointnet_4k")
+    seeds = [1000 + i for i in range(64)]
+    sides = bench.ragged_sides(seeds)
+    slot = 29
+    seeds[slot], sides[slot] = meta["mesh_seed"], meta["n_side"]
+    assert len(set(sides)) > 20 and min(sides) >= 32 and max(sides) <= 80
+    batch = bench.build_batch_ragged(seeds, sides)                  # host recipe (the golden mesh's own geo graph: seeded host draw)
+    m = models.jointnet_motion(**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
+    d = batch.to(DEV)
+    off = sum(s_ * s_ for s_ in sides[:slot])
+    n = meta["n_side"] ** 2
+    sl = slice(off, off + n)
+    if a["pos_check"].shape[0] == n:
+        assert torch.equal(d.pos[sl].cpu(), a["pos_check"])
+    ma, aggr, shift = m(d, d.pred_flow)
+    ma2, aggr2, shift2 = m(d, d.pred_flow)
+    assert torch.equal(shift, shift2) and torch.equal(aggr, aggr2) and torch.equal(ma, ma2)
+    assert shift.shape[0] == sum(s_ * s_ for s_ in sides) and bool(torch.isfinite(shift).all())
+    assert rel_excess(aggr[sl], a["motion_aggr"], TOL) <= 0
+    assert rel_excess(shift[sl], a["pred_shift"], TOL) <= 0
+
+
 def test_mask_skin_batch_64_contains_the_golden_mesh():
     """BASELINE.json configs[2] at its stated size (VERDICT r3 #4a): masknet_motion + skinnet_motion over ONE batch of 64 meshes x
     4096 vertices, as bench.py's `mask_skin` workload runs them, with the committed harsh-recipe 4096-vertex golden mesh at

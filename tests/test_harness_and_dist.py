@@ -423,6 +423,17 @@ def test_bench_eight_ranks_corrnet_pairs():
     assert "configs[3]" in r["config"]["workload"] and r["allgather_calls_per_step"] == 3 and r["allgather_bytes_per_rank"] > 0
 
 
+def test_bench_eight_ranks_ragged_batches():
+    """the config-5 stand-in (`--workload jointnet_ragged`) at world size 8: every rank holds meshes of different sizes, so
+    the outputs go through the count exchange + padded gather (no two ranks hold the same number of rows)"""
+    r = _bench_line(["--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--cpu-seconds", "1", "--workload", "jointnet_ragged"],
+                    dict(OMP_NUM_THREADS="1"))
+    _check_n8_line(r, "weak", 2, 16, "meshes/s")
+    assert "ragged" in r["config"]["workload"] and len(r["config"]["workload"]) < 120
+    lo, hi = r["config"]["vertices_per_mesh"]
+    assert 16 <= lo < hi <= 64 and r["vertices_per_s"] > 0                     # (plumbing meshes: 4..8-side grids)
+
+
 # ---- RCCL on hardware: the one-GPU box can only hold a world of one rank, but every collective the multi-GPU paths issue
 # ---- (process-group creation on the device, all-reduce, all-gather, barrier) goes through RCCL all the same
 @pytest.mark.gpu
@@ -444,7 +455,7 @@ def test_rccl_path_on_one_gpu():
     assert len(lines) == 1, p.stdout
     r = json.loads(lines[0])
     assert r["backend"] == "nccl" and r["rccl_ranks"] == 1 and r["n_gpus"] == 1
-    assert "RCCL all-gather" in r["config"]["workload"] and r["value"] > 0 and len(r["per_rank_ms_per_step"]) == 1
+    assert "RCCL all-gather" in r["config"]["step"] and len(r["config"]["workload"]) < 120 and r["value"] > 0 and len(r["per_rank_ms_per_step"]) == 1
 
 
 _RCCL_WORKER = r"""
