@@ -84,7 +84,11 @@ def test_networks_against_reference_goldens(name, outs):
     for r, key in zip(res, outs):
         if key is not None:
             assert r.is_cuda and r.shape == a[key].shape
-            assert rel_excess(r, a[key], TOL) <= 0, key
+            # the SkinNet logits of the Dg = 1 switch combinations reach |37|: the relative reading passes them at 2.5e-6 of scale; the
+            # ABSOLUTE reading of "within 1e-4" holds as well (9.3e-5 / 8.2e-5 measured, 24 ulp at that magnitude) and is asserted, so
+            # that a regression of the margin is seen
+            strict = True if (name.startswith("skinnet_dg1") and key == "skin_cls_pred") else None
+            assert rel_excess(r, a[key], TOL, strict=strict) <= 0, key
 
 
 def test_jointnet_headline_size_mesh_against_reference_golden():
@@ -603,3 +607,29 @@ def test_captured_forward_replays_bit_identically(sides):
     d.pred_flow.mul_(1.0e7)
     cf.replay()
     assert cf.check() is (native.get_ops().precision == "f32")
+
+
+def test_forward_server_serves_small_batches_from_captured_graphs():
+    """morig_amd.serving.ForwardServer: batches of up to N vertices are served from a HIP graph captured per
+    SHAPE -- a second batch of the same shape but different content is copied into the graph's static inputs and replayed -- larger
+    ones run eagerly; results equal the eager forward bit for bit; an out-of-range input falls back to the eager (fp32) forward."""
+    from morig_amd import native
+    from morig_amd.serving import ForwardServer
+    m = _jointnet(4)
+    srv = ForwardServer(m, graph_max_vertices=2 * 24 * 24)
+    a = synth.collate([synth.make_mesh(31, n_side=24)]).to(DEV)
+    b = synth.collate([synth.make_mesh(32, n_side=24)]).to(DEV)           # same vertex / tpl-edge counts; the geo edge count may differ
+    big = synth.collate([synth.make_mesh(33 + i, n_side=24) for i in range(3)]).to(DEV)
+    for d in (a, b, a, big, b):
+        want = [t.clone() for t in m(d, d.pred_flow)]
+        got = srv(d, d.pred_flow)
+        for x, y in zip(want, got):
+            assert torch.equal(x, y)
+    same_shape = a.geo_edge_index.shape == b.geo_edge_index.shape
+    assert srv.stats["eager"] == 1 and srv.stats["captures"] == (1 if same_shape else 2) and srv.stats["replays"] == 4, srv.stats
+    if native.get_ops().precision != "f32":
+        hot = synth.MeshData(**{k: v for k, v in a.__dict__.items()})
+        hot.pred_flow = a.pred_flow * 1.0e7
+        want = m(hot, hot.pred_flow)
+        got = srv(hot, hot.pred_flow)
+        assert srv.stats["fallbacks"] == 1 and torch.equal(want[2], got[2])
