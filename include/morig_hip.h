@@ -40,7 +40,7 @@ extern "C" {
  * caller's memory would spell there, or garbage) is MORIG_E_INVALID. */
 #define MORIG_INIT_ARGS(type, var) type var; memset(&(var), 0, sizeof(var)); (var).struct_size = (uint32_t)sizeof(var)
 #define MORIG_GEMM_ARGS_V3_SIZE        192u
-#define MORIG_EDGECONV_ARGS_V3_SIZE    184u
+#define MORIG_EDGECONV_ARGS_V3_SIZE    192u
 #define MORIG_EDGECONV_X3_ARGS_V3_SIZE 168u
 #define MORIG_SEGMAX_ARGS_V3_SIZE      144u
 #define MORIG_POINTCONV_ARGS_V3_SIZE   176u
@@ -87,6 +87,11 @@ int morig_csr_build(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes,
 #define MORIG_CSR_PAD4          2   /* every target's segment is padded to a multiple of 4 entries by repeating
                                        its self loop (max-aggregation is idempotent); capacity n_edges + 4*n_nodes.
                                        morig_edgeconv's `quad_aligned` fast epilogue requires it.              */
+#define MORIG_CSR_MIN4          4   /* morig_csr_build_bipartite (not with PAD4) / morig_csr_build_dual: every segment of the PLAIN CSR holds at least 4 rows (a shorter one is filled
+                                       up with copies of its self loop; capacity n_edges + 4*n_nodes). A quad of 4 consecutive rows then
+                                       never holds more than two segments, which is what morig_edgeconv's `seg_min4` form needs: the
+                                       H = 256 kernel reduces a quad that straddles two segments into two values instead of requiring
+                                       4-ALIGNED segments (MORIG_CSR_PAD4 costs 9-14 % extra rows on the rig graphs, this ~0).           */
 int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_t n_src_nodes, int32_t n_nodes,
                               int32_t flags, int32_t* rowptr, int32_t* src_sorted, int32_t* dst_sorted,
                               int32_t* cursor, int32_t* status, void* stream);
@@ -189,6 +194,10 @@ typedef struct morig_edgeconv_args {
                                           Needs W2_split + overflow, `out` 128-byte aligned, ldo % 32 == 0 and the launch on one of the
                                           4-aligned-CSR kernels (H = 128 / 256): ask morig_edgeconv_can_split_out first;
                                           MORIG_E_UNSUPPORTED otherwise. *overflow is raised when a result leaves the fp16 range. */
+    int32_t seg_min4;                  /* [ABI 3] the CSR was built with MORIG_CSR_MIN4 (segments of >= 4 rows, NOT 4-aligned; quad_aligned = 0):
+                                          H = 256 split-fp16 launches with out_split then take the mixed-quad form of the W2-stationary
+                                          kernel (morig_edgeconv_can_split_out answers for it); everywhere else the flag is ignored -- a
+                                          MIN4 CSR is a valid plain CSR for every other kernel (max over a repeated row is the same max). */
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 /* 1 when morig_edgeconv would honour out_split for these arguments (pointers, widths, CSR form and the library's environment
@@ -321,9 +330,11 @@ int morig_frame_reduce(const float* x, int32_t n, int32_t T, int32_t C, int32_t 
  * ranks inside a segment are shared, both fills happen in one kernel (the rig networks need both per graph and per forward:
  * models/basic_modules.py:188-189 is normalised once instead of once per layer). Same results as two morig_csr_build_bipartite
  * calls up to the order of a target's edges inside its segment. ws: 2 * n_nodes + 1 ints of scratch. */
+/* [ABI 3] flags: 0, or MORIG_CSR_MIN4 (the plain CSR's segments are filled up to 4 rows; src_sorted / dst_sorted then need the padded
+ * CSR's capacity n_edges + 4 * n_nodes). */
 int morig_csr_build_dual(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes, int32_t* rowptr, int32_t* src_sorted,
                          int32_t* dst_sorted, int32_t* rowptr4, int32_t* src_sorted4, int32_t* dst_sorted4, int32_t* ws,
-                         int32_t* status, void* stream);
+                         int32_t flags, int32_t* status, void* stream);
 /* The same normalised CSR as morig_csr_build_bipartite(MORIG_CSR_SKIP_NEGATIVE) for the slot table morig_ball_query
  * writes (target k owns slots [k*max_nbrs, (k+1)*max_nbrs) of row 0 of `coo`, max_nbrs <= 64, unused = -1): counted
  * and filled per target without atomics (replaces torch_cluster.radius -> PointConv's remove/add_self_loops,

@@ -53,6 +53,7 @@ struct EdgePcParams {
     int run;                                     // edge_rl.hip / edge_ws.hip: consecutive tiles per wave / workgroup (open segments are carried)
     int* ovf;
     int quad;                                    // CSR segments are 4-aligned (MORIG_CSR_PAD4)
+    int min4;                                    // CSR segments hold >= 4 rows, not aligned (MORIG_CSR_MIN4): edge_ws.hip's mixed-quad form
     unsigned long long* trace;                   // -DMORIG_PP_TRACE builds only
     int dbg;                                     // ablation (tools/microbench.py): 1 no epilogue, 2 no MFMA, 4 no gathers, 8 no W loads
 };

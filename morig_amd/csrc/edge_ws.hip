@@ -39,7 +39,7 @@ typedef __attribute__((address_space(1))) const void glb_void_t;
 template <int C> using WC = std::integral_constant<int, C>;
 
 #ifdef MORIG_WS_TRACE
-#define WS_TS(k) do { if (j == 3 && blockIdx.x == 8 && lane == 0 && wave == 0) p.trace[(k)] = __builtin_readcyclecounter(); } while (0)
+#define WS_TS(k) do { if (j == 3 && blockIdx.x == 8 && lane == 0) p.trace[(k) * 8 + wave] = __builtin_readcyclecounter(); } while (0)
 #else
 #define WS_TS(k) do { } while (0)
 #endif
@@ -52,8 +52,16 @@ template <int H> struct WsGeom { static constexpr int BM = H == 256 ? 64 : 128, 
 
 // Y16: whole segments leave as split-fp16 halves (per 32-column chunk 32 hi, then 32 lo: the layout the unit's MLP GEMM DMAs into LDS);
 // tile-straddling segments stay fp32 atomics and are rewritten by split_boundary_rows (tile_gemm.hip)
-template <int H, bool Y16 = false>
+// MIX [r06]: the CSR's segments are NOT 4-aligned, only at least 4 rows long (MORIG_CSR_MIN4): a quad of 4 consecutive tile rows then holds
+// the rows of at most TWO segments -- `s` leading rows of the segment of its first row, 4 - s rows of the next one -- and at most one
+// segment starts in it. What changes: a wave gathers the A row of the FIRST and of the LAST row of each of its quads (4 instead of 2 A
+// rows per chunk: the same one wave-instruction, now unmasked) and a converting lane adds the one its row belongs to; the quad max
+// becomes two values (T = max over the first segment's rows, Hd = over the second's: two planes of the scan region) wherever one of a
+// register pair's two quads is mixed (a wave-uniform test; pure quads keep the 2-instruction form); the segmented max starts a mid-quad
+// segment from the Hd plane and ends the segment in front of it with that quad's T. No padded rows: 9-14 % fewer MFMAs on the rig graphs.
+template <int H, bool Y16 = false, bool MIX = false>
 __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
+    static_assert(!MIX || (H == 256 && Y16), "the mixed-quad form exists for the H = 256 split-rows kernel");
     constexpr int BM = WsGeom<H>::BM, KC = WsGeom<H>::KC;
     constexpr int LDB = 4 * KC + 16;                     // bytes per Z row = [KC hi | KC lo | 16 pad]
     constexpr int NWN = H / 32;                          // waves along the output columns
@@ -67,7 +75,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     constexpr int NDMA = 3;                              // LDS-DMA instructions per wave and chunk
     constexpr int RPW = BM / 8;                          // tile rows gathered and converted by one wave
     constexpr int NQ = BM / 4;                           // quad rows per tile
-    constexpr int RAWW = 2048 + 512;                     // raw bytes per wave and stage: B rows, then A quads
+    constexpr int RAWW = 2048 + (MIX ? 1024 : 512);      // raw bytes per wave and stage: B rows, then A quads (MIX: first and last row's)
     constexpr int RAWS = 8 * RAWW;
     constexpr int ZSTAGE = BM * LDB;
     constexpr int ZQ = H + 4;                            // scan region: NQ quad rows x H columns (+4: 16-byte rows)
@@ -75,15 +83,17 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     constexpr int SWITCHC = NC >= 3 ? NC - 3 : (NC + NC - 3) % NC;   // chunk whose D() is the first of the NEXT tile
     static_assert(NC == 4, "index prefetch schedule");
 
-    __shared__ __attribute__((aligned(128))) char smem[3 * RAWS + 2 * ZSTAGE + NQ * ZQ * 4 + 3 * 32 * 4 + 64 + 3 * H * 4 + 2 * H * 4 + 16];
+    constexpr int NPL = MIX ? 2 : 1;                     // planes of the scan region (MIX: T, then Hd)
+    __shared__ __attribute__((aligned(128))) char smem[3 * RAWS + 2 * ZSTAGE + NPL * NQ * ZQ * 4 + 3 * 32 * 4 + 64 + 3 * H * 4 + 2 * H * 4 + 16 + 32];
     char* raw = smem;
     char* zring = smem + 3 * RAWS;
     float* Z = reinterpret_cast<float*>(zring + 2 * ZSTAGE);
-    int* sq_all = reinterpret_cast<int*>(zring + 2 * ZSTAGE + NQ * ZQ * 4);   // [3][32] destination id per quad row
+    int* sq_all = reinterpret_cast<int*>(zring + 2 * ZSTAGE + NPL * NQ * ZQ * 4);   // [3][32] destination id per quad row (MIX: [16] first row's, [16] last row's)
     int* sflag = sq_all + 3 * 32;                                              // [3][2] first / last segment continues
     float* sbias = reinterpret_cast<float*>(sflag + 16);                       // [3][H] bias, BN scale, BN shift
     float* carry = sbias + 3 * H;                                              // [2][H] open segment handed to the next tile of the run (tile parity)
     int* cshared = reinterpret_cast<int*>(carry + 2 * H);                      // [2] ... and whether it entered over the run's first boundary
+    unsigned* ssp = reinterpret_cast<unsigned*>(cshared + 4);                  // MIX [3][2]: byte w = wave w's quads: (s - 1) of quad 2 w | (s - 1) of quad 2 w + 1 << 2
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -150,7 +160,8 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     const int drow = lane >> 3, dpiece = lane & 7;
     const int aq = KC == 64 ? (lane >> 4) & 1 : drow & 3, apiece = KC == 64 ? lane & 15 : dpiece;    // lanes 0..31
     unsigned ob0 = 0, ob1 = 0, oq = 0;                   // byte offsets (< 4 GB per replica)
-    int ns0 = 0, ns1 = 0, nq = 0, nfl = 0;               // next tile's indices, in flight
+    int ns0 = 0, ns1 = 0, nq = 0, nfl = 0;               // next tile's indices, in flight (MIX: nq = the destination of THIS lane's row)
+    int snext = 0x44;                                    // MIX (scalar): s of the gather tile's two quads of this wave, s0 | s1 << 4
     int nrow0 = 0, nrep = 0;
     const char* abase = reinterpret_cast<const char*>(p.A);
     const char* bbase = reinterpret_cast<const char*>(p.B);
@@ -160,7 +171,8 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         const int r = nrow0 + RPW * wave + drow;
         ns0 = p.srcS[min(r, Etot - 1)];
         if constexpr (KC == 32) ns1 = p.srcS[min(r + 8, Etot - 1)];
-        nq = p.dstS[min(nrow0 + 4 * ((RPW / 4) * wave + aq), Etot - 1)];
+        if constexpr (MIX) nq = p.dstS[min(r, Etot - 1)];                      // per ROW (rows past the end repeat the last edge)
+        else nq = p.dstS[min(nrow0 + 4 * ((RPW / 4) * wave + aq), Etot - 1)];
         // wave 0, lanes 0..2: the ids just outside / at the end of the tile (segment continuation flags)
         const int fr = lane == 0 ? nrow0 - 1 : (lane == 1 ? nrow0 + BM - 1 : nrow0 + BM);
         nfl = p.dstS[min(max(fr, 0), Etot - 1)];
@@ -171,11 +183,31 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         ob0 = ((unsigned)ns0 * (unsigned)p.ldb + 4u * dpiece) * 4u;           // rows past the end re-read the last edge:
         if constexpr (KC == 32) ob1 = ((unsigned)ns1 * (unsigned)p.ldb + 4u * dpiece) * 4u;   // finite, ignored by the scan (id -1)
         else ob1 = ob0 + 128u;
-        oq = ((unsigned)nq * (unsigned)p.lda + 4u * apiece) * 4u;
         int* sq = sq_all + slot * 32;
-        if (lane < 32 && apiece == 0) {
-            const int q = (RPW / 4) * wave + aq;                                // Etot is a multiple of 4: a quad is valid as a whole
-            sq[q] = (nrow0 + 4 * q < Etot) ? nq : -1;
+        if constexpr (MIX) {
+            // rows 0..3 of quad 0 sit in lanes 0, 8, 16, 24 (8 lanes per row), those of quad 1 in lanes 32 .. 56
+            const int dF0 = __builtin_amdgcn_readlane(nq, 0), dL0 = __builtin_amdgcn_readlane(nq, 24),
+                      dF1 = __builtin_amdgcn_readlane(nq, 32), dL1 = __builtin_amdgcn_readlane(nq, 56);
+            const unsigned long long eq = __ballot(nq == (lane < 32 ? dF0 : dF1));
+            const int s0 = __builtin_popcount((unsigned)eq & 0x01010101u), s1 = __builtin_popcount((unsigned)(eq >> 32) & 0x01010101u);
+            snext = s0 | (s1 << 4);
+            // A rows of this wave: [quad 0 first | quad 0 last | quad 1 first | quad 1 last] x 16 pieces = the 64 lanes
+            const int arow = lane >> 4;
+            const int aid = arow == 0 ? dF0 : (arow == 1 ? dL0 : (arow == 2 ? dF1 : dL1));
+            oq = ((unsigned)aid * (unsigned)p.lda + 4u * (unsigned)(lane & 15)) * 4u;
+            if (lane == 0) {
+                const int qa = 2 * wave;
+                const bool v0 = nrow0 + 4 * qa < Etot, v1 = nrow0 + 4 * (qa + 1) < Etot;      // a quad counts while its FIRST row exists
+                sq[qa] = v0 ? dF0 : -1; sq[16 + qa] = v0 ? dL0 : -1;
+                sq[qa + 1] = v1 ? dF1 : -1; sq[16 + qa + 1] = v1 ? dL1 : -1;
+                reinterpret_cast<unsigned char*>(ssp + slot * 2)[wave] = (unsigned char)((s0 - 1) | ((s1 - 1) << 2));
+            }
+        } else {
+            oq = ((unsigned)nq * (unsigned)p.lda + 4u * apiece) * 4u;
+            if (lane < 32 && apiece == 0) {
+                const int q = (RPW / 4) * wave + aq;                            // Etot is a multiple of 4: a quad is valid as a whole
+                sq[q] = (nrow0 + 4 * q < Etot) ? nq : -1;
+            }
         }
         if (wave == 0) {
             const int prev = __builtin_amdgcn_readlane(nfl, 0), last = __builtin_amdgcn_readlane(nfl, 1),
@@ -198,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         asm volatile("" : "+v"(o0), "+v"(o1), "+v"(o2));
         __builtin_amdgcn_global_load_lds((glb_void_t*)(bbase + c * (KC * 4) + o0), (lds_void_t*)(dst), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((glb_void_t*)(bbase + c * (KC * 4) + o1), (lds_void_t*)(dst + 1024), 16, 0, 0);
-        if (lane < 32) __builtin_amdgcn_global_load_lds((glb_void_t*)(abase + c * (KC * 4) + o2), (lds_void_t*)(dst + 2048), 16, 0, 0);
+        if (MIX || lane < 32) __builtin_amdgcn_global_load_lds((glb_void_t*)(abase + c * (KC * 4) + o2), (lds_void_t*)(dst + 2048), 16, 0, 0);
 #else
         const unsigned d0 = raww_lds + rs * RAWS;
         const unsigned vo0 = ob0, vo1 = ob1, vo2 = oq;
@@ -208,8 +240,8 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
                      :: "s"(d0), "v"(vo0), "s"(sb), "n"(0) : "memory");
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
                      :: "s"(d0 + 1024u), "v"(vo1), "s"(sb), "n"(0) : "memory");
-        // one wave-instruction whatever the exec mask: vmcnt counts 3 per chunk
-        if (lane < 32) {
+        // one wave-instruction whatever the exec mask: vmcnt counts 3 per chunk (MIX: all 64 lanes -- 4 A rows)
+        if (MIX || lane < 32) {
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3"
                          :: "s"(d0 + 2048u), "v"(vo2), "s"(sa), "n"(0) : "memory");
         }
@@ -220,7 +252,13 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     float amax = 0.f;
     constexpr int TPR = KC / 8;                           // converting threads per row
     const int vrow = lane / TPR, vq = lane % TPR;
-    const int vb = vrow * 128 + 16 * vq, va = 2048 + (vrow >> 2) * (KC * 4) + 16 * vq;
+    const int vb = vrow * 128 + 16 * vq;
+    int va = 2048 + (vrow >> 2) * (KC * 4) * (MIX ? 2 : 1) + 16 * vq;        // MIX: per tile -- the first or the last row's A of my quad
+    // MIX: the A row of MY row for the tile whose indices were switched in last: row position (vrow & 3) >= s of its quad -> the LAST row's
+    auto va_of = [&](int sn) __attribute__((always_inline)) {
+        const int sk = (vrow >> 2) ? (sn >> 4) : (sn & 15);
+        return 2048 + ((vrow >> 2) * 2 + ((vrow & 3) >= sk ? 1 : 0)) * (KC * 4) + 16 * vq;
+    };
     auto raw_load = [&](int rs, auto halfc, f32x4& a, f32x4& b) __attribute__((always_inline)) {
         constexpr int hf = decltype(halfc)::value;
         const char* src = raww + rs * RAWS;
@@ -294,21 +332,37 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     };
     // y = relu(sg x + b) * sc + sh is rising in the stored accumulator x (see the W2 slice above): the scan region receives the max of
     // a quad's four accumulators, the affine waits for the end of the segmented max
-    auto write_z = [&]() __attribute__((always_inline)) {
+    auto write_z = [&](int slot) __attribute__((always_inline)) {
         // the max below reads the accumulators from inline assembly: ordered behind the MFMAs and given their wait states by
         // hand (see edge_pp.hip write_z_quad; DESIGN section 5, lesson 11)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) asm volatile("s_nop 15" : "+v"(acc[mt]));
         const int col = 32 * wn + l31;
+        unsigned spw[2] = {0u, 0u};
+        if constexpr (MIX) { spw[0] = ssp[slot * 2]; spw[1] = ssp[slot * 2 + 1]; }      // (broadcast reads: the 16 quads' split bytes)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float a0 = acc[mt][4 * q], a1 = acc[mt][4 * q + 1], a2 = acc[mt][4 * q + 2], a3 = acc[mt][4 * q + 3];
-                float hi4, t3;
-                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
-                asm("v_max_f32 %0, %1, %2" : "=v"(hi4) : "v"(t3), "v"(a3));
-                Z[((wm * MT + mt) * 8 + 2 * q + hi) * ZQ + col] = hi4;
+                float* zt = Z + ((wm * MT + mt) * 8 + 2 * q + hi) * ZQ + col;
+                bool pure = true;
+                if constexpr (MIX) pure = ((__builtin_amdgcn_readfirstlane(spw[mt]) >> (8 * q)) & 0xFu) == 0xFu;    // both quads of the register pair (hi = 0, 1)
+                if (pure || (p.dbg & 128)) {                  // (dbg 128: timing experiment, wrong results on mixed quads)
+                    float hi4, t3;
+                    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(t3) : "v"(a0), "v"(a1), "v"(a2));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(hi4) : "v"(t3), "v"(a3));
+                    *zt = hi4;
+                } else {
+                    // rows 0 .. sm1 of the quad belong to the segment of its first row (T), the others to the next one (Hd)
+                    const int sm1 = (int)((spw[mt] >> (8 * q + 2 * hi)) & 3u);
+                    const float NI = -INFINITY;
+                    const bool c1 = sm1 >= 1, c2 = sm1 >= 2, c3 = sm1 == 3;
+                    const float t1 = c1 ? a1 : NI, t2 = c2 ? a2 : NI, t3 = c3 ? a3 : NI;
+                    const float h1 = c1 ? NI : a1, h2 = c2 ? NI : a2, h3 = c3 ? NI : a3;
+                    zt[0] = fmaxf(fmaxf(a0, t1), fmaxf(t2, t3));
+                    zt[NQ * ZQ] = fmaxf(h1, fmaxf(h2, h3));
+                }
             }
     };
     // ([r04] measured and not adopted here, profiles/r04r_*: segments dealt round-robin to the waves instead of by quad-row ownership,
@@ -434,9 +488,154 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         }
     };
 
+    // MIX: the segmented max over quad rows that may hold two segments each (see the kernel's header). Per quad row q: id of its first /
+    // last row (sq[q], sq[16 + q]), s - 1 of it (ssp). A segment STARTS in q when q is mixed (mid-quad start, from the Hd plane) or when
+    // q's first row differs from q - 1's last row (aligned start, T plane); it ends with the T of the quad the next one starts in when
+    // that start is mid-quad. The tile's head piece -- quad 0 mixed: T[0] alone is the tail of a segment that began above the tile --
+    // is handled by quad 0's owner behind the walk, like the tile's first / last segment (carry in / carry out / shared row).
+    auto scan_mix = [&](int js, int slot) __attribute__((always_inline)) {
+        typedef float fvec __attribute__((ext_vector_type(VEC)));
+        if (p.dbg & (1 | 64)) return;                                         // (dbg 64: timing experiment, no segmented max)
+        const int t = tile_of(js);
+        const bool run_first = (js & (R - 1)) == 0, run_last = (js & (R - 1)) == R - 1 || js == n_my - 1;
+        const int rep = t / tpr;
+        const int* sq = sq_all + slot * 32;
+        const bool first_cont = __builtin_amdgcn_readfirstlane(sflag[slot * 2]) != 0,
+                   last_cont = __builtin_amdgcn_readfirstlane(sflag[slot * 2 + 1]) != 0;
+        const int q0 = __builtin_amdgcn_readfirstlane(wave * (NQ / 8));
+        const float* zl = Z + VEC * lane;
+        asm volatile("" : "+v"(zl));                                          // (rebuilt per scan: hoisted out of the tile loop it was spilled)
+        float* obase = p.Y + (size_t)rep * p.rep_out * p.ldy + VEC * lane;
+        int lane_v = lane;
+        asm volatile("" : "+v"(lane_v));                                      // (the lane constants below are rebuilt per scan, not kept across the tile loop)
+        const int ql = lane_v & (NQ - 1);
+        const int sv = sq[ql], sl = sq[16 + ql];
+        const int slp = sq[16 + (ql > 0 ? ql - 1 : 0)];
+        const unsigned spw = ssp[slot * 2 + (ql >> 3)];
+        const bool valid = sv >= 0;
+        const bool midq = valid && ((spw >> (8 * ((ql >> 1) & 3) + 2 * (ql & 1))) & 3u) != 3u;
+        const unsigned START = (unsigned)__ballot(lane_v < NQ && (ql == 0 || midq || sv != slp));
+        const unsigned VALID = (unsigned)__ballot(lane_v < NQ && valid);
+        const unsigned MID = (unsigned)__ballot(lane_v < NQ && midq);
+        // the segments are DEALT to the waves in start order (k-th start -> wave k % 8), not owned by quad row: unaligned segments put up
+        // to three starts into one wave's two quad rows (7-row segments: waves 0 and 7 took 2 + the head piece), and the chunk barrier
+        // waits for the slowest wave
+        const unsigned sv_all = START & VALID;
+        unsigned mine = 0u;
+        {
+            unsigned bits = sv_all;
+            int r = (8 - (q0 >> 1)) & 7;                                      // (q0 >> 1 = my wave) my turn whenever r % 8 == 0
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                if ((r & 7) == 0) mine |= 1u << b;
+                ++r;
+            }
+        }
+        // bias / scale / shift, then the store of one finished segment (max domain in, see the W2 slice): plain split rows, or atomics
+        // (ONE LDS address register per use site, rebuilt behind an asm barrier, + immediate offsets for the panels and the carry rows: hoisted
+        // per-row addresses spilled, and a spill's reload brings an s_waitcnt vmcnt(0) with it that drains the gather ring -- measured:
+        // +10 % on the tpl graph with three spilled address registers)
+        auto finish = [&](fvec m, int sg, bool shared, const float* sbl) __attribute__((always_inline)) {
+            {
+                const fvec cb = *reinterpret_cast<const fvec*>(sbl);
+                const fvec cs = *reinterpret_cast<const fvec*>(sbl + H);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf((cs[v] < 0.f ? -m[v] : m[v]) + cb[v], 0.f);
+                __builtin_amdgcn_sched_barrier(0);
+                const fvec ct = *reinterpret_cast<const fvec*>(sbl + 2 * H);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = m[v] * cs[v] + ct[v];
+            }
+            float* o = obase + (size_t)sg * p.ldy;
+            if (shared) {
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) atomic_max_f32(o + v, m[v]);
+            } else {
+                char* oc = reinterpret_cast<char*>(o - VEC * lane) + ((VEC * lane) >> 5) * 128 + ((VEC * lane) & 31) * 2;
+                typedef float hvec __attribute__((ext_vector_type(VEC / 2)));
+                hvec hv, lv;
+#pragma unroll
+                for (int v = 0; v < VEC; v += 2) {
+                    float hb, lb;
+                    split_pair_f16(m[v], m[v + 1], hb, lb);
+                    if constexpr (VEC == 2) { hv = hb; lv = lb; } else { hv[v >> 1] = hb; lv[v >> 1] = lb; }
+                    amax = fmaxf(amax, fmaxf(fabsf(m[v]), fabsf(m[v + 1])));
+                }
+                *reinterpret_cast<hvec*>(oc) = hv;
+                *reinterpret_cast<hvec*>(oc + 64) = lv;
+            }
+        };
+        auto segment = [&](int b, auto special_c) __attribute__((always_inline)) {
+            constexpr bool SPECIAL = decltype(special_c)::value;
+            const unsigned later = START & ~((2u << b) - 1u);
+            const int e = later ? __builtin_ctz(later) : NQ;                 // the next start (or the tile's end)
+            const bool midb = ((MID >> b) & 1u) != 0, mide = e < NQ && ((MID >> e) & 1u) != 0;
+            const int sg = midb ? __builtin_amdgcn_readlane(sl, b) : __builtin_amdgcn_readlane(sv, b);
+            fvec m = *reinterpret_cast<const fvec*>(zl + (midb ? NQ * ZQ : 0) + b * ZQ);
+            const int qe = mide ? e + 1 : e;                                  // T rows (b, qe) belong to it as well
+            for (int q = b + 1; q < qe; q += 2) {
+                const fvec z0 = *reinterpret_cast<const fvec*>(zl + q * ZQ);
+                const fvec z1 = *reinterpret_cast<const fvec*>(zl + min(q + 1, qe - 1) * ZQ);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], fmaxf(z0[v], z1[v]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float* sbl = sbias + VEC * lane;
+            asm volatile("" : "+v"(sbl));
+            bool shared = false;
+            if constexpr (SPECIAL) {
+                const bool fc = b == 0 && first_cont && !midb;                // began above the tile (a mixed quad 0: that is the head piece)
+                shared = fc && run_first;
+                if (fc && !run_first) {
+                    const fvec cv = *reinterpret_cast<const fvec*>(sbl + 3 * H + ((js & 1) ^ 1) * H);
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], cv[v]);
+                    shared = __builtin_amdgcn_readfirstlane(cshared[(js & 1) ^ 1]) != 0;
+                }
+                if (e == NQ && last_cont && !run_last) {                      // goes on in my next tile: left in `carry`, not stored
+                    *reinterpret_cast<fvec*>(const_cast<float*>(sbl) + 3 * H + (js & 1) * H) = m;
+                    if (lane == 0) cshared[js & 1] = shared ? 1 : 0;
+                    return;
+                }
+                shared = shared || (e == NQ && last_cont);
+            }
+            finish(m, sg, shared, sbl);
+        };
+        const int lastb = sv_all ? 31 - __builtin_clz(sv_all) : 0;            // where the tile's last segment starts
+        const bool mid0 = (MID & 1u) != 0;
+        const bool own_first = first_cont && !mid0 && (mine & 1u) != 0;
+        const bool own_last = last_cont && sv_all != 0 && ((mine >> lastb) & 1u) != 0 && !(own_first && lastb == 0);
+        // quad 0 is mixed: its T is the tail of the segment above the tile -- one more piece, dealt like one more start
+        const bool own_head = mid0 && ((__builtin_popcount(sv_all) - (q0 >> 1)) & 7) == 0;
+        if (own_first) mine &= ~1u;
+        if (own_last) mine &= ~(1u << lastb);
+        while (mine) {                                                       // wave-uniform: SALU bit walking
+            const int b = __builtin_ctz(mine);
+            mine &= mine - 1u;
+            segment(b, std::false_type{});
+        }
+        if (own_first) segment(0, std::true_type{});
+        if (own_last) segment(lastb, std::true_type{});
+        if (own_head) {
+            fvec m = *reinterpret_cast<const fvec*>(zl);
+            const float* sbl = sbias + VEC * lane;
+            asm volatile("" : "+v"(sbl));
+            bool shared = first_cont && run_first;
+            if (first_cont && !run_first) {
+                const fvec cv = *reinterpret_cast<const fvec*>(sbl + 3 * H + ((js & 1) ^ 1) * H);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) m[v] = fmaxf(m[v], cv[v]);
+                shared = __builtin_amdgcn_readfirstlane(cshared[(js & 1) ^ 1]) != 0;
+            }
+            finish(m, __builtin_amdgcn_readlane(sv, 0), shared, sbl);
+        }
+    };
+
     // ---- prologue: tile 0's chunks 0..2 in flight, chunk 0 converted ----
     load_indices(0);
     switch_tile(0);
+    if constexpr (MIX) va = va_of(snext);
     load_indices(1);                                      // the gather switches tiles at chunk 1: indices are loaded a tile ahead
     dma(WC<0>{}, 0); dma(WC<1>{}, 1); dma(WC<2>{}, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -458,6 +657,8 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
         constexpr int zs = c & 1;
         const int rs_v = rs == 2 ? 0 : rs + 1;
         f32x4 ra0, rb0, ra1, rb1;
+        // MIX: from here on the conversions read the NEXT tile's chunks (its indices were switched in at chunk SWITCHC)
+        if constexpr (MIX && c == 3) va = va_of(snext);
         // ---- block 0: pending group
         load_frag(F0, zs, 0);
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");           // D(g+1) landed; D(g+2) may be in flight
@@ -468,7 +669,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
             constexpr int cp = (c + NC - 1) % NC;
             mma(F1, WC<SPC * cp + SPC - 1>{}, WC<0>{});
 #ifndef WS_NO_WRITEZ
-            if constexpr (c == 0) { WS_TS(1); if (!(p.dbg & 1)) write_z(); WS_TS(2); }
+            if constexpr (c == 0) { WS_TS(1); if (!(p.dbg & 1)) write_z((j + 2) % 3); WS_TS(2); }
 #endif
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -501,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
 #endif
         if constexpr (c == 3) load_indices(j + 2);
         rs = rs_v;
-        if constexpr (c == 1) { if (j > 0) { WS_TS(4); scan(j - 1, (j - 1) % 3); WS_TS(5); } }
+        if constexpr (c == 1) { if (j > 0) { WS_TS(4); if constexpr (MIX) scan_mix(j - 1, (j - 1) % 3); else scan(j - 1, (j - 1) % 3); WS_TS(5); } }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #ifndef WS_NO_BARRIER
         __builtin_amdgcn_s_barrier();
@@ -520,10 +721,10 @@ __global__ __launch_bounds__(512, 2) void edge_ws_kernel(const EdgePcParams p) {
     }
     // ---- drain: last group of the last tile, its epilogue ----
     mma(F1, WC<NS - 1>{}, WC<0>{});
-    if (!(p.dbg & 1)) write_z();
+    if (!(p.dbg & 1)) write_z((n_my - 1) % 3);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");             // no LDS-DMA may outlive the workgroup
     __builtin_amdgcn_s_barrier();
-    scan(n_my - 1, (n_my - 1) % 3);
+    if constexpr (MIX) scan_mix(n_my - 1, (n_my - 1) % 3); else scan(n_my - 1, (n_my - 1) % 3);
     if (!(amax < 65000.f)) *p.ovf = 1;
 }
 
@@ -545,7 +746,7 @@ int launch_edge_ws(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     EdgePcParams p = p0;
     static const int dbg = [] { const char* e = getenv("MORIG_DEBUG_FLAGS"); return e ? atoi(e) : 0; }();
     p.dbg = dbg;
-    if (!p.quad) return MORIG_E_UNSUPPORTED;
+    if (!p.quad && !(p.min4 && p.H == 256 && p.y16)) return MORIG_E_UNSUPPORTED;
     // ([r04] a four-wave / 512-register form of this kernel -- a wave owns 64 output columns: W2 in 256 AGPRs, half the LDS fragment
     // traffic; edge_w4.hip in commit b3bd7ab, bit-identical to this one -- reached this kernel's main-loop time and lost 5 % overall: a
     // lone wave per SIMD has nobody to hide the quad epilogue, the scan and the per-tile bookkeeping behind (3 500 of a tile's 14 000
@@ -560,7 +761,8 @@ int launch_edge_ws(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     int avail = ncu - ((reserved_cus() + 7) / 8) * 8;
     if (avail < 8) avail = 8;
     const int grid = nblocks < avail ? ((nblocks + 7) / 8) * 8 : avail;      // one persistent workgroup per CU, multiple of 8 (XCDs)
-    if (p.H == 256 && p.y16) hipLaunchKernelGGL((edge_ws_kernel<256, true>), dim3(grid), dim3(512), 0, s, p);
+    if (p.H == 256 && p.y16 && !p.quad) hipLaunchKernelGGL((edge_ws_kernel<256, true, true>), dim3(grid), dim3(512), 0, s, p);
+    else if (p.H == 256 && p.y16) hipLaunchKernelGGL((edge_ws_kernel<256, true>), dim3(grid), dim3(512), 0, s, p);
     else if (p.H == 256) hipLaunchKernelGGL((edge_ws_kernel<256>), dim3(grid), dim3(512), 0, s, p);
     else if (p.H == 128 && p.y16) hipLaunchKernelGGL((edge_ws_kernel<128, true>), dim3(grid), dim3(512), 0, s, p);
     else if (p.H == 128) hipLaunchKernelGGL((edge_ws_kernel<128>), dim3(grid), dim3(512), 0, s, p);
@@ -570,9 +772,12 @@ int launch_edge_ws(const EdgePcParams& p0, int nblocks, hipStream_t s) {
     {
         unsigned long long h[64];
         if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(h, p.trace, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            fprintf(stderr, "WS_TRACE H=%d:", p.H);
-            for (int q = 1; q < 8; ++q) fprintf(stderr, " %lld", (long long)(h[q] - h[q - 1]));
-            fprintf(stderr, "\n");
+            fprintf(stderr, "WS_TRACE H=%d quad=%d (per wave: write_z start, write_z, rest of chunk 0, chunk 1 to scan, scan, rest of chunk 1, chunks 2-3):\n", p.H, p.quad);
+            for (int w = 0; w < 8; ++w) {
+                fprintf(stderr, "  w%d", w);
+                for (int q = 1; q < 8; ++q) fprintf(stderr, " %6lld", (long long)(h[q * 8 + w] - h[(q - 1) * 8 + w]));
+                fprintf(stderr, "\n");
+            }
         }
     }
 #endif

@@ -51,7 +51,14 @@ __device__ __forceinline__ int block_excl_scan(int v, int* sh /* >= SCAN_T/64 + 
 // (the padding slots repeat the self loop: max-aggregation is idempotent, and 4-aligned segments let the
 // EdgeConv epilogue reduce each lane's 4 consecutive accumulator rows in registers)
 // (pad4 == 2: the plain count -- the prefix sums of morig_geo_ball_graph's per-row member counts)
-__device__ __forceinline__ int seg_len(int cnt, int pad4) { if (pad4 == 2) return cnt; const int d = cnt + 1; return pad4 ? ((d + 3) & ~3) : d; }
+// (pad4 == 3, MORIG_CSR_MIN4: at least 4 rows per segment -- self-loop copies behind a short one -- so that a quad of 4 consecutive rows
+// never holds more than two segments: what the mixed-quad epilogue of edge_ws.hip needs instead of 4-ALIGNED segments)
+__device__ __forceinline__ int seg_len(int cnt, int pad4) {
+    if (pad4 == 2) return cnt;
+    const int d = cnt + 1;
+    if (pad4 == 3) return d < 4 ? 4 : d;
+    return pad4 ? ((d + 3) & ~3) : d;
+}
 
 __global__ __launch_bounds__(SCAN_T) void scan_reduce_kernel(const int* __restrict__ cnt, int n, int pad4, int* __restrict__ bsum) {
     __shared__ int sh[SCAN_T / 64 + 1];
@@ -118,12 +125,12 @@ __global__ void csr_fill_kernel(const int64_t* __restrict__ ei, int64_t E, int n
 // ---- dual build: the plain and the 4-aligned CSR of ONE graph from one count pass (the rig networks use both: the narrow layers
 // run on the plain one, the 128 / 256-wide kernels on the padded one). Segment lengths differ (d + 1 vs round4(d + 1)), edge ranks
 // inside a segment are shared: one atomic per edge claims rank k, the edge lands at rowptr[d] + k and rowptr4[d] + k.
-__global__ __launch_bounds__(SCAN_T) void scan2_reduce_kernel(const int* __restrict__ cnt, int n, int* __restrict__ bsum, int* __restrict__ bsum4) {
+__global__ __launch_bounds__(SCAN_T) void scan2_reduce_kernel(const int* __restrict__ cnt, int n, int* __restrict__ bsum, int* __restrict__ bsum4, int mode0) {
     __shared__ int sh[SCAN_T / 64 + 1];
     const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
     int v = 0, v4 = 0;
 #pragma unroll
-    for (int i = 0; i < SCAN_I; ++i) if (base + i < n) { const int c = cnt[base + i]; v += seg_len(c, 0); v4 += seg_len(c, 1); }
+    for (int i = 0; i < SCAN_I; ++i) if (base + i < n) { const int c = cnt[base + i]; v += seg_len(c, mode0); v4 += seg_len(c, 1); }
     int tot, tot4;
     (void)block_excl_scan(v, sh, &tot);
     (void)block_excl_scan(v4, sh, &tot4);
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(SCAN_T) void scan2_blocksums_kernel(int* bsum, int*
 }
 
 __global__ __launch_bounds__(SCAN_T) void scan2_apply_kernel(const int* __restrict__ cnt, int n, const int* __restrict__ bsum,
-                                                            const int* __restrict__ bsum4, int* __restrict__ rowptr, int* __restrict__ rowptr4) {
+                                                            const int* __restrict__ bsum4, int* __restrict__ rowptr, int* __restrict__ rowptr4, int mode0) {
     __shared__ int sh[SCAN_T / 64 + 1];
     const int base = blockIdx.x * SCAN_B + threadIdx.x * SCAN_I;
     int item[SCAN_I], item4[SCAN_I];
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(SCAN_T) void scan2_apply_kernel(const int* __restri
 #pragma unroll
     for (int i = 0; i < SCAN_I; ++i) {
         const int c = (base + i < n) ? cnt[base + i] : 0;
-        item[i] = (base + i < n) ? seg_len(c, 0) : 0; item4[i] = (base + i < n) ? seg_len(c, 1) : 0;
+        item[i] = (base + i < n) ? seg_len(c, mode0) : 0; item4[i] = (base + i < n) ? seg_len(c, 1) : 0;
         v += item[i]; v4 += item4[i];
     }
     int tot;
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(SCAN_T) void scan2_apply_kernel(const int* __restri
 
 __global__ void csr_fill_dual_kernel(const int64_t* __restrict__ ei, int64_t E, int n, const int* __restrict__ cnt, int* __restrict__ rank,
                                      const int* __restrict__ rowptr, int* __restrict__ srcS, int* __restrict__ dstS,
-                                     const int* __restrict__ rowptr4, int* __restrict__ srcS4, int* __restrict__ dstS4) {
+                                     const int* __restrict__ rowptr4, int* __restrict__ srcS4, int* __restrict__ dstS4, int mode0) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t total = E + n;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
@@ -185,8 +192,8 @@ __global__ void csr_fill_dual_kernel(const int64_t* __restrict__ ei, int64_t E, 
             // node i: its self loop behind the cnt[i] real in-edges; the 4-aligned copy repeats it up to the segment's end
             const int i = (int)(e - E);
             const int c = cnt[i];
-            const int p = rowptr[i] + c;
-            srcS[p] = i; dstS[p] = i;
+            const int e0 = rowptr[i] + seg_len(c, mode0);          // (MORIG_CSR_MIN4: copies of the self loop up to 4 rows)
+            for (int q = rowptr[i] + c; q < e0; ++q) { srcS[q] = i; dstS[q] = i; }
             const int e4 = rowptr4[i] + seg_len(c, 1);
             for (int q = rowptr4[i] + c; q < e4; ++q) { srcS4[q] = i; dstS4[q] = i; }
         }
@@ -512,7 +519,8 @@ extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_ed
                                          int32_t* cursor, int32_t* status, void* stream) {
     if (n_src_nodes < n_nodes) return MORIG_E_INVALID;
     const int skip_negative = flags & MORIG_CSR_SKIP_NEGATIVE ? 1 : 0;
-    const int pad4 = flags & MORIG_CSR_PAD4 ? 1 : 0;
+    if ((flags & MORIG_CSR_PAD4) && (flags & MORIG_CSR_MIN4)) return MORIG_E_INVALID;
+    const int pad4 = flags & MORIG_CSR_PAD4 ? 1 : (flags & MORIG_CSR_MIN4 ? 3 : 0);       // seg_len's mode
     if (!rowptr || !src_sorted || !dst_sorted || !cursor || !status) return MORIG_E_INVALID;
     if (n_edges < 0 || n_nodes <= 0 || (n_edges > 0 && !edge_index)) return MORIG_E_INVALID;
     if (n_edges + 4 * (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;   // int32 edge ids
@@ -544,7 +552,8 @@ extern "C" int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_ed
 
 extern "C" int morig_csr_build_dual(const int64_t* edge_index, int64_t n_edges, int32_t n_nodes, int32_t* rowptr, int32_t* src_sorted,
                                     int32_t* dst_sorted, int32_t* rowptr4, int32_t* src_sorted4, int32_t* dst_sorted4, int32_t* ws,
-                                    int32_t* status, void* stream) {
+                                    int32_t flags, int32_t* status, void* stream) {
+    if (flags & ~MORIG_CSR_MIN4) return MORIG_E_INVALID;
     if (!rowptr || !src_sorted || !dst_sorted || !rowptr4 || !src_sorted4 || !dst_sorted4 || !ws || !status) return MORIG_E_INVALID;
     if (n_edges < 0 || n_nodes <= 0 || (n_edges > 0 && !edge_index)) return MORIG_E_INVALID;
     if (n_edges + 4 * (int64_t)n_nodes > 0x7fffffffLL) return MORIG_E_UNSUPPORTED;
@@ -561,14 +570,15 @@ extern "C" int morig_csr_build_dual(const int64_t* edge_index, int64_t n_edges, 
         hipLaunchKernelGGL(csr_count_kernel, dim3(grid_for(n_edges)), dim3(256), 0, s, edge_index, n_edges, n_nodes, n_nodes, 0, cnt, status);
         MORIG_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(scan2_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cnt, n_nodes, bsum, bsum4);
+    const int mode0 = (flags & MORIG_CSR_MIN4) ? 3 : 0;
+    hipLaunchKernelGGL(scan2_reduce_kernel, dim3(nb), dim3(SCAN_T), 0, s, cnt, n_nodes, bsum, bsum4, mode0);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(scan2_blocksums_kernel, dim3(1), dim3(SCAN_T), 0, s, bsum, bsum4, nb, rowptr + n_nodes, rowptr4 + n_nodes);
     MORIG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(scan2_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cnt, n_nodes, bsum, bsum4, rowptr, rowptr4);
+    hipLaunchKernelGGL(scan2_apply_kernel, dim3(nb), dim3(SCAN_T), 0, s, cnt, n_nodes, bsum, bsum4, rowptr, rowptr4, mode0);
     MORIG_LAUNCH_CHECK();
     hipLaunchKernelGGL(csr_fill_dual_kernel, dim3(grid_for(n_edges + n_nodes)), dim3(256), 0, s, edge_index, n_edges, n_nodes, cnt, rank,
-                       rowptr, src_sorted, dst_sorted, rowptr4, src_sorted4, dst_sorted4);
+                       rowptr, src_sorted, dst_sorted, rowptr4, src_sorted4, dst_sorted4, mode0);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -935,7 +935,7 @@ extern "C" int morig_segmax_gemm(const morig_segmax_args* a_in, void* stream) {
 
 // which kernel a morig_edgeconv launch takes: H = 256 / 128 on the split-fp16 path go to the specialised kernels; with a 4-aligned CSR
 // the W2-stationary one (edge_ws.hip), whose H = 256 tiles are 64 rows. MORIG_EDGE_KERNEL=pp|pc keeps the older kernels (A/B runs).
-struct EdgePlan { bool wide, one_shot, pp_ok, use_rl, use_ws, split_ok; int tile_rows, run; };
+struct EdgePlan { bool wide, one_shot, pp_ok, use_rl, use_ws, mix, split_ok; int tile_rows, run; };
 static EdgePlan edge_plan(const morig_edgeconv_args* a) {
     EdgePlan pl = {};
     const bool f16 = a->W2_split != nullptr;
@@ -955,7 +955,12 @@ static EdgePlan edge_plan(const morig_edgeconv_args* a) {
     static const bool rl128 = [] { const char* e = getenv("MORIG_RL128"); return !(e && e[0] == '0'); }();
     const bool quad_ok = pl.wide && !one_shot && !want_pp && pl.pp_ok && a->quad_aligned && (a->lda & 3) == 0 && (a->ldb & 3) == 0;
     pl.use_rl = quad_ok && a->H == 128 && rl128 && !ws128;
-    pl.use_ws = quad_ok && !pl.use_rl && (a->H == 256 || ws128);
+    // [r06] H = 256 on a MORIG_CSR_MIN4 CSR (segments of >= 4 rows, NOT 4-aligned): the mixed-quad form of the W2-stationary kernel, which
+    // exists for split rows only (edge_ws.hip <256, true, true>). MORIG_EDGE_MIX=0: such a CSR takes the generic kernels (A/B runs)
+    static const bool want_mix = [] { const char* e = getenv("MORIG_EDGE_MIX"); return !(e && e[0] == '0'); }();
+    pl.mix = pl.wide && !one_shot && !want_pp && pl.pp_ok && !a->quad_aligned && a->seg_min4 && a->H == 256 && want_mix &&
+             (a->lda & 3) == 0 && (a->ldb & 3) == 0;
+    pl.use_ws = (quad_ok && !pl.use_rl && (a->H == 256 || ws128)) || (pl.mix && a->out_split);
     pl.tile_rows = ((pl.use_ws && a->H == 256) || pl.use_rl) ? 64 : 128;   // edge_ws.hip at H = 256, edge_rl.hip: 64-row tiles
     // the two kernels above carry a segment that is still open at the end of a tile into the next tile of the same RUN of consecutive
     // tiles (one wave / one workgroup works through a run): only rows that straddle a run boundary are shared through atomics.
@@ -971,7 +976,7 @@ static EdgePlan edge_plan(const morig_edgeconv_args* a) {
     }
     // split-fp16 results: the two kernels above, chunk-aligned output window (MORIG_EDGE_SPLIT_OUT=0: never, A/B runs)
     static const bool no_split = [] { const char* e = getenv("MORIG_EDGE_SPLIT_OUT"); return e && e[0] == '0'; }();
-    pl.split_ok = (pl.use_rl || pl.use_ws) && !no_split && a->overflow != nullptr && (a->ldo & 31) == 0 &&
+    pl.split_ok = (pl.use_rl || pl.use_ws || pl.mix) && !no_split && a->overflow != nullptr && (a->ldo & 31) == 0 &&
                   (reinterpret_cast<uintptr_t>(a->out) & 127) == 0;
     return pl;
 }
@@ -1021,7 +1026,7 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a_in, void* stream) {
         q.A = p.A; q.lda = p.lda; q.B = p.B; q.ldb = p.ldb;
         q.rowptr = p.rowptr; q.srcS = p.srcS; q.dstS = p.dstS; q.n_nodes = p.n_nodes;
         q.rep_in = p.rep_in; q.rep_out = p.rep_out; q.tiles_per_rep = p.tiles_per_rep; q.replicas = a->replicas;
-        q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0;
+        q.Y = p.Y; q.ldy = p.ldy; q.ovf = p.ovf; q.quad = a->quad_aligned ? 1 : 0; q.min4 = a->seg_min4 ? 1 : 0;
         q.y16 = a->out_split ? 1 : 0; q.run = pl.run;
         ProfScope ps(a->H == 256 ? K_EDGE16_H256 : K_EDGE16_H128, s, flops, bytes);
         if (use_rl || use_ws) {

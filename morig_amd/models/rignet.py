@@ -193,6 +193,14 @@ class GCNRig(NativeModule):
         ct = csr_tpl_wide or csr_tpl
         self.gcu_2.run(ops, posm, Mat.of(wide, self.X1, self.WIDTHS[0]), ct, cg, Mat.of(wide, self.X2, self.WIDTHS[1]), R, split=sp,
                        pos_feat=pf[1])
+        # [r06] MORIG_EDGE_MIX=1 (opt-in): the 256-wide edge layers run WITHOUT padded rows on plain CSRs built with segments of >= 4 rows
+        # (MORIG_CSR_MIN4): the mixed-quad form of the W2-stationary kernel splits a quad that straddles two segments instead of asking
+        # for 4-aligned ones -- 14 % (tpl) / 9 % (geo) fewer rows, bit-compatible results, but measured NO faster: under the MFMA load a
+        # VALU instruction of the epilogue costs ~15 cycles, and the split quad max + the extra segment pieces eat the rows saved
+        # (profiles/r06h_*, r06i_*)
+        if (sp and self.WIDTHS[2] == 512 and getattr(csr_tpl, "min4", False) and getattr(csr_geo, "min4", False)
+                and os.environ.get("MORIG_EDGE_MIX", "0") == "1"):
+            ct, cg = csr_tpl, csr_geo
         self.gcu_3.run(ops, posm, Mat.of(wide, self.X2, self.WIDTHS[1]), ct, cg, Mat.of(wide, self.X3, self.WIDTHS[2]), R, split=sp,
                        pos_feat=pf[2])
         pooled = ops.empty(R * n_graphs, 1024, dev)

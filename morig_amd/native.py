@@ -60,6 +60,7 @@ class EdgeConvArgs(C.Structure):
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
         ("quad_aligned", C.c_int32),
         ("out_split", C.c_int32),
+        ("seg_min4", C.c_int32),
     ]
 
 
@@ -132,7 +133,8 @@ _SIGNATURES = {
     "morig_ball_query": (C.c_int, [c_f32p, C.c_int32, c_i32p, c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, c_i64p, C.c_void_p]),
     "morig_radius_sample": (C.c_int, [c_f32p, C.c_int32, C.c_int32, c_f32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
                                       c_i64p, c_i32p, C.c_void_p]),
-    "morig_csr_build_dual": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
+    "morig_csr_build_dual": (C.c_int, [c_i64p, C.c_int64, C.c_int32, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_int32, c_i32p,
+                                       C.c_void_p]),
     "morig_geo_ball_graph": (C.c_int, [c_f32p, C.c_int32, c_i32p, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_uint32,
                                        c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, C.c_void_p]),
     "morig_geo_ball_graph_dist": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int32, C.c_uint32,
@@ -311,6 +313,7 @@ class CSR:
     status: torch.Tensor      # int32 [1], non-zero = index out of range (read once per forward by NativeOps.guarded)
     edge_count: int = 0       # exact E' when known (accounting only)
     quad: bool = False        # segments padded to multiples of 4 (MORIG_CSR_PAD4)
+    min4: bool = False        # segments of at least 4 rows, not aligned (MORIG_CSR_MIN4: the mixed-quad form of the H = 256 EdgeConv kernel)
     _transposed: Optional[tuple] = None
 
     def transposed(self, n_src: Optional[int] = None):
@@ -505,42 +508,49 @@ class NativeOps:
 
     # -- graph --------------------------------------------------------------------------------
     def csr_build(self, edge_index: torch.Tensor, n_nodes: int, n_src: Optional[int] = None,
-                  skip_negative: bool = False, pad4: bool = False) -> CSR:
+                  skip_negative: bool = False, pad4: bool = False, min4: bool = False) -> CSR:
         """pad4: pad every target's segment to a multiple of 4 by repeating its self loop (exact for
-        max-aggregation); enables the in-register quad reduction of the EdgeConv epilogue."""
+        max-aggregation); enables the in-register quad reduction of the EdgeConv epilogue.
+        min4: fill every segment up to 4 rows instead (MORIG_CSR_MIN4: the mixed-quad form of the H = 256 kernel; not with pad4)."""
+        assert not (pad4 and min4)
         _need_gpu(edge_index)
         ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
         E = ei.shape[1]
         dev = ei.device
-        cap = E + (4 if pad4 else 1) * n_nodes
+        cap = E + (4 if (pad4 or min4) else 1) * n_nodes
         rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
         src = torch.empty(cap, dtype=torch.int32, device=dev)
         dst = torch.empty(cap, dtype=torch.int32, device=dev)
         cursor = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
         status = torch.empty(1, dtype=torch.int32, device=dev)
-        if n_src is None and not skip_negative and not pad4:
+        if n_src is None and not skip_negative and not pad4 and not min4:
             check(self.lib.morig_csr_build(_p(ei), E, n_nodes, _p(rowptr), _p(src), _p(dst), _p(cursor), _p(status), _stream()),
                   "morig_csr_build")
         else:
             check(self.lib.morig_csr_build_bipartite(_p(ei), E, n_nodes if n_src is None else n_src, n_nodes,
-                                                     (1 if skip_negative else 0) | (2 if pad4 else 0), _p(rowptr), _p(src),
+                                                     (1 if skip_negative else 0) | (2 if pad4 else 0) | (4 if min4 else 0), _p(rowptr), _p(src),
                                                      _p(dst), _p(cursor), _p(status), _stream()), "morig_csr_build_bipartite")
-        csr = CSR(rowptr, src, dst, n_nodes, cap, status, quad=pad4)
+        csr = CSR(rowptr, src, dst, n_nodes, cap, status, quad=pad4, min4=min4)
         if getattr(self, "_csr_status", None) is not None:
             self._csr_status.append(status)            # read with the precision flag at the end of the guarded forward
         key = (ei.data_ptr(), E, n_nodes)
-        if self.learn_edge_counts and not pad4 and key not in self._edge_counts:
+        if self.learn_edge_counts and not pad4 and not min4 and key not in self._edge_counts:
             self._edge_counts[key] = int(rowptr[-1].item())
         csr.edge_count = self._edge_counts.get(key, 0)
         return csr
 
-    def csr_build_dual(self, edge_index: torch.Tensor, n_nodes: int):
-        """-> (plain CSR, 4-aligned CSR) of one square graph from one pass over the COO (morig_csr_build_dual)."""
+    def csr_build_dual(self, edge_index: torch.Tensor, n_nodes: int, min4: Optional[bool] = None):
+        """-> (plain CSR, 4-aligned CSR) of one square graph from one pass over the COO (morig_csr_build_dual).
+        min4 (default: off; MORIG_EDGE_MIX=1 switches it on): the plain CSR's segments are filled up to 4 rows with copies of the self
+        loop -- still a plain CSR for every kernel, and the form the H = 256 EdgeConv kernel takes WITHOUT 4-aligned segments (the
+        mixed-quad kernel: correct and tested, measured no faster than the 4-aligned form -- DESIGN.md section 5.2 -- hence opt-in)."""
+        if min4 is None:
+            min4 = os.environ.get("MORIG_EDGE_MIX", "0") == "1"
         _need_gpu(edge_index)
         ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
         E = ei.shape[1]
         dev = ei.device
-        cap, cap4 = E + n_nodes, E + 4 * n_nodes
+        cap, cap4 = E + (4 if min4 else 1) * n_nodes, E + 4 * n_nodes
         rowptr = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
         rowptr4 = torch.empty(n_nodes + 1, dtype=torch.int32, device=dev)
         src, dst = torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev)
@@ -548,11 +558,11 @@ class NativeOps:
         ws = torch.empty(2 * n_nodes + 1, dtype=torch.int32, device=dev)
         status = torch.empty(1, dtype=torch.int32, device=dev)
         check(self.lib.morig_csr_build_dual(_p(ei), E, n_nodes, _p(rowptr), _p(src), _p(dst), _p(rowptr4), _p(src4), _p(dst4), _p(ws),
-                                            _p(status), _stream()), "morig_csr_build_dual")
+                                            4 if min4 else 0, _p(status), _stream()), "morig_csr_build_dual")
         if getattr(self, "_csr_status", None) is not None:
             self._csr_status.append(status)
         key = (ei.data_ptr(), E, n_nodes)
-        a = CSR(rowptr, src, dst, n_nodes, cap, status)
+        a = CSR(rowptr, src, dst, n_nodes, cap, status, min4=bool(min4))
         b = CSR(rowptr4, src4, dst4, n_nodes, cap4, status, quad=True)
         a.edge_count = b.edge_count = self._edge_counts.get(key, 0)
         return a, b
@@ -675,6 +685,7 @@ class NativeOps:
         a.b2, a.s2, a.t2 = ec.b2.data_ptr(), ec.s2.data_ptr(), ec.t2.data_ptr()
         a.out, a.ldo = out.ptr, out.ld
         a.quad_aligned = 1 if csr.quad else 0
+        a.seg_min4 = 1 if getattr(csr, "min4", False) else 0
         if self.fast and ec.W2split is not None:
             a.W2_split, a.overflow = ec.W2split.data_ptr(), self._flag(A.base.device).data_ptr()
         return a

@@ -29,7 +29,7 @@ class EmuOps:
         return torch.full((rows, cols), float("nan"), dtype=dtype, device=device)
 
     # -- graph ----------------------------------------------------------------------------------
-    def csr_build(self, edge_index, n_nodes, n_src=None, skip_negative=False, pad4=False):
+    def csr_build(self, edge_index, n_nodes, n_src=None, skip_negative=False, pad4=False, min4=False):
         src, dst = edge_index[0].long(), edge_index[1].long()
         if skip_negative:
             keep = (src >= 0) & (dst >= 0)
@@ -44,18 +44,22 @@ class EmuOps:
             deg = torch.bincount(dst, minlength=n_nodes)
             extra = torch.repeat_interleave(loop, (-deg) % 4)
             src, dst = torch.cat([src, extra]), torch.cat([dst, extra])
+        if min4:        # MORIG_CSR_MIN4: fill every segment up to 4 rows with copies of its self loop
+            deg = torch.bincount(dst, minlength=n_nodes)
+            extra = torch.repeat_interleave(loop, (4 - deg).clamp(min=0))
+            src, dst = torch.cat([src, extra]), torch.cat([dst, extra])
         order = torch.sort(dst, stable=True)[1]
         src, dst = src[order], dst[order]
         rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64)
         rowptr[1:] = torch.cumsum(torch.bincount(dst, minlength=n_nodes), 0)
-        cap = edge_index.shape[1] + (4 if pad4 else 1) * n_nodes
+        cap = edge_index.shape[1] + (4 if (pad4 or min4) else 1) * n_nodes
         pad = cap - src.numel()
         junk = torch.full((pad,), -12345, dtype=torch.int32)
         return CSR(rowptr.int(), torch.cat([src.int(), junk]), torch.cat([dst.int(), junk]), n_nodes, cap,
-                   torch.zeros(1, dtype=torch.int32), edge_count=int(src.numel()), quad=pad4)
+                   torch.zeros(1, dtype=torch.int32), edge_count=int(src.numel()), quad=pad4, min4=min4)
 
-    def csr_build_dual(self, edge_index, n_nodes):
-        return self.csr_build(edge_index, n_nodes), self.csr_build(edge_index, n_nodes, pad4=True)
+    def csr_build_dual(self, edge_index, n_nodes, min4=False):
+        return self.csr_build(edge_index, n_nodes, min4=min4), self.csr_build(edge_index, n_nodes, pad4=True)
 
     def csr_from_slots(self, coo, n_nodes, max_nbrs, n_src):
         assert coo.shape == (2, n_nodes * max_nbrs)
@@ -137,7 +141,8 @@ class EmuOps:
     # -- fused edge conv ---------------------------------------------------------------------------
     def edgeconv_can_split_out(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0):
         # the library's rule (tile_gemm.hip edge_plan): the 4-aligned-CSR kernels at H = 128 / 256, chunk-aligned output window
-        return bool(self.emulate_split and csr.quad and ec.H in (128, 256) and ec.s1 is None and out.col0 % 32 == 0 and out.ld % 32 == 0)
+        return bool(self.emulate_split and (csr.quad or (getattr(csr, "min4", False) and ec.H == 256)) and ec.H in (128, 256) and ec.s1 is None
+                    and out.col0 % 32 == 0 and out.ld % 32 == 0)
 
     def edgeconv(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas=1, in_rep_stride=0, out_rep_stride=0, out_split=False):
         assert A.ld % 4 == 0 and A.col0 % 4 == 0 and B.ld % 4 == 0 and B.col0 % 4 == 0

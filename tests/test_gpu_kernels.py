@@ -77,7 +77,7 @@ def test_csr_build_dual(ops, n, e, hub):
     """morig_csr_build_dual: the plain and the 4-aligned CSR of one graph from one pass -- each equal to its own single build
     (same rowptr, same destinations, same multiset of sources per segment), out-of-range indices flagged once for both"""
     ei = _rand_graph(n, e, 5, hub) if e else torch.zeros((2, 0), dtype=torch.long)
-    a, b = ops.csr_build_dual(ei.to(DEV), n)
+    a, b = ops.csr_build_dual(ei.to(DEV), n, min4=False)
     torch.cuda.synchronize()
     assert int(a.status.item()) == 0 and b.quad and not a.quad
     for got, pad4 in ((a, False), (b, True)):
@@ -291,9 +291,32 @@ def test_edgeconv_persistent_many_tiles(ops, H, pad4):
     assert torch.equal(out[:n], out[n:])                      # replicas of one input: identical bits
 
 
-@pytest.mark.parametrize("H", [128, 256])
-@pytest.mark.parametrize("n,e,hub,reps", [(700, 5000, 3, 2), (20000, 300000, 777, 2), (64, 200, None, 1)])
-def test_edgeconv_split_fp16_rows(H, n, e, hub, reps):
+@pytest.mark.parametrize("n,e,hub", [(50, 300, None), (3000, 2500, None), (4097, 30000, 7)])
+def test_csr_build_min4_segments(ops, n, e, hub):
+    """MORIG_CSR_MIN4 (single and dual build): the plain CSR with every segment filled up to 4 rows by copies of its self loop -- the
+    same edges otherwise (the form the mixed-quad H = 256 EdgeConv kernel takes instead of 4-aligned segments)"""
+    ei = _rand_graph(n, e, 9, hub)
+    want = ops.csr_build(ei.to(DEV), n)
+    single = ops.csr_build(ei.to(DEV), n, min4=True)
+    dual, quad = ops.csr_build_dual(ei.to(DEV), n, min4=True)
+    plain_dual, _ = ops.csr_build_dual(ei.to(DEV), n, min4=False)
+    torch.cuda.synchronize()
+    assert torch.equal(plain_dual.rowptr, want.rowptr) and not plain_dual.min4 and dual.min4 and single.min4 and quad.quad
+    deg = (want.rowptr[1:] - want.rowptr[:-1]).cpu()
+    for got in (single, dual):
+        assert int(got.status.item()) == 0
+        glen = (got.rowptr[1:] - got.rowptr[:-1]).cpu()
+        assert torch.equal(glen, deg.clamp(min=4))
+        E = int(got.rowptr[-1])
+        segs, ref = _segments(got, E), _segments(want, int(want.rowptr[-1]))
+        for v in range(0, n, max(1, n // 300)):
+            extra = [v] * int(glen[v] - deg[v])
+            assert sorted(segs[v]) == sorted(list(ref[v]) + extra), v
+
+
+@pytest.mark.parametrize("H,kind", [(128, "pad4"), (256, "pad4"), (256, "min4")])
+@pytest.mark.parametrize("n,e,hub,reps", [(700, 5000, 3, 2), (20000, 300000, 777, 2), (64, 200, None, 1), (3000, 2500, None, 3)])
+def test_edgeconv_split_fp16_rows(H, kind, n, e, hub, reps):
     """morig_edgeconv out_split: the 4-aligned-CSR kernels store split-fp16 rows (chunk = [32 hi | 32 lo]) into a chunk-aligned column
     window -- whole segments from the kernel, tile-straddling ones (atomics in fp32) through the boundary pass, a hub longer than several
     tiles converted exactly once. Decoded, every element is the fp32 launch's result to the split's resolution (lo is fp16(v - hi):
@@ -309,7 +332,9 @@ def test_edgeconv_split_fp16_rows(H, n, e, hub, reps):
     ab = torch.randn(n * reps, 2 * H, generator=g).to(DEV)
     ec = packing.to_device(_edge_pack(H, 5, folded=True), DEV)
     ec.s2 = ec.s2 * torch.where(torch.arange(ec.s2.numel(), device=DEV) % 3 == 0, -1.0, 1.0)       # both signs of the BN scale
-    csr = o.csr_build(ei.to(DEV), n, pad4=True)
+    # kind "min4" [r06]: segments of >= 4 rows, NOT 4-aligned -- the mixed-quad form of the H = 256 kernel (quads that straddle two
+    # segments, mid-quad starts, a mixed first quad of a tile); its fp32 reference launch runs on the generic kernel (same CSR)
+    csr = o.csr_build(ei.to(DEV), n, pad4=True) if kind == "pad4" else o.csr_build(ei.to(DEV), n, min4=True)
     ld = 2 * H + 64
     kw = dict(replicas=reps, in_rep_stride=n, out_rep_stride=n)
     plain = torch.zeros(n * reps, ld, device=DEV)
@@ -317,7 +342,7 @@ def test_edgeconv_split_fp16_rows(H, n, e, hub, reps):
     rows = torch.full((n * reps, ld), 7.0, device=DEV)
     if not o.edgeconv_can_split_out(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(rows, H, H), **kw):
         import os
-        assert any(os.environ.get(k) for k in ("MORIG_RL128", "MORIG_EDGE_KERNEL", "MORIG_NO_EDGE_PC", "MORIG_EDGE_SPLIT_OUT")), \
+        assert any(os.environ.get(k) for k in ("MORIG_RL128", "MORIG_EDGE_KERNEL", "MORIG_NO_EDGE_PC", "MORIG_EDGE_SPLIT_OUT", "MORIG_EDGE_MIX")), \
             "split rows refused without a kernel-selection switch in the environment"
         with pytest.raises(native.MorigNativeError):             # ... and the launch refuses them too
             o.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr, ec, Mat.of(rows, H, H), out_split=True, **kw)
@@ -329,7 +354,10 @@ def test_edgeconv_split_fp16_rows(H, n, e, hub, reps):
     got = packing.unsplit_f16(rows[:, H:2 * H].contiguous().cpu(), H)
     want = plain[:, H:2 * H].cpu()
     assert not torch.isnan(got).any()
-    assert ((got - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** -24).all(), maxdiff(got, want)
+    if kind == "pad4":      # same kernel, same accumulation order: only the split's resolution separates the two
+        assert ((got - want).abs() <= 2.0 ** -21 * want.abs() + 2.0 ** -24).all(), maxdiff(got, want)
+    else:                   # the fp32 reference launch of a MIN4 CSR runs on the generic kernel: another summation order
+        assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
     assert float((rows[:, :H] - 7.0).abs().sum()) == 0 and float((rows[:, 2 * H:] - 7.0).abs().sum()) == 0
     # twice the same bits (no order dependence through the atomics + the boundary pass)
     again = torch.full((n * reps, ld), 7.0, device=DEV)

@@ -633,3 +633,27 @@ def test_forward_server_serves_small_batches_from_captured_graphs():
         want = m(hot, hot.pred_flow)
         got = srv(hot, hot.pred_flow)
         assert srv.stats["fallbacks"] == 1 and torch.equal(want[2], got[2])
+
+
+def test_mixed_quad_edgeconv_network_equals_the_golden(monkeypatch):
+    """MORIG_EDGE_MIX=1 (opt-in): the 256-wide edge layers on MORIG_CSR_MIN4 CSRs -- no padded rows, quads that straddle two
+    segments split in the epilogue (edge_ws.hip <256, true, true>) -- give the reference's outputs on the 4096-vertex golden mesh and on a
+    ragged batch, like the default 4-aligned form."""
+    monkeypatch.setenv("MORIG_EDGE_MIX", "1")
+    meta, a = load_golden("jointnet_4k")
+    mesh = synth.collate([synth.make_mesh(meta["mesh_seed"], n_side=meta["n_side"])])
+    m = models.jointnet_motion(**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"], mild=meta["mild"]).to(DEV)
+    d = mesh.to(DEV)
+    _, aggr, shift = m(d, d.pred_flow)
+    assert rel_excess(aggr, a["motion_aggr"], TOL) <= 0 and rel_excess(shift, a["pred_shift"], TOL) <= 0
+    monkeypatch.setenv("MORIG_EDGE_MIX", "0")
+    _, aggr0, shift0 = m(d, d.pred_flow)
+    assert maxdiff(shift, shift0) <= 2e-5 and maxdiff(aggr, aggr0) <= 2e-5
+    monkeypatch.setenv("MORIG_EDGE_MIX", "1")
+    meta, a = load_golden("jointnet_ragged")
+    m = models.__dict__[meta["arch"]](**meta["kwargs"]).eval()
+    synth.load_recipe(m, meta["recipe_seed"]).to(DEV)
+    d = data_from(a, DEV)
+    res = m(d, d.pred_flow)
+    assert rel_excess(res[2], a["pred_shift"], TOL) <= 0
