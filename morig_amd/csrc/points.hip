@@ -60,6 +60,9 @@ __device__ __forceinline__ int wave_min_int(int x) {
 // running min-distance in registers; per sample one block-wide arg-max (value desc, index asc).
 // ---------------------------------------------------------------------------------------------------
 constexpr int FPS_T = 1024;
+#ifndef MORIG_FPS_T_DEFAULT
+#define MORIG_FPS_T_DEFAULT 1024
+#endif
 
 template <int PPT>
 __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
@@ -215,15 +218,17 @@ __device__ __forceinline__ float wave_max_f(float v) {
     return v;
 }
 
-template <int PPT>                                        // even, <= 8
-__global__ __launch_bounds__(FPS_T) void fps_bkt_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
+// BT [r06]: threads per cloud. 1024 = 16 waves (4 per SIMD, 8 points per lane at 8192 points); 256 = ONE wave per SIMD with 32 points per lane:
+// the per-sample chain then meets a 4-wave barrier and no wave shares its SIMD's issue port (MORIG_BT selects, see morig_fps)
+template <int PPT, int BT = FPS_T>                        // PPT even, PPT * BT <= 8192
+__global__ __launch_bounds__(BT) void fps_bkt_kernel(const float* __restrict__ pos, int ldp, const int* __restrict__ ptr,
                                                         const int* __restrict__ out_ptr, const int* __restrict__ start,
                                                         int* __restrict__ idx_out) {
-    constexpr int NP = PPT * FPS_T, H = PPT / 2, NCELL = 512;
+    constexpr int NP = PPT * BT, H = PPT / 2, NCELL = 512;
     __shared__ float sx[NP], sy[NP], sz[NP];              // coordinates in SORTED order
     __shared__ unsigned short sorig[NP];                  // original index of a sorted position
     __shared__ int s_hist[NCELL + 1];
-    __shared__ float s_box[6 * (FPS_T / 64)];
+    __shared__ float s_box[6 * (BT / 64)];
     __shared__ unsigned long long s_key[3];
     __shared__ int s_start;
     const int b = blockIdx.x;
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(FPS_T) void fps_bkt_kernel(const float* __restrict_
     float qx[PPT], qy[PPT], qz[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int j = tid + i * FPS_T;
+        const int j = tid + i * BT;
         qx[i] = qy[i] = qz[i] = 0.f;
         if (j < n) {
             const float* q = pos + (size_t)(p0 + j) * ldp;
@@ -250,10 +255,10 @@ __global__ __launch_bounds__(FPS_T) void fps_bkt_kernel(const float* __restrict_
     }
     lx = wave_min_f(lx); ly = wave_min_f(ly); lz = wave_min_f(lz); hx = wave_max_f(hx); hy = wave_max_f(hy); hz = wave_max_f(hz);
     if (lane == 0) { s_box[w * 6] = lx; s_box[w * 6 + 1] = ly; s_box[w * 6 + 2] = lz; s_box[w * 6 + 3] = hx; s_box[w * 6 + 4] = hy; s_box[w * 6 + 5] = hz; }
-    for (int i = tid; i <= NCELL; i += FPS_T) s_hist[i] = 0;
+    for (int i = tid; i <= NCELL; i += BT) s_hist[i] = 0;
     if (tid < 3) s_key[tid] = 0ull;
     __syncthreads();
-    for (int k = 0; k < FPS_T / 64; ++k) {
+    for (int k = 0; k < BT / 64; ++k) {
         lx = fminf(lx, s_box[k * 6]); ly = fminf(ly, s_box[k * 6 + 1]); lz = fminf(lz, s_box[k * 6 + 2]);
         hx = fmaxf(hx, s_box[k * 6 + 3]); hy = fmaxf(hy, s_box[k * 6 + 4]); hz = fmaxf(hz, s_box[k * 6 + 5]);
     }
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(FPS_T) void fps_bkt_kernel(const float* __restrict_
     int cell[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int j = tid + i * FPS_T;
+        const int j = tid + i * BT;
         cell[i] = j < n ? cell_of(qx[i], qy[i], qz[i]) : -1;
         if (j < n) atomicAdd(&s_hist[cell[i]], 1);
     }
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(FPS_T) void fps_bkt_kernel(const float* __restrict_
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-        const int j = tid + i * FPS_T;
+        const int j = tid + i * BT;
         if (j < n) {
             const int d = atomicAdd(&s_hist[cell[i]], 1);
             sx[d] = qx[i]; sy[d] = qy[i]; sz[d] = qz[i]; sorig[d] = (unsigned short)j;
@@ -336,42 +341,47 @@ __global__ __launch_bounds__(FPS_T) void fps_bkt_kernel(const float* __restrict_
         }
         if (need != 0ull) {                                // wave-uniform
             const fps_f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
-            int bmi[H];                                    // max of this lane's pair, as int bits (>= 0 or the -1.0 pattern)
+            // [r06] only the buckets that NEED the update are touched: their distances, their wave maximum (one DPP chain each) and
+            // their record in lane h. (The round-5 form reduced all H pair maxima and compared all PPT points whenever the wave had
+            // one bucket to update; measured on the thread-count sweep, profiles/r06j_*: the per-sample time follows this per-lane
+            // work -- 4.4 / 6.2 / 9.7 ms at 8 / 16 / 32 points per lane -- not the barrier.) An untouched bucket's record is already its
+            // maximum, so the results are the same bits.
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                if (need & (1ull << h)) {
+                if (need & (1ull << h)) {                  // wave-uniform
 #pragma clang fp contract(off)
                     const fps_f2 dx = px[h] - c2x, dy = py[h] - c2y, dz = pz[h] - c2z;
                     const fps_f2 d = (dx * dx + dy * dy) + dz * dz;
                     dist[h][0] = fminf(dist[h][0], d[0]); dist[h][1] = fminf(dist[h][1], d[1]);
+                    int b = __float_as_int(fmaxf(fmaxf(dist[h][0], dist[h][1]), 0.f));     // >= 0 as int bits (lanes without a point: 0)
+                    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0xB1, 0xF, 0xF, false));
+                    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0x4E, 0xF, 0xF, false));
+                    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0x141, 0xF, 0xF, false));
+                    b = max(b, __builtin_amdgcn_update_dpp(0, b, 0x140, 0xF, 0xF, false));
+                    const int m4 = max(max(__builtin_amdgcn_readlane(b, 0), __builtin_amdgcn_readlane(b, 16)),
+                                       max(__builtin_amdgcn_readlane(b, 32), __builtin_amdgcn_readlane(b, 48)));
+                    if (lane == h) pmax = __int_as_float(m4);                              // (a bucket that needs an update has points)
                 }
-                bmi[h] = __float_as_int(fmaxf(fmaxf(dist[h][0], dist[h][1]), 0.f));
             }
-            // H wave maxima side by side (independent DPP chains: the latency of one); buckets without points stay at -1
-#pragma unroll
-            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0xB1, 0xF, 0xF, false));
-#pragma unroll
-            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0x4E, 0xF, 0xF, false));
-#pragma unroll
-            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0x141, 0xF, 0xF, false));
-#pragma unroll
-            for (int h = 0; h < H; ++h) bmi[h] = max(bmi[h], __builtin_amdgcn_update_dpp(0, bmi[h], 0x140, 0xF, 0xF, false));
+            // the wave's maximum = the largest bucket record (empty buckets hold -1.0: negative as int), and this lane's best point there
             int wvi = -1;
+            int pm[H];
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const int m4 = max(max(__builtin_amdgcn_readlane(bmi[h], 0), __builtin_amdgcn_readlane(bmi[h], 16)),
-                                   max(__builtin_amdgcn_readlane(bmi[h], 32), __builtin_amdgcn_readlane(bmi[h], 48)));
-                const bool live_h = __builtin_amdgcn_readlane(__float_as_int(pmax), h) >= 0;        // pmax >= 0 (incl. +inf): the bucket has points
-                if (lane == h && live_h) pmax = __int_as_float(m4);
-                if (live_h) wvi = max(wvi, m4);
-            }
+            for (int h = 0; h < H; ++h) { pm[h] = __builtin_amdgcn_readlane(__float_as_int(pmax), h); wvi = max(wvi, pm[h]); }
             wv = wvi >= 0 ? __int_as_float(wvi) : -1.f;
             mykey = 0u;                                    // valid bit | (~orig & 0x1fff) << 13 | sorted position: larger = lower original index
             if (wvi >= 0) {
 #pragma unroll
-                for (int i = 0; i < PPT; ++i)
-                    if (dist[i >> 1][i & 1] == wv)
-                        mykey = max(mykey, (1u << 26) | ((0x1fffu - (unsigned)org[i]) << 13) | (unsigned)(w * 64 * PPT + i * 64 + lane));
+                for (int h = 0; h < H; ++h) {
+                    if (pm[h] == wvi) {                    // wave-uniform: only a bucket whose record IS the maximum can hold it
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int i = 2 * h + e;
+                            if (dist[h][e] == wv)
+                                mykey = max(mykey, (1u << 26) | ((0x1fffu - (unsigned)org[i]) << 13) | (unsigned)(w * 64 * PPT + i * 64 + lane));
+                        }
+                    }
+                }
             }
         }
         if (mykey != 0u) atomicMax(&s_key[s % 3], ((unsigned long long)__float_as_uint(wv) << 32) | (unsigned long long)mykey);
@@ -591,7 +601,18 @@ extern "C" int morig_fps(const float* pos, int32_t ldp, const int32_t* ptr, cons
     static const bool old_fps = getenv("MORIG_FPS_OLD") != nullptr;
     static const bool bkt = [] { const char* e = getenv("MORIG_FPS_BKT"); return !(e && e[0] == '0'); }();
 #define MORIG_FPS_BKT_CASE(P) hipLaunchKernelGGL((fps_bkt_kernel<P>), dim3(n_clouds), dim3(FPS_T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
-    if (ppt <= 8 && !old_fps && bkt) {
+#define MORIG_FPS_BKT_T(P, T) hipLaunchKernelGGL((fps_bkt_kernel<P, T>), dim3(n_clouds), dim3(T), 0, s, pos, ldp, ptr, out_ptr, start, idx_out)
+    // threads per cloud of the bucketed kernel: MORIG_FPS_T = 256 | 512 | 1024 (A/B switch)
+    static const int fps_t = [] { const char* e = getenv("MORIG_FPS_T"); const int v = e ? atoi(e) : MORIG_FPS_T_DEFAULT; return (v == 256 || v == 512) ? v : 1024; }();
+    if (max_cloud_points <= 8192 && !old_fps && bkt && fps_t != 1024) {
+        const int pp = cdiv(max_cloud_points, fps_t);
+        if (fps_t == 256) {
+            if (pp <= 4) MORIG_FPS_BKT_T(4, 256); else if (pp <= 8) MORIG_FPS_BKT_T(8, 256); else if (pp <= 16) MORIG_FPS_BKT_T(16, 256); else MORIG_FPS_BKT_T(32, 256);
+        } else {
+            if (pp <= 2) MORIG_FPS_BKT_T(2, 512); else if (pp <= 4) MORIG_FPS_BKT_T(4, 512); else if (pp <= 8) MORIG_FPS_BKT_T(8, 512); else MORIG_FPS_BKT_T(16, 512);
+        }
+    }
+    else if (ppt <= 8 && !old_fps && bkt) {
         if (ppt <= 2) MORIG_FPS_BKT_CASE(2);
         else if (ppt <= 4) MORIG_FPS_BKT_CASE(4);
         else MORIG_FPS_BKT_CASE(8);
