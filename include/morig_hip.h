@@ -116,6 +116,10 @@ int morig_csr_build_bipartite(const int64_t* edge_index, int64_t n_edges, int32_
  */
 #define MORIG_SPLIT_F16 0
 #define MORIG_SPLIT_BF16 1
+#define MORIG_SPLIT_BF16X6 2   /* [ABI 3] W_split == NULL: plain fp32 X and W, both split into three bf16 limbs IN the kernel, six MFMAs per
+                                  product: float32-class results (dropped terms <= 2^-24 relative), float32's exponent range (no range word),
+                                  2.7x the fp32-MFMA rate. What the train-mode forward and the exact re-run behind the range guard take
+                                  instead of v_mfma_f32_32x32x2_f32. Plain stores and pooled launches. */
 typedef struct morig_gemm_args {
     uint32_t struct_size;     /* sizeof(morig_gemm_args) of the caller's build (ABI 3)                */
     int32_t M, N, K;          /* logical sizes: Y is M x N, X is M x K                            */
@@ -194,6 +198,8 @@ typedef struct morig_edgeconv_args {
                                           Needs W2_split + overflow, `out` 128-byte aligned, ldo % 32 == 0 and the launch on one of the
                                           4-aligned-CSR kernels (H = 128 / 256): ask morig_edgeconv_can_split_out first;
                                           MORIG_E_UNSUPPORTED otherwise. *overflow is raised when a result leaves the fp16 range. */
+    int32_t exact_arith;               /* [ABI 3] arithmetic of the EXACT path (W2_split == NULL): 0 = v_mfma_f32_32x32x2_f32, 1 = the bf16 x 6
+                                          split of MORIG_SPLIT_BF16X6 (H >= 32; morig_edgeconv, morig_edge_hidden) */
     int32_t seg_min4;                  /* [ABI 3] the CSR was built with MORIG_CSR_MIN4 (segments of >= 4 rows, NOT 4-aligned; quad_aligned = 0):
                                           H = 256 split-fp16 launches with out_split then take the mixed-quad form of the W2-stationary
                                           kernel (morig_edgeconv_can_split_out answers for it); everywhere else the flag is ignored -- a

@@ -176,6 +176,19 @@ __device__ inline void split_pair_bf16(float v0, float v1, float& hi, float& lo)
 }
 #endif
 
+#ifdef __HIPCC__
+// the same first limb together with the EXACT remainders r = v - hi (fp32: the difference of a float and its bf16 rounding is exact):
+// the input of the next limb of a three-limb split (tile_gemm.hip PREC_BF16X6)
+__device__ inline void split_pair_bf16_rem(float v0, float v1, float& hi, float& r0, float& r1) {
+    typedef __bf16 split_b2 __attribute__((ext_vector_type(2)));
+    const split_b2 h = {(__bf16)v0, (__bf16)v1};
+    const unsigned hb = __builtin_bit_cast(unsigned, h);
+    hi = __builtin_bit_cast(float, h);
+    r0 = v0 - __uint_as_float(hb << 16);
+    r1 = v1 - __uint_as_float(hb & 0xffff0000u);
+}
+#endif
+
 // V consecutive floats of a row (V = 4: one 16-byte access; V = 1: any alignment). vec4_ok(): the host-side predicate
 template <int V> struct VecF { float v[V]; };
 #ifdef __HIPCC__

@@ -37,7 +37,12 @@ typedef __fp16 f16x2 __attribute__((ext_vector_type(2)));        // what __built
 //                16 k = 5.3x the fp32-MFMA rate). fp16 products are exact in fp32, the dropped lo*lo term
 //                and the rounding of lo are both ~2^-22 relative: fp32-class accuracy. |x| must stay below
 //                the fp16 range; the loader raises `ovf` otherwise and the host re-runs in PREC_F32.
-enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16X3 = 2 };   // BF16X3 [r04]: the same 3-MFMA split on bf16 halves (float32 exponent range: the
+//   PREC_BF16X6 [r06]: both fp32 operands are split IN THE KERNEL into three bf16 limbs x = b1 + b2 + b3 (8 + 8 + 8 mantissa bits, float32's
+//                exponent range: no range condition) and the product is the six terms down to 2^-16 of the leading one --
+//                b1 b1 + b1 b2 + b2 b1 + b2 b2 + b1 b3 + b3 b1 -- on v_mfma_f32_32x32x16_bf16: float32-class products (the dropped terms are
+//                <= 2^-24 relative) at 16/6 = 2.7x the fp32-MFMA rate. Takes plain fp32 X and W (weights that change every step need no
+//                host-side image): the train-mode forward contractions and the exact path behind the range guard.
+enum { PREC_F32 = 0, PREC_F16X3 = 1, PREC_BF16X3 = 2, PREC_BF16X6 = 3 };   // BF16X3 [r04]: the same 3-MFMA split on bf16 halves (float32 exponent range: the
                                                           // backward contractions, whose operands are gradients); dense fp32-X stores only
 
 // LOAD_EDGE3: an EdgeConv whose vertex input has 3 channels (positions; the keyframe flow of motionNet's first unit): instead of
@@ -81,14 +86,14 @@ static int debug_flags() {
 // launcher; the row / column tests, zero fills and switch tests compile out (dense store GEMMs with fp32 X: the GCU units' MLPs of the
 // forward, dX of the training step; the counters of the general form: 7.0 VALU + 3.6 SALU instructions per MFMA, matrix pipe 39 % busy).
 template <int BN, int KC, int LOAD, int MODE, int PREC, bool FAST = false>
-__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD != LOAD_DENSE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC != PREC_F32) ? 3 :
+__global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 32 && LOAD != LOAD_DENSE) ? ((PREC == PREC_F32 && KC == 16) ? 6 : 4) : (BN == 64 && LOAD == LOAD_EDGE && PREC == PREC_F16X3) ? 4 : (PREC == PREC_BF16X6) ? (BN >= 256 ? 1 : 2) : (BN == 128 && KC == 32 && LOAD == LOAD_DENSE && MODE != MODE_EDGEMAX && PREC != PREC_F32) ? 3 :
                                (BN == 64 && LOAD == LOAD_DENSE && MODE == MODE_STORE && PREC != PREC_F32) ? 4 : 1)) void tile_kernel(const TileParams p) {
     constexpr int BM = 128;
     constexpr int WN = (BN >= 128) ? 2 : 1;
     constexpr int WM = 4 / WN;
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
-    constexpr int LDK = KC + 4;
+    constexpr int LDK = (PREC == PREC_BF16X6 ? (KC / 32) * 48 : KC) + 4;      // floats per LDS row (BF16X6: three limbs = 192 B per 32-column chunk)
     constexpr int TPR = KC / 4;                 // loader threads per tile row
     constexpr int RPP = 256 / TPR;              // tile rows per loader pass
     constexpr int PA = BM / RPP;
@@ -230,6 +235,25 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
                 rw[i] = *reinterpret_cast<const f32x4*>(pw + (size_t)i * RPP * p.ldw + k0);
         }
     };
+    // BF16X6: four fp32 values -> their three bf16 limbs, 4 halves (8 bytes) each into the [b1 | b2 | b3] thirds of the row's 192-byte chunk
+    auto split3_store = [&](char* rowp, const f32x4& v) __attribute__((always_inline)) {
+        typedef float b32x2 __attribute__((ext_vector_type(2)));
+        b32x2 l1, l2, l3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float h, r0, r1, m, t;
+            split_pair_bf16_rem(v[2 * q], v[2 * q + 1], h, r0, r1);       // h = bf16 pair, r = the exact remainders
+            l1[q] = h;
+            float s0, s1;
+            split_pair_bf16_rem(r0, r1, m, s0, s1);
+            l2[q] = m;
+            split_pair_bf16(s0, s1, t, h);                                // third limb (h: the fourth, dropped)
+            l3[q] = t;
+        }
+        *reinterpret_cast<b32x2*>(rowp) = l1;
+        *reinterpret_cast<b32x2*>(rowp + 64) = l2;
+        *reinterpret_cast<b32x2*>(rowp + 128) = l3;
+    };
     auto stage = [&](int k0) {
         const int k = k0 + 4 * lkq;
         f32x4 v3[PA];
@@ -270,6 +294,8 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
             }
             if (PREC == PREC_F32) {
                 *reinterpret_cast<f32x4*>(&sA[(lrow + i * RPP) * LDK + 4 * lkq]) = v;
+            } else if (PREC == PREC_BF16X6) {
+                split3_store(reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 192 * (lkq >> 3) + 8 * (lkq & 7), v);
             } else if (PREC == PREC_F16X3 && LOAD == LOAD_DENSE && p.x16) {
                 // the producer already wrote [32 halves hi | 32 halves lo] per 32-column chunk: plain copy
                 *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(sA) + (lrow + i * RPP) * (LDK * 4) + 16 * lkq) = ra[i];
@@ -296,8 +322,15 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
-            if (BN % RPP == 0 || lrow + i * RPP < BN)
-                *reinterpret_cast<f32x4*>(&sB[(lrow + i * RPP) * LDK + 4 * lkq]) = rw[i];
+            if (BN % RPP == 0 || lrow + i * RPP < BN) {
+                if (PREC == PREC_BF16X6) {                  // plain fp32 weights in, three limbs out (columns past K are zero in the packed rows)
+                    f32x4 w = rw[i];
+                    if (!FAST && (p.dbg & DBG_NO_WLOAD)) w = f32x4{0.f, 0.f, 0.f, 0.f};
+                    split3_store(reinterpret_cast<char*>(sB) + (lrow + i * RPP) * (LDK * 4) + 192 * (lkq >> 3) + 8 * (lkq & 7), w);
+                } else {
+                    *reinterpret_cast<f32x4*>(&sB[(lrow + i * RPP) * LDK + 4 * lkq]) = rw[i];
+                }
+            }
         }
     };
 
@@ -318,6 +351,40 @@ __global__ __launch_bounds__(256, ((BN == 256 && PREC == PREC_F32) ? 2 : (BN == 
         __syncthreads();
         if (c + 1 < nchunk) fetch((c + 1) * KC);
         if (!FAST && (p.dbg & DBG_NO_MFMA)) continue;
+        if (PREC == PREC_BF16X6) {
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            const char* a0 = reinterpret_cast<const char*>(sA) + (wm * MT * 32 + l31) * (LDK * 4) + 16 * hi;
+            const char* b0 = reinterpret_cast<const char*>(sB) + (wn * NT * 32 + l31) * (LDK * 4) + 16 * hi;
+#pragma unroll
+            for (int st2 = 0; st2 < KC / 16; ++st2) {
+                const int off = 192 * (st2 >> 1) + 32 * (st2 & 1);     // 32-column chunk, 16-k step inside each 64-byte limb block
+                bf16x8 x1[MT], x2[MT], x3[MT], w1[NT], w2[NT], w3[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    x1[mt] = *reinterpret_cast<const bf16x8*>(a0 + mt * 32 * LDK * 4 + off);
+                    x2[mt] = *reinterpret_cast<const bf16x8*>(a0 + mt * 32 * LDK * 4 + off + 64);
+                    x3[mt] = *reinterpret_cast<const bf16x8*>(a0 + mt * 32 * LDK * 4 + off + 128);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    w1[nt] = *reinterpret_cast<const bf16x8*>(b0 + nt * 32 * LDK * 4 + off);
+                    w2[nt] = *reinterpret_cast<const bf16x8*>(b0 + nt * 32 * LDK * 4 + off + 64);
+                    w3[nt] = *reinterpret_cast<const bf16x8*>(b0 + nt * 32 * LDK * 4 + off + 128);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {           // smallest terms first
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x3[mt], w1[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[mt], w3[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2[mt], w2[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x2[mt], w1[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[mt], w2[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x1[mt], w1[nt], acc[mt][nt], 0, 0, 0);
+                    }
+            }
+            continue;
+        }
         if (PREC != PREC_F32) {
             const char* a0 = reinterpret_cast<const char*>(sA) + (wm * MT * 32 + l31) * (LDK * 4) + 16 * hi;
             const char* b0 = reinterpret_cast<const char*>(sB) + (wn * NT * 32 + l31) * (LDK * 4) + 16 * hi;
@@ -759,6 +826,9 @@ extern "C" int morig_gemm(const morig_gemm_args* a_in, void* stream) {
     const double flops = 2.0 * a->M * (double)a->N * a->K;
     const double bytes = 4.0 * ((double)a->M * a->K + (double)a->N * a->K + (pool ? 0.0 : (double)a->M * a->N));
 
+    // [r06] MORIG_SPLIT_BF16X6 without an image: the exact path on three bf16 limbs per operand (split in the kernel)
+    const bool x6 = a->W_split == nullptr && a->w_split_format == MORIG_SPLIT_BF16X6;
+    if (x6 && (a->x_split || a->y_split)) return MORIG_E_INVALID;
     const bool f16 = a->W_split != nullptr;
     // the bf16 split (W_split holds bf16 halves; bf16 has float32's exponent range, so there is no range guard to report through):
     // fp32 X, fp32 Y, plain stores -- the backward contractions. Selected by w_split_format, never inferred from a missing overflow
@@ -797,7 +867,8 @@ extern "C" int morig_gemm(const morig_gemm_args* a_in, void* stream) {
         p.tiles_n = cdiv(a->N, 128);
         ProfScope ps(f16 ? K_GEMM16_POOL : K_GEMM_POOL, s, flops, bytes);
         int st;
-        if (f16 && kc64 && getenv("MORIG_KC64")) st = launch_tile<128, 64, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
+        if (x6) st = launch_tile<128, 32, LOAD_DENSE, MODE_POOL, PREC_BF16X6>(p, tiles_m * p.tiles_n, s);
+        else if (f16 && kc64 && getenv("MORIG_KC64")) st = launch_tile<128, 64, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s);
         else st = f16 ? launch_tile<128, 32, LOAD_DENSE, MODE_POOL, PREC_F16X3>(p, tiles_m * p.tiles_n, s)
                       : launch_tile<128, 32, LOAD_DENSE, MODE_POOL>(p, tiles_m * p.tiles_n, s);
         return st != MORIG_OK ? st : pool_finalize(a->pool, a->n_seg, a->ld_pool, s);
@@ -821,6 +892,13 @@ extern "C" int morig_gemm(const morig_gemm_args* a_in, void* stream) {
         p.tiles_n = 1;
         if (a->N > 32) return launch_tile<64, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X3>(p, tiles_m, s);
         return launch_tile<32, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X3>(p, tiles_m, s);
+    }
+    if (x6) {
+        ProfScope ps(a->N > 64 ? K_GEMM_BN128 : (a->N > 32 ? K_GEMM_BN64 : K_GEMM_BN32), s, flops, bytes);
+        if (a->N > 64) { p.tiles_n = cdiv(a->N, 128); return launch_tile<128, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X6>(p, tiles_m * p.tiles_n, s); }
+        p.tiles_n = 1;
+        if (a->N > 32) return launch_tile<64, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X6>(p, tiles_m, s);
+        return launch_tile<32, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X6>(p, tiles_m, s);
     }
     if (a->N > 64) {
         p.tiles_n = cdiv(a->N, 128);
@@ -881,6 +959,15 @@ extern "C" int morig_edge_hidden(const morig_edgeconv_args* a_in, void* stream) 
     const double flops = 2.0 * E * a->H * (double)a->H;
     const bool f16 = a->W2_split != nullptr;
     ProfScope ps(f16 ? K_POINTCONV16 : K_POINTCONV, s, flops, 4.0 * 3.0 * E * a->H);
+    if (!f16 && a->exact_arith == 1) {            // the exact path on three bf16 limbs (MORIG_SPLIT_BF16X6)
+        switch (a->H) {
+            case 32:  return launch_tile<32, 32, LOAD_EDGE, MODE_STORE, PREC_BF16X6>(p, p.tiles_per_rep, s);
+            case 64:  return launch_tile<64, 32, LOAD_EDGE, MODE_STORE, PREC_BF16X6>(p, p.tiles_per_rep, s);
+            case 128: return launch_tile<128, 32, LOAD_EDGE, MODE_STORE, PREC_BF16X6>(p, p.tiles_per_rep, s);
+            case 256: return launch_tile<256, 32, LOAD_EDGE, MODE_STORE, PREC_BF16X6>(p, p.tiles_per_rep, s);
+            default: break;
+        }
+    }
     switch (a->H) {
         case 16:  return launch_tile<32, 16, LOAD_EDGE, MODE_STORE>(p, p.tiles_per_rep, s);     // fp32 MFMA (no split image below 32)
         case 32:  return f16 ? launch_tile<32, 32, LOAD_EDGE, MODE_STORE, PREC_F16X3>(p, p.tiles_per_rep, s)
@@ -1054,6 +1141,15 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a_in, void* stream) {
             case 128: { ProfScope ps(K_EDGE16_H128, s, flops, bytes); return launch_tile<128, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
             case 256: { ProfScope ps(K_EDGE16_H256, s, flops, bytes); return launch_tile<256, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
             default: return MORIG_E_UNSUPPORTED;
+        }
+    }
+    if (a->exact_arith == 1) {                    // the exact path on three bf16 limbs (MORIG_SPLIT_BF16X6)
+        switch (a->H) {
+            case 32:  { ProfScope ps(K_EDGE_H32, s, flops, bytes);  return launch_tile<32, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_BF16X6>(p, nblocks, s); }
+            case 64:  { ProfScope ps(K_EDGE_H64, s, flops, bytes);  return launch_tile<64, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_BF16X6>(p, nblocks, s); }
+            case 128: { ProfScope ps(K_EDGE_H128, s, flops, bytes); return launch_tile<128, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_BF16X6>(p, nblocks, s); }
+            case 256: { ProfScope ps(K_EDGE_H256, s, flops, bytes); return launch_tile<256, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_BF16X6>(p, nblocks, s); }
+            default: break;
         }
     }
     switch (a->H) {

@@ -60,6 +60,7 @@ class EdgeConvArgs(C.Structure):
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
         ("quad_aligned", C.c_int32),
         ("out_split", C.c_int32),
+        ("exact_arith", C.c_int32),
         ("seg_min4", C.c_int32),
     ]
 
@@ -377,6 +378,11 @@ class NativeOps:
         # (default), "f32" = fp32 MFMA everywhere. MORIG_PRECISION overrides.
         self.precision = os.environ.get("MORIG_PRECISION", "f16x3")
         assert self.precision in ("f16x3", "f32")
+        # arithmetic of the EXACT path (precision "f32", the re-run behind the range guard, the train-mode forward): "bf16x6" = both fp32
+        # operands split into three bf16 limbs in the kernel, six MFMAs per product (float32-class products, float32's range, 2.7x the
+        # fp32-MFMA rate: MORIG_SPLIT_BF16X6); "f32" = v_mfma_f32_32x32x2_f32. MORIG_EXACT_ARITH overrides.
+        self.exact_arith = os.environ.get("MORIG_EXACT_ARITH", "bf16x6")
+        assert self.exact_arith in ("bf16x6", "f32")
         # guard state is PER THREAD (two threads / streams may run forwards concurrently on the one NativeOps): nesting depth,
         # forced-fp32 switch, the CSR status words of the forward in flight and the overflow flag word of each device
         self._tls = threading.local()
@@ -629,6 +635,8 @@ class NativeOps:
             a.W_split, a.overflow, a.w_split_format = lin.Wsplit_bf16.data_ptr(), 0, 1     # MORIG_SPLIT_BF16
         elif self.fast and lin.Wsplit is not None:
             a.W_split, a.overflow = lin.Wsplit.data_ptr(), self._flag(X.base.device).data_ptr()
+        elif self.exact_arith == "bf16x6" and not x_split and not y_split:
+            a.w_split_format = 2                                                             # MORIG_SPLIT_BF16X6, no image: split in the kernel
         a.x_split, a.y_split = int(x_split), int(y_split)
         check(self.lib.morig_gemm(C.byref(a), _stream()), "morig_gemm")
 
@@ -686,6 +694,7 @@ class NativeOps:
         a.out, a.ldo = out.ptr, out.ld
         a.quad_aligned = 1 if csr.quad else 0
         a.seg_min4 = 1 if getattr(csr, "min4", False) else 0
+        a.exact_arith = 1 if self.exact_arith == "bf16x6" else 0
         if self.fast and ec.W2split is not None:
             a.W2_split, a.overflow = ec.W2split.data_ptr(), self._flag(A.base.device).data_ptr()
         return a
