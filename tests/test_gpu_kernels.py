@@ -138,6 +138,35 @@ def test_gemm_store(ops, M, N, K, relu, bn):
     assert float(yb[:, :2].abs().sum()) == 0 and float(yb[:, 2 + N:].abs().sum()) == 0     # window respected
 
 
+@pytest.mark.parametrize("M,N,K,scale", [(1000, 256, 864, 1.0), (513, 64, 300, 1.0e3), (700, 1024, 256, 1.0e-3), (300, 32, 64, 3.0e4)])
+def test_exact_path_on_bf16x6_is_float32_class(M, N, K, scale):
+    """The exact path's default arithmetic [r06] (MORIG_SPLIT_BF16X6: both fp32 operands split into three bf16 limbs in the kernel, six
+    MFMAs per product) against float64, beside v_mfma_f32_32x32x2_f32 on the same inputs: its error is of the fp32-MFMA kernel's size (the
+    dropped limb products are <= 2^-24 of a product), at every magnitude -- bf16 keeps float32's exponent range, so inputs of 3e4 x 1e3 need no
+    range guard and inputs of 1e-3 lose nothing to subnormals."""
+    o = native.get_ops()
+    o.precision = "f32"
+    prev = o.exact_arith
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, (K + 3) // 4 * 4, generator=g) * scale)
+    lin = _lin(N, K, 4, bn=False)
+    lin.W = lin.W * (1.0e3 if scale > 1.0e4 else 1.0)
+    ref = (x[:, :K].double() @ lin.W[:N, :K].double().t() + lin.bias[:N].double())
+    errs = {}
+    try:
+        for mode in ("f32", "bf16x6"):
+            o.exact_arith = mode
+            y = torch.zeros(M, N, device=DEV)
+            o.gemm(Mat.of(x.to(DEV), 0, K), packing.to_device(lin, DEV), False, Y=Mat.of(y))
+            torch.cuda.synchronize()
+            errs[mode] = (y.cpu().double() - ref).abs().max().item()
+    finally:
+        o.exact_arith = prev
+    mag = ref.abs().max().item()
+    assert errs["bf16x6"] <= 4.0 * errs["f32"] + 1e-7 * mag, (errs, mag)
+    assert errs["bf16x6"] <= 3e-6 * mag, (errs, mag)              # float32-class: a K-term sum of float32 products
+
+
 def test_gemm_refuses_a_split_image_without_its_range_guard():
     """the weight format of morig_gemm is explicit (w_split_format): an fp16-split image handed over WITHOUT the overflow word is
     MORIG_E_INVALID, not silently taken for the bf16 split; an unknown format value is refused as well"""

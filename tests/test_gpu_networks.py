@@ -421,6 +421,22 @@ def test_ragged_batch_64_meshes_contains_the_golden_mesh():
     assert shift.shape[0] == sum(s_ * s_ for s_ in sides) and bool(torch.isfinite(shift).all())
     assert rel_excess(aggr[sl], a["motion_aggr"], TOL) <= 0
     assert rel_excess(shift[sl], a["pred_shift"], TOL) <= 0
+    # ... and two more meshes of the batch -- the smallest one and one of about 2.5 k vertices -- against the CPU oracle run on each of
+    # them ALONE (a mesh's outputs do not depend on its batch mates): ragged batches are held to the reference at more sizes than the
+    # <= 1 k-vertex `*_ragged` goldens
+    from oracle import nets
+    ref = synth.load_recipe(nets.jointnet_motion(**meta["kwargs"]).eval(), meta["recipe_seed"], mild=meta["mild"])
+    order = sorted(range(64), key=lambda i: sides[i])
+    picks = [order[0], min(range(64), key=lambda i: abs(sides[i] - 50) + (1000 if i == slot else 0))]
+    for i in picks:
+        one = synth.collate([synth.make_mesh(seeds[i], n_side=sides[i], geo_radius=bench.GEO_RADIUS, with_skin=False)])
+        with torch.no_grad():
+            _, waggr, wshift = ref(one, one.pred_flow)
+        o_i = sum(s_ * s_ for s_ in sides[:i])
+        sl_i = slice(o_i, o_i + sides[i] ** 2)
+        assert torch.equal(d.pos[sl_i].cpu(), one.pos)
+        assert rel_excess(aggr[sl_i], waggr, TOL) <= 0, (i, sides[i])
+        assert rel_excess(shift[sl_i], wshift, TOL) <= 0, (i, sides[i])
 
 
 def test_mask_skin_batch_64_contains_the_golden_mesh():
