@@ -41,6 +41,7 @@ class _ForwardContext(threading.local):
     each walking its own parameter subtree (one traversal of ~450 tensors per forward, ~1 ms of host time)."""
     key = None
     root = None
+    shift = 0          # range shift k of the forward in flight (see NativeModule.forward): homogeneous stacks run at 2^-k
 
 
 _ctx = _ForwardContext()
@@ -56,11 +57,23 @@ class NativeModule(torch.nn.Module):
     NOT seen: edits made through ``.data`` (``p.data.copy_(ema)``, ``p.data.clamp_()``) -- they bypass the version counter;
     call ``invalidate_packed()`` after such an edit."""
 
+    # Range shift [r06]. _RANGE_SCALED: this module's packed constants belong to a positively homogeneous stack (packing.scale_additive) --
+    # GCNRig, GCUMotion, SkinNet_inner, the position groups of the rig networks; _RANGE_SHIFT_ROOT: this network's plan scales the inputs of
+    # those stacks by 2^-k and their outputs by 2^k (rignet.py), so its forward may answer a split-fp16 range overflow by raising k
+    # instead of re-running on the exact path.
+    _RANGE_SCALED = False
+    _RANGE_SHIFT_ROOT = False
+    # (small steps: the smallest sufficient k keeps the most of fp16's narrow exponent range for the ordinary activations -- at 2^-12 values of
+    # O(1) would reach fp16's subnormals; the search runs on the first overflowing forward only, k is sticky)
+    RANGE_SHIFT_STEP, RANGE_SHIFT_MAX = 2, 10
+
     def __init__(self):
         super().__init__()
         self._packed = None
         self._packed_device = None
         self._packed_key = None
+        self._packed_shift = 0
+        self.range_shift = 0               # k, sticky: found by the first forward that overflowed (not part of the state_dict)
         self.register_load_state_dict_post_hook(_invalidate_packed)
 
     def __getstate__(self):
@@ -68,6 +81,7 @@ class NativeModule(torch.nn.Module):
         st = super().__getstate__() if hasattr(super(), "__getstate__") else self.__dict__.copy()
         st = dict(st)
         st["_packed"], st["_packed_key"], st["_packed_device"] = None, None, None
+        st["_packed_shift"] = 0
         st.pop("_last_key", None)
         return st
 
@@ -116,10 +130,15 @@ class NativeModule(torch.nn.Module):
             key = _ctx.key = _ctx.root._param_key()
         elif key is None:
             key = self._param_key()
-        if self._packed is None or self._packed_device != device or self._packed_key != key:
-            self._packed = packing.to_device(self._pack(), device)
+        shift = _ctx.shift if self._RANGE_SCALED else 0
+        if self._packed is None or self._packed_device != device or self._packed_key != key or self._packed_shift != shift:
+            pk = self._pack()
+            if shift:
+                pk = packing.scale_additive(pk, 2.0 ** -shift)
+            self._packed = packing.to_device(pk, device)
             self._packed_device = device
             self._packed_key = key
+            self._packed_shift = shift
         return self._packed
 
     def _pack(self):
@@ -151,6 +170,19 @@ class NativeModule(torch.nn.Module):
             torch.set_rng_state(rng)
             return self._forward(*args, **kwargs)
         outer = _ctx.key
+        retry = None
+        if outer is None and self._RANGE_SHIFT_ROOT and os.environ.get("MORIG_RANGE_SHIFT", "1") != "0":
+            # [r06] an operand beyond the split-fp16 range: before the exact path (2.8 x the time, on EVERY later forward too), run the
+            # homogeneous stacks at 2^-k -- inputs and additive constants scaled down, outputs scaled back, all by exact powers of two --
+            # and keep k for the forwards that follow (sticky: the weights that overflowed once will again)
+            _ctx.shift = self.range_shift
+
+            def retry():
+                if self.range_shift >= self.RANGE_SHIFT_MAX:
+                    return False
+                self.range_shift += self.RANGE_SHIFT_STEP
+                _ctx.shift = self.range_shift
+                return True
         if outer is None:
             # (storage, version) of every tensor below the outermost module -- computed at the first packed() call of the forward,
             # not here: the plans enqueue their weight-free launches first (CSR builds, sampling), so the ~0.2 ms walk runs while
@@ -160,12 +192,13 @@ class NativeModule(torch.nn.Module):
             if dev.type == "cuda":
                 # launches go to torch's current stream OF THE MODEL'S DEVICE, whatever the caller's current device is
                 with torch.cuda.device(dev):
-                    return ops.guarded(dev, attempt)
-            return ops.guarded(dev, attempt)
+                    return ops.guarded(dev, attempt, retry=retry)
+            return ops.guarded(dev, attempt, retry=retry)
         finally:
             _ctx.key = outer
             if outer is None:
                 _ctx.root = None
+                _ctx.shift = 0
 
     def forward_async(self, *args, **kwargs):
         """The eval forward with its guard read DEFERRED: -> (outputs, pending). ``pending.result()`` (morig_amd.native.PendingGuard)
@@ -178,6 +211,7 @@ class NativeModule(torch.nn.Module):
         outer = _ctx.key
         assert outer is None, "forward_async is for the outermost module"
         _ctx.key, _ctx.root = _LAZY_KEY, self
+        _ctx.shift = self.range_shift if self._RANGE_SHIFT_ROOT else 0
         try:
             with torch.cuda.device(dev):
                 if not ops.fast:                        # exact-fp32 mode: nothing can overflow, the status words still are checked
@@ -185,6 +219,7 @@ class NativeModule(torch.nn.Module):
                 return ops.guarded_async(dev, lambda: self._forward(*args, **kwargs))
         finally:
             _ctx.key, _ctx.root = outer, None
+            _ctx.shift = 0
 
     def _forward(self, *args, **kwargs):
         raise NotImplementedError
@@ -328,9 +363,17 @@ class GCU(NativeModule):
         return out
 
 
+def range_scale() -> float:
+    """2^-k of the forward in flight (1.0 outside a range-shifted forward): what the plans of the homogeneous stacks multiply their
+    INPUTS by; their outputs are multiplied by the inverse"""
+    return 2.0 ** -_ctx.shift
+
+
 class GCUMotion(NativeModule):
     """models/basic_modules.py:205-219. ``run`` supports R keyframe replicas of the feature with ONE
     position branch (nn_pos depends only on pos and the graph: models/rignet.py:85-86)."""
+
+    _RANGE_SCALED = True
 
     def __init__(self, in_channels, out_channels, in_channel_pos=3, dim_pos_feat=16, aggr="max"):
         super().__init__()

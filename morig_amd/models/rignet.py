@@ -24,7 +24,7 @@ from torch.nn import Linear, Sequential
 from .. import packing
 from ..native import Mat
 from ..runtime import get_ops
-from .basic_modules import MLP, GCUMotion, NativeModule, _padded_copy, run_pos_groups
+from .basic_modules import MLP, GCUMotion, NativeModule, _padded_copy, range_scale, run_pos_groups
 
 __all__ = ["jointnet_motion", "masknet_motion", "skinnet_motion"]
 
@@ -94,6 +94,7 @@ class GCNRig(NativeModule):
     # every window starts on a 32-column chunk so the buffer can be kept in the split-fp16 layout
     WIDTHS = (64, 256, 512)
     TRANSFORM = "mlp_transform"
+    _RANGE_SCALED = True          # positively homogeneous in (pos, feature, additive constants): NativeModule's range shift
 
     def __init__(self, chn_feature, chn_output, aggr="max"):
         super().__init__()
@@ -233,6 +234,9 @@ class _MotionBackbone(NativeModule):
     """Shared front half of JointNetMotion / MaskNetMotion / SkinMotion: motionNet over the keyframes,
     row normalisation, aggregation (models/rignet.py:82-98, 115-131, 194-203)."""
 
+    _RANGE_SCALED = True          # its own pack = the position groups of the GCNRig stacks
+    _RANGE_SHIFT_ROOT = True      # its plans scale the stacks' inputs / outputs (range_scale())
+
     def _pos_units(self):
         """the GCUMotion units whose position branches see data.pos with 3 coordinates and D = 16: motionNet's, then the head's"""
         return [self.motionNet.gcu_1, self.motionNet.gcu_2, self.motionNet.gcu_3]
@@ -252,6 +256,13 @@ class _MotionBackbone(NativeModule):
         assert flow.shape[1] >= 3 * T
         pos4 = torch.zeros((n, 4), dtype=torch.float32, device=dev)
         ops.copy2d(Mat.of(data.pos.float().contiguous()), Mat.of(pos4, 0, 3))
+        c = range_scale()
+        if c != 1.0:
+            # range shift [r06]: the GCNRig stacks (and the position branches they share) run at 2^-k -- positions and flows in, every
+            # additive constant of their packs (packing.scale_additive), hence every activation; motionNet's output meets F.normalize,
+            # which does not see the factor; the head's output is multiplied back (_MotionHead / SkinMotion)
+            pos4.mul_(c)
+            flow = flow * c
         # both CSR variants of a graph (plain for the narrow layers, 4-aligned for the 128 / 256-wide kernels) from ONE pass over its COO
         csr_tpl, csr_tpl4 = ops.csr_build_dual(data.tpl_edge_index, n)
         csr_geo, csr_geo4 = ops.csr_build_dual(data.geo_edge_index, n)
@@ -275,6 +286,8 @@ class _MotionBackbone(NativeModule):
         self.motionNet.run(ops, pos4, write_flow, csr_tpl, csr_geo, seg_T, ng, T, Mat.of(raw), csr_geo_wide=csr_geo4,
                            csr_tpl_wide=csr_tpl4, pos_feats=pos_feats[:3], feat3=Mat.of(pf8, 4, 4), posfeat8=Mat.of(pf8))
         motion_all = torch.empty((n, T, C), dtype=torch.float32, device=dev)
+        if c != 1.0:
+            raw.mul_(1.0 / c)                                         # (F.normalize's eps clamp sees the unscaled rows)
         ops.rownorm(Mat.of(raw), n, T, motion_all, T * C, C)          # F.normalize + torch.stack(dim=1)
 
         pre = ops.empty(n, aggr_out_dim, dev)
@@ -316,8 +329,12 @@ class _MotionHead(_MotionBackbone):
         n = data.pos.shape[0]
         aggr = st["motion_aggr"]
         out = torch.empty((n, head.chn_output), dtype=torch.float32, device=aggr.device)
-        head.run(ops, st["pos4"], lambda w, sp: ops.copy2d_pad(Mat.of(aggr), w, split=sp), st["csr_tpl"], st["csr_geo"],
+        c = range_scale()
+        feat_in = aggr if c == 1.0 else aggr * c                      # (pos4 in `st` is scaled already)
+        head.run(ops, st["pos4"], lambda w, sp: ops.copy2d_pad(Mat.of(feat_in), w, split=sp), st["csr_tpl"], st["csr_geo"],
                  st["seg"], st["ng"], 1, Mat.of(out), csr_geo_wide=st["csr_geo4"], csr_tpl_wide=st["csr_tpl4"], pos_feats=st["pos_feats"])
+        if c != 1.0:
+            out.mul_(1.0 / c)
         return st["motion_all"], aggr, out
 
 
@@ -344,6 +361,8 @@ class MaskNetMotion(_MotionHead):
 
 class SkinNet_inner(NativeModule):
     """models/rignet.py:136-182."""
+
+    _RANGE_SCALED = True
 
     def __init__(self, nearest_bone, use_Dg, use_Lf, motion_dim, use_motion, aggr="max"):
         super().__init__()
@@ -389,6 +408,10 @@ class SkinNet_inner(NativeModule):
         skin = data.skin_input.float().contiguous()
         cols = torch.tensor(self.sample_columns(skin.shape[1]), dtype=torch.int32, device=dev)
         ops.gather_cols(Mat.of(skin), cols, Mat.of(raw, 3, P - 3))
+        c = range_scale()
+        if c != 1.0:                                   # range shift: this stack runs at 2^-k too (its caller multiplies `out` back)
+            raw.mul_(c)
+            motion = motion * c
         posm = Mat.of(raw, 0, P)
         sp = ops.split_activations                    # GEMM -> GEMM activations in the split-fp16 layout
         x1 = ops.empty(n, 256, dev)
@@ -439,6 +462,8 @@ class SkinMotion(_MotionBackbone):
         aggr = st["motion_aggr"]
         out = torch.empty((n, self.skinNet.num_nearest_bone), dtype=torch.float32, device=aggr.device)
         self.skinNet.run(ops, data, aggr, st["csr_tpl4"], st["csr_geo4"], st["seg"], st["ng"], Mat.of(out))     # all three GCUs are 256 wide
+        if range_scale() != 1.0:
+            out.mul_(1.0 / range_scale())
         return st["motion_all"], aggr, out
 
     def _forward_train(self, data, input_flow):

@@ -438,9 +438,12 @@ class NativeOps:
             ovf[key] = torch.zeros(1, dtype=torch.int32, device=device)
         return ovf[key]
 
-    def guarded(self, device, fn, rerun: bool = True):
+    def guarded(self, device, fn, rerun: bool = True, retry=None):
         """Run ``fn()`` (a whole forward) on the fast path; if any kernel reported an operand outside the
-        fp16 range, run it again on the fp32 path. Nested calls run inside the outer guard.
+        fp16 range, run it again on the exact path. Nested calls run inside the outer guard.
+        retry (optional callable -> bool): asked after a range overflow BEFORE the exact path is taken; True = the caller changed
+        something (the rig networks raise their range shift: morig_amd.models.basic_modules.NativeModule.forward) and the fast
+        path is worth another attempt, False = give up and run exactly.
         rerun=False (train-mode forward: it has side effects on the BatchNorm running buffers, so it must run ONCE):
         the whole forward runs on the exact fp32 MFMA path."""
         if self._depth > 0:
@@ -455,21 +458,24 @@ class NativeOps:
         if not self.fast:
             return self._run_once(device, fn)          # exact-fp32 mode: no range flag to read, but the CSR status words still are
         flag = self._flag(device)
-        flag.zero_()
-        self._depth += 1
-        self._csr_status = []
-        try:
-            out = fn()
-        finally:
-            self._depth -= 1
-            stats, self._csr_status = self._csr_status, None
-        # ONE small D2H read per forward: the split-fp16 range flag and the status word of every CSR built on the way
-        # (an out-of-range / negative edge or ball-query index is dropped by the count and fill kernels; the reference would
-        # raise an index error, so does this)
-        words = torch.cat([flag] + stats).tolist() if stats else [int(flag.item())]
-        if any(w != 0 for w in words[1:]):
-            raise MorigNativeError("edge_index / neighbour index out of range for the vertex count it was built with "
-                                   "(morig_csr_build status %s)" % [w for w in words[1:] if w != 0][:4])
+        while True:
+            flag.zero_()
+            self._depth += 1
+            self._csr_status = []
+            try:
+                out = fn()
+            finally:
+                self._depth -= 1
+                stats, self._csr_status = self._csr_status, None
+            # ONE small D2H read per forward: the split-fp16 range flag and the status word of every CSR built on the way
+            # (an out-of-range / negative edge or ball-query index is dropped by the count and fill kernels; the reference would
+            # raise an index error, so does this)
+            words = torch.cat([flag] + stats).tolist() if stats else [int(flag.item())]
+            if any(w != 0 for w in words[1:]):
+                raise MorigNativeError("edge_index / neighbour index out of range for the vertex count it was built with "
+                                       "(morig_csr_build status %s)" % [w for w in words[1:] if w != 0][:4])
+            if words[0] == 0 or retry is None or not retry():
+                break
         if words[0] != 0:
             self._force_f32 = True
             try:

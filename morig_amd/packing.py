@@ -261,6 +261,29 @@ def pack_pointconv(local_nn: nn.Sequential, cx: int):
     return dict(src=src, tgt=tgt, edge=edge, last=pack_mlp_layer(l3), fused=fused)
 
 
+def scale_additive(obj, c: float):
+    """A (nested) packed structure with every ADDITIVE constant multiplied by c (a power of two: exact) -- biases, BatchNorm shifts, the
+    first-layer bias of a ``pack_first_x3`` triple -- and everything multiplicative left alone. The GCU / GCNRig stacks are positively
+    homogeneous of degree one in (inputs, additive constants) jointly: Linear, ReLU, the BN scale, max aggregation and max pooling all
+    commute with a positive factor, so a stack whose inputs AND additive constants are scaled by c produces c times its outputs. That is
+    the range shift of ``NativeModule`` (activations beyond the split-fp16 range: run the stack at 2^-k, multiply the result by 2^k)."""
+    if c == 1.0:
+        return obj
+    if isinstance(obj, PackedLinear):
+        return PackedLinear(obj.W, None if obj.bias is None else obj.bias * c, obj.scale, None if obj.shift is None else obj.shift * c,
+                            obj.N, obj.K, obj.Wsplit, obj.Wsplit_bf16)
+    if isinstance(obj, PackedEdge):
+        return PackedEdge(obj.H, obj.s1, None if obj.t1 is None else obj.t1 * c, obj.W2, obj.b2 * c, obj.s2, obj.t2 * c, obj.W2split)
+    if isinstance(obj, dict):
+        return {k: scale_additive(v, c) for k, v in obj.items()}
+    if isinstance(obj, tuple) and len(obj) == 3 and all(isinstance(t, torch.Tensor) for t in obj) and \
+            tuple(obj[0].shape) == (32, 4) and tuple(obj[1].shape) == (32, 4) and tuple(obj[2].shape) == (32,):
+        return (obj[0], obj[1], obj[2] * c)                 # pack_first_x3: (W1a, W1b, b1)
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(scale_additive(v, c) for v in obj)
+    return obj
+
+
 def to_device(obj, device):
     """move a (nested) packed structure to ``device``."""
     if isinstance(obj, torch.Tensor):

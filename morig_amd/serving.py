@@ -31,6 +31,9 @@ class CapturedForward:
             self.graph = torch.cuda.CUDAGraph()
             outer = _bm._ctx.key
             _bm._ctx.key, _bm._ctx.root = model._param_key(), model     # the packed weights are current: no walk inside the capture
+            # the range shift the model settled on (NativeModule.forward): the capture runs the stacks at the same 2^-k
+            self.range_shift = model.range_shift if getattr(model, "_RANGE_SHIFT_ROOT", False) else 0
+            _bm._ctx.shift = self.range_shift
             try:
                 with torch.cuda.stream(side):
                     run = lambda: ops.guarded_async(dev, lambda: model._forward(*args, **kwargs))
@@ -40,6 +43,7 @@ class CapturedForward:
                         self.outputs, self.pending = run()
             finally:
                 _bm._ctx.key, _bm._ctx.root = outer, None
+                _bm._ctx.shift = 0
             torch.cuda.current_stream(dev).wait_stream(side)
         self._key = model._param_key()
 
@@ -141,8 +145,11 @@ class ForwardServer:
             self._graphs.pop(key, None)
             return self(data, input_flow)
         self.stats["replays"] += 1
-        if not cf.check():                                  # an operand left the split-fp16 range: the eager forward re-runs on fp32 MFMA
+        if not cf.check():
+            # an operand left the split-fp16 range: the eager forward answers (it raises the model's range shift, or re-runs on the exact
+            # path); the graph was captured at the old shift and would overflow again -- dropped, the next batch of this shape captures anew
             self.stats["fallbacks"] += 1
+            self._graphs.pop(key, None)
             with torch.no_grad():
                 return self.model(data, input_flow)
         return tuple(o.clone() for o in out) if self.copy_outputs else out

@@ -17,7 +17,7 @@ class EmuOps:
     name = "emulated"
     precision = "f32"
 
-    def guarded(self, device, fn, rerun=True):
+    def guarded(self, device, fn, rerun=True, retry=None):
         return fn()
 
     @property

@@ -673,3 +673,49 @@ def test_mixed_quad_edgeconv_network_equals_the_golden(monkeypatch):
     d = data_from(a, DEV)
     res = m(d, d.pred_flow)
     assert rel_excess(res[2], a["pred_shift"], TOL) <= 0
+
+
+def test_range_shift_keeps_large_activations_on_the_fast_path():
+    """[r06] activations beyond the split-fp16 range (|x| ~ 1e6 inside the stacks) no longer send every forward to the exact path: the
+    GCNRig stacks are positively homogeneous in (inputs, additive constants), so the forward that overflows raises the model's range
+    shift k (sticky), the stacks run at 2^-k -- exact powers of two in, the inverse out -- and the results stay within 1e-4 (of scale) of
+    the CPU oracle WITHOUT the exact-path re-run; the next forward starts at that k and runs once."""
+    from morig_amd import native
+    from oracle import nets
+    o = native.get_ops()
+    if o.precision == "f32":
+        pytest.skip("no range guard on the exact path")
+    kw = dict(num_keyframes=5, chn_output=3, aggr_method="attn")
+    batch = synth.make_batch([3, 4], n_side=12)
+    ours = synth.load_recipe(models.jointnet_motion(**kw).eval(), 3, mild=True)
+    ref = synth.load_recipe(nets.jointnet_motion(**kw).eval(), 3, mild=True)
+    # blow the activations of the head up with weights that stay ordinary: the BatchNorm affine behind its first unit x 3e5, so that x_1 --
+    # and, the stack being homogeneous, everything behind it up to the outputs -- is 1e5 ... 1e7 (the weights of every contraction keep
+    # their magnitudes: the split-fp16 image of a weight needs the fp16 range too, in both directions)
+    for net in (ours, ref):
+        sd = net.state_dict()
+        for k_ in ("jointnet.gcu_1.mlp.0.2.weight", "jointnet.gcu_1.mlp.0.2.bias"):
+            sd[k_] = sd[k_] * 3.0e5
+        net.load_state_dict(sd)
+    ours = ours.to(DEV)
+    with torch.no_grad():
+        want = ref(batch, batch.pred_flow)
+    d = batch.to(DEV)
+    assert ours.range_shift == 0
+    got = ours(d, d.pred_flow)
+    assert ours.range_shift > 0, "the forward did not overflow: the test's weights are too tame"
+    k1 = ours.range_shift
+    got2 = ours(d, d.pred_flow)                                    # starts at the sticky shift: one pass, same bits
+    assert ours.range_shift == k1
+    for a, b in zip(got, got2):
+        assert torch.equal(a, b)
+    for name, g_, w_ in zip(("motion_all", "motion_aggr", "pred_shift"), got, want):
+        assert rel_excess(g_, w_, TOL) <= 0, name
+    # and it really is the fast path: at the sticky shift a forward with its guard read deferred reports no overflow ...
+    out_async, pending = ours.forward_async(d, d.pred_flow)
+    assert pending.result() is True and torch.equal(out_async[2], got[2])
+    # ... while at shift 0 the same forward does
+    ours.range_shift = 0
+    _, pending0 = ours.forward_async(d, d.pred_flow)
+    assert pending0.result() is False
+    ours.range_shift = k1

@@ -146,6 +146,28 @@ def test_position_blocks_enter_the_unit_mlps_as_k_tails(emulated_ops):
         assert calls["tail_gemms"] == 0 and calls["pack"] == 0, calls
 
 
+@pytest.mark.parametrize("name,outs", [("jointnet_ragged", ("motion_all", "motion_aggr", "pred_shift")),
+                                       ("masknet_ragged", ("motion_all", "motion_aggr", "pred_mask")),
+                                       ("skinnet_ragged", ("motion_all", "motion_aggr", "skin_cls_pred")),
+                                       ("skinnet_dg1_lf1", (None, None, "skin_cls_pred"))])
+def test_range_shift_is_an_exact_rescaling_of_the_stacks(name, outs):
+    """[r06] NativeModule's range shift: with range_shift = k the GCNRig / SkinNet stacks run at 2^-k -- inputs and every additive constant of
+    their packs scaled down (packing.scale_additive), outputs scaled back -- and the networks still reproduce the reference's goldens:
+    the bookkeeping of which tensors are scaled (positions, flows, the aggregated motion feature, biases, BN shifts, the first-layer
+    bias of the x3 form; NOT the attention block between the stacks) on the op-layer emulation, where a power of two is exact."""
+    meta, a = load_golden(name)
+    d = data_from(a)
+    m = synth.load_recipe(models.__dict__[meta["arch"]](**meta["kwargs"]).eval(), meta["recipe_seed"])
+    base = m(d, d.pred_flow)
+    m.range_shift = 6
+    res = m(d, d.pred_flow)
+    assert m.range_shift == 6
+    for r, b, key in zip(res, base, outs):
+        if key is not None:
+            assert rel_excess(r, a[key], TOL) <= 0, key
+            assert maxdiff(r, b) <= 2e-6 * max(1.0, float(b.abs().max())), key      # fp32 emulation: only rounding positions move
+
+
 def test_packed_cache_invalidation():
     meta, a = load_golden("gcu_3_32")
     m = bm.GCU(3, 32).eval()
