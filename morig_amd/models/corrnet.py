@@ -137,14 +137,16 @@ class CorrNet(NativeModule):
         in_cols = [self.VTX + i for i in range(3)] + list(range(864))      # feature buffer: [x_1..x_4 | vtx chunk]
         fp4 = self.pts_fp4_module.nn     # input order (FPModule): [interpolated global(512) | x_skip(256)]
         W4 = fp4[0][0].weight.detach()
+        t1 = packing.pack_linear(W[:, 1024:], l1[0].bias, l1[2], in_cols=in_cols, k_total=self.VTX + 32)
+        fp4_1 = packing.pack_linear(W4[:, 512:], fp4[0][0].bias, fp4[0][2])
         return dict(
             glb=packing.pack_mlp_layer(self.vtx_mlp_glb[0]),
-            g=packing.pack_linear(W[:, :1024]),
-            t1=packing.pack_linear(W[:, 1024:], l1[0].bias, l1[2], in_cols=in_cols, k_total=self.VTX + 32),
+            g=packing.couple_rowbias(packing.pack_linear(W[:, :1024]), t1),      # (the row bias arrives in t1's normalised row units)
+            t1=t1,
             t2=packing.pack_mlp_layer(self.vtx_mlp[0][1]),
             t3=packing.pack_linear(self.vtx_mlp[1].weight, self.vtx_mlp[1].bias),
-            fp4_g=packing.pack_linear(W4[:, :512]),
-            fp4_1=packing.pack_linear(W4[:, 512:], fp4[0][0].bias, fp4[0][2]),
+            fp4_g=packing.couple_rowbias(packing.pack_linear(W4[:, :512]), fp4_1),
+            fp4_1=fp4_1,
             fp4_2=packing.pack_mlp_layer(fp4[1]),
             pm1=packing.pack_mlp_layer(self.pts_mlp[0][0]),
             pm2=packing.pack_linear(self.pts_mlp[1].weight, self.pts_mlp[1].bias),

@@ -135,16 +135,20 @@ class GCNRig(NativeModule):
         # reference column order of the transform's input (:65): [x_global(1024) | pos(3) | feature(F) | x_1 x_2 x_3]
         Wg, Wrest = W[:, :1024], W[:, 1024:]
         in_cols = ([self.POS + i for i in range(3)] + [self.FEAT + i for i in range(F)] + list(range(self.POS)))
+        t1 = packing.pack_linear(Wrest, l1[0].bias, l1[2], in_cols=in_cols, k_total=self.FEAT + F)
+        t1m = (packing.pack_linear(Wrest, l1[0].bias, l1[2],
+                                   in_cols=[self.POS + i for i in range(3)] + [self.POS + 4 + i for i in range(F)] + list(range(self.POS)),
+                                   k_total=self.POS + 4 + F) if F == 3 else None)
+        # t1 and t1m hold the same rows in two column orders, so their row factors agree and ONE row bias `g` serves both
+        assert t1m is None or t1.row_factor is None or torch.equal(t1.row_factor, t1m.row_factor)
         return dict(
             glb=packing.pack_mlp_layer(self.mlp_glb[0]),
-            g=packing.pack_linear(Wg),                                   # x_global @ Wg^T  -> per-mesh row bias
-            t1=packing.pack_linear(Wrest, l1[0].bias, l1[2], in_cols=in_cols, k_total=self.FEAT + F),
+            g=packing.couple_rowbias(packing.pack_linear(Wg), t1),       # x_global @ Wg^T  -> per-mesh row bias (in t1's row units)
+            t1=t1,
             # [r05] merged layout (3-channel feature next to the positions in ONE 32-column chunk: K = POS + 7 -> POS + 32 instead of
             # POS + 35 -> POS + 64, one K chunk of 28 less in the largest GEMM of the motion pass); used when gcu_1 runs on the raw
             # 3-channel rows (morig_edgeconv_x3) and therefore never reads the feature window of the wide buffer (`run`)
-            t1m=(packing.pack_linear(Wrest, l1[0].bias, l1[2],
-                                     in_cols=[self.POS + i for i in range(3)] + [self.POS + 4 + i for i in range(F)] + list(range(self.POS)),
-                                     k_total=self.POS + 4 + F) if F == 3 else None),
+            t1m=t1m,
             t2=packing.pack_mlp_layer(tr[0][1]),
             t3=packing.pack_linear(tr[1].weight, tr[1].bias),
         )
@@ -386,11 +390,12 @@ class SkinNet_inner(NativeModule):
     def _pack(self):
         l1 = self.cls_branch[0][0]
         W = l1[0].weight.detach()                     # input order (:180): [x_3(256) | x_global(1024)]
+        c1 = packing.pack_linear(W[:, :256], l1[0].bias, l1[2])
         return dict(
             m1=packing.pack_mlp_layer(self.multi_layer_tranform2[0]),
             m2=packing.pack_mlp_layer(self.multi_layer_tranform2[1]),
-            g=packing.pack_linear(W[:, 256:]),
-            c1=packing.pack_linear(W[:, :256], l1[0].bias, l1[2]),
+            g=packing.couple_rowbias(packing.pack_linear(W[:, 256:]), c1),
+            c1=c1,
             c2=packing.pack_mlp_layer(self.cls_branch[0][1]),
             c3=packing.pack_linear(self.cls_branch[1].weight, self.cls_branch[1].bias),
         )

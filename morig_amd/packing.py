@@ -13,11 +13,44 @@ Weights are zero padded to the kernels' tile grid: rows to 32/64/128, K to a mul
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
 import torch
 import torch.nn as nn
+
+# Row normalisation [r06]. fp16 has a 5-bit exponent: the (hi, lo) split of a weight w carries 22 bits only while lo = fp16(w - hi) is a
+# NORMAL half, i.e. |w| >= 0.125; below that lo is a subnormal with absolute precision 2^-25, so a row whose largest entry is m is carried
+# to 2^-25 / m of its size: 21 bits for the rows of a He-initialised Linear (m ~ 0.08), 12 bits for a row folded with a small BatchNorm
+# scale (W2 diag(s1), m ~ 1e-4), and a row above 65 000 has no image at all (the exact path for ever). A row is therefore multiplied by the
+# power of two that puts its largest entry into [4096, 8192) -- exact -- and the factor is undone where it costs nothing:
+# s act(W x + b) + t = (s / f) act((f W) x + f b) + t for f > 0, so bias and BN scale absorb it at pack time and no kernel changes.
+# Where it is applied (MORIG_PACK_NORMALISE): "auto" (default) -- only a layer with a row that needs it (largest entry < 2^-6: fewer than
+# 19 bits; or >= 2^14: about to leave the range); "all"; "0" = off. Why not everywhere, when it is exact and free of kernel changes:
+# measured on the headline (tools/gpu_r06w*.sh, same box, interleaved) "all" costs 0.3-0.7 % of the step and lowers the network-level
+# errors of the goldens by 0-45 % (4.2e-6 -> 3.2e-6 on the headline mesh) -- the bias-only [A | B] producers gain a scale vector to read,
+# and the EdgeConv kernel itself runs 1 % slower on normalised W2 images: with every lo half a NORMAL fp16 number its mantissa bits are
+# all live, the MFMA operands toggle more, and the kernel sits on the power cap. Ordinary layers already carry 20-21 bits.
+PACK_NORMALISE = os.environ.get("MORIG_PACK_NORMALISE", "auto")
+PACK_NORMALISE = {"1": "all", "": "auto"}.get(PACK_NORMALISE, PACK_NORMALISE)
+assert PACK_NORMALISE in ("auto", "all", "0"), PACK_NORMALISE
+_ROW_TARGET = 8192.0
+
+
+def _rows_need_normalising(W: torch.Tensor) -> bool:
+    m = W.detach().abs().amax(dim=1)
+    m = m[m > 0]
+    return bool(m.numel()) and (not bool(torch.isfinite(m).all()) or float(m.min()) < 2.0 ** -6 or float(m.max()) >= 2.0 ** 14)
+
+
+def _row_factors(W: torch.Tensor) -> torch.Tensor:
+    """per row the power of two f with max|row| * f in [4096, 8192) (1 for an all-zero or non-finite row)"""
+    m = W.detach().abs().amax(dim=1).double()
+    e = torch.floor(torch.log2(_ROW_TARGET / m.clamp_min(1e-300)))
+    ok = torch.isfinite(m) & (m > 0)
+    e = torch.where(ok, e, torch.zeros_like(e)).clamp(-120.0, 120.0)
+    return torch.exp2(e).float()
 
 
 def _roundup(x: int, m: int) -> int:
@@ -45,6 +78,7 @@ class PackedLinear:
     K: int
     Wsplit: Optional[torch.Tensor] = None   # split-fp16 image of W (same shape/stride), None = fp32 only
     Wsplit_bf16: Optional[torch.Tensor] = None   # split-bf16 image (gradient contractions, train_backward.py): takes precedence when set
+    row_factor: Optional[torch.Tensor] = None    # [Npad] the power of two every row of W (and bias) was multiplied by; scale carries 1 / it
 
 
 @dataclass
@@ -136,8 +170,37 @@ def pack_linear(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, bn: O
     if bn is not None:
         s, t = bn_affine(bn)
     Wp = Wp.contiguous()
-    return PackedLinear(Wp, _pad_vec(bias.detach() if bias is not None else torch.zeros(N, device=W.device), Npad),
-                        _pad_vec(s, Npad, 1.0), _pad_vec(t, Npad), N, K, split_f16(Wp) if split else None)
+    bp = _pad_vec(bias.detach() if bias is not None else torch.zeros(N, device=W.device), Npad)
+    sp, tp, rf = _pad_vec(s, Npad, 1.0), _pad_vec(t, Npad), None
+    if split and (PACK_NORMALISE == "all" or (PACK_NORMALISE == "auto" and _rows_need_normalising(Wp))):
+        rf = _row_factors(Wp)
+        Wp = (Wp * rf[:, None]).contiguous()
+        bp = bp * rf
+        sp = (sp if sp is not None else torch.ones(Npad, dtype=torch.float32, device=W.device)) / rf
+        tp = tp if tp is not None else torch.zeros(Npad, dtype=torch.float32, device=W.device)
+    return PackedLinear(Wp, bp, sp, tp, N, K, split_f16(Wp) if split else None, None, rf)
+
+
+def couple_rowbias(g: PackedLinear, main: PackedLinear) -> PackedLinear:
+    """`g` produces the per-segment row bias that `main` adds in front of its activation (morig_gemm: act(X W^T + bias + rowbias[seg])):
+    the row bias has to arrive in main's normalised row units, so g's output scale takes main's row factors on top of undoing its own."""
+    if main.row_factor is None:
+        return g
+    one = torch.ones_like(main.row_factor)
+    gs = g.scale if g.scale is not None else one[: g.W.shape[0]]
+    n = min(gs.numel(), main.row_factor.numel())
+    gs = gs.clone()
+    gs[:n] = gs[:n] * main.row_factor[:n]
+    shift = g.shift if g.shift is not None else torch.zeros_like(gs)
+    return PackedLinear(g.W, g.bias, gs, shift, g.N, g.K, g.Wsplit, g.Wsplit_bf16, g.row_factor)
+
+
+def _normalise_edge(W2: torch.Tensor, b2: torch.Tensor, s2: torch.Tensor):
+    """row normalisation of the second edge Linear: (f W2, f b2, s2 / f); the kernels' sign trick reads sign(s2), which f > 0 leaves"""
+    if PACK_NORMALISE == "0" or (PACK_NORMALISE == "auto" and not _rows_need_normalising(W2)):
+        return W2, b2, s2
+    rf = _row_factors(W2)
+    return (W2 * rf[:, None]).contiguous(), b2 * rf, s2 / rf
 
 
 def pack_mlp_layer(layer: nn.Sequential, **kw) -> PackedLinear:
@@ -164,9 +227,9 @@ def pack_edge_pair(mlps: Sequence[nn.Sequential]):
         Wf, bf = fold_hidden_affine(lin2.weight.detach().float(), lin2.bias.detach().float(), s1, t1)
         W2 = torch.zeros((Hp, Kp), dtype=torch.float32, device=W1.device)
         W2[:H, :H] = Wf
-        W2 = W2.contiguous()
-        edges.append(PackedEdge(H, None, None, W2, _pad_vec(bf, Hp), _pad_vec(s2, Hp, 1.0), _pad_vec(t2, Hp),
-                                split_f16(W2) if H >= 32 else None))
+        W2, b2p, s2p = _normalise_edge(W2.contiguous(), _pad_vec(bf, Hp), _pad_vec(s2, Hp, 1.0)) if H >= 32 else \
+            (W2.contiguous(), _pad_vec(bf, Hp), _pad_vec(s2, Hp, 1.0))
+        edges.append(PackedEdge(H, None, None, W2, b2p, s2p, _pad_vec(t2, Hp), split_f16(W2) if H >= 32 else None))
     vertex = pack_linear(torch.cat(rows, 0), torch.cat(biases, 0))
     return vertex, edges
 
@@ -219,10 +282,11 @@ def pack_pos_groups(units):
             W2 = torch.zeros((max(H, 32), _roundup(H, 32)), dtype=torch.float32, device=rows[-1].device)
             W2[:D, :D] = W2s[0]
             W2[D:H, D:H] = W2s[1]
-            W2 = W2.contiguous()
             Hp = max(H, 32)
-            pe.append(PackedEdge(H, None, None, W2, _pad_vec(torch.cat(b2s), Hp), _pad_vec(torch.cat(s2s), Hp, 1.0), _pad_vec(torch.cat(t2s), Hp),
-                                 split_f16(W2) if H >= 32 else None))
+            W2, b2p, s2p = W2.contiguous(), _pad_vec(torch.cat(b2s), Hp), _pad_vec(torch.cat(s2s), Hp, 1.0)
+            if H >= 32:
+                W2, b2p, s2p = _normalise_edge(W2, b2p, s2p)
+            pe.append(PackedEdge(H, None, None, W2, b2p, s2p, _pad_vec(torch.cat(t2s), Hp), split_f16(W2) if H >= 32 else None))
         # (et, eg, first_tpl, first_geo): `first_*` = the first Linear in the form morig_edgeconv_x3 evaluates in its loader (P == 3)
         edges.append((pe[0], pe[1], firsts[-2], firsts[-1]))
     vertex = pack_linear(torch.cat(rows, 0), torch.cat(biases, 0))
@@ -271,7 +335,7 @@ def scale_additive(obj, c: float):
         return obj
     if isinstance(obj, PackedLinear):
         return PackedLinear(obj.W, None if obj.bias is None else obj.bias * c, obj.scale, None if obj.shift is None else obj.shift * c,
-                            obj.N, obj.K, obj.Wsplit, obj.Wsplit_bf16)
+                            obj.N, obj.K, obj.Wsplit, obj.Wsplit_bf16, obj.row_factor)
     if isinstance(obj, PackedEdge):
         return PackedEdge(obj.H, obj.s1, None if obj.t1 is None else obj.t1 * c, obj.W2, obj.b2 * c, obj.s2, obj.t2 * c, obj.W2split)
     if isinstance(obj, dict):

@@ -152,6 +152,8 @@ def test_exact_path_on_bf16x6_is_float32_class(M, N, K, scale):
     lin = _lin(N, K, 4, bn=False)
     lin.W = lin.W * (1.0e3 if scale > 1.0e4 else 1.0)
     ref = (x[:, :K].double() @ lin.W[:N, :K].double().t() + lin.bias[:N].double())
+    if lin.scale is not None:                      # (row-normalised pack: the power-of-two factors are undone through scale)
+        ref = ref * lin.scale[:N].double() + lin.shift[:N].double()
     errs = {}
     try:
         for mode in ("f32", "bf16x6"):

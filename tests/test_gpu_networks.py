@@ -719,3 +719,48 @@ def test_range_shift_keeps_large_activations_on_the_fast_path():
     _, pending0 = ours.forward_async(d, d.pred_flow)
     assert pending0.result() is False
     ours.range_shift = k1
+
+
+def test_row_normalised_weights_keep_odd_magnitudes_accurate_and_on_the_fast_path():
+    """[r06] packing.py's row normalisation. (1) A small BatchNorm scale behind the first edge Linear (gamma x 1e-5, undone behind the
+    second: the network's function is unchanged) makes the folded W2 diag(s1) ~ 1e-6, an fp16 SUBNORMAL: its split image used to carry
+    4-5 bits and the fast path answered with percent-level errors without any overflow to report. (2) A Linear whose weights are ~ 2e5
+    (its BatchNorm statistics scaled to match) used to have no fp16 image at all: every forward re-ran on the exact path. Both are now
+    ordinary fast-path layers: every row is scaled by a power of two into [4096, 8192) and the factor is undone through bias / scale."""
+    from morig_amd import native, packing
+    from oracle import nets
+    o = native.get_ops()
+    if o.precision == "f32":
+        pytest.skip("the split-fp16 images are not used on the exact path")
+    if packing.PACK_NORMALISE == "0":
+        pytest.skip("MORIG_PACK_NORMALISE=0")
+    kw = dict(num_keyframes=5, chn_output=3, aggr_method="attn")
+    batch = synth.make_batch([3, 4], n_side=12)
+    ours = synth.load_recipe(models.jointnet_motion(**kw).eval(), 3, mild=True)
+    ref = synth.load_recipe(nets.jointnet_motion(**kw).eval(), 3, mild=True)
+    with torch.no_grad():
+        want0 = ref(batch, batch.pred_flow)
+    c, big = 1.0e-5, 2.0e6
+    for net in (ours, ref):
+        sd = net.state_dict()
+        for conv in ("edge_conv_tpl", "edge_conv_geo"):
+            p = "jointnet.gcu_2.%s.nn_x." % conv
+            for k_ in ("0.2.weight", "0.2.bias", "1.0.bias", "1.2.running_mean"):
+                sd[p + k_] = sd[p + k_] * c
+            sd[p + "1.2.weight"] = sd[p + "1.2.weight"] / c
+        p = "jointnet.gcu_2.mlp.0."
+        for k_ in ("0.weight", "0.bias", "2.running_mean"):
+            sd[p + k_] = sd[p + k_] * big
+        sd[p + "2.running_var"] = sd[p + "2.running_var"] * big * big
+        net.load_state_dict(sd)
+    with torch.no_grad():
+        want = ref(batch, batch.pred_flow)
+    for a, b in zip(want, want0):                                   # the rescaling left the function alone (the oracle says so)
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max()))
+    ours = ours.to(DEV)
+    d = batch.to(DEV)
+    got, pending = ours.forward_async(d, d.pred_flow)
+    assert pending.result() is True, "a layer fell off the fast path (no fp16 image of its weights?)"
+    assert ours.range_shift == 0
+    for name, g_, w_ in zip(("motion_all", "motion_aggr", "pred_shift"), got, want):
+        assert rel_excess(g_, w_, TOL) <= 0, name

@@ -478,3 +478,45 @@ def test_canonical_csr_does_not_depend_on_the_slot_order_of_the_build():
             assert bool((seg[1:] >= seg[:-1]).all())
         outs.append(csr.src[:E].clone())
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_row_normalisation_is_an_exact_refactoring_of_the_layer():
+    """packing.py [r06]: every output row of a split-packed Linear is multiplied by a power of two (largest entry into [4096, 8192)) and
+    the factor is undone through bias / scale, so s act(W x + b) + t is unchanged -- bit for bit in exact arithmetic; rows of any
+    magnitude (1e-7 ... 1e6) then have a full-precision split-fp16 image, and a row-bias producer is coupled to its consumer's factors"""
+    import torch
+    from morig_amd import packing
+    if packing.PACK_NORMALISE == "0":
+        pytest.skip("MORIG_PACK_NORMALISE=0")
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(40, 24)
+    bn = torch.nn.BatchNorm1d(24).eval()
+    with torch.no_grad():
+        lin.weight.mul_(torch.logspace(-7, 6, 24)[:, None])
+        lin.bias.mul_(torch.logspace(-7, 6, 24))
+        bn.running_var.uniform_(0.5, 2.0), bn.running_mean.normal_(), bn.weight.normal_(), bn.bias.normal_()
+    pk = packing.pack_linear(lin.weight, lin.bias, bn)
+    f = pk.row_factor
+    assert f is not None and torch.equal(torch.exp2(torch.log2(f).round()), f)                    # powers of two
+    m = pk.W[:24].abs().amax(1)
+    assert bool(((m >= 4096) & (m < 8192)).all()) and bool((f[24:] == 1).all())
+    assert pk.Wsplit is not None                                                                   # 1e6-scale rows: an image all the same
+    img = packing.unsplit_f16(pk.Wsplit, pk.W.shape[1])
+    assert float((img - pk.W).abs().max()) <= 8192 * 2.0 ** -21                                  # 22 bits of the row maximum, every row
+    x = torch.randn(64, 40, dtype=torch.float64)
+    want = bn.double()(torch.relu(lin.double()(x)))
+    got = pk.scale[:24].double() * torch.relu(x @ pk.W[:24, :40].double().T + pk.bias[:24].double()) + pk.shift[:24].double()
+    assert torch.allclose(got, want.detach(), rtol=1e-6, atol=1e-9 * float(want.abs().max()))
+    # the row-bias producer of a layer arrives in that layer's row units
+    g = packing.couple_rowbias(packing.pack_linear(torch.randn(24, 16)), pk)
+    own = g.row_factor[:24] if g.row_factor is not None else 1.0
+    assert torch.allclose(g.scale[:24] * own, f[:24])
+    # a layer with ordinary rows is left alone ("auto") ...
+    assert packing.PACK_NORMALISE != "auto" or packing.pack_linear(torch.randn(24, 16) * 0.1, torch.randn(24)).scale is None
+    # ... but not one whose rows the fp16 split would truncate, or could not hold at all
+    for mag in (1e-5, 3e5):
+        q = packing.pack_linear(torch.randn(24, 16) * mag, torch.randn(24))
+        assert q.row_factor is not None and q.Wsplit is not None and q.scale is not None
+    # the second edge Linear: sign(s2) (which the kernels' max trick reads) is untouched
+    W2, b2, s2 = packing._normalise_edge(torch.randn(32, 32) * 1e-5, torch.randn(32), -torch.rand(32) - 0.1)
+    assert bool((s2 < 0).all()) and 4096 <= float(W2.abs().amax(1).min())
