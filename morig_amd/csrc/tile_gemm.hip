@@ -886,6 +886,12 @@ extern "C" int morig_gemm(const morig_gemm_args* a_in, void* stream) {
         return launch_gemm16_dma(q, tiles_m, s);
     }
     if (tail) return MORIG_E_UNSUPPORTED;
+    // [r06] a few rows (per-mesh vectors): weights spread over the chip, plain fp32 FMAs (vertex_ops.hip); a->W is the fp32 matrix on
+    // every path, so the fast and the exact mode run the same kernel here
+    if (!bf16 && !a->rowbias && !a->x_split && !a->y_split && few_rows_gemm_takes(a->M, a->N, a->K, a->ldx, a->ldw)) {
+        ProfScope ps(K_MISC, s, flops, bytes);
+        return launch_few_rows_gemm(a->X, a->ldx, a->M, a->W, a->ldw, a->N, a->K, a->bias, a->scale, a->shift, a->relu, a->Y, a->ldy, s);
+    }
     if (bf16) {
         ProfScope ps(K_MISC, s, flops, bytes);
         if (a->N > 64) { p.tiles_n = cdiv(a->N, 128); return launch_tile<128, 32, LOAD_DENSE, MODE_STORE, PREC_BF16X3>(p, tiles_m * p.tiles_n, s); }

@@ -137,6 +137,84 @@ __global__ void frame_reduce_kernel(const float* __restrict__ x, int n, int T, i
     }
 }
 
+// Dense layer on a FEW rows (M <= 512: one row per mesh and keyframe -- the Linear behind the pooled global feature that produces the
+// row bias of `mlp_transform`, models/rignet.py:60-63 / models/corrnet.py:66-68; K <= 1024). The 128-row tile engine runs such a launch as
+// 8 ... 24 workgroups walking 32 K-chunks each, a chain of dependent load -> LDS -> barrier -> MFMA steps: 50 us whether M is 2 or 320
+// (profiles/r06z_timeline_B1.txt: two of them are 5 % of the one-mesh forward). Here the WEIGHTS are what is distributed: a workgroup
+// owns NC = 4 output columns, every lane keeps its K-slice of those 4 rows of W in registers (lane l: columns 4 l .. 4 l + 3 of every
+// 256-column block), and a wave takes rows m = wave, wave + 4, ... eight at a time (32 independent 16-byte loads in flight), multiplies in
+// fp32 FMAs and reduces over its lanes in a fixed order (deterministic). N / 4 workgroups: 256 for the 1024-wide layers. Plain float32
+// arithmetic -- no fp16 conversion, hence no range guard to report to.
+template <int NC, int KJ, int RB>
+__global__ __launch_bounds__(256) void few_rows_gemm_kernel(const float* __restrict__ X, int ldx, int M, const float* __restrict__ W, int ldw,
+                                                            int N, int K, const float* __restrict__ bias, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, int relu, float* __restrict__ Y, int ldy) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * NC;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 w[NC][KJ];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            const int k = 4 * lane + 256 * j;
+            w[c][j] = (n0 + c < N && k < K) ? *reinterpret_cast<const float4*>(W + (size_t)(n0 + c) * ldw + k) : zero4;
+        }
+    // lane c < NC finishes column n0 + c
+    const int nc = n0 + (lane < NC ? lane : 0);
+    const bool owner = lane < NC && nc < N;
+    const float b = (owner && bias) ? bias[nc] : 0.f, sc = (owner && scale) ? scale[nc] : 1.f, sh = (owner && shift) ? shift[nc] : 0.f;
+    for (int m0 = wave; m0 < M; m0 += 4 * RB) {                       // wave-uniform
+        float4 x[RB][KJ];
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int m = m0 + 4 * u;
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                const int k = 4 * lane + 256 * j;
+                x[u][j] = (m < M && k < K) ? *reinterpret_cast<const float4*>(X + (size_t)m * ldx + k) : zero4;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RB; ++u) {
+            const int m = m0 + 4 * u;
+            if (m >= M) break;                                        // wave-uniform
+            float mine = 0.f;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < KJ; ++j) {
+                    a = fmaf(x[u][j].x, w[c][j].x, a); a = fmaf(x[u][j].y, w[c][j].y, a);
+                    a = fmaf(x[u][j].z, w[c][j].z, a); a = fmaf(x[u][j].w, w[c][j].w, a);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+                if (lane == c) mine = a;
+            }
+            if (owner) {
+                float v = mine + b;
+                if (relu) v = v > 0.f ? v : 0.f;
+                Y[(size_t)m * ldy + nc] = v * sc + sh;
+            }
+        }
+    }
+}
+
+bool few_rows_gemm_takes(int M, int N, int K, int ldx, int ldw) {
+    static const bool off = getenv("MORIG_NO_FEW_ROWS") != nullptr;
+    return !off && M <= 512 && N >= 128 && K >= 128 && K <= 1024 && (K & 3) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0;
+}
+
+int launch_few_rows_gemm(const float* X, int ldx, int M, const float* W, int ldw, int N, int K, const float* bias, const float* scale,
+                         const float* shift, int relu, float* Y, int ldy, hipStream_t s) {
+    constexpr int NC = 4;
+    hipLaunchKernelGGL((few_rows_gemm_kernel<NC, 4, 8>), dim3(cdiv(N, NC)), dim3(256), 0, s, X, ldx, M, W, ldw, N, K, bias, scale, shift, relu,
+                       Y, ldy);
+    MORIG_LAUNCH_CHECK();
+    return MORIG_OK;
+}
+
 }  // namespace morig
 
 using namespace morig;

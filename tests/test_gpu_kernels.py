@@ -138,6 +138,38 @@ def test_gemm_store(ops, M, N, K, relu, bn):
     assert float(yb[:, :2].abs().sum()) == 0 and float(yb[:, 2 + N:].abs().sum()) == 0     # window respected
 
 
+@pytest.mark.parametrize("M,N,K,relu,bn", [(1, 1024, 1024, False, False), (2, 1024, 1024, True, True), (10, 1024, 1024, False, True),
+                                          (64, 1024, 1024, False, False), (320, 1024, 1024, True, True), (512, 300, 260, True, True),
+                                          (33, 130, 128, False, False), (7, 1024, 512, True, False), (5, 131, 1024, False, True)])
+def test_gemm_on_a_few_rows(ops, M, N, K, relu, bn):
+    """[r06] morig_gemm with at most 512 rows of fp32 X (the per-mesh vectors: the Linear behind the pooled global feature, models/rignet.py:
+    60-63) runs on vertex_ops.hip's few-rows kernel -- weights spread over N / 4 workgroups, fp32 FMAs, a fixed reduction order: float32-class
+    results (against float64), the column window respected, nothing beyond K read, bit-identical from run to run, the same in both modes"""
+    g = torch.Generator().manual_seed(M + N + K)
+    ld = K + 8
+    xb = torch.randn(M, ld, generator=g)
+    xb[:, 4 + K:] = float("nan")
+    xb[:, :4] = float("nan")
+    lin = _lin(N, K, 13, bn)
+    ref = xb[:, 4:4 + K].double() @ lin.W[:N, :K].double().t() + lin.bias[:N].double()
+    if relu:
+        ref = ref.clamp_min(0.0)
+    if lin.scale is not None:
+        ref = ref * lin.scale[:N].double() + lin.shift[:N].double()
+    xg, ling = xb.to(DEV), packing.to_device(lin, DEV)
+    outs = []
+    for _ in range(2):
+        yb = torch.zeros(M, N + 5, device=DEV)
+        ops.gemm(Mat.of(xg, 4, K), ling, relu, Y=Mat.of(yb, 2, N))
+        torch.cuda.synchronize()
+        outs.append(yb)
+    assert torch.equal(outs[0], outs[1])
+    yb = outs[0].cpu()
+    scale = max(1.0, ref.abs().max().item())
+    assert float((yb[:, 2:2 + N].double() - ref).abs().max()) <= 3e-6 * scale
+    assert float(yb[:, :2].abs().sum()) == 0 and float(yb[:, 2 + N:].abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,N,K,scale", [(1000, 256, 864, 1.0), (513, 64, 300, 1.0e3), (700, 1024, 256, 1.0e-3), (300, 32, 64, 3.0e4)])
 def test_exact_path_on_bf16x6_is_float32_class(M, N, K, scale):
     """The exact path's default arithmetic [r06] (MORIG_SPLIT_BF16X6: both fp32 operands split into three bf16 limbs in the kernel, six
