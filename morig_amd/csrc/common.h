@@ -91,7 +91,7 @@ struct EdgeX3Params {
 
 int launch_edge_x3(const EdgeX3Params& p, int n_tiles_cap, hipStream_t s);      // edge_x3.hip (persistent 32-wide EdgeConv on 3-channel inputs)
 int launch_gemm16_dmap(const GemmDmaParams& p, hipStream_t s);                // gemm_dmap.hip (persistent, 256 x 256 tiles)
-// vertex_ops.hip: a dense layer on at most 512 rows (fp32 X, W, Y; bias / ReLU / column affine), weights distributed over the chip
+// vertex_ops.hip: a dense layer on at most 128 rows (fp32 X, W, Y; bias / ReLU / column affine), weights distributed over the chip
 bool few_rows_gemm_takes(int M, int N, int K, int ldx, int ldw);
 int launch_few_rows_gemm(const float* X, int ldx, int M, const float* W, int ldw, int N, int K, const float* bias, const float* scale,
                          const float* shift, int relu, float* Y, int ldy, hipStream_t s);

@@ -291,7 +291,7 @@ __global__ void copy2d_pad_rep4_kernel(const float* __restrict__ src, int lds, i
     }
 }
 
-// K tails of several concatenations in one launch (morig_pack_tails): a thread = (tail t, row v, 4 adjacent columns) -> two 8-byte stores
+// K tails of several concatenations in one launch (morig_pack_tails): a thread = (row v, tail t, 4 adjacent columns) -> two 8-byte stores
 // (hi pairs, lo pairs) of the row's ONE split chunk; columns [0, wa) from src[v][col_a[t] ..], [wa, wa + wb) from src[v][col_b[t] ..], zeros behind
 struct TailCols { int a[MORIG_MAX_TAILS], b[MORIG_MAX_TAILS]; };
 __global__ void pack_tails_kernel(const float* __restrict__ src, int lds, int rows, TailCols tc, int wa, int wb, int n_tails,
@@ -301,7 +301,7 @@ __global__ void pack_tails_kernel(const float* __restrict__ src, int lds, int ro
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const int c = (int)(i & 7) * 4;
         const int64_t rv = i >> 3;
-        const int t = (int)(rv / rows); const int64_t r = rv - (int64_t)t * rows;
+        const int64_t r = rv / n_tails; const int t = (int)(rv - r * n_tails);     // row-major: a source row is read once, by neighbouring threads
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -710,8 +710,14 @@ extern "C" int morig_copy2d_pad(const float* src, int32_t lds, int32_t rows, int
     if (rows == 0 || slot_cols == 0) return MORIG_OK;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_COPY, s, 0.0, 4.0 * rows * (cols + slot_cols));
-    hipLaunchKernelGGL(copy2d_pad_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, dst, ldd,
-                       slot_cols, split, overflow);
+    // [r06] four columns per thread and 8- / 16-byte stores where the slot allows it (the one-replica case of copy2d_pad_rep4_kernel): the
+    // element-per-thread form below pays a 64-bit division and two 2-byte stores per element -- 75 us for the 1.3 M x 32 feature slot
+    if ((slot_cols & 3) == 0 && (ldd & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0)
+        hipLaunchKernelGGL(copy2d_pad_rep4_kernel, dim3(grid_for((int64_t)rows * (slot_cols >> 2))), dim3(256), 0, s, src, lds, rows, cols, 0,
+                           dst, ldd, slot_cols, 1, (int64_t)0, split, overflow);
+    else
+        hipLaunchKernelGGL(copy2d_pad_kernel, dim3(grid_for((int64_t)rows * slot_cols)), dim3(256), 0, s, src, lds, rows, cols, dst, ldd,
+                           slot_cols, split, overflow);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

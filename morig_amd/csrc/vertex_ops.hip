@@ -125,6 +125,61 @@ __global__ __launch_bounds__(256) void cls_attention_kernel(const float* __restr
     for (int i = threadIdx.x; i < nv * HC; i += blockDim.x) { const int v = i / HC, c = i - v * HC; y[(size_t)(v0 + v) * ldy + c] = so[v * (HC + 1) + c]; }
 }
 
+// The same operator for C = 32 channels (the networks' motion feature) without LDS [r06]: 8 lanes share a vertex, a lane owns 4 adjacent
+// channels of every frame (16-byte loads: a wave instruction moves 8 whole 128-byte rows), the T + 1 scores per head are 4-channel partial
+// dot products reduced over the 8 lanes (3 exchange steps), softmax and the weighted token sum stay in registers, 16-byte stores. The
+// LDS form above spends its time in index arithmetic (a division per staged element) and in (vertex, head) threads that leave half of
+// the block idle at 2 heads: 260 us for the headline's 262 144 vertices, 0.9 TB/s of the operator's 235 MB.
+template <int TMAX, int HMAX>
+__global__ __launch_bounds__(256) void cls_attention_c32_kernel(const float* __restrict__ x, int n, int T, int heads,
+                                                                const float* __restrict__ g, const float* __restrict__ cls,
+                                                                float* __restrict__ y, int ldy) {
+    const int lane = threadIdx.x & 63, q = lane & 7, vs = lane >> 3;
+    auto dot4 = [](const float4& a, const float4& b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); };
+    auto sum8 = [](float v) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); return v; };
+    const float4 c4 = *reinterpret_cast<const float4*>(cls + 4 * q);
+    float4 g4[HMAX];
+    float s0[HMAX];
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        g4[h] = h < heads ? *reinterpret_cast<const float4*>(g + h * 32 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s0[h] = sum8(dot4(c4, g4[h]));
+    }
+    const int64_t waves = (int64_t)gridDim.x * 4;
+    for (int64_t vb = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8; vb < n; vb += waves * 8) {        // wave-uniform
+        const int64_t v = vb + vs;
+        const bool live = v < n;
+        const float* xv = x + (live ? v : 0) * T * 32 + 4 * q;
+        float4 xt[TMAX];
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) xt[t] = t < T ? *reinterpret_cast<const float4*>(xv + t * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            if (h >= heads) break;                                    // uniform
+            float sc[TMAX];
+            float mx = s0[h];
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                if (t >= T) break;
+                sc[t] = sum8(dot4(xt[t], g4[h]));
+                mx = fmaxf(mx, sc[t]);
+            }
+            const float p0 = __expf(s0[h] - mx);
+            float den = p0;
+            float4 a = make_float4(p0 * c4.x, p0 * c4.y, p0 * c4.z, p0 * c4.w);
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                if (t >= T) break;
+                const float pt = __expf(sc[t] - mx);
+                den += pt;
+                a.x += pt * xt[t].x; a.y += pt * xt[t].y; a.z += pt * xt[t].z; a.w += pt * xt[t].w;
+            }
+            const float inv = 1.0f / den;
+            if (live) *reinterpret_cast<float4*>(y + v * ldy + h * 32 + 4 * q) = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+        }
+    }
+}
+
 __global__ void frame_reduce_kernel(const float* __restrict__ x, int n, int T, int C, int mode, float* __restrict__ y, int ldy) {
     const int64_t total = (int64_t)n * C;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -137,14 +192,15 @@ __global__ void frame_reduce_kernel(const float* __restrict__ x, int n, int T, i
     }
 }
 
-// Dense layer on a FEW rows (M <= 512: one row per mesh and keyframe -- the Linear behind the pooled global feature that produces the
+// Dense layer on a FEW rows (M <= 128: one row per mesh and keyframe -- the Linear behind the pooled global feature that produces the
 // row bias of `mlp_transform`, models/rignet.py:60-63 / models/corrnet.py:66-68; K <= 1024). The 128-row tile engine runs such a launch as
 // 8 ... 24 workgroups walking 32 K-chunks each, a chain of dependent load -> LDS -> barrier -> MFMA steps: 50 us whether M is 2 or 320
 // (profiles/r06z_timeline_B1.txt: two of them are 5 % of the one-mesh forward). Here the WEIGHTS are what is distributed: a workgroup
 // owns NC = 4 output columns, every lane keeps its K-slice of those 4 rows of W in registers (lane l: columns 4 l .. 4 l + 3 of every
 // 256-column block), and a wave takes rows m = wave, wave + 4, ... eight at a time (32 independent 16-byte loads in flight), multiplies in
 // fp32 FMAs and reduces over its lanes in a fixed order (deterministic). N / 4 workgroups: 256 for the 1024-wide layers. Plain float32
-// arithmetic -- no fp16 conversion, hence no range guard to report to.
+// arithmetic -- no fp16 conversion, hence no range guard to report to. Measured (profiles/r07b_*): M = 2 ... 64 rows 7 ... 27 us against the
+// tile engine's 50; M = 320 115 us (a wave walks 80 rows, six exchange steps per row and column) -- hence the 128-row limit.
 template <int NC, int KJ, int RB>
 __global__ __launch_bounds__(256) void few_rows_gemm_kernel(const float* __restrict__ X, int ldx, int M, const float* __restrict__ W, int ldw,
                                                             int N, int K, const float* __restrict__ bias, const float* __restrict__ scale,
@@ -203,7 +259,7 @@ __global__ __launch_bounds__(256) void few_rows_gemm_kernel(const float* __restr
 
 bool few_rows_gemm_takes(int M, int N, int K, int ldx, int ldw) {
     static const bool off = getenv("MORIG_NO_FEW_ROWS") != nullptr;
-    return !off && M <= 512 && N >= 128 && K >= 128 && K <= 1024 && (K & 3) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0;
+    return !off && M <= 128 && N >= 128 && K >= 128 && K <= 1024 && (K & 3) == 0 && (ldx & 3) == 0 && (ldw & 3) == 0;
 }
 
 int launch_few_rows_gemm(const float* X, int ldx, int M, const float* W, int ldw, int N, int K, const float* bias, const float* scale,
@@ -250,6 +306,15 @@ extern "C" int morig_cls_attention(const float* x, int32_t n, int32_t T, int32_t
     if (T < 1 || T > ATT_TMAX) return MORIG_E_UNSUPPORTED;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ProfScope ps(K_ATTN, s, 4.0 * n * heads * (T + 1) * C, 4.0 * n * (T * C + heads * C));
+    static const bool no_c32 = getenv("MORIG_ATTN_LDS") != nullptr;
+    if (C == 32 && heads <= 4 && !no_c32 && (ldy & 3) == 0 &&
+        ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(cls)) & 15) == 0) {
+        int blocks = cdiv(n, 32);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        hipLaunchKernelGGL((cls_attention_c32_kernel<ATT_TMAX, 4>), dim3(blocks), dim3(256), 0, s, x, n, T, heads, g, cls, y, ldy);
+        MORIG_LAUNCH_CHECK();
+        return MORIG_OK;
+    }
     const size_t lds = ((size_t)(heads + 1) * C + (size_t)ATT_VB * (T * C + 1) + (size_t)ATT_VB * (heads * C + 1)) * sizeof(float);
     if (lds > 64 * 1024) return MORIG_E_UNSUPPORTED;
     hipLaunchKernelGGL(cls_attention_kernel, dim3(cdiv(n, ATT_VB)), dim3(256), lds, s, x, n, T, C, heads, g, cls, y, ldy);

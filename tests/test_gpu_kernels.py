@@ -138,11 +138,27 @@ def test_gemm_store(ops, M, N, K, relu, bn):
     assert float(yb[:, :2].abs().sum()) == 0 and float(yb[:, 2 + N:].abs().sum()) == 0     # window respected
 
 
+@pytest.mark.parametrize("n,T,C,heads", [(1003, 5, 32, 2), (7, 1, 32, 1), (4099, 8, 32, 4), (70, 5, 32, 3), (130, 5, 16, 2), (65, 2, 48, 2)])
+def test_cls_attention_register_and_lds_forms(ops, n, T, C, heads):
+    """morig_cls_attention (models/rignet.py:28-43, CLS row only): the register-resident form for C = 32 [r06] (8 lanes per vertex, 16-byte
+    loads / stores, vertex counts that are not multiples of 8, 1 ... 4 heads, 1 ... 8 frames) and the LDS-staged form for other widths,
+    both against the float32 emulation of the reference's softmax(QK^T)V"""
+    g = torch.Generator().manual_seed(n + T + heads)
+    xa = torch.nn.functional.normalize(torch.randn(n, T, C, generator=g), dim=2) * 3.0
+    gq, cls = torch.randn(heads, C, generator=g), torch.randn(C, generator=g)
+    a_ref, a = torch.zeros(n, heads * C + 4), torch.full((n, heads * C + 4), 7.0, device=DEV)
+    EmuOps().cls_attention(xa, gq, cls, Mat.of(a_ref, 0, heads * C))
+    ops.cls_attention(xa.to(DEV), gq.to(DEV), cls.to(DEV), Mat.of(a, 0, heads * C))
+    torch.cuda.synchronize()
+    assert maxdiff(a[:, :heads * C], a_ref[:, :heads * C]) <= 3e-6
+    assert bool((a[:, heads * C:] == 7.0).all())                       # the window is respected
+
+
 @pytest.mark.parametrize("M,N,K,relu,bn", [(1, 1024, 1024, False, False), (2, 1024, 1024, True, True), (10, 1024, 1024, False, True),
-                                          (64, 1024, 1024, False, False), (320, 1024, 1024, True, True), (512, 300, 260, True, True),
+                                          (64, 1024, 1024, False, False), (128, 1024, 1024, True, True), (129, 1024, 1024, True, True), (100, 300, 260, True, True),
                                           (33, 130, 128, False, False), (7, 1024, 512, True, False), (5, 131, 1024, False, True)])
 def test_gemm_on_a_few_rows(ops, M, N, K, relu, bn):
-    """[r06] morig_gemm with at most 512 rows of fp32 X (the per-mesh vectors: the Linear behind the pooled global feature, models/rignet.py:
+    """[r06] morig_gemm with at most 128 rows of fp32 X (the per-mesh vectors: the Linear behind the pooled global feature, models/rignet.py:
     60-63) runs on vertex_ops.hip's few-rows kernel -- weights spread over N / 4 workgroups, fp32 FMAs, a fixed reduction order: float32-class
     results (against float64), the column window respected, nothing beyond K read, bit-identical from run to run, the same in both modes"""
     g = torch.Generator().manual_seed(M + N + K)
