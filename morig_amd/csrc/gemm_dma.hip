@@ -348,13 +348,19 @@ int launch_gemm16_dma(const GemmDmaParams& p0, int tiles_m128, hipStream_t s) {
                         ((reinterpret_cast<uintptr_t>(p.Y) & 15) == 0 && (p.ldy & 3) == 0 &&
                          (!p.rowbias || ((reinterpret_cast<uintptr_t>(p.rowbias) & 15) == 0 && (p.ld_rowbias & 3) == 0)));
     if (p.Xt && !(mode == 256 && p.N % 256 == 0 && !p.pool)) return MORIG_E_UNSUPPORTED;      // K tails: the 256 x 256 store kernel only
-    if (!p.Xt && mode == 256 && p.N % 256 == 0 && p.K > 32 && vec_ok && (persist == 2 || (persist == 1 && deep_wide))) {
+    // [r06] few rows (one to four meshes per launch: M = 4 096 is 16 row tiles of 256): when the launch has at most MORIG_DMA_SMALL_TILES
+    // (default 256 = one per CU) 256 x 256 tiles, CUs idle or run a single workgroup -- the 128 x 128 kernel below makes four times as many
+    // workgroups of it, two per CU (its extra LDS-DMA pieces per MFMA do not matter where the chip is not full). Served one-mesh forward
+    // 1.79 -> 1.66-1.69 ms, two meshes 2.34 -> 2.27, eight 6.29 -> 6.26 (thresholds 0 / 64 / 128 / 256 on one box: profiles/r07g_*)
+    static const int small_tiles = [] { const char* e = getenv("MORIG_DMA_SMALL_TILES"); return e ? atoi(e) : 256; }();
+    const bool few_tiles = !p.Xt && p.N % 256 == 0 && (long)cdiv(p.M, 256) * (p.N / 256) <= small_tiles;
+    if (!few_tiles && !p.Xt && mode == 256 && p.N % 256 == 0 && p.K > 32 && vec_ok && (persist == 2 || (persist == 1 && deep_wide))) {
         // (a ping-pong schedule for these launches -- the two waves of a SIMD alternating 48-MFMA slots and load slots, gemm_pp.hip in
         // commit a267b6e -- was built, bit-identical, and measured 3-11 % slower: profiles/r04b..r04d, DESIGN section 5 [r04])
         if (!p.pool) prof_retag(K_GEMM16_DMAP);       // the pooled kind already names this kernel
         return launch_gemm16_dmap(p0, s);
     }
-    if (mode == 256 && p.N % 256 == 0) {
+    if (mode == 256 && p.N % 256 == 0 && !few_tiles) {
         p.tiles_n = p.N / 256;
         const int nb = cdiv(p.M, 256) * p.tiles_n;
 #ifdef MORIG_DMA_TRACE

@@ -895,7 +895,8 @@ def test_gemm_fp32_x_wide_outputs(M, N, K, y_split, relu, bn):
     assert maxdiff(got, want) <= 2e-5 * max(1.0, want.abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 512, 544), (1000, 1024, 867), (129, 64, 64), (4096, 256, 1024)])
+# (launches of at most 256 tiles of 256 x 256 run on the 128 x 128 LDS-DMA kernel [r06], larger ones on the 256 x 256 kernels: both sizes)
+@pytest.mark.parametrize("M,N,K", [(300, 512, 544), (1000, 1024, 867), (129, 64, 64), (4096, 256, 1024), (17000, 1024, 867), (66000, 256, 96)])
 def test_gemm_split_fp16_activation_layout(M, N, K):
     """X consumed and Y produced in the split-fp16 activation layout (chunk = [32 hi | 32 lo])."""
     from morig_amd import native
@@ -928,11 +929,13 @@ def test_gemm_split_fp16_activation_layout(M, N, K):
     assert maxdiff(pg[present.to(DEV)], pw[present]) <= 2e-5 * max(1.0, pw[present].abs().max().item())
 
 
-@pytest.mark.parametrize("M,N,K", [(1000, 1024, 867), (700, 512, 256), (4133, 256, 1024), (513, 1024, 64), (2600, 1024, 899)])
+@pytest.mark.parametrize("M,N,K", [(1000, 1024, 867), (700, 512, 256), (4133, 256, 1024), (513, 1024, 64), (2600, 1024, 899),
+                                   (17000, 1024, 800), (16500, 1024, 288), (33000, 512, 64), (66000, 256, 1024)])
 @pytest.mark.parametrize("segs", ["one", "tiles", "ragged"])
 @pytest.mark.parametrize("y_split,relu", [(False, False), (True, True)])
 def test_gemm_dma_register_epilogue(M, N, K, segs, y_split, relu):
-    """the LDS-DMA GEMMs' store launches (gemm_dma.hip one tile per workgroup, gemm_dmap.hip persistent) run their MFMAs
+    """the LDS-DMA GEMMs' store launches (gemm_dma.hip one tile per workgroup, gemm_dmap.hip persistent; the first five shapes are
+    few-tile launches, which run on the 128 x 128 kernel [r06], the last four fill more than 256 tiles of 256 x 256) run their MFMAs
     transposed and store from registers (epilogue_store.h: store_tile_regs): bias and -- when a 256-row tile lies in one mesh --
     the row bias are the accumulators' initial value ("one", "tiles": every tile in one mesh), otherwise the row bias is added
     per row ("ragged": mesh boundaries inside tiles); fp32 and split-fp16 outputs, rows past M never written."""
