@@ -44,6 +44,11 @@ extern "C" {
 #define MORIG_EDGECONV_X3_ARGS_V3_SIZE 168u
 #define MORIG_SEGMAX_ARGS_V3_SIZE      144u
 #define MORIG_POINTCONV_ARGS_V3_SIZE   176u
+/* members appended since (a struct only grows at its end; a caller built against the smaller struct passes its own size and the library reads
+ * the new members as 0): round 6 -- init_with / split_with / skip_init / skip_split of morig_edgeconv_args, init_with / skip_init of
+ * morig_edgeconv_x3_args. sizeof of the CURRENT structs: */
+#define MORIG_EDGECONV_ARGS_SIZE       216u
+#define MORIG_EDGECONV_X3_ARGS_SIZE    184u
 
 /* status codes */
 #define MORIG_OK              0
@@ -204,6 +209,17 @@ typedef struct morig_edgeconv_args {
                                           H = 256 split-fp16 launches with out_split then take the mixed-quad form of the W2-stationary
                                           kernel (morig_edgeconv_can_split_out answers for it); everywhere else the flag is ignored -- a
                                           MIN4 CSR is a valid plain CSR for every other kernel (max over a repeated row is the same max). */
+    /* [ABI 3, appended in round 6: callers built against the 192-byte struct leave these zero] the boundary passes of TWO launches in one
+     * launch each. A launch whose target segments straddle tile boundaries is bracketed by two small passes over exactly those rows of
+     * `out` (identity pattern in front of the kernel's atomics; with out_split the conversion of those rows behind it). The two EdgeConvs
+     * of a unit -- template graph and geodesic graph, models/basic_modules.py:165-177, 205-219 -- write disjoint column blocks and do not
+     * read each other's results, so their passes can share launches: call the FIRST launch with init_with = &second (its pass also
+     * prepares the second's rows) and skip_split = 1, then the SECOND with skip_init = 1 and split_with = &first (its conversion pass
+     * also converts the first's rows; both must be out_split launches for that half). Both structs must stay valid for both calls, the
+     * calls go to the same stream in that order, and nothing may read `out` of the first before the second has been enqueued. */
+    const struct morig_edgeconv_args* init_with;
+    const struct morig_edgeconv_args* split_with;
+    int32_t skip_init, skip_split;
 } morig_edgeconv_args;
 int morig_edgeconv(const morig_edgeconv_args* a, void* stream);
 /* 1 when morig_edgeconv would honour out_split for these arguments (pointers, widths, CSR form and the library's environment
@@ -230,6 +246,10 @@ typedef struct morig_edgeconv_x3_args {
     const float* b2; const float* s2; const float* t2;
     float* out; int32_t ldo;
     const void* W2_split; int32_t* overflow;
+    /* [ABI 3, appended in round 6] as morig_edgeconv_args.init_with / skip_init: the first launch of a pair prepares the shared rows of
+     * both, the second skips its pass (these launches never store split rows, so there is no conversion pass to share) */
+    const struct morig_edgeconv_x3_args* init_with;
+    int32_t skip_init, reserved0;
 } morig_edgeconv_x3_args;
 int morig_edgeconv_x3(const morig_edgeconv_x3_args* a, void* stream);
 

@@ -101,6 +101,8 @@ int launch_few_rows_gemm(const float* X, int ldx, int M, const float* W, int ldw
 static_assert(sizeof(morig_gemm_args) >= MORIG_GEMM_ARGS_V3_SIZE && sizeof(morig_edgeconv_args) >= MORIG_EDGECONV_ARGS_V3_SIZE &&
               sizeof(morig_edgeconv_x3_args) >= MORIG_EDGECONV_X3_ARGS_V3_SIZE && sizeof(morig_segmax_args) >= MORIG_SEGMAX_ARGS_V3_SIZE &&
               sizeof(morig_pointconv_args) >= MORIG_POINTCONV_ARGS_V3_SIZE, "argument structs only grow");
+static_assert(sizeof(morig_edgeconv_args) == MORIG_EDGECONV_ARGS_SIZE && sizeof(morig_edgeconv_x3_args) == MORIG_EDGECONV_X3_ARGS_SIZE,
+              "include/morig_hip.h states the current sizes");
 template <class T> static inline bool take_args(const T* a, T& mine, uint32_t v3_size) {
     if (!a) return false;
     const uint32_t n = a->struct_size;

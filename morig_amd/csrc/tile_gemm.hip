@@ -661,11 +661,20 @@ __device__ __forceinline__ int straddled_row(const int* __restrict__ rowptr, con
     return rep * rep_out + d;
 }
 
-__global__ __launch_bounds__(256) void init_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
-                                                                 int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out,
-                                                                 int tile_rows, int run, int replicas, int n_cand) {
+// One boundary pass may serve TWO launches [r06]: the template-graph and the geodesic-graph EdgeConv of a unit write disjoint column
+// blocks of the same rows, their passes are independent of each other's kernels, and at one mesh per forward a pass is a launch plus one
+// dependent index chain (7-9 us, 26 of them = 12 % of the forward): blockIdx.y selects the job.
+struct BoundaryJob { const int* rowptr; const int* dstS; int n_nodes, H; float* out; int ldo, rep_out, tile_rows, run, replicas, n_cand; int* ovf; };
+struct BoundaryJobs { BoundaryJob j[2]; };
+
+__global__ __launch_bounds__(256) void init_boundary_rows_kernel(const BoundaryJobs js) {
+    const BoundaryJob& b = js.j[blockIdx.y];
+    if ((int)blockIdx.x * 256 >= b.n_cand) return;
+    const int* __restrict__ rowptr = b.rowptr; const int* __restrict__ dstS = b.dstS;
+    float* __restrict__ out = b.out;
+    const int H = b.H, ldo = b.ldo;
     const int lane = threadIdx.x & 63;
-    const int d = straddled_row(rowptr, dstS, n_nodes, tile_rows, run, replicas, rep_out, blockIdx.x * 256 + threadIdx.x + 1, n_cand, false);
+    const int d = straddled_row(rowptr, dstS, b.n_nodes, b.tile_rows, b.run, b.replicas, b.rep_out, blockIdx.x * 256 + threadIdx.x + 1, b.n_cand, false);
     const bool vec = ((reinterpret_cast<uintptr_t>(out) | (uintptr_t)(ldo * 4) | (uintptr_t)(H * 4)) & 15) == 0;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     unsigned long long todo = __ballot(d >= 0);
@@ -683,14 +692,30 @@ __global__ __launch_bounds__(256) void init_boundary_rows_kernel(const int* __re
     }
 }
 
-static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
-                              int rep_out, int slots, hipStream_t s, int tile_rows = 128, int run = 1) {
+static BoundaryJob boundary_job(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo, int rep_out,
+                                int slots, int tile_rows, int run, int* ovf) {
+    BoundaryJob b = {};
+    b.rowptr = rowptr; b.dstS = dstS; b.n_nodes = n_nodes; b.H = H; b.out = out; b.ldo = ldo; b.rep_out = rep_out;
+    b.tile_rows = tile_rows; b.run = run; b.replicas = slots; b.ovf = ovf;
     const int n_cand = cdiv((long)cdiv(edge_capacity, tile_rows) * slots, run) - 1;      // upper bound (capacity >= E')
-    if (n_cand <= 0) return MORIG_OK;
-    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(cdiv(n_cand, 256)), dim3(256), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out,
-                       tile_rows, run, slots, n_cand);
+    b.n_cand = n_cand > 0 ? n_cand : 0;
+    return b;
+}
+
+static int init_boundary_rows(const BoundaryJob* jobs, int n, hipStream_t s) {
+    BoundaryJobs js = {};
+    int m = 0, most = 0;
+    for (int i = 0; i < n; ++i) if (jobs[i].n_cand > 0) { js.j[m++] = jobs[i]; most = jobs[i].n_cand > most ? jobs[i].n_cand : most; }
+    if (m == 0) return MORIG_OK;
+    hipLaunchKernelGGL(init_boundary_rows_kernel, dim3(cdiv(most, 256), m), dim3(256), 0, s, js);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
+}
+
+static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
+                              int rep_out, int slots, hipStream_t s, int tile_rows = 128, int run = 1) {
+    const BoundaryJob b = boundary_job(rowptr, dstS, n_nodes, edge_capacity, H, out, ldo, rep_out, slots, tile_rows, run, nullptr);
+    return init_boundary_rows(&b, 1, s);
 }
 
 // out_split launches (edge_rl.hip / edge_ws.hip): whole segments leave the kernel as split-fp16 halves, the shared rows above as fp32
@@ -699,14 +724,18 @@ static int init_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, i
 // instruction covers whole chunks, so every read of a chunk precedes every write to it). A segment that straddles several shared
 // boundaries is converted at the LAST one (once). Same lane-per-candidate index phase as the pass above; the rows are taken four at a
 // time so that four loads are in flight.
-__global__ __launch_bounds__(256) void split_boundary_rows_kernel(const int* __restrict__ rowptr, const int* __restrict__ dstS,
-                                                                  int n_nodes, int H, float* __restrict__ out, int ldo, int rep_out,
-                                                                  int tile_rows, int run, int replicas, int n_cand, int* __restrict__ ovf) {
+__global__ __launch_bounds__(256) void split_boundary_rows_kernel(const BoundaryJobs js) {
+    const BoundaryJob& b = js.j[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= b.n_cand) return;
+    const int* __restrict__ rowptr = b.rowptr; const int* __restrict__ dstS = b.dstS;
+    float* __restrict__ out = b.out;
+    int* __restrict__ ovf = b.ovf;
+    const int H = b.H, ldo = b.ldo;
     // 16 candidates per wave (lanes 0..15 run the index chain): a wave converts its rows one group of four after the other, a load
     // round trip each -- with 64 candidates per wave the launch was one long latency chain (24 us on average for 5 k rows)
     const int lane = threadIdx.x & 63;
     const int g = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + lane + 1;
-    const int d = lane < 16 ? straddled_row(rowptr, dstS, n_nodes, tile_rows, run, replicas, rep_out, g, n_cand, true) : -1;
+    const int d = lane < 16 ? straddled_row(rowptr, dstS, b.n_nodes, b.tile_rows, b.run, b.replicas, b.rep_out, g, b.n_cand, true) : -1;
     unsigned long long todo = __ballot(d >= 0);
     float am = 0.f;
     bool bad = false;                                                 // a NaN: fmaxf drops NaN operands, so the amax below never sees one
@@ -743,12 +772,12 @@ __global__ __launch_bounds__(256) void split_boundary_rows_kernel(const int* __r
     if (bad || !(am < 65000.f)) *ovf = 1;
 }
 
-static int split_boundary_rows(const int* rowptr, const int* dstS, int n_nodes, int edge_capacity, int H, float* out, int ldo,
-                               int rep_out, int slots, hipStream_t s, int tile_rows, int run, int* ovf) {
-    const int n_cand = cdiv((long)cdiv(edge_capacity, tile_rows) * slots, run) - 1;
-    if (n_cand <= 0) return MORIG_OK;
-    hipLaunchKernelGGL(split_boundary_rows_kernel, dim3(cdiv(n_cand, 64)), dim3(256), 0, s, rowptr, dstS, n_nodes, H, out, ldo, rep_out,
-                       tile_rows, run, slots, n_cand, ovf);
+static int split_boundary_rows(const BoundaryJob* jobs, int n, hipStream_t s) {
+    BoundaryJobs js = {};
+    int m = 0, most = 0;
+    for (int i = 0; i < n; ++i) if (jobs[i].n_cand > 0) { js.j[m++] = jobs[i]; most = jobs[i].n_cand > most ? jobs[i].n_cand : most; }
+    if (m == 0) return MORIG_OK;
+    hipLaunchKernelGGL(split_boundary_rows_kernel, dim3(cdiv(most, 64), m), dim3(256), 0, s, js);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }
@@ -1096,16 +1125,39 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a_in, void* stream) {
     const bool f16 = a->W2_split != nullptr;
     const EdgePlan pl = edge_plan(a);
     const bool wide = pl.wide, one_shot = pl.one_shot, pp_ok = pl.pp_ok, use_rl = pl.use_rl, use_ws = pl.use_ws;
-    const int tile_rows = pl.tile_rows;
     if (a->out_split && !pl.split_ok) return MORIG_E_UNSUPPORTED;
 
-    // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows
-    {
-        const int slots = a->replicas;
-        const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo,
-                                           a->out_rep_stride, slots, s, tile_rows, pl.run);
+    // tile-straddling target segments combine through integer-atomic float max: identity in exactly those rows -- of this launch and,
+    // with init_with, of the partner launch that follows (which then comes with skip_init)
+    auto job_of = [](const morig_edgeconv_args* q, const EdgePlan& qp) {
+        return boundary_job(q->rowptr, q->dst_sorted, q->n_nodes, q->edge_capacity, q->H, q->out, q->ldo, q->out_rep_stride, q->replicas,
+                            qp.tile_rows, qp.run, q->overflow);
+    };
+    // the partner's arguments, checked as its own call will check them (nothing of it is launched here but the pass over its rows)
+    morig_edgeconv_args other;
+    auto partner = [&](const morig_edgeconv_args* q_in, EdgePlan& qp) -> int {
+        if (!take_args(q_in, other, MORIG_EDGECONV_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+        TileParams tp = {};
+        const int stp = edge_common(&other, tp);
+        if (stp != MORIG_OK) return stp;
+        if (other.in_rep_stride < 0 || (other.replicas > 1 && other.out_rep_stride < other.n_nodes)) return MORIG_E_INVALID;
+        qp = edge_plan(&other);
+        if (other.out_split && !qp.split_ok) return MORIG_E_UNSUPPORTED;
+        return MORIG_OK;
+    };
+    if (!a->skip_init) {
+        BoundaryJob jobs[2];
+        int nj = 0;
+        jobs[nj++] = job_of(a, pl);
+        if (a->init_with) {
+            EdgePlan qp;
+            const int stp = partner(a->init_with, qp);
+            if (stp != MORIG_OK) return stp;
+            jobs[nj++] = job_of(&other, qp);
+        }
+        const int st2 = init_boundary_rows(jobs, nj, s);
         if (st2 != MORIG_OK) return st2;
-    }
+    } else if (a->init_with) return MORIG_E_INVALID;
 
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
     const double flops = 2.0 * E * a->H * (double)a->H;
@@ -1131,15 +1183,28 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a_in, void* stream) {
                 if (a->H == 128) prof_retag(K_EDGE16_H128_WS);
                 st3 = launch_edge_ws(q, cdiv(a->edge_capacity, a->H == 256 ? 64 : 128) * a->replicas, s);
             }
-            if (st3 != MORIG_OK || !a->out_split) return st3;
-            // the rows two tiles share were combined as fp32 atomics: into the split layout now
-            return split_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, a->H, a->out, a->ldo, a->out_rep_stride,
-                                       a->replicas, s, tile_rows, pl.run, a->overflow);
+            if (st3 != MORIG_OK || !a->out_split) return (st3 == MORIG_OK && (a->split_with || a->skip_split)) ? MORIG_E_INVALID : st3;
+            // the rows two tiles share were combined as fp32 atomics: into the split layout now (skip_split: the partner's pass does it,
+            // behind its own kernel; split_with: this pass also converts the partner's rows, whose kernel ran in front of this one)
+            if (a->skip_split) return a->split_with ? MORIG_E_INVALID : MORIG_OK;
+            BoundaryJob jobs[2];
+            int nj = 0;
+            jobs[nj++] = job_of(a, pl);
+            if (a->split_with) {
+                EdgePlan qp;
+                const int stp = partner(a->split_with, qp);
+                if (stp != MORIG_OK) return stp;
+                if (!other.out_split || !(qp.use_rl || qp.use_ws)) return MORIG_E_INVALID;
+                jobs[nj++] = job_of(&other, qp);
+            }
+            return split_boundary_rows(jobs, nj, s);
         }
+        if (a->split_with || a->skip_split) return MORIG_E_INVALID;      // (only the split-rows kernels have a conversion pass)
         if (one_shot || !pp_ok) { prof_retag(K_EDGE16_PC); return launch_edge_pc(q, nblocks, s); }
         if (a->H == 256) prof_retag(K_EDGE16_H256_PP);
         return launch_edge_pp(q, nblocks, s);
     }
+    if (a->split_with || a->skip_split) return MORIG_E_INVALID;
     if (f16) {
         switch (a->H) {
             case 32:  { ProfScope ps(K_EDGE16_H32, s, flops, bytes);  return launch_tile<32, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
@@ -1198,9 +1263,20 @@ extern "C" int morig_edgeconv_x3(const morig_edgeconv_x3_args* a_in, void* strea
         p.W = static_cast<const float*>(a->W2_split); p.ovf = a->overflow;
     }
     const int nblocks = p.tiles_per_rep * a->replicas;
-    { const int st2 = init_boundary_rows(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, 32, a->out, a->ldo, a->out_rep_stride,
-                                         a->replicas, s, 128);
-      if (st2 != MORIG_OK) return st2; }
+    if (!a->skip_init) {
+        BoundaryJob jobs[2];
+        int nj = 0;
+        jobs[nj++] = boundary_job(a->rowptr, a->dst_sorted, a->n_nodes, a->edge_capacity, 32, a->out, a->ldo, a->out_rep_stride, a->replicas, 128, 1, nullptr);
+        if (a->init_with) {                                // the partner launch that follows (with skip_init): its rows in the same pass
+            morig_edgeconv_x3_args o;
+            if (!take_args(a->init_with, o, MORIG_EDGECONV_X3_ARGS_V3_SIZE)) return MORIG_E_INVALID;
+            if (!o.rowptr || !o.dst_sorted || !o.out || o.H != 32 || o.n_nodes <= 0 || o.replicas <= 0 || o.edge_capacity <= 0 || o.ldo < 32 ||
+                (o.replicas > 1 && o.out_rep_stride < o.n_nodes)) return MORIG_E_INVALID;
+            jobs[nj++] = boundary_job(o.rowptr, o.dst_sorted, o.n_nodes, o.edge_capacity, 32, o.out, o.ldo, o.out_rep_stride, o.replicas, 128, 1, nullptr);
+        }
+        const int st2 = init_boundary_rows(jobs, nj, s);
+        if (st2 != MORIG_OK) return st2;
+    } else if (a->init_with) return MORIG_E_INVALID;
     const double E = (double)(a->edge_count > 0 ? a->edge_count : a->edge_capacity) * a->replicas;
     // algorithmic work: second layer 2 H^2 + first layer 2 * 6 * H per edge row; bytes: the two gathered 16-byte inputs
     ProfScope ps(f16 ? K_EDGE16_X3 : K_EDGE_X3, s, E * (2.0 * 32 * 32 + 12.0 * 32), 32.0 * E);

@@ -349,8 +349,9 @@ class GCU(NativeModule):
         # [r05] where the library takes it (wide layers on 4-aligned CSRs), the two EdgeConvs store split-fp16 rows and the unit MLP reads
         # them through the LDS-DMA GEMM (morig_edgeconv out_split); [x_tpl | x_geo] is the reference's order (:176), both chunk-aligned
         sp = H % 32 == 0 and _edge_rows_can_split(ops, ab, ec, csr_tpl, csr_geo, pk["et"], pk["eg"], H, 1, 0)
-        ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["et"], Mat.of(ec, 0, H), out_split=sp)
-        ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["eg"], Mat.of(ec, H, H), out_split=sp)
+        # (one call for the pair: the boundary passes of the two launches share launches, native.edgeconv_pair)
+        ops.edgeconv_pair(dict(A=Mat.of(ab, 0, H), B=Mat.of(ab, H, H), csr=csr_tpl, ec=pk["et"], out=Mat.of(ec, 0, H), out_split=sp),
+                          dict(A=Mat.of(ab, 2 * H, H), B=Mat.of(ab, 3 * H, H), csr=csr_geo, ec=pk["eg"], out=Mat.of(ec, H, H), out_split=sp))
         ops.gemm(Mat.of(ec), pk["mlp"], relu=True, Y=out, x_split=sp, y_split=split_out)
 
     def _forward(self, pos, tpl_edge_index, geo_edge_index):
@@ -437,10 +438,10 @@ class GCUMotion(NativeModule):
         ec = ops.empty(M, ldo, dev)          # [x_tpl(H) | pos_tpl(D) | x_geo(H) | pos_geo(D)] = torch.cat order (:216)
         if not use_x3 and "mlp_s" in pk and _edge_rows_can_split(ops, ab, ec, csr_tpl, csr_geo, pk["xt"], pk["xg"], H, replicas, n):
             # split-fp16 rows [x_tpl | x_geo | pos_tpl | pos_geo] straight from the EdgeConv kernels into the LDS-DMA GEMM
-            ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
-                         replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
-            ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H, H),
-                         replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True)
+            ops.edgeconv_pair(dict(A=Mat.of(ab, 0, H), B=Mat.of(ab, H, H), csr=csr_tpl, ec=pk["xt"], out=Mat.of(ec, 0, H),
+                                   replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True),
+                              dict(A=Mat.of(ab, 2 * H, H), B=Mat.of(ab, 3 * H, H), csr=csr_geo, ec=pk["xg"], out=Mat.of(ec, H, H),
+                                   replicas=replicas, in_rep_stride=n, out_rep_stride=n, out_split=True))
             if use_tail:
                 # [r06] the replica-invariant block is not copied into the replicas' rows: the GEMM reads it from the one tail row per vertex
                 # (the pos columns of `ec` stay unwritten and unread)
@@ -453,26 +454,28 @@ class GCUMotion(NativeModule):
                 ops.copy2d(pos_feat[0], Mat.of(p2, 0, D))
                 ops.copy2d(pos_feat[1], Mat.of(p2, D, D))
             else:
-                ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(p2, 0, D))
-                ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(p2, D, D))
+                ops.edgeconv_pair(dict(A=Mat.of(pab, 0, D), B=Mat.of(pab, D, D), csr=csr_tpl, ec=pk["pt"], out=Mat.of(p2, 0, D)),
+                                  dict(A=Mat.of(pab, 2 * D, D), B=Mat.of(pab, 3 * D, D), csr=csr_geo, ec=pk["pg"], out=Mat.of(p2, D, D)))
             ops.copy2d_rep(Mat.of(p2), Mat.of(ec, 2 * H, 2 * D, 0, n), replicas, n, split=True)
             ops.gemm(Mat.of(ec), pk["mlp_s"], relu=True, Y=out, x_split=True, y_split=split_out)
             return
         if use_x3:
-            ops.edgeconv_x3(x3, pk["x3t"], csr_tpl, pk["xt"], Mat.of(ec, 0, H), replicas=replicas, in_rep_stride=n, out_rep_stride=n)
-            ops.edgeconv_x3(x3, pk["x3g"], csr_geo, pk["xg"], Mat.of(ec, H + D, H), replicas=replicas, in_rep_stride=n, out_rep_stride=n)
+            ops.edgeconv_x3_pair(dict(X=x3, first=pk["x3t"], csr=csr_tpl, ec=pk["xt"], out=Mat.of(ec, 0, H),
+                                      replicas=replicas, in_rep_stride=n, out_rep_stride=n),
+                                 dict(X=x3, first=pk["x3g"], csr=csr_geo, ec=pk["xg"], out=Mat.of(ec, H + D, H),
+                                      replicas=replicas, in_rep_stride=n, out_rep_stride=n))
         else:
-            ops.edgeconv(Mat.of(ab, 0, H), Mat.of(ab, H, H), csr_tpl, pk["xt"], Mat.of(ec, 0, H),
-                         replicas=replicas, in_rep_stride=n, out_rep_stride=n)
-            ops.edgeconv(Mat.of(ab, 2 * H, H), Mat.of(ab, 3 * H, H), csr_geo, pk["xg"], Mat.of(ec, H + D, H),
-                         replicas=replicas, in_rep_stride=n, out_rep_stride=n)
+            ops.edgeconv_pair(dict(A=Mat.of(ab, 0, H), B=Mat.of(ab, H, H), csr=csr_tpl, ec=pk["xt"], out=Mat.of(ec, 0, H),
+                                   replicas=replicas, in_rep_stride=n, out_rep_stride=n),
+                              dict(A=Mat.of(ab, 2 * H, H), B=Mat.of(ab, 3 * H, H), csr=csr_geo, ec=pk["xg"], out=Mat.of(ec, H + D, H),
+                                   replicas=replicas, in_rep_stride=n, out_rep_stride=n))
         # position branch: independent of the keyframe -> computed once, copied to every replica
         if pos_feat is not None:
             ops.copy2d_rep(pos_feat[0], Mat.of(ec, H, D, 0, n), replicas, n)
             ops.copy2d_rep(pos_feat[1], Mat.of(ec, 2 * H + D, D, 0, n), replicas, n)
         else:
-            ops.edgeconv(Mat.of(pab, 0, D), Mat.of(pab, D, D), csr_tpl, pk["pt"], Mat.of(ec, H, D, 0, n))
-            ops.edgeconv(Mat.of(pab, 2 * D, D), Mat.of(pab, 3 * D, D), csr_geo, pk["pg"], Mat.of(ec, 2 * H + D, D, 0, n))
+            ops.edgeconv_pair(dict(A=Mat.of(pab, 0, D), B=Mat.of(pab, D, D), csr=csr_tpl, ec=pk["pt"], out=Mat.of(ec, H, D, 0, n)),
+                              dict(A=Mat.of(pab, 2 * D, D), B=Mat.of(pab, 3 * D, D), csr=csr_geo, ec=pk["pg"], out=Mat.of(ec, 2 * H + D, D, 0, n)))
             if replicas > 1:                            # one launch per column window instead of one per replica
                 ops.copy2d_rep(Mat.of(ec, H, D, 0, n), Mat.of(ec, H, D, n, n), replicas - 1, n)
                 ops.copy2d_rep(Mat.of(ec, 2 * H + D, D, 0, n), Mat.of(ec, 2 * H + D, D, n, n), replicas - 1, n)
@@ -514,12 +517,12 @@ def run_pos_groups(ops, packed_groups, pos: Mat, csr_tpl, csr_geo):
     out = []
     for g, (et, eg, ft, fg) in enumerate(edges):
         if x3:
-            ops.edgeconv_x3(pos, ft, csr_tpl, et, Mat.of(side, 2 * H * g, H))
-            ops.edgeconv_x3(pos, fg, csr_geo, eg, Mat.of(side, 2 * H * g + H, H))
+            ops.edgeconv_x3_pair(dict(X=pos, first=ft, csr=csr_tpl, ec=et, out=Mat.of(side, 2 * H * g, H)),
+                                 dict(X=pos, first=fg, csr=csr_geo, ec=eg, out=Mat.of(side, 2 * H * g + H, H)))
         else:
             c0 = 4 * H * g
-            ops.edgeconv(Mat.of(pab, c0, H), Mat.of(pab, c0 + H, H), csr_tpl, et, Mat.of(side, 2 * H * g, H))
-            ops.edgeconv(Mat.of(pab, c0 + 2 * H, H), Mat.of(pab, c0 + 3 * H, H), csr_geo, eg, Mat.of(side, 2 * H * g + H, H))
+            ops.edgeconv_pair(dict(A=Mat.of(pab, c0, H), B=Mat.of(pab, c0 + H, H), csr=csr_tpl, ec=et, out=Mat.of(side, 2 * H * g, H)),
+                              dict(A=Mat.of(pab, c0 + 2 * H, H), B=Mat.of(pab, c0 + 3 * H, H), csr=csr_geo, ec=eg, out=Mat.of(side, 2 * H * g + H, H)))
         for j in range(2):
             out.append((Mat.of(side, 2 * H * g + j * D, D), Mat.of(side, 2 * H * g + H + j * D, D)))
     if ops.split_activations and 2 * D <= 32 and len(out) <= 8 and hasattr(ops, "pack_tails") and os.environ.get("MORIG_GEMM_TAIL", "1") != "0":

@@ -62,6 +62,8 @@ class EdgeConvArgs(C.Structure):
         ("out_split", C.c_int32),
         ("exact_arith", C.c_int32),
         ("seg_min4", C.c_int32),
+        ("init_with", C.c_void_p), ("split_with", C.c_void_p),          # the boundary passes of a pair of launches (include/morig_hip.h)
+        ("skip_init", C.c_int32), ("skip_split", C.c_int32),
     ]
 
 
@@ -79,6 +81,7 @@ class EdgeConvX3Args(C.Structure):
         ("b2", c_f32p), ("s2", c_f32p), ("t2", c_f32p),
         ("out", c_f32p), ("ldo", C.c_int32),
         ("W2_split", C.c_void_p), ("overflow", c_i32p),
+        ("init_with", C.c_void_p), ("skip_init", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -266,6 +269,9 @@ def check(status: int, what: str) -> None:
         if status == -3:
             msg += f" [hipError_t={lib.morig_last_hip_error()}]"
         raise MorigNativeError(f"{what}: {msg}")
+
+
+PAIR_PASSES = os.environ.get("MORIG_EDGE_PAIR", "1") != "0"
 
 
 def _stream() -> C.c_void_p:
@@ -677,6 +683,43 @@ class NativeOps:
         a.out_split = 1 if out_split else 0
         check(self.lib.morig_edgeconv(C.byref(a), _stream()), "morig_edgeconv")
 
+    def edgeconv_pair(self, first: dict, second: dict):
+        """Two EdgeConv launches that write disjoint column blocks of the same rows and do not read each other's results (the template-
+        and the geodesic-graph EdgeConv of a unit): ``first`` / ``second`` are the keyword arguments of ``edgeconv``. Same results as the
+        two calls; their boundary passes share launches (morig_edgeconv_args.init_with / split_with: one identity pass in front of both
+        kernels, one conversion pass behind both when both store split rows) -- 2 x 2 small launches less per unit.
+        MORIG_EDGE_PAIR=0: two plain calls (A/B runs)."""
+        if not PAIR_PASSES:
+            self.edgeconv(**first)
+            self.edgeconv(**second)
+            return
+        calls = []
+        for kw in (first, second):
+            kw = dict(kw)
+            sp = bool(kw.pop("out_split", False))
+            _need_gpu(kw["A"].base, kw["B"].base, kw["out"].base)
+            a = self._edge_args(kw["A"], kw["B"], kw["csr"], kw["ec"], kw["out"], kw.get("replicas", 1), kw.get("in_rep_stride", 0),
+                                kw.get("out_rep_stride", 0))
+            a.out_split = 1 if sp else 0
+            calls.append(a)
+        a1, a2 = calls
+        a1.init_with, a2.skip_init = C.addressof(a2), 1
+        if a1.out_split and a2.out_split:
+            a1.skip_split, a2.split_with = 1, C.addressof(a1)
+        check(self.lib.morig_edgeconv(C.byref(a1), _stream()), "morig_edgeconv")
+        check(self.lib.morig_edgeconv(C.byref(a2), _stream()), "morig_edgeconv")
+
+    def edgeconv_x3_pair(self, first: dict, second: dict):
+        """the same for two ``edgeconv_x3`` launches (keyword arguments of ``edgeconv_x3``): one identity pass for both"""
+        if not PAIR_PASSES:
+            self.edgeconv_x3(**first)
+            self.edgeconv_x3(**second)
+            return
+        a1, a2 = (self._x3_args(**kw) for kw in (first, second))
+        a1.init_with, a2.skip_init = C.addressof(a2), 1
+        check(self.lib.morig_edgeconv_x3(C.byref(a1), _stream()), "morig_edgeconv_x3")
+        check(self.lib.morig_edgeconv_x3(C.byref(a2), _stream()), "morig_edgeconv_x3")
+
     def edgeconv_can_split_out(self, A: Mat, B: Mat, csr: CSR, ec, out: Mat, replicas: int = 1,
                                in_rep_stride: int = 0, out_rep_stride: int = 0) -> bool:
         """Would ``edgeconv(..., out_split=True)`` run for these arguments? (kernel choice, alignment, environment switches: the library
@@ -708,6 +751,10 @@ class NativeOps:
     def edgeconv_x3(self, X: Mat, first, csr: CSR, ec, out: Mat, replicas: int = 1, in_rep_stride: int = 0, out_rep_stride: int = 0):
         """EdgeConv on a 3-channel vertex input with the first Linear evaluated in the kernel (morig_edgeconv_x3). X: [rows, >= 4]
         window starting at column 0 of 16-byte aligned rows; first = (W1a [32, 4], W1b [32, 4], b1 [32]) from packing.pack_first_x3."""
+        a = self._x3_args(X, first, csr, ec, out, replicas, in_rep_stride, out_rep_stride)
+        check(self.lib.morig_edgeconv_x3(C.byref(a), _stream()), "morig_edgeconv_x3")
+
+    def _x3_args(self, X: Mat, first, csr: CSR, ec, out: Mat, replicas: int = 1, in_rep_stride: int = 0, out_rep_stride: int = 0):
         _need_gpu(X.base, out.base)
         assert ec.H == 32 and ec.s1 is None and X.col0 % 4 == 0 and X.ld % 4 == 0
         a = _args(EdgeConvX3Args)
@@ -723,7 +770,7 @@ class NativeOps:
         a.out, a.ldo = out.ptr, out.ld
         if self.fast and ec.W2split is not None:
             a.W2_split, a.overflow = ec.W2split.data_ptr(), self._flag(X.base.device).data_ptr()
-        check(self.lib.morig_edgeconv_x3(C.byref(a), _stream()), "morig_edgeconv_x3")
+        return a
 
     def edge_hidden(self, A: Mat, B: Mat, csr: CSR, ec, Z: Mat):
         """per-edge hidden activations Z [capacity, H] (rows >= E' untouched)."""

@@ -24,6 +24,14 @@ class EmuOps:
     def split_activations(self):
         return self.emulate_split
 
+    def edgeconv_pair(self, first, second):
+        self.edgeconv(**first)
+        self.edgeconv(**second)
+
+    def edgeconv_x3_pair(self, first, second):
+        self.edgeconv_x3(**first)
+        self.edgeconv_x3(**second)
+
     def empty(self, rows, cols, device, dtype=torch.float32):
         # poison, so a plan that reads something it never wrote fails loudly
         return torch.full((rows, cols), float("nan"), dtype=dtype, device=device)

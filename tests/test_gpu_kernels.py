@@ -393,6 +393,67 @@ def test_csr_build_min4_segments(ops, n, e, hub):
             assert sorted(segs[v]) == sorted(list(ref[v]) + extra), v
 
 
+@pytest.mark.parametrize("H,split", [(256, True), (128, True), (256, False), (32, False), (16, False)])
+@pytest.mark.parametrize("n,e1,e2,hub,reps", [(700, 5000, 9000, 3, 2), (20000, 120000, 300000, 777, 1), (64, 200, 90, None, 3)])
+def test_edgeconv_pair_shares_the_boundary_passes(ops, H, split, n, e1, e2, hub, reps):
+    """[r06] morig_edgeconv_args.init_with / split_with (native.edgeconv_pair): the two EdgeConvs of a unit -- two graphs, two column
+    blocks of the same rows -- with ONE identity pass in front of both kernels and, for split rows, ONE conversion pass behind both:
+    bit-identical to two plain calls, on the wide split-rows kernels, their fp32-rows form and the narrow tile engine, with hubs that
+    straddle many tiles and graphs of different sizes (the shared launch covers the larger candidate count); a pair whose flags do not
+    fit together is refused. The 3-channel form (morig_edgeconv_x3_args.init_with) likewise."""
+    from morig_amd import native
+    o = ops
+    if split and o.precision != "f16x3":
+        pytest.skip("split rows exist on the split-fp16 path only")
+    g = torch.Generator().manual_seed(H + n)
+    ei1, ei2 = _rand_graph(n, e1, 13, hub), _rand_graph(n, e2, 29, None if hub is None else hub + 5)
+    Hc = max(H, 32)
+    ab = torch.randn(n * reps, 4 * Hc, generator=g).to(DEV)
+    ec1, ec2 = (packing.to_device(_edge_pack(H, sd, folded=True), DEV) for sd in (5, 6))
+    wide = H >= 128
+    csr1, csr2 = (o.csr_build(ei.to(DEV), n, pad4=wide) for ei in (ei1, ei2))
+    ld = 2 * Hc + 64
+    kw = dict(replicas=reps, in_rep_stride=n, out_rep_stride=n)
+    c1 = dict(A=Mat.of(ab, 0, H), B=Mat.of(ab, Hc, H), csr=csr1, ec=ec1, **kw)
+    c2 = dict(A=Mat.of(ab, 2 * Hc, H), B=Mat.of(ab, 3 * Hc, H), csr=csr2, ec=ec2, **kw)
+    if split and not (o.edgeconv_can_split_out(out=Mat.of(torch.zeros(n * reps, ld, device=DEV), 0, H), **c1)):
+        pytest.skip("this launch runs on a kernel without split rows (environment switch)")
+    sep = torch.full((n * reps, ld), 7.0, device=DEV)
+    o.edgeconv(out=Mat.of(sep, 0, H), out_split=split, **c1)
+    o.edgeconv(out=Mat.of(sep, Hc, H), out_split=split, **c2)
+    par = torch.full((n * reps, ld), 7.0, device=DEV)
+    o.edgeconv_pair(dict(out=Mat.of(par, 0, H), out_split=split, **c1), dict(out=Mat.of(par, Hc, H), out_split=split, **c2))
+    torch.cuda.synchronize()
+    assert torch.equal(sep.view(torch.int32), par.view(torch.int32))
+    assert not torch.isnan(par[:, :H]).any() or split          # (split rows are half pairs: NaN patterns are possible bit-wise, not as values)
+    if split:
+        assert not torch.isnan(packing.unsplit_f16(par[:, :2 * Hc].contiguous().cpu(), 2 * Hc)).any()
+    # flags that do not fit together: a skipped pass without a partner that does it is the caller's business, but a partner pointer on
+    # a launch that skips its own pass, or conversion flags on fp32 rows, are refused
+    a = o._edge_args(c1["A"], c1["B"], csr1, ec1, Mat.of(par, 0, H), reps, n, n)
+    b = o._edge_args(c2["A"], c2["B"], csr2, ec2, Mat.of(par, Hc, H), reps, n, n)
+    import ctypes as C
+    a.skip_init, a.init_with = 1, C.addressof(b)
+    assert o.lib.morig_edgeconv(C.byref(a), native._stream()) == -1
+    a.skip_init, a.init_with, a.skip_split = 0, None, 1          # fp32 rows have no conversion pass
+    assert o.lib.morig_edgeconv(C.byref(a), native._stream()) == -1
+    torch.cuda.synchronize()
+    if H == 32 and o.precision == "f16x3":
+        x = torch.zeros(n * reps, 4)
+        x[:, :3] = torch.randn(n * reps, 3, generator=g)
+        x = x.to(DEV)
+        firsts = [tuple(t.to(DEV) for t in packing.pack_first_x3(torch.randn(32, 3, generator=g), torch.randn(32, 3, generator=g),
+                                                                 torch.randn(32, generator=g))) for _ in range(2)]
+        sep3 = torch.full((n * reps, ld), 7.0, device=DEV)
+        o.edgeconv_x3(Mat.of(x), firsts[0], csr1, ec1, Mat.of(sep3, 0, 32), **kw)
+        o.edgeconv_x3(Mat.of(x), firsts[1], csr2, ec2, Mat.of(sep3, 32, 32), **kw)
+        par3 = torch.full((n * reps, ld), 7.0, device=DEV)
+        o.edgeconv_x3_pair(dict(X=Mat.of(x), first=firsts[0], csr=csr1, ec=ec1, out=Mat.of(par3, 0, 32), **kw),
+                           dict(X=Mat.of(x), first=firsts[1], csr=csr2, ec=ec2, out=Mat.of(par3, 32, 32), **kw))
+        torch.cuda.synchronize()
+        assert torch.equal(sep3, par3) and not torch.isnan(par3).any()
+
+
 @pytest.mark.parametrize("H,kind", [(128, "pad4"), (256, "pad4"), (256, "min4")])
 @pytest.mark.parametrize("n,e,hub,reps", [(700, 5000, 3, 2), (20000, 300000, 777, 2), (64, 200, None, 1), (3000, 2500, None, 3)])
 def test_edgeconv_split_fp16_rows(H, kind, n, e, hub, reps):

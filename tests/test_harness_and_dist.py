@@ -67,8 +67,10 @@ def test_c_abi_argument_structs_carry_their_size():
     mirrors = dict(GEMM=native.GemmArgs, EDGECONV=native.EdgeConvArgs, EDGECONV_X3=native.EdgeConvX3Args, SEGMAX=native.SegmaxArgs,
                    POINTCONV=native.PointConvArgs)
     assert set(sizes) == set(mirrors)
+    current = {k: int(v) for k, v in re.findall(r"#define MORIG_([A-Z0-9_]+)_ARGS_SIZE\s+(\d+)u", hdr)}     # structs that grew since
+    assert set(current) == {"EDGECONV", "EDGECONV_X3"} and all(current[k] > sizes[k] and current[k] % 8 == 0 for k in current)
     for k, cls in mirrors.items():
-        assert C.sizeof(cls) == sizes[k], (k, C.sizeof(cls), sizes[k])          # nothing appended since version 3
+        assert C.sizeof(cls) == current.get(k, sizes[k]), (k, C.sizeof(cls), sizes[k])     # the mirrors have the header's CURRENT sizes
         assert cls._fields_[0] == ("struct_size", C.c_uint32)
         assert native._args(cls).struct_size == C.sizeof(cls)
     lib = native.load_library()
@@ -80,6 +82,10 @@ def test_c_abi_argument_structs_carry_their_size():
             a.struct_size = bad
             assert calls[k](C.byref(a), None) == -1, (k, bad)                    # MORIG_E_INVALID
     assert lib.morig_edgeconv_can_split_out(C.byref(native.EdgeConvArgs())) == 0
+    # a caller built against the 192-byte round-5/6 struct (no pair members) is still taken: same answer as the full struct with NULL pointers
+    a = native._args(native.EdgeConvArgs)
+    a.struct_size = sizes["EDGECONV"]
+    assert lib.morig_edgeconv(C.byref(a), None) == -1 and lib.morig_edgeconv_can_split_out(C.byref(a)) == 0
 
     class GemmArgsV2(C.Structure):             # the round-5 layout: M first, no struct_size, no K tail
         _fields_ = [f for f in native.GemmArgs._fields_ if f[0] not in ("struct_size", "X_tail", "ld_tail", "tail_rows", "tail_cols")]

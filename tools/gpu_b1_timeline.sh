@@ -5,5 +5,5 @@ export TMPDIR=/tmp
 D=$(pwd); TAG=${1:-b1}; B=${2:-1}
 ( cd /tmp && rm -rf /tmp/tl_b1 && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_b1 -- python $D/tools/b1_profile.py $B 12 > /tmp/tl_b1.log 2>&1 )
 f=$(find /tmp/tl_b1 -name "*kernel_trace.csv" | head -1)
-python tools/step_timeline.py "$f" cls_attention_kernel > gpurun_out/timeline_B${B}_$TAG.txt 2>&1
+python tools/step_timeline.py "$f" cls_attention > gpurun_out/timeline_B${B}_$TAG.txt 2>&1
 head -3 gpurun_out/timeline_B${B}_$TAG.txt; tail -1 gpurun_out/timeline_B${B}_$TAG.txt
