@@ -81,6 +81,7 @@ int launch_gemm16_dma(const GemmDmaParams& p, int tiles_m128, hipStream_t s); //
 struct EdgeX3Params {
     const float* X; int ldx;                       // [rows][ldx >= 4]: 3 input channels per vertex
     const float* W1a; const float* W1b; const float* b1;      // [32][4], [32][4], [32]
+    const float* A; int lda; const float* B; int ldb;          // X == nullptr: the per-vertex first-layer terms [rows][>= 32] instead (morig_edgeconv, H = 32)
     const float* W2s; int ldw;                     // split-fp16 image of W2 [32][ldw]
     const float* bias; const float* scale; const float* shift;
     const int* rowptr; const int* srcS; const int* dstS; int n_nodes; int cap;
@@ -89,7 +90,7 @@ struct EdgeX3Params {
     int* ovf;
 };
 
-int launch_edge_x3(const EdgeX3Params& p, int n_tiles_cap, hipStream_t s);      // edge_x3.hip (persistent 32-wide EdgeConv on 3-channel inputs)
+int launch_edge_x3(const EdgeX3Params& p, int n_tiles_cap, hipStream_t s);      // edge_x3.hip (persistent 32-wide EdgeConv: 3-channel inputs, or gathered [A | B] rows)
 int launch_gemm16_dmap(const GemmDmaParams& p, hipStream_t s);                // gemm_dmap.hip (persistent, 256 x 256 tiles)
 // vertex_ops.hip: a dense layer on at most 128 rows (fp32 X, W, Y; bias / ReLU / column affine), weights distributed over the chip
 bool few_rows_gemm_takes(int M, int N, int K, int ldx, int ldw);

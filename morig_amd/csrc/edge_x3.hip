@@ -27,6 +27,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int X3_BM = 128, X3_LINE = 144;          // rows per tile; bytes per LDS line: [32 hi | 32 lo | pad] = [32 fp32 | pad]
 
+// AB = true [r06]: the same kernel for morig_edgeconv at H = 32 -- the first layer's per-vertex terms come as [A | B] rows (32 floats each,
+// one vertex GEMM: the first unit of the head, the point networks' vertex branch), so a lane gathers the 16 hidden channels it stages
+// from A[dst] and B[src] (4 + 4 16-byte loads, both half-waves), adds, ReLUs and splits them; everything behind the staging is shared.
+// The tile engine ran these launches one 128-row tile per workgroup: 96 + 196 us per headline step against 58 + 127 us for the 3-channel
+// form on the same graphs.
+template <bool AB>
 __global__ __launch_bounds__(256, 4) void edge_x3_kernel(const EdgeX3Params p) {
     __shared__ __attribute__((aligned(16))) char lines[2][X3_BM * X3_LINE];
     __shared__ int sseg[2][X3_BM];
@@ -48,7 +54,7 @@ __global__ __launch_bounds__(256, 4) void edge_x3_kernel(const EdgeX3Params p) {
     f16x8 w1h, w1l, wh[2], wl[2];
     {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (hi == 0) {
+        if (!AB && hi == 0) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) { v[j] = p.W1a[l31 * 4 + j]; v[3 + j] = p.W1b[l31 * 4 + j]; }
             v[6] = p.b1[l31];
@@ -76,19 +82,34 @@ __global__ __launch_bounds__(256, 4) void edge_x3_kernel(const EdgeX3Params p) {
         if (tid < 2) edge = p.dstS[min(max(tid == 0 ? r0 - 1 : r0 + X3_BM, 0), Etot - 1)];     // thread 0: id in front of the tile, 1: behind
     };
     auto load_x = [&](int t, int d, int sidx, f32x4& a, f32x4& b) __attribute__((always_inline)) {
-        if (t >= T || hi != 0) return;
+        if (AB || t >= T || hi != 0) return;
         int rep; const int r0 = tile_row0(t, rep);
         const bool live = r0 + row < Etot;
         const size_t base = (size_t)rep * p.rep_in;
         a = *reinterpret_cast<const f32x4*>(p.X + (base + (live ? d : 0)) * p.ldx);
         b = *reinterpret_cast<const f32x4*>(p.X + (base + (live ? sidx : 0)) * p.ldx);
     };
+    // AB: the 16 channels this lane stages, (8 g4 + 4 hi .. + 3) for g4 = 0 .. 3, of A[dst] and of B[src]
+    auto load_ab = [&](int t, int d, int sidx, f32x4 (&a)[4], f32x4 (&b)[4]) __attribute__((always_inline)) {
+        if (!AB || t >= T) return;
+        int rep; const int r0 = tile_row0(t, rep);
+        const bool live = r0 + row < Etot;
+        const size_t base = (size_t)rep * p.rep_in;
+        const float* ar = p.A + (base + (live ? d : 0)) * p.lda + 4 * hi;
+        const float* br = p.B + (base + (live ? sidx : 0)) * p.ldb + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) { a[g4] = *reinterpret_cast<const f32x4*>(ar + 8 * g4); b[g4] = *reinterpret_cast<const f32x4*>(br + 8 * g4); }
+    };
     const int t0 = blockIdx.x, tstep = gridDim.x;
     int d_cur = 0, s_cur = 0, e_cur = 0, d_nxt = 0, s_nxt = 0, e_nxt = 0;
     f32x4 xi_cur = {0.f, 0.f, 0.f, 0.f}, xj_cur = xi_cur, xi_nxt = xi_cur, xj_nxt = xi_cur;
+    f32x4 ga_cur[4], gb_cur[4], ga_nxt[4], gb_nxt[4];
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) ga_cur[g4] = gb_cur[g4] = ga_nxt[g4] = gb_nxt[g4] = xi_cur;
     load_ids(t0, d_cur, s_cur, e_cur);
     load_ids(t0 + tstep, d_nxt, s_nxt, e_nxt);
     load_x(t0, d_cur, s_cur, xi_cur, xj_cur);
+    load_ab(t0, d_cur, s_cur, ga_cur, gb_cur);
     bool amax_bad = false;
 
     int par = 0;
@@ -97,40 +118,52 @@ __global__ __launch_bounds__(256, 4) void edge_x3_kernel(const EdgeX3Params p) {
         const bool live = r0 + row < Etot;
         // the next tile's inputs (its ids arrived a tile ago) and the ids of the tile after it
         load_x(t + tstep, d_nxt, s_nxt, xi_nxt, xj_nxt);
+        load_ab(t + tstep, d_nxt, s_nxt, ga_nxt, gb_nxt);
         int d_nn = 0, s_nn = 0, e_nn = 0;
         load_ids(t + 2 * tstep, d_nn, s_nn, e_nn);
 
         char* L = lines[par];
         if (hi == 0) sseg[par][row] = live ? d_cur : -1;
         if (tid == 0) sflag[par][0] = (r0 > 0 && d_cur == e_cur) ? 1 : 0;                          // thread 0 holds row 0 and the id in front
-        // ---- first layer: Xext fragment (B operand) of this lane's row, 3 MFMAs, ReLU, split, staged into the row's line ----
+        // ---- first layer: Xext fragment (B operand) of this lane's row, 3 MFMAs (AB: the gathered terms added), ReLU, split, staged
+        // into the row's line ----
         {
-            f32x4 hb = {0.f, 0.f, 0.f, 0.f}, lb = hb;
-            if (hi == 0) {
-                float h2, l2;
-                split_pair_f16(xi_cur[0], xi_cur[1], h2, l2); hb[0] = h2; lb[0] = l2;
-                split_pair_f16(xi_cur[2], xj_cur[0], h2, l2); hb[1] = h2; lb[1] = l2;
-                split_pair_f16(xj_cur[1], xj_cur[2], h2, l2); hb[2] = h2; lb[2] = l2;
-                split_pair_f16(1.0f, 0.0f, h2, l2);           hb[3] = h2; lb[3] = l2;
-                const float am = fmaxf(fmaxf(fmaxf(fabsf(xi_cur[0]), fabsf(xi_cur[1])), fmaxf(fabsf(xi_cur[2]), fabsf(xj_cur[0]))),
-                                       fmaxf(fabsf(xj_cur[1]), fabsf(xj_cur[2])));
-                if (!(am < 65000.f)) amax_bad = true;
-            }
-            const f16x8 xh = __builtin_bit_cast(f16x8, hb), xl = __builtin_bit_cast(f16x8, lb);
             f32x16 a1;
+            if constexpr (AB) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a1[r] = 0.f;
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, xh, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xl, a1, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xh, a1, 0, 0, 0);
+                for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a1[4 * g4 + q] = ga_cur[g4][q] + gb_cur[g4][q];
+            } else {
+                f32x4 hb = {0.f, 0.f, 0.f, 0.f}, lb = hb;
+                if (hi == 0) {
+                    float h2, l2;
+                    split_pair_f16(xi_cur[0], xi_cur[1], h2, l2); hb[0] = h2; lb[0] = l2;
+                    split_pair_f16(xi_cur[2], xj_cur[0], h2, l2); hb[1] = h2; lb[1] = l2;
+                    split_pair_f16(xj_cur[1], xj_cur[2], h2, l2); hb[2] = h2; lb[2] = l2;
+                    split_pair_f16(1.0f, 0.0f, h2, l2);           hb[3] = h2; lb[3] = l2;
+                    const float am = fmaxf(fmaxf(fmaxf(fabsf(xi_cur[0]), fabsf(xi_cur[1])), fmaxf(fabsf(xi_cur[2]), fabsf(xj_cur[0]))),
+                                           fmaxf(fabsf(xj_cur[1]), fabsf(xj_cur[2])));
+                    if (!(am < 65000.f)) amax_bad = true;
+                }
+                const f16x8 xh = __builtin_bit_cast(f16x8, hb), xl = __builtin_bit_cast(f16x8, lb);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a1[r] = 0.f;
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, xh, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xl, a1, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, xh, a1, 0, 0, 0);
+            }
             // register r of a1 = hidden channel (r & 3) + 8 (r >> 2) + 4 hi of row `row`
             char* line = L + row * X3_LINE;
-            float am = 0.f;
+            float am = 0.f, chk = 0.f;
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
                 float h[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { h[q] = fmaxf(a1[4 * g4 + q], 0.f); am = fmaxf(am, h[q]); }
+                for (int q = 0; q < 4; ++q) {
+                    if (AB) chk = fmaf(a1[4 * g4 + q], 0.f, chk);                // NaN / Inf of a gathered term: fmaxf would drop it (-> 0)
+                    h[q] = fmaxf(a1[4 * g4 + q], 0.f); am = fmaxf(am, h[q]);
+                }
                 float h0, l0, h1, l1;
                 split_pair_f16(h[0], h[1], h0, l0);
                 split_pair_f16(h[2], h[3], h1, l1);
@@ -140,7 +173,7 @@ __global__ __launch_bounds__(256, 4) void edge_x3_kernel(const EdgeX3Params p) {
                 *reinterpret_cast<f32x2*>(line + 2 * c0) = hv;
                 *reinterpret_cast<f32x2*>(line + 64 + 2 * c0) = lv;
             }
-            if (!(am < 65000.f)) amax_bad = true;
+            if (!(chk == 0.f) || !(am < 65000.f)) amax_bad = true;
         }
         asm volatile("" ::: "memory");                     // lines written as float pairs, read back as halves (type punning: DESIGN 5 (13))
         // ---- second layer on this wave's own 32 rows: same-wave LDS traffic is in order, no barrier ----
@@ -215,6 +248,10 @@ __global__ __launch_bounds__(256, 4) void edge_x3_kernel(const EdgeX3Params p) {
         // (no barrier here: the next tile works on the other parity's lines / lists; the tile after it passes the next tile's
         // barriers first, which every wave reaches only after this scan)
         d_cur = d_nxt; s_cur = s_nxt; e_cur = e_nxt; xi_cur = xi_nxt; xj_cur = xj_nxt;
+        if constexpr (AB) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) { ga_cur[g4] = ga_nxt[g4]; gb_cur[g4] = gb_nxt[g4]; }
+        }
         d_nxt = d_nn; s_nxt = s_nn; e_nxt = e_nn;
     }
     if (amax_bad) *p.ovf = 1;
@@ -231,7 +268,8 @@ int launch_edge_x3(const EdgeX3Params& p, int n_tiles_cap, hipStream_t s) {
     int grid = avail * 4;                                  // 4 workgroups per CU (LDS: 2 x 18 KB of lines each)
     if (grid > n_tiles_cap) grid = n_tiles_cap;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(edge_x3_kernel, dim3(grid), dim3(256), 0, s, p);
+    if (p.X) hipLaunchKernelGGL(edge_x3_kernel<false>, dim3(grid), dim3(256), 0, s, p);
+    else     hipLaunchKernelGGL(edge_x3_kernel<true>, dim3(grid), dim3(256), 0, s, p);
     MORIG_LAUNCH_CHECK();
     return MORIG_OK;
 }

@@ -1205,6 +1205,21 @@ extern "C" int morig_edgeconv(const morig_edgeconv_args* a_in, void* stream) {
         return launch_edge_pp(q, nblocks, s);
     }
     if (a->split_with || a->skip_split) return MORIG_E_INVALID;
+    // [r06] H = 32 on the split-fp16 path with the hidden BatchNorm folded (packing.fold_hidden_affine: every pack of the networks): the
+    // persistent 32-wide kernel with gathered [A | B] rows (edge_x3.hip <true>); MORIG_X3_TILE=1 keeps the tile engine (A/B runs)
+    static const bool x3_tile = [] { const char* e = getenv("MORIG_X3_TILE"); return e && e[0] == '1'; }();
+    if (f16 && a->H == 32 && !a->s1 && !x3_tile && (a->ldo & 3) == 0 && aligned16(a->out) && (a->lda & 3) == 0 && (a->ldb & 3) == 0 &&
+        aligned16(a->b2) && a->ldw >= 32) {
+        EdgeX3Params q = {};
+        q.A = a->A; q.lda = a->lda; q.B = a->B; q.ldb = a->ldb;
+        q.W2s = static_cast<const float*>(a->W2_split); q.ldw = a->ldw;
+        q.bias = a->b2; q.scale = a->s2; q.shift = a->t2;
+        q.rowptr = a->rowptr; q.srcS = a->src_sorted; q.dstS = a->dst_sorted; q.n_nodes = a->n_nodes; q.cap = a->edge_capacity;
+        q.rep_in = a->in_rep_stride; q.rep_out = a->out_rep_stride; q.replicas = a->replicas;
+        q.Y = a->out; q.ldy = a->ldo; q.ovf = a->overflow;
+        ProfScope ps(K_EDGE16_H32, s, flops, bytes);
+        return launch_edge_x3(q, nblocks, s);
+    }
     if (f16) {
         switch (a->H) {
             case 32:  { ProfScope ps(K_EDGE16_H32, s, flops, bytes);  return launch_tile<32, 32, LOAD_EDGE, MODE_EDGEMAX, PREC_F16X3>(p, nblocks, s); }
