@@ -568,6 +568,8 @@ def test_forward_async_defers_the_guard_read():
     synchronous one acts on -- ok / operand outside the split-fp16 range / edge index out of range -- even when it is read only
     after the NEXT forward was enqueued (the snapshot is per forward)."""
     from morig_amd import native
+    if native.get_ops().precision == "f32":
+        pytest.skip("MORIG_PRECISION=f32: the exact path has no range guard to defer (forward_async returns no pending read)")
     m = _jointnet()
     d = synth.collate([synth.make_mesh(5, n_side=16), synth.make_mesh(6, n_side=12)]).to(DEV)
     want = m(d, d.pred_flow)
